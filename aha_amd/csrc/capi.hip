@@ -1,0 +1,359 @@
+// extern "C" surface of libaha_hip.so -- see include/aha_hip.h for the contract of every entry point.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+#include "model.h"
+#include "vision.h"
+
+namespace aha {
+const char* last_error_cstr();
+}
+using namespace aha;
+
+#define API_GUARD_BEGIN try {
+#define API_GUARD_END                                   \
+  }                                                     \
+  catch (const std::exception& e) {                     \
+    set_error(std::string("exception: ") + e.what());   \
+    return AHA_ERR_INVALID;                             \
+  }                                                     \
+  catch (...) {                                         \
+    set_error("unknown exception");                     \
+    return AHA_ERR_INVALID;                             \
+  }
+
+extern "C" {
+
+const char* aha_hip_last_error(void) { return last_error_cstr(); }
+const char* aha_hip_version(void) { return "aha-hip 0.1 (gfx950)"; }
+
+int aha_hip_init(int device, aha_ctx** out) {
+  API_GUARD_BEGIN
+  if (!out) {
+    set_error("aha_hip_init: out is null");
+    return AHA_ERR_INVALID;
+  }
+  int n = 0;
+  AHA_HIP_CHECK(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) {
+    set_error("aha_hip_init: device " + std::to_string(device) + " out of range (" + std::to_string(n) + " visible)");
+    return AHA_ERR_INVALID;
+  }
+  AHA_HIP_CHECK(hipSetDevice(device));
+  aha_ctx* c = new aha_ctx();
+  c->device = device;
+  AHA_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  *out = c;
+  return AHA_OK;
+  API_GUARD_END
+}
+
+void aha_hip_shutdown(aha_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int aha_hip_model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view* weights, size_t n_weights,
+                         aha_model** out) {
+  API_GUARD_BEGIN
+  return model_create(ctx, desc, weights, n_weights, out);
+  API_GUARD_END
+}
+void aha_hip_model_destroy(aha_model* m) { model_destroy(m); }
+
+int aha_hip_forward_initial(aha_model* m, const uint32_t* input_ids, size_t n_ids, size_t seqlen_offset,
+                            const aha_mm_input* mm, float* logits_out, uint32_t* argmax_out) {
+  API_GUARD_BEGIN
+  if (!m) {
+    set_error("null model");
+    return AHA_ERR_INVALID;
+  }
+  return model_forward_initial(m, input_ids, n_ids, seqlen_offset, mm, logits_out, argmax_out);
+  API_GUARD_END
+}
+int aha_hip_forward_step(aha_model* m, uint32_t token, size_t seqlen_offset, float* logits_out, uint32_t* argmax_out) {
+  API_GUARD_BEGIN
+  if (!m) {
+    set_error("null model");
+    return AHA_ERR_INVALID;
+  }
+  return model_forward_step(m, token, seqlen_offset, logits_out, argmax_out);
+  API_GUARD_END
+}
+int aha_hip_clear_cache(aha_model* m) {
+  if (!m) {
+    set_error("null model");
+    return AHA_ERR_INVALID;
+  }
+  return model_clear_cache(m);
+}
+int aha_hip_stop_token_ids(const aha_model* m, uint32_t* out, size_t cap) {
+  if (!m) {
+    set_error("null model");
+    return AHA_ERR_INVALID;
+  }
+  const int n = m->desc.n_stop_tokens;
+  for (int i = 0; i < n && (size_t)i < cap; ++i) out[i] = m->desc.stop_tokens[i];
+  return n;
+}
+int aha_hip_decode_greedy(aha_model* m, uint32_t first_token, size_t seqlen_offset, size_t max_new, uint32_t* tokens_out) {
+  API_GUARD_BEGIN
+  if (!m || !tokens_out) {
+    set_error("null argument");
+    return AHA_ERR_INVALID;
+  }
+  return model_decode_greedy(m, first_token, seqlen_offset, max_new, tokens_out);
+  API_GUARD_END
+}
+
+size_t aha_hip_cache_len(const aha_model* m) { return m ? m->cache_len : 0; }
+
+int aha_hip_set_profiling(aha_model* m, int enable) {
+  if (!m) return AHA_ERR_INVALID;
+  int rc = prof_collect(m);
+  if (rc) return rc;
+  m->profiling = enable != 0;
+  if (enable)
+    for (auto& a : m->prof_acc) a = aha_model::ProfAcc();
+  return AHA_OK;
+}
+int aha_hip_get_profile(aha_model* m, const char* kernel_class, double* total_ms, int64_t* launches, double* bytes,
+                        double* flops) {
+  if (!m || !kernel_class) return AHA_ERR_INVALID;
+  int rc = prof_collect(m);
+  if (rc) return rc;
+  auto it = m->prof_cls.find(kernel_class);
+  aha_model::ProfAcc a;
+  if (it != m->prof_cls.end()) a = m->prof_acc[it->second];
+  if (total_ms) *total_ms = a.ms;
+  if (launches) *launches = a.n;
+  if (bytes) *bytes = a.bytes;
+  if (flops) *flops = a.flops;
+  return AHA_OK;
+}
+int aha_hip_debug_scramble_pages(aha_model* m, int enable) {
+  if (!m) return AHA_ERR_INVALID;
+  m->scramble_pages = enable != 0;
+  if (enable && !m->free_pages.empty()) {
+    uint64_t s = 0x2545F4914F6CDD1Dull;
+    for (size_t i = m->free_pages.size(); i > 1; --i) {
+      s = s * 6364136223846793005ull + 1442695040888963407ull;
+      std::swap(m->free_pages[i - 1], m->free_pages[(s >> 33) % i]);
+    }
+  }
+  return AHA_OK;
+}
+int aha_hip_debug_last_hidden(aha_model* m, float* out, size_t n) {
+  API_GUARD_BEGIN
+  if (!m || !out || n != (size_t)m->desc.hidden_size) {
+    set_error("debug_last_hidden: bad size");
+    return AHA_ERR_INVALID;
+  }
+  std::vector<uint16_t> tmp(n);
+  AHA_HIP_CHECK(hipMemcpy(tmp.data(), m->d_hlast, n * 2, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t u = (uint32_t)tmp[i] << 16;
+    memcpy(&out[i], &u, 4);
+  }
+  return AHA_OK;
+  API_GUARD_END
+}
+
+// ---- op-level entry points --------------------------------------------------------------------------------------
+int aha_hip_rmsnorm(const void* x, const void* w, void* y, int64_t rows, int32_t dim, float eps, void* stream) {
+  if (!x || !w || !y || dim % 8 || dim > 8192) {
+    set_error("rmsnorm: dim must be a multiple of 8 and <= 8192");
+    return AHA_ERR_INVALID;
+  }
+  launch_rmsnorm_rows(x, w, y, rows, dim, dim, dim, eps, (hipStream_t)stream);
+  AHA_HIP_CHECK(hipGetLastError());
+  return AHA_OK;
+}
+
+int aha_hip_gemv(const void* W, const void* x, void* y, int32_t N, int32_t K, const void* norm_w, float eps,
+                 const void* residual, void* stream) {
+  if (!W || !x || !y || K % 8 || K > 32768) {
+    set_error("gemv: K must be a multiple of 8 and <= 32768");
+    return AHA_ERR_INVALID;
+  }
+  GemvArgs g{};
+  g.W = W; g.x = x; g.y = y; g.N = N; g.K = K; g.norm_w = norm_w; g.eps = eps; g.residual = residual;
+  launch_gemv(g, residual ? GEMV_RESIDUAL : GEMV_STORE, (hipStream_t)stream);
+  AHA_HIP_CHECK(hipGetLastError());
+  return AHA_OK;
+}
+
+int aha_hip_gemv_gate_up(const void* Wg, const void* Wu, const void* x, void* y, int32_t I, int32_t K,
+                         const void* norm_w, float eps, void* stream) {
+  if (!Wg || !Wu || !x || !y || K % 8 || K > 32768) {
+    set_error("gemv_gate_up: bad arguments");
+    return AHA_ERR_INVALID;
+  }
+  GemvArgs g{};
+  g.W = Wg; g.W2 = Wu; g.x = x; g.y = y; g.N = I; g.K = K; g.norm_w = norm_w; g.eps = eps;
+  launch_gemv(g, GEMV_SILU_MUL, (hipStream_t)stream);
+  AHA_HIP_CHECK(hipGetLastError());
+  return AHA_OK;
+}
+
+int aha_hip_gemm(const void* A, const void* W, void* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw,
+                 int32_t ldc, const void* bias, const void* residual, int32_t act, void* stream) {
+  if (!A || !W || !C || K % 8 || N % 8 || lda % 8 || ldw % 8 || ldc % 4 || act < 0 || act > ACT_SILU_MUL_PAIRS) {
+    set_error("gemm: K, N, lda, ldw must be multiples of 8 (16-byte rows), ldc of 4");
+    return AHA_ERR_INVALID;
+  }
+  if (act == ACT_SILU_MUL_PAIRS && (N % 32 || bias || residual)) {
+    set_error("gemm: ACT_SILU_MUL_PAIRS needs N % 32 == 0 and no bias/residual");
+    return AHA_ERR_INVALID;
+  }
+  GemmArgs g{};
+  g.A = A; g.W = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.bias = bias; g.residual = residual; g.act = act;
+  launch_gemm(g, (hipStream_t)stream);
+  AHA_HIP_CHECK(hipGetLastError());
+  return AHA_OK;
+}
+
+int aha_hip_qknorm_rope(const void* qkv, const void* q_norm_w, const void* k_norm_w, const int32_t* pos,
+                        const int32_t* axis_map, void* q_out, void* k_out, void* v_out, int32_t S, int32_t nh,
+                        int32_t kvh, int32_t d, float eps, float theta, void* stream) {
+  API_GUARD_BEGIN
+  if (d != 128) {
+    set_error("qknorm_rope: head_dim must be 128");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<float> inv(d / 2);
+  for (int i = 0; i < d / 2; ++i) inv[i] = 1.0f / powf(theta, (float)(2 * i) / (float)d);
+  float* d_inv = nullptr;
+  AHA_HIP_CHECK(hipMalloc((void**)&d_inv, inv.size() * 4));
+  AHA_HIP_CHECK(hipMemcpy(d_inv, inv.data(), inv.size() * 4, hipMemcpyHostToDevice));
+  RopeArgs r{};
+  r.qkv = qkv; r.ld = (int64_t)(nh + 2 * kvh) * d; r.q_norm_w = q_norm_w; r.k_norm_w = k_norm_w; r.pos = pos; r.pos_ld = S;
+  r.inv_freq = d_inv; r.axis_map = axis_map; r.q_out = q_out; r.k_out = k_out; r.v_out = v_out;
+  r.kv.page_ptrs = nullptr; r.S = S; r.nh = nh; r.kvh = kvh; r.d = d; r.eps = eps;
+  launch_qknorm_rope(r, st);
+  AHA_HIP_CHECK(hipGetLastError());
+  AHA_HIP_CHECK(hipStreamSynchronize(st));
+  hipFree(d_inv);
+  return AHA_OK;
+  API_GUARD_END
+}
+
+namespace {
+struct TmpPages {
+  void* store = nullptr;
+  uint64_t* d_ptrs = nullptr;
+  int32_t* d_len = nullptr;
+  KvLayer kv{};
+  ~TmpPages() {
+    if (store) hipFree(store);
+    if (d_ptrs) hipFree(d_ptrs);
+    if (d_len) hipFree(d_len);
+  }
+};
+int build_tmp_pages(TmpPages& t, const void* k, const void* v, int L, int kvh, int d, hipStream_t st) {
+  const int npages = (L + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS;
+  const size_t page_bytes = (size_t)2 * kvh * KV_PAGE_TOKENS * d * 2;
+  AHA_HIP_CHECK(hipMalloc(&t.store, page_bytes * npages));
+  AHA_HIP_CHECK(hipMemsetAsync(t.store, 0, page_bytes * npages, st));
+  std::vector<uint64_t> ptrs(npages);
+  // hand the pages out back to front so the test exercises the indirection
+  for (int i = 0; i < npages; ++i) ptrs[i] = (uint64_t)(uintptr_t)t.store + (size_t)(npages - 1 - i) * page_bytes;
+  AHA_HIP_CHECK(hipMalloc((void**)&t.d_ptrs, npages * 8));
+  AHA_HIP_CHECK(hipMemcpy(t.d_ptrs, ptrs.data(), npages * 8, hipMemcpyHostToDevice));
+  AHA_HIP_CHECK(hipMalloc((void**)&t.d_len, 4));
+  AHA_HIP_CHECK(hipMemcpy(t.d_len, &L, 4, hipMemcpyHostToDevice));
+  t.kv.page_ptrs = t.d_ptrs;
+  t.kv.layer_off = 0;
+  t.kv.kvh = kvh;
+  t.kv.d = d;
+  launch_kv_pack_pages(k, v, t.kv, L, st);
+  AHA_HIP_CHECK(hipGetLastError());
+  return AHA_OK;
+}
+}  // namespace
+
+int aha_hip_attn_decode(const void* q, const void* k, const void* v, void* o, int32_t nh, int32_t kvh, int32_t d,
+                        int32_t L, float scale, void* stream) {
+  API_GUARD_BEGIN
+  if (d != 128 || L <= 0 || nh % kvh || nh / kvh > 16) {
+    set_error("attn_decode: head_dim must be 128, L > 0, group size <= 16");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  TmpPages t;
+  int rc = build_tmp_pages(t, k, v, L, kvh, d, st);
+  if (rc) return rc;
+  const int npages = (L + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS;
+  const int nsplit = std::max(1, std::min((npages + 3) / 4, 64));
+  float *po = nullptr, *pml = nullptr;
+  AHA_HIP_CHECK(hipMalloc((void**)&po, (size_t)nsplit * 4 * nh * d * 4));
+  AHA_HIP_CHECK(hipMalloc((void**)&pml, (size_t)nsplit * 4 * nh * 2 * 4));
+  AttnDecodeArgs a{};
+  a.q = q; a.kv = t.kv; a.kv_len = t.d_len; a.part_o = po; a.part_ml = pml; a.o = o; a.nh = nh; a.kvh = kvh; a.d = d;
+  a.nsplit = nsplit; a.scale = scale;
+  launch_attn_decode(a, st);
+  hipError_t e = hipGetLastError();
+  hipStreamSynchronize(st);
+  hipFree(po);
+  hipFree(pml);
+  AHA_HIP_CHECK(e);
+  return AHA_OK;
+  API_GUARD_END
+}
+
+int aha_hip_attn_prefill(const void* q, const void* k, const void* v, void* o, int32_t S, int32_t L, int32_t nh,
+                         int32_t kvh, int32_t d, int32_t kv_offset, int32_t causal, float scale, void* stream) {
+  API_GUARD_BEGIN
+  if (d != 128 || L <= 0 || S <= 0 || nh % kvh) {
+    set_error("attn_prefill: head_dim must be 128");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  TmpPages t;
+  int rc = build_tmp_pages(t, k, v, L, kvh, d, st);
+  if (rc) return rc;
+  AttnPrefillArgs a{};
+  a.q = q; a.kv = t.kv; a.o = o; a.S = S; a.nh = nh; a.kvh = kvh; a.d = d; a.kv_offset = kv_offset; a.kv_total = L;
+  a.causal = causal; a.scale = scale;
+  launch_attn_prefill(a, st);
+  hipError_t e = hipGetLastError();
+  hipStreamSynchronize(st);
+  AHA_HIP_CHECK(e);
+  return AHA_OK;
+  API_GUARD_END
+}
+
+int aha_hip_argmax(const float* x, int64_t n, uint32_t* out_dev, void* stream) {
+  API_GUARD_BEGIN
+  if (!x || !out_dev || n <= 0) {
+    set_error("argmax: bad arguments");
+    return AHA_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* wv = nullptr;
+  uint32_t* wi = nullptr;
+  AHA_HIP_CHECK(hipMalloc((void**)&wv, 256 * 4));
+  AHA_HIP_CHECK(hipMalloc((void**)&wi, 256 * 4));
+  launch_argmax_f32(x, n, wv, wi, out_dev, st);
+  hipError_t e = hipGetLastError();
+  hipStreamSynchronize(st);
+  hipFree(wv);
+  hipFree(wi);
+  AHA_HIP_CHECK(e);
+  return AHA_OK;
+  API_GUARD_END
+}
+
+int aha_hip_debug_image_embeds(aha_model* m, int which, float* out, size_t n) {
+  (void)m; (void)which; (void)out; (void)n;
+  set_error("vision tower not built");
+  return AHA_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

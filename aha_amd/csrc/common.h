@@ -1,0 +1,58 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes; bf16 storage, f32 arithmetic).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace aha {
+
+typedef uint16_t bf16_t;  // raw bf16 bit pattern in HBM / LDS
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;  // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // MFMA 16x16 C/D fragment
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even f32 -> bf16 (what a Candle op does when it materialises a bf16 tensor)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+// value of f after a round trip through bf16
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+
+// low / high bf16 of a packed dword as f32
+__device__ __forceinline__ float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pack_bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// streamed-once 16-byte load (weights in decode: one CU reads each line once -> non-temporal)
+__device__ __forceinline__ u32x4_t ld_nt16(const void* p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+}
+__device__ __forceinline__ u32x4_t ld16(const void* p) { return *reinterpret_cast<const u32x4_t*>(p); }
+
+constexpr int KV_PAGE_TOKENS = 64;  // tokens per KV page
+
+// Slot of token t (0..63) inside a V page row.  The V block is dim-major [d][64] and its 64 token slots are permuted
+// so that the 8 tokens one MFMA lane group needs for the P.V step (two 4-token runs that come out of the S^T = K.Q^T
+// accumulator fragments of token sub-tiles 2kk and 2kk+1) are 16 contiguous bytes: t = kk*32 + sub1*16 + G*4 + j
+// lives at slot kk*32 + G*8 + sub1*4 + j.
+__host__ __device__ __forceinline__ int v_slot(int t) {
+  return (t & 32) | (((t >> 2) & 3) << 3) | (((t >> 4) & 1) << 2) | (t & 3);
+}
+
+}  // namespace aha

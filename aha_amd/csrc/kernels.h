@@ -1,0 +1,104 @@
+// Host-callable launchers for the gfx950 kernels.  All pointers are device pointers; all launches are asynchronous
+// on `st`.  Shapes/strides are in elements unless a name says bytes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace aha {
+
+// Paged KV cache view of ONE layer.  Page p of this layer lives at page_ptrs[p] + layer_off (bytes):
+//   K block  [kvh][KV_PAGE_TOKENS][d]   token-major   (QK^T operand rows are contiguous 2*d bytes)
+//   V block  [kvh][d][KV_PAGE_TOKENS]   dim-major     (P.V operand rows are contiguous in tokens)
+struct KvLayer {
+  const uint64_t* page_ptrs;  // device array, byte addresses of each logical page's layer-0 storage
+  uint64_t layer_off;         // byte offset of this layer inside a page's slab slot
+  int kvh, d;
+};
+
+enum GemvEpi { GEMV_STORE = 0, GEMV_RESIDUAL = 1, GEMV_SILU_MUL = 2, GEMV_LOGITS = 3 };
+
+struct GemvArgs {
+  const void* W;         // (N,K) bf16 row-major; for GEMV_SILU_MUL the gate matrix (I,K)
+  const void* W2;        // GEMV_SILU_MUL: the up matrix (I,K)
+  const void* x;         // (K) bf16
+  const void* norm_w;    // optional (K) bf16: fuse h = RMSNorm(x; norm_w, eps)
+  const void* residual;  // GEMV_RESIDUAL: (N) bf16, may alias y
+  void* y;               // (N) bf16   [GEMV_LOGITS: unused]
+  float* y_f32;          // GEMV_LOGITS: (N) f32 logits
+  float* blk_max;        // GEMV_LOGITS: per-tile (max value, index) partials for the on-device argmax
+  uint32_t* blk_idx;
+  void* h_out;           // optional (K) bf16: block 0 also writes the normalised input (debug / last hidden)
+  int N, K;
+  float eps;
+};
+void launch_gemv(const GemvArgs& a, GemvEpi epi, hipStream_t st);
+int gemv_num_tiles(int N, int K);  // number of (max,idx) partials GEMV_LOGITS writes
+
+void launch_argmax_partials(const float* blk_max, const uint32_t* blk_idx, int n, uint32_t* out, hipStream_t st);
+void launch_argmax_f32(const float* x, int64_t n, float* ws_max, uint32_t* ws_idx, uint32_t* out, hipStream_t st);
+
+void launch_embed_gather(const void* table, const uint32_t* ids, void* out, int S, int H, hipStream_t st);
+void launch_rmsnorm_rows(const void* x, const void* w, void* y, int64_t rows, int dim, int64_t ldx, int64_t ldy,
+                         float eps, hipStream_t st);
+
+struct RopeArgs {
+  const void* qkv;      // (S, ld) bf16: [q heads | k heads | v heads] per token
+  int64_t ld;
+  const void* q_norm_w; // (d) bf16
+  const void* k_norm_w;
+  const int32_t* pos;   // (3, pos_ld) rows T,H,W
+  int64_t pos_ld;
+  const float* inv_freq;    // (d/2)
+  const int32_t* axis_map;  // (d/2) frequency slot -> row of pos
+  void* q_out;          // (S, nh*d) bf16
+  // paged destination (kv.page_ptrs != nullptr) or contiguous token-major k_out/v_out (S, kvh*d)
+  KvLayer kv;
+  const int32_t* kv_start;  // device scalar: cache position of token 0 of this call
+  void* k_out;
+  void* v_out;
+  int S, nh, kvh, d;
+  float eps;
+};
+void launch_qknorm_rope(const RopeArgs& a, hipStream_t st);
+
+// contiguous token-major (L, kvh*d) K,V -> pages (op-level tests and TP KV gather)
+void launch_kv_pack_pages(const void* k, const void* v, KvLayer kv, int L, hipStream_t st);
+
+struct AttnDecodeArgs {
+  const void* q;           // (nh*d) bf16, normed + roped
+  KvLayer kv;
+  const int32_t* kv_len;   // device scalar: number of valid tokens (including the one just appended)
+  float* part_o;           // workspace (nsplit, nh, d) f32 un-normalised
+  float* part_ml;          // workspace (nsplit, nh, 2) running max / sum
+  void* o;                 // (nh*d) bf16
+  int nh, kvh, d, nsplit;
+  float scale;
+};
+void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t st);
+
+struct AttnPrefillArgs {
+  const void* q;           // (S, nh*d) bf16
+  KvLayer kv;
+  void* o;                 // (S, nh*d) bf16
+  int S, nh, kvh, d;
+  int kv_offset;           // q row i sees cache positions <= kv_offset + i (causal) or < kv_total (full)
+  int kv_total;            // number of valid cache tokens
+  int causal;
+  float scale;
+};
+void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st);
+
+enum GemmAct { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_SILU_MUL_PAIRS = 4 };
+struct GemmArgs {
+  const void* A;  // (M,K) bf16, row stride lda
+  const void* W;  // (N,K) bf16, row stride ldw
+  void* C;        // (M,N) bf16, row stride ldc   [ACT_SILU_MUL_PAIRS: (M,N/2)]
+  const void* bias;      // optional (N) bf16
+  const void* residual;  // optional (M,N) bf16 with stride ldc, may alias C
+  int M, N, K;
+  int64_t lda, ldw, ldc;
+  int act;
+};
+void launch_gemm(const GemmArgs& a, hipStream_t st);
+
+}  // namespace aha

@@ -1,0 +1,267 @@
+// GQA attention over the paged KV cache: flash-style, no S x S score tensor, no repeat_kv
+// copies, no mask tensor.  Reference semantics being reproduced (eager_attention_forward,
+// /root/reference/src/models/common/modules.rs:757-813; repeat_kv /root/reference/src/utils/tensor_utils.rs:108-124;
+// causal mask tensor_utils.rs:78-106):
+//     scores = bf16(q . k^T) ; scores = bf16(scores * scale) ; (+ -inf above the diagonal) ; softmax ; P . v ; -> bf16
+// q head i reads kv head i / g.  Softmax runs online in f32; P feeds the MFMA as bf16.
+//
+// Fragment scheme (v_mfma_f32_16x16x32_bf16, wave64; G = lane>>4, c = lane&15):
+//   S^T tile = K . Q^T :  A = K   (row = token c, k = dims G*8..+8  -> 16 B straight from a token-major K row)
+//                         B = Q^T (col = q row c, k = dims G*8..+8  -> 16 B straight from a q row)
+//                         C[reg] = S[token G*4+reg][q c]            -> softmax statistics are per lane column
+//   O^T tile = V^T . P^T: A = V^T (row = dim c,  k = 8 token slots  -> 16 B from the dim-major, slot-permuted V page)
+//                         B = P^T (col = q c,    k = the two S^T fragments of token sub-tiles 2kk, 2kk+1, in registers)
+//                         C[reg] = O[q c][dim G*4+reg]
+// so no operand ever needs a transpose or a cross-lane shuffle; see v_slot() in common.h for the V slot permutation.
+#include "common.h"
+#include "kernels.h"
+
+namespace aha {
+
+namespace {
+
+__device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8_t as_frag(u32x4_t v) {
+  union { u32x4_t u; bf16x8_t b; } x;
+  x.u = v;
+  return x.b;
+}
+__device__ __forceinline__ float group_max(float v) {  // across the 4 lane groups (same column c)
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// Online-softmax update for one 64-token tile.  st[sub][reg] holds raw S for token sub*16+G*4+reg, column c.
+// valid(tok_in_tile) masks both causality and the tail of the last page.  Returns the two P^T fragments.
+template <typename ValidFn>
+__device__ __forceinline__ void softmax_tile(f32x4_t (&st)[4], float scale, ValidFn valid, int G, float& m, float& l,
+                                             float& alpha, bf16x8_t (&pf)[2]) {
+  float tmax = -INFINITY;
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s = rbf(rbf(st[sub][r]) * scale);  // matmul output -> bf16, then `* scaling` -> bf16 (modules.rs:782-783)
+      if (!valid(sub * 16 + G * 4 + r)) s = -INFINITY;
+      st[sub][r] = s;
+      tmax = fmaxf(tmax, s);
+    }
+  tmax = group_max(tmax);
+  const float m_new = fmaxf(m, tmax);
+  const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: keep everything at zero
+  alpha = __expf(m - m_use);                               // m = -inf -> 0
+  float psum = 0.f;
+  uint32_t pk[2][4];
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) {
+    float p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p[r] = __expf(st[sub][r] - m_use);
+      psum += p[r];
+    }
+    pk[sub >> 1][(sub & 1) * 2 + 0] = pack_bf(p[0], p[1]);
+    pk[sub >> 1][(sub & 1) * 2 + 1] = pack_bf(p[2], p[3]);
+  }
+  l = l * alpha + psum;
+  m = m_new;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    u32x4_t u = {pk[kk][0], pk[kk][1], pk[kk][2], pk[kk][3]};
+    pf[kk] = as_frag(u);
+  }
+}
+
+constexpr int K_ROW_BYTES = 128 * 2 + 16;            // padded LDS row of the K tile (bank-conflict-free b128 reads)
+constexpr int V_ROW_BYTES = KV_PAGE_TOKENS * 2 + 16;  // padded LDS row of the V^T tile
+
+// ---- prefill: 4 waves x 16 q rows per block, K / V^T page staged in LDS and shared by the 4 waves --------------
+__global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ks = smem;
+  char* vs = smem + KV_PAGE_TOKENS * K_ROW_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, c = lane & 15;
+  const int head = blockIdx.y;
+  const int kvhd = head / (a.nh / a.kvh);
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int qrow = min(q0 + c, a.S - 1);
+  const bf16_t* qp = (const bf16_t*)a.q + ((int64_t)qrow * a.nh + head) * 128;
+  bf16x8_t qf[4];
+#pragma unroll
+  for (int k4 = 0; k4 < 4; ++k4) qf[k4] = as_frag(ld16(qp + k4 * 32 + G * 8));
+
+  const int qpos = a.kv_offset + q0 + c;  // cache position of this lane's q row
+  const int blk_last_q = min(blockIdx.x * 64 + 63, a.S - 1);
+  const int last_tok = a.causal ? min(a.kv_offset + blk_last_q, a.kv_total - 1) : a.kv_total - 1;
+  const int ntiles = last_tok / KV_PAGE_TOKENS + 1;
+  const int wave_last_tok = a.causal ? a.kv_offset + q0 + 15 : a.kv_total - 1;
+
+  float m = -INFINITY, l = 0.f;
+  f32x4_t o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = 0; tile < ntiles; ++tile) {
+    __syncthreads();  // everyone is done with the previous tile
+    {
+      const char* base = reinterpret_cast<const char*>(a.kv.page_ptrs[tile] + a.kv.layer_off);
+      const char* kb = base + (size_t)kvhd * KV_PAGE_TOKENS * 256;
+      const char* vb = base + (size_t)a.kvh * KV_PAGE_TOKENS * 256 + (size_t)kvhd * 128 * (KV_PAGE_TOKENS * 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = tid + i * 256;  // 1024 16-byte pieces per 16-KiB tile
+        *reinterpret_cast<u32x4_t*>(ks + (p >> 4) * K_ROW_BYTES + (p & 15) * 16) = ld16(kb + (size_t)p * 16);
+        *reinterpret_cast<u32x4_t*>(vs + (p >> 3) * V_ROW_BYTES + (p & 7) * 16) = ld16(vb + (size_t)p * 16);
+      }
+    }
+    __syncthreads();
+    const int t0 = tile * KV_PAGE_TOKENS;
+    if (t0 > wave_last_tok) continue;  // wave-uniform: this wave's 16 rows see nothing of the tile
+
+    f32x4_t st[4];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      st[sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const bf16x8_t kf = as_frag(*reinterpret_cast<const u32x4_t*>(ks + (sub * 16 + c) * K_ROW_BYTES + (k4 * 32 + G * 8) * 2));
+        st[sub] = mfma16(kf, qf[k4], st[sub]);
+      }
+    }
+    float alpha;
+    bf16x8_t pf[2];
+    const int lim = a.causal ? min(qpos, a.kv_total - 1) : a.kv_total - 1;
+    softmax_tile(st, a.scale, [&](int t) { return t0 + t <= lim; }, G, m, l, alpha, pf);
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) {
+      o[ds] *= alpha;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8_t vf = as_frag(*reinterpret_cast<const u32x4_t*>(vs + (ds * 16 + c) * V_ROW_BYTES + (kk * 32 + G * 8) * 2));
+        o[ds] = mfma16(vf, pf[kk], o[ds]);
+      }
+    }
+  }
+  l = group_sum(l);
+  if (q0 + c < a.S) {
+    const float inv = 1.0f / l;
+    bf16_t* op = (bf16_t*)a.o + ((int64_t)(q0 + c) * a.nh + head) * 128;
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) {
+      uint2 w;
+      w.x = pack_bf(o[ds][0] * inv, o[ds][1] * inv);
+      w.y = pack_bf(o[ds][2] * inv, o[ds][3] * inv);
+      *reinterpret_cast<uint2*>(op + ds * 16 + G * 4) = w;
+    }
+  }
+}
+
+// ---- decode: one wave = one work unit striding over KV pages; K / V^T fragments straight from HBM --------------
+// grid (kvh, nsplit), 4 waves per block => 4*nsplit units per kv head; unit u takes pages u, u + nunits, ...
+// All g = nh/kvh q heads of the kv head ride along as MFMA columns, so every KV byte is read exactly once.
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, c = lane & 15;
+  const int kvhd = blockIdx.x;
+  const int g = a.nh / a.kvh;
+  const int nunits = gridDim.y * 4;
+  const int unit = blockIdx.y * 4 + wave;
+  const int L = *a.kv_len;
+  const int npages = (L + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS;
+
+  bf16x8_t qf[4];
+  {
+    const bf16_t* qp = (const bf16_t*)a.q + (int64_t)(kvhd * g + min(c, g - 1)) * 128;
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      u32x4_t v = ld16(qp + k4 * 32 + G * 8);
+      if (c >= g) v = u32x4_t{0u, 0u, 0u, 0u};
+      qf[k4] = as_frag(v);
+    }
+  }
+  float m = -INFINITY, l = 0.f;
+  f32x4_t o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  for (int page = unit; page < npages; page += nunits) {
+    const char* base = reinterpret_cast<const char*>(a.kv.page_ptrs[page] + a.kv.layer_off);
+    const char* kb = base + (size_t)kvhd * KV_PAGE_TOKENS * 256;
+    const char* vb = base + (size_t)a.kvh * KV_PAGE_TOKENS * 256 + (size_t)kvhd * 128 * (KV_PAGE_TOKENS * 2);
+    u32x4_t kf[4][4], vf[8][2];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) kf[sub][k4] = ld_nt16(kb + (size_t)(sub * 16 + c) * 256 + (k4 * 32 + G * 8) * 2);
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) vf[ds][kk] = ld_nt16(vb + (size_t)(ds * 16 + c) * (KV_PAGE_TOKENS * 2) + (kk * 32 + G * 8) * 2);
+
+    f32x4_t st[4];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      st[sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) st[sub] = mfma16(as_frag(kf[sub][k4]), qf[k4], st[sub]);
+    }
+    float alpha;
+    bf16x8_t pf[2];
+    const int t0 = page * KV_PAGE_TOKENS;
+    softmax_tile(st, a.scale, [&](int t) { return t0 + t < L; }, G, m, l, alpha, pf);
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) {
+      o[ds] *= alpha;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) o[ds] = mfma16(as_frag(vf[ds][kk]), pf[kk], o[ds]);
+    }
+  }
+  l = group_sum(l);
+  if (c < g) {
+    const int head = kvhd * g + c;
+    float* po = a.part_o + ((int64_t)unit * a.nh + head) * 128;
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds)
+      *reinterpret_cast<float4*>(po + ds * 16 + G * 4) = make_float4(o[ds][0], o[ds][1], o[ds][2], o[ds][3]);
+    if (G == 0) {
+      a.part_ml[((int64_t)unit * a.nh + head) * 2 + 0] = m;
+      a.part_ml[((int64_t)unit * a.nh + head) * 2 + 1] = l;
+    }
+  }
+}
+
+// merge the per-unit partials: o = sum_u e^{m_u - M} o_u / sum_u e^{m_u - M} l_u  -> bf16 (the P.V matmul output tensor)
+__global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnDecodeArgs a, int nunits) {
+  const int head = blockIdx.x, d = threadIdx.x;
+  float M = -INFINITY;
+  for (int u = 0; u < nunits; ++u) M = fmaxf(M, a.part_ml[((int64_t)u * a.nh + head) * 2]);
+  float acc = 0.f, lsum = 0.f;
+  for (int u = 0; u < nunits; ++u) {
+    const float mu = a.part_ml[((int64_t)u * a.nh + head) * 2];
+    if (mu == -INFINITY) continue;
+    const float w = __expf(mu - M);
+    acc += w * a.part_o[((int64_t)u * a.nh + head) * 128 + d];
+    lsum += w * a.part_ml[((int64_t)u * a.nh + head) * 2 + 1];
+  }
+  ((bf16_t*)a.o)[head * 128 + d] = f2bf(acc / lsum);
+}
+
+}  // namespace
+
+void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st) {
+  if (a.S <= 0) return;
+  const size_t lds = KV_PAGE_TOKENS * K_ROW_BYTES + 128 * V_ROW_BYTES;
+  hipLaunchKernelGGL(attn_prefill_kernel, dim3((a.S + 63) / 64, a.nh), dim3(256), lds, st, a);
+}
+
+void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(attn_decode_kernel, dim3(a.kvh, a.nsplit), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(a.nh), dim3(128), 0, st, a, a.nsplit * 4);
+}
+
+}  // namespace aha

@@ -1,0 +1,233 @@
+// Row-wise / index kernels of the Qwen3 decoder stack: embedding gather (D0), RMSNorm rows (D3),
+// q/k-norm + rotary + KV append (D4/D5/D6, M1), argmax (D11).  All HBM-bound: 16-byte accesses, one wave per row.
+#include "common.h"
+#include "kernels.h"
+
+namespace aha {
+
+// ---- D0: embedding gather ------------------------------------------------------------------------------------
+// candle_nn::Embedding via Qwen3Model::embedding_token_id (/root/reference/src/models/qwen3/model.rs:191-193)
+__global__ __launch_bounds__(256) void embed_gather_kernel(const bf16_t* __restrict__ table, const uint32_t* __restrict__ ids,
+                                                           bf16_t* __restrict__ out, int S, int H) {
+  const int row = blockIdx.x;
+  const uint32_t id = ids[row];
+  const u32x4_t* src = reinterpret_cast<const u32x4_t*>(table + (size_t)id * H);
+  u32x4_t* dst = reinterpret_cast<u32x4_t*>(out + (size_t)row * H);
+  for (int i = threadIdx.x; i < H / 8; i += blockDim.x) dst[i] = src[i];
+}
+void launch_embed_gather(const void* table, const uint32_t* ids, void* out, int S, int H, hipStream_t st) {
+  if (S <= 0) return;
+  hipLaunchKernelGGL(embed_gather_kernel, dim3(S), dim3(256), 0, st, (const bf16_t*)table, ids, (bf16_t*)out, S, H);
+}
+
+// ---- D3: RMSNorm over rows ------------------------------------------------------------------------------------
+// candle_nn::RmsNorm (/root/reference/src/models/qwen3/model.rs:53-62,79,83,186): y = x / sqrt(mean(x^2)+eps) * w.
+// One wave per row; the row is read once (kept in registers for dim <= 8192), f32 sum, single bf16 rounding.
+template <int VPL>  // 16-byte vectors per lane (dim = VPL*512 max)
+__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                           bf16_t* __restrict__ y, int64_t rows, int dim, int64_t ldx,
+                                                           int64_t ldy, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + row * ldx;
+  bf16_t* yr = y + row * ldy;
+  const int nvec = dim / 8;
+  u32x4_t v[VPL];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int vi = i * 64 + lane;
+    if (vi < nvec) {
+      v[i] = ld16(xr + vi * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = lo_bf(v[i][j]), b = hi_bf(v[i][j]);
+        ss += a * a + b * b;
+      }
+    }
+  }
+  ss = wave_sum(ss);
+  const float rinv = 1.0f / sqrtf(ss / (float)dim + eps);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int vi = i * 64 + lane;
+    if (vi < nvec) {
+      const u32x4_t wv = ld16(w + vi * 8);
+      u32x4_t o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        o[j] = pack_bf(lo_bf(v[i][j]) * rinv * lo_bf(wv[j]), hi_bf(v[i][j]) * rinv * hi_bf(wv[j]));
+      *reinterpret_cast<u32x4_t*>(yr + vi * 8) = o;
+    }
+  }
+}
+void launch_rmsnorm_rows(const void* x, const void* w, void* y, int64_t rows, int dim, int64_t ldx, int64_t ldy,
+                         float eps, hipStream_t st) {
+  if (rows <= 0) return;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  const int vpl = (dim / 8 + 63) / 64;
+#define RMS_CASE(V)                                                                                              \
+  hipLaunchKernelGGL(rmsnorm_rows_kernel<V>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, \
+                     rows, dim, ldx, ldy, eps)
+  if (vpl <= 1) RMS_CASE(1);
+  else if (vpl <= 2) RMS_CASE(2);
+  else if (vpl <= 4) RMS_CASE(4);
+  else if (vpl <= 8) RMS_CASE(8);
+  else if (vpl <= 10) RMS_CASE(10);
+  else RMS_CASE(16);
+#undef RMS_CASE
+}
+
+// ---- D4/D5/D6/M1: per-head q/k RMSNorm + rotary embedding + KV append ----------------------------------------
+// QKNormAttention::forward (/root/reference/src/models/common/modules.rs:530-566): q_norm/k_norm over head_dim,
+// apply_rotary_pos_emb (/root/reference/src/position_embed/rope.rs:96-132) with the half-split rotate_half
+// (rope.rs:15-22), then the roped K and the raw V are appended to the cache (modules.rs:558-566).
+// cos/sin follow RoPE::forward (rope.rs:593-612) / Qwen3VLTextRotaryEmbedding::forward (rope.rs:541-580):
+// angle = f32(pos[axis(i)]) * inv_freq[i], cos/sin in f32, cast to bf16 before use; each of q*cos, rot(q)*sin and
+// their sum is a materialised bf16 tensor in the reference, so each is rounded here too.
+// One wave per (token, head): lane l owns elements l and l+64 of the 128-wide head == one rotate_half pair.
+__global__ __launch_bounds__(256) void qknorm_rope_kernel(RopeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nslot = a.nh + 2 * a.kvh;
+  if (wid >= (int64_t)a.S * nslot) return;
+  const int s = (int)(wid / nslot);
+  const int slot = (int)(wid % nslot);
+  const bf16_t* src = (const bf16_t*)a.qkv + (int64_t)s * a.ld + (int64_t)slot * 128;
+  float x0 = bf2f(src[lane]), x1 = bf2f(src[lane + 64]);
+  const bool is_q = slot < a.nh;
+  const bool is_k = !is_q && slot < a.nh + a.kvh;
+  if (is_q || is_k) {
+    const bf16_t* nw = (const bf16_t*)(is_q ? a.q_norm_w : a.k_norm_w);
+    const float ss = wave_sum(x0 * x0 + x1 * x1);
+    const float rinv = 1.0f / sqrtf(ss / 128.0f + a.eps);
+    x0 = rbf(x0 * rinv * bf2f(nw[lane]));
+    x1 = rbf(x1 * rinv * bf2f(nw[lane + 64]));
+    const int ax = a.axis_map[lane];
+    const float ang = (float)a.pos[(int64_t)ax * a.pos_ld + s] * a.inv_freq[lane];
+    const float c = rbf(cosf(ang)), sn = rbf(sinf(ang));
+    const float y0 = rbf(rbf(x0 * c) + rbf(-x1 * sn));
+    const float y1 = rbf(rbf(x1 * c) + rbf(x0 * sn));
+    x0 = y0;
+    x1 = y1;
+  }
+  const bf16_t b0 = f2bf(x0), b1 = f2bf(x1);
+  if (is_q) {
+    bf16_t* dst = (bf16_t*)a.q_out + (int64_t)s * a.nh * 128 + (int64_t)slot * 128;
+    dst[lane] = b0;
+    dst[lane + 64] = b1;
+    return;
+  }
+  const int h = is_k ? slot - a.nh : slot - a.nh - a.kvh;
+  if (a.kv.page_ptrs == nullptr) {
+    bf16_t* dst = (bf16_t*)(is_k ? a.k_out : a.v_out) + (int64_t)s * a.kvh * 128 + (int64_t)h * 128;
+    dst[lane] = b0;
+    dst[lane + 64] = b1;
+    return;
+  }
+  const int tok = *a.kv_start + s;
+  const int page = tok / KV_PAGE_TOKENS, t = tok % KV_PAGE_TOKENS;
+  char* base = reinterpret_cast<char*>(a.kv.page_ptrs[page] + a.kv.layer_off);
+  if (is_k) {
+    bf16_t* dst = reinterpret_cast<bf16_t*>(base) + ((int64_t)h * KV_PAGE_TOKENS + t) * 128;
+    dst[lane] = b0;
+    dst[lane + 64] = b1;
+  } else {
+    bf16_t* dst = reinterpret_cast<bf16_t*>(base) + (int64_t)a.kvh * KV_PAGE_TOKENS * 128 + (int64_t)h * 128 * KV_PAGE_TOKENS;
+    dst[(int64_t)lane * KV_PAGE_TOKENS + v_slot(t)] = b0;
+    dst[(int64_t)(lane + 64) * KV_PAGE_TOKENS + v_slot(t)] = b1;
+  }
+}
+void launch_qknorm_rope(const RopeArgs& a, hipStream_t st) {
+  const int64_t waves = (int64_t)a.S * (a.nh + 2 * a.kvh);
+  if (waves <= 0) return;
+  hipLaunchKernelGGL(qknorm_rope_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+}
+
+// contiguous token-major K,V (L, kvh*128) -> pages.  One wave per (token, kv head, K|V).
+__global__ __launch_bounds__(256) void kv_pack_pages_kernel(const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                            KvLayer kv, int L) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= (int64_t)L * kv.kvh * 2) return;
+  const int which = (int)(wid % 2);
+  const int h = (int)((wid / 2) % kv.kvh);
+  const int tok = (int)(wid / 2 / kv.kvh);
+  const bf16_t* src = (which ? v : k) + ((int64_t)tok * kv.kvh + h) * 128;
+  const int page = tok / KV_PAGE_TOKENS, t = tok % KV_PAGE_TOKENS;
+  bf16_t* base = reinterpret_cast<bf16_t*>(kv.page_ptrs[page] + kv.layer_off);
+  if (!which) {
+    bf16_t* dst = base + ((int64_t)h * KV_PAGE_TOKENS + t) * 128;
+    dst[lane] = src[lane];
+    dst[lane + 64] = src[lane + 64];
+  } else {
+    bf16_t* dst = base + (int64_t)kv.kvh * KV_PAGE_TOKENS * 128 + (int64_t)h * 128 * KV_PAGE_TOKENS;
+    dst[(int64_t)lane * KV_PAGE_TOKENS + v_slot(t)] = src[lane];
+    dst[(int64_t)(lane + 64) * KV_PAGE_TOKENS + v_slot(t)] = src[lane + 64];
+  }
+}
+void launch_kv_pack_pages(const void* k, const void* v, KvLayer kv, int L, hipStream_t st) {
+  const int64_t waves = (int64_t)L * kv.kvh * 2;
+  if (waves <= 0) return;
+  hipLaunchKernelGGL(kv_pack_pages_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, (const bf16_t*)k,
+                     (const bf16_t*)v, kv, L);
+}
+
+// ---- D11: greedy argmax (first maximal index, as candle's argmax / Sampling::ArgMax) ---------------------------
+__device__ __forceinline__ void argmax_combine(float& bv, uint32_t& bi, float v, uint32_t i) {
+  if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+}
+__device__ __forceinline__ void wave_argmax(float& bv, uint32_t& bi) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const uint32_t oi = __shfl_xor(bi, o, 64);
+    argmax_combine(bv, bi, ov, oi);
+  }
+}
+__global__ __launch_bounds__(256) void argmax_partials_kernel(const float* __restrict__ pv, const uint32_t* __restrict__ pi,
+                                                              int n, uint32_t* __restrict__ out) {
+  __shared__ float sv[4];
+  __shared__ uint32_t si[4];
+  float bv = -INFINITY;
+  uint32_t bi = 0xffffffffu;
+  for (int i = threadIdx.x; i < n; i += 256) argmax_combine(bv, bi, pv[i], pi[i]);
+  wave_argmax(bv, bi);
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) argmax_combine(bv, bi, sv[w], si[w]);
+    *out = bi;
+  }
+}
+void launch_argmax_partials(const float* blk_max, const uint32_t* blk_idx, int n, uint32_t* out, hipStream_t st) {
+  hipLaunchKernelGGL(argmax_partials_kernel, dim3(1), dim3(256), 0, st, blk_max, blk_idx, n, out);
+}
+__global__ __launch_bounds__(256) void argmax_f32_stage1(const float* __restrict__ x, int64_t n, float* __restrict__ pv,
+                                                         uint32_t* __restrict__ pi) {
+  __shared__ float sv[4];
+  __shared__ uint32_t si[4];
+  float bv = -INFINITY;
+  uint32_t bi = 0xffffffffu;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = x[i];
+    // NaN never wins (v > bv is false), matching a partial_cmp-style scan that keeps the first non-NaN max
+    argmax_combine(bv, bi, v, (uint32_t)i);
+  }
+  wave_argmax(bv, bi);
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) argmax_combine(bv, bi, sv[w], si[w]);
+    pv[blockIdx.x] = bv;
+    pi[blockIdx.x] = bi;
+  }
+}
+void launch_argmax_f32(const float* x, int64_t n, float* ws_max, uint32_t* ws_idx, uint32_t* out, hipStream_t st) {
+  const int blocks = (int)((n + 4095) / 4096 < 256 ? (n + 4095) / 4096 : 256);
+  hipLaunchKernelGGL(argmax_f32_stage1, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, x, n, ws_max, ws_idx);
+  launch_argmax_partials(ws_max, ws_idx, blocks > 0 ? blocks : 1, out, st);
+}
+
+}  // namespace aha

@@ -1,0 +1,245 @@
+// Batch-1 weight-streaming matvec: the kernel that bounds decode throughput.
+//
+//   y[n] = sum_k h[k] * W[n,k]     W (N,K) bf16 row-major (HF / candle_nn::Linear layout), h (K) bf16, f32 accumulate
+//
+// HBM-bound: every weight byte is read exactly once per token, so the design goal is nothing but keeping enough
+// 16-byte non-temporal loads in flight per CU.  No LDS staging of W (read once, not shared between waves); the
+// activation vector lives in LDS as f32 in a lane-linear image so each ds_read_b128 is conflict-free.
+//   * one wave owns R consecutive rows; per 512-column chunk it issues R x U independent 1-KiB loads
+//   * persistent grid-stride over row tiles; the (optional) fused RMSNorm prologue runs once per block
+//   * epilogues fuse the reference's next op: residual add (qwen3/model.rs:81,86), silu(gate)*up
+//     (modules.rs:81-87), f32 logits + argmax partials (generate.rs:75-84)
+// Rounding points follow the reference's op boundaries: Linear output -> bf16, then each further op -> bf16.
+#include "common.h"
+#include "kernels.h"
+
+namespace aha {
+
+namespace {
+
+constexpr int GEMV_THREADS = 256;
+constexpr int GEMV_WAVES = 4;
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+// LDS image of h: chunk c (512 elements) is stored as [half(2)][lane(64)][4] f32 so that a wave reading
+// "its" 8 elements of the chunk does two fully contiguous 1-KiB ds_read_b128.
+__device__ __forceinline__ int xs_index(int k) {
+  const int c = k >> 9, r = k & 511, lane = r >> 3, e = r & 7;
+  return (c << 9) + ((e >> 2) << 8) + (lane << 2) + (e & 3);
+}
+
+template <int R, int U, int EPI>
+__global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // K f32 + 8 floats reduction scratch
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.K, N = a.N;
+  const int nchunks = (K + 511) >> 9;  // K % 8 == 0; the tail of the last chunk is zero-filled
+  float* red = xs + (nchunks << 9);
+
+  // ---- prologue: h = x, or h = bf16(RMSNorm(x) * norm_w) (qwen3/model.rs:79,83,186) ------------------------
+  {
+    const bf16_t* x = (const bf16_t*)a.x;
+    const bf16_t* nw = (const bf16_t*)a.norm_w;
+    float ss = 0.f;
+    for (int v = tid; v < (nchunks << 6); v += GEMV_THREADS) {
+      u32x4_t xv = {0u, 0u, 0u, 0u};
+      if (v * 8 < K) xv = ld16(x + v * 8);
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { f[2 * j] = lo_bf(xv[j]); f[2 * j + 1] = hi_bf(xv[j]); }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+      const int base = xs_index(v * 8);
+      *reinterpret_cast<float4*>(xs + base) = make_float4(f[0], f[1], f[2], f[3]);
+      *reinterpret_cast<float4*>(xs + base + 256) = make_float4(f[4], f[5], f[6], f[7]);
+    }
+    if (nw != nullptr) {
+      ss = wave_sum(ss);
+      if (lane == 0) red[wave] = ss;
+      __syncthreads();
+      const float tot = red[0] + red[1] + red[2] + red[3];
+      const float rinv = 1.0f / sqrtf(tot / (float)K + a.eps);
+      for (int v = tid; v < (K >> 3); v += GEMV_THREADS) {
+        const u32x4_t wv = ld16(nw + v * 8);
+        const int base = xs_index(v * 8);
+        float4 lo = *reinterpret_cast<float4*>(xs + base), hi = *reinterpret_cast<float4*>(xs + base + 256);
+        lo.x = rbf(lo.x * rinv * lo_bf(wv[0])); lo.y = rbf(lo.y * rinv * hi_bf(wv[0]));
+        lo.z = rbf(lo.z * rinv * lo_bf(wv[1])); lo.w = rbf(lo.w * rinv * hi_bf(wv[1]));
+        hi.x = rbf(hi.x * rinv * lo_bf(wv[2])); hi.y = rbf(hi.y * rinv * hi_bf(wv[2]));
+        hi.z = rbf(hi.z * rinv * lo_bf(wv[3])); hi.w = rbf(hi.w * rinv * hi_bf(wv[3]));
+        *reinterpret_cast<float4*>(xs + base) = lo;
+        *reinterpret_cast<float4*>(xs + base + 256) = hi;
+        if (a.h_out != nullptr && blockIdx.x == 0) {
+          u32x4_t o;
+          o[0] = pack_bf(lo.x, lo.y); o[1] = pack_bf(lo.z, lo.w); o[2] = pack_bf(hi.x, hi.y); o[3] = pack_bf(hi.z, hi.w);
+          *reinterpret_cast<u32x4_t*>((bf16_t*)a.h_out + v * 8) = o;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- main: grid-stride over tiles of GEMV_WAVES*R rows -----------------------------------------------------
+  constexpr int ROWS_PER_TILE = GEMV_WAVES * R;
+  // for SILU_MUL a "row" index runs over the I outputs; the wave streams gate row j and up row j together
+  const int n_out = N;
+  const int ntiles = (n_out + ROWS_PER_TILE - 1) / ROWS_PER_TILE;
+  constexpr int NW = (EPI == GEMV_SILU_MUL) ? 2 : 1;
+  float tile_best = -INFINITY;
+  uint32_t tile_best_i = 0xffffffffu;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row0 = tile * ROWS_PER_TILE + wave * R;
+    const bf16_t* wp[NW][R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = min(row0 + r, n_out - 1);  // clamp: out-of-range rows are computed but never stored
+      if (NW == 2) {
+        if (a.W2 != nullptr) {  // separate gate / up matrices (op-level entry point)
+          wp[0][r] = (const bf16_t*)a.W + (size_t)row * K + lane * 8;
+          wp[NW - 1][r] = (const bf16_t*)a.W2 + (size_t)row * K + lane * 8;
+        } else {  // the model's fused matrix: 16-row blocks alternating gate / up
+          const size_t fr = (size_t)(row >> 4) * 32 + (row & 15);
+          wp[0][r] = (const bf16_t*)a.W + fr * K + lane * 8;
+          wp[NW - 1][r] = (const bf16_t*)a.W + (fr + 16) * K + lane * 8;
+        }
+      } else {
+        wp[0][r] = (const bf16_t*)a.W + (size_t)row * K + lane * 8;
+      }
+    }
+    float acc[NW][R];
+#pragma unroll
+    for (int m = 0; m < NW; ++m)
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
+
+    for (int c0 = 0; c0 < nchunks; c0 += U) {
+      u32x4_t wv[U][NW][R];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int m = 0; m < NW; ++m)
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            if (c0 + u < nchunks) {
+              wv[u][m][r] = u32x4_t{0u, 0u, 0u, 0u};
+              if (((c0 + u) << 9) + lane * 8 < K) wv[u][m][r] = ld_nt16(wp[m][r] + ((size_t)(c0 + u) << 9));
+            }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (c0 + u < nchunks) {
+          const float4 xlo = *reinterpret_cast<const float4*>(xs + ((c0 + u) << 9) + (lane << 2));
+          const float4 xhi = *reinterpret_cast<const float4*>(xs + ((c0 + u) << 9) + 256 + (lane << 2));
+#pragma unroll
+          for (int m = 0; m < NW; ++m)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              const u32x4_t w = wv[u][m][r];
+              float s = acc[m][r];
+              s = fmaf(lo_bf(w[0]), xlo.x, s); s = fmaf(hi_bf(w[0]), xlo.y, s);
+              s = fmaf(lo_bf(w[1]), xlo.z, s); s = fmaf(hi_bf(w[1]), xlo.w, s);
+              s = fmaf(lo_bf(w[2]), xhi.x, s); s = fmaf(hi_bf(w[2]), xhi.y, s);
+              s = fmaf(lo_bf(w[3]), xhi.z, s); s = fmaf(hi_bf(w[3]), xhi.w, s);
+              acc[m][r] = s;
+            }
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < NW; ++m)
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[m][r] = wave_sum(acc[m][r]);
+
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int row = row0 + r;
+        if (row < n_out) {
+          const float lin = rbf(acc[0][r]);  // candle_nn::Linear output tensor (bf16)
+          if (EPI == GEMV_STORE) {
+            ((bf16_t*)a.y)[row] = f2bf(lin);
+          } else if (EPI == GEMV_RESIDUAL) {
+            ((bf16_t*)a.y)[row] = f2bf(bf2f(((const bf16_t*)a.residual)[row]) + lin);
+          } else if (EPI == GEMV_SILU_MUL) {
+            const float g = rbf(silu_f(lin));            // gate_proj -> act_fn   (modules.rs:82)
+            const float up = rbf(acc[NW - 1][r]);        // up_proj               (modules.rs:83)
+            ((bf16_t*)a.y)[row] = f2bf(g * up);          // lhs * rhs             (modules.rs:84)
+          } else {  // GEMV_LOGITS: logits tensor is bf16 in the reference, read back as f32 (generate.rs:75)
+            a.y_f32[row] = lin;
+            if (lin > tile_best || (lin == tile_best && (uint32_t)row < tile_best_i)) { tile_best = lin; tile_best_i = row; }
+          }
+        }
+      }
+    }
+  }
+  if (EPI == GEMV_LOGITS) {
+    // per-block argmax partial: 4 wave leaders -> slot blockIdx.x
+    __syncthreads();
+    if (lane == 0) { red[wave] = tile_best; reinterpret_cast<uint32_t*>(red)[4 + wave] = tile_best_i; }
+    __syncthreads();
+    if (tid == 0) {
+      float bv = red[0];
+      uint32_t bi = reinterpret_cast<uint32_t*>(red)[4];
+      for (int w = 1; w < 4; ++w) {
+        const float v = red[w];
+        const uint32_t i = reinterpret_cast<uint32_t*>(red)[4 + w];
+        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+      }
+      a.blk_max[blockIdx.x] = bv;
+      a.blk_idx[blockIdx.x] = bi;
+    }
+  }
+}
+
+struct GemvPlan { int R, U, grid; };
+
+// Pick rows-per-wave so that there are at least ~2 tiles per CU (256 CUs), and keep R*U*NW <= 16 loads in flight.
+GemvPlan plan_gemv(int N, int K, GemvEpi epi) {
+  const int nchunks = (K + 511) / 512;
+  const int nw = epi == GEMV_SILU_MUL ? 2 : 1;
+  int R = 4;
+  while (R > 1 && (N + 4 * R - 1) / (4 * R) < 1024) R >>= 1;
+  if (nw == 2 && R > 2) R = 2;
+  int U = 16 / (R * nw);
+  if (U > nchunks) U = nchunks;
+  if (U > 8) U = 8;
+  if (U < 1) U = 1;
+  // U must be one of the instantiated values {1,2,4,8}
+  int Up = 1;
+  while (Up * 2 <= U) Up *= 2;
+  const int ntiles = (N + 4 * R - 1) / (4 * R);
+  int grid = ntiles < 2048 ? ntiles : 2048;
+  return {R, Up, grid};
+}
+
+}  // namespace
+
+int gemv_num_tiles(int N, int K) { return plan_gemv(N, K, GEMV_LOGITS).grid; }
+
+template <int EPI>
+static void launch_gemv_epi(const GemvArgs& a, const GemvPlan& p, hipStream_t st) {
+  const size_t lds = (size_t)((a.K + 511) / 512) * 512 * 4 + 64;
+  dim3 grid(p.grid), block(GEMV_THREADS);
+#define GV(RR, UU) hipLaunchKernelGGL((gemv_kernel<RR, UU, EPI>), grid, block, lds, st, a)
+  if (p.R == 4) {
+    if (p.U >= 4) GV(4, 4); else if (p.U == 2) GV(4, 2); else GV(4, 1);
+  } else if (p.R == 2) {
+    if (p.U >= 8) GV(2, 8); else if (p.U == 4) GV(2, 4); else if (p.U == 2) GV(2, 2); else GV(2, 1);
+  } else {
+    if (p.U >= 8) GV(1, 8); else if (p.U == 4) GV(1, 4); else if (p.U == 2) GV(1, 2); else GV(1, 1);
+  }
+#undef GV
+}
+
+void launch_gemv(const GemvArgs& a, GemvEpi epi, hipStream_t st) {
+  const GemvPlan p = plan_gemv(a.N, a.K, epi);
+  switch (epi) {
+    case GEMV_STORE: launch_gemv_epi<GEMV_STORE>(a, p, st); break;
+    case GEMV_RESIDUAL: launch_gemv_epi<GEMV_RESIDUAL>(a, p, st); break;
+    case GEMV_SILU_MUL: launch_gemv_epi<GEMV_SILU_MUL>(a, p, st); break;
+    case GEMV_LOGITS: launch_gemv_epi<GEMV_LOGITS>(a, p, st); break;
+  }
+}
+
+}  // namespace aha

@@ -1,0 +1,144 @@
+// Host-side model object behind the C ABI (include/aha_hip.h).  Mirrors the reference's Qwen3Model
+// (/root/reference/src/models/qwen3/model.rs:94-214) and its InferenceModel impl, re-designed for one MI355X:
+// fused weight layouts, a paged KV cache that grows without reallocating, device-resident step state.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/aha_hip.h"
+#include "kernels.h"
+
+struct aha_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+};
+
+namespace aha {
+
+void set_error(const std::string& msg);
+#define AHA_HIP_CHECK(expr)                                                                          \
+  do {                                                                                               \
+    hipError_t _e = (expr);                                                                          \
+    if (_e != hipSuccess) {                                                                          \
+      ::aha::set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e));                    \
+      return AHA_ERR_HIP;                                                                            \
+    }                                                                                                \
+  } while (0)
+
+struct LayerWeights {
+  void* wqkv = nullptr;     // ((nh+2kvh)*d, H): q rows, then k rows, then v rows
+  void* wo = nullptr;       // (H, nh*d)
+  void* wgu = nullptr;      // (2I, H): 16-row blocks alternating gate / up (see kernels_gemm.hip ACT_SILU_MUL_PAIRS)
+  void* wdown = nullptr;    // (H, I)
+  void* in_norm = nullptr;  // (H)
+  void* post_norm = nullptr;
+  void* q_norm = nullptr;   // (d)
+  void* k_norm = nullptr;
+};
+
+// device-resident scalars every decode kernel reads (so a step can be enqueued / replayed without host values)
+struct StepState {
+  uint32_t token;
+  int32_t pos[3];     // rope position rows T,H,W of the current token
+  int32_t kv_start;   // cache slot the current token is written to
+  int32_t kv_len;     // valid cache tokens after the append
+  uint32_t next_token;  // argmax of the last logits
+  int32_t step;       // index into the device token log
+};
+
+struct ProfRec { int cls; hipEvent_t e0, e1; double bytes, flops; };
+
+struct VisionModel;  // vision.h
+
+}  // namespace aha
+
+struct aha_model {
+  aha_ctx* ctx = nullptr;
+  aha_model_desc desc{};
+  hipStream_t stream = nullptr;
+  // weights
+  void* embed = nullptr;
+  void* lm_head = nullptr;  // == embed when tied
+  void* final_norm = nullptr;
+  std::vector<aha::LayerWeights> layers;
+  std::vector<void*> owned;  // every hipMalloc'd block (weights, scratch), freed on destroy
+  // rope constants
+  float* d_inv_freq = nullptr;
+  int32_t* d_axis_map = nullptr;
+  float attn_scale = 0.f;
+  // paged KV cache
+  std::vector<void*> slabs;
+  std::vector<uint64_t> h_page_ptrs;  // logical page -> byte address of its layer-0 storage
+  uint64_t* d_page_ptrs = nullptr;
+  size_t page_table_cap = 0;
+  size_t pages_per_slab = 0;
+  uint64_t page_bytes = 0;      // bytes of one page of one layer (K block + V block)
+  uint64_t layer_stride = 0;    // bytes between layers inside a slab
+  size_t n_pages = 0;           // pages currently mapped
+  size_t cache_len = 0;         // tokens in the cache (== reference kv_cache.dim(2))
+  bool scramble_pages = false;
+  std::vector<uint64_t> free_pages;
+  // step state
+  aha::StepState* d_state = nullptr;
+  aha::StepState* h_state = nullptr;  // pinned
+  uint32_t* d_token_log = nullptr;
+  size_t token_log_cap = 0;
+  bool rope_delta_valid = false;  // Qwen3VLModel::rope_deltas.is_some() (qwen3vl/model.rs:1229-1236)
+  int64_t rope_delta = 0;  // Qwen3-VL: decode position = seqlen_offset + rope_delta (qwen3vl/model.rs:1235-1264)
+  // decode scratch
+  void *d_x = nullptr, *d_qkv = nullptr, *d_q = nullptr, *d_attn = nullptr, *d_act = nullptr, *d_hlast = nullptr;
+  float* d_logits = nullptr;
+  float* d_blk_max = nullptr;
+  uint32_t* d_blk_idx = nullptr;
+  float* d_part_o = nullptr;
+  float* d_part_ml = nullptr;
+  int max_nsplit = 64;
+  float* h_logits = nullptr;  // pinned
+  // prefill scratch (grown on demand)
+  size_t pf_cap = 0;
+  uint32_t* p_ids = nullptr;
+  int32_t* p_pos = nullptr;
+  void *p_x = nullptr, *p_h = nullptr, *p_qkv = nullptr, *p_q = nullptr, *p_attn = nullptr, *p_act = nullptr;
+  std::vector<void*> pf_owned;
+  // vision tower (Qwen3-VL)
+  aha::VisionModel* vision = nullptr;
+  // profiling
+  bool profiling = false;
+  std::vector<aha::ProfRec> prof;
+  std::map<std::string, int> prof_cls;
+  std::vector<std::string> prof_names;
+  struct ProfAcc { double ms = 0, bytes = 0, flops = 0; int64_t n = 0; };
+  std::vector<ProfAcc> prof_acc;
+};
+
+namespace aha {
+
+// model.hip
+int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view* w, size_t nw, aha_model** out);
+void model_destroy(aha_model* m);
+int model_forward_initial(aha_model* m, const uint32_t* ids, size_t n, size_t offset, const aha_mm_input* mm,
+                          float* logits_out, uint32_t* argmax_out);
+int model_forward_step(aha_model* m, uint32_t token, size_t offset, float* logits_out, uint32_t* argmax_out);
+int model_decode_greedy(aha_model* m, uint32_t first_token, size_t offset, size_t max_new, uint32_t* out);
+int model_clear_cache(aha_model* m);
+int model_ensure_pages(aha_model* m, size_t tokens);
+KvLayer model_kv_layer(aha_model* m, int layer);
+int prof_collect(aha_model* m);
+
+// helpers shared with vision.hip
+const aha_tensor_view* find_tensor(const aha_tensor_view* w, size_t nw, const std::string& name);
+int upload_tensor(aha_model* m, const aha_tensor_view* t, const std::vector<int64_t>& shape, void** out,
+                  int64_t pad_rows_to = 0, int64_t pad_cols_to = 0);
+int dev_alloc(aha_model* m, size_t bytes, void** out, bool zero = false);
+
+struct ProfScope {
+  aha_model* m;
+  int idx = -1;
+  ProfScope(aha_model* m, const char* cls, double bytes, double flops);
+  ~ProfScope();
+};
+
+}  // namespace aha

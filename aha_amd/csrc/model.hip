@@ -1,0 +1,815 @@
+// Host orchestration of the Qwen3 decoder stack on one MI355X.
+//   create      <- Qwen3Model::new                      /root/reference/src/models/qwen3/model.rs:104-134
+//   prefill     <- Qwen3Model::forward_hidden (S > 1)   /root/reference/src/models/qwen3/model.rs:146-189
+//   decode step <- the same with S == 1, mask = None    (generate.rs:135-143 drives it once per token)
+// The KV cache is paged (64-token pages, K token-major / V dim-major, see kernels.h) and must be indistinguishable from
+// the reference's Tensor::cat growth (modules.rs:558-566).
+#include "model.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "common.h"
+#include "vision.h"
+
+namespace aha {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+const char* last_error_cstr() { return g_last_error.c_str(); }
+
+// ---------------------------------------------------------------------------------------------------------------
+ProfScope::ProfScope(aha_model* m_, const char* cls, double bytes, double flops) : m(m_) {
+  if (!m->profiling) return;
+  auto it = m->prof_cls.find(cls);
+  int c;
+  if (it == m->prof_cls.end()) {
+    c = (int)m->prof_names.size();
+    m->prof_cls[cls] = c;
+    m->prof_names.push_back(cls);
+    m->prof_acc.emplace_back();
+  } else {
+    c = it->second;
+  }
+  ProfRec r;
+  r.cls = c;
+  r.bytes = bytes;
+  r.flops = flops;
+  hipEventCreate(&r.e0);
+  hipEventCreate(&r.e1);
+  hipEventRecord(r.e0, m->stream);
+  idx = (int)m->prof.size();
+  m->prof.push_back(r);
+}
+ProfScope::~ProfScope() {
+  if (idx >= 0) hipEventRecord(m->prof[idx].e1, m->stream);
+}
+int prof_collect(aha_model* m) {
+  if (m->prof.empty()) return AHA_OK;
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  for (auto& r : m->prof) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, r.e0, r.e1);
+    auto& a = m->prof_acc[r.cls];
+    a.ms += ms;
+    a.bytes += r.bytes;
+    a.flops += r.flops;
+    a.n += 1;
+    hipEventDestroy(r.e0);
+    hipEventDestroy(r.e1);
+  }
+  m->prof.clear();
+  return AHA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+int dev_alloc(aha_model* m, size_t bytes, void** out, bool zero) {
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+  if (e != hipSuccess) {
+    set_error("hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? AHA_ERR_OOM : AHA_ERR_HIP;
+  }
+  if (zero) AHA_HIP_CHECK(hipMemsetAsync(p, 0, bytes, m->stream));
+  m->owned.push_back(p);
+  *out = p;
+  return AHA_OK;
+}
+
+const aha_tensor_view* find_tensor(const aha_tensor_view* w, size_t nw, const std::string& name) {
+  for (size_t i = 0; i < nw; ++i)
+    if (w[i].name && name == w[i].name) return &w[i];
+  return nullptr;
+}
+
+static inline uint16_t f32_to_bf16_host(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float f16_to_f32_host(uint16_t h) {
+  const uint32_t s = (h >> 15) & 1u, e = (h >> 10) & 0x1fu, f = h & 0x3ffu;
+  uint32_t u;
+  if (e == 0) {
+    if (f == 0) u = s << 31;
+    else {
+      int sh = 0;
+      uint32_t ff = f;
+      while (!(ff & 0x400u)) { ff <<= 1; ++sh; }
+      u = (s << 31) | ((uint32_t)(127 - 15 - sh + 1) << 23) | ((ff & 0x3ffu) << 13);
+    }
+  } else if (e == 31) u = (s << 31) | 0x7f800000u | (f << 13);
+  else u = (s << 31) | ((e + 112u) << 23) | (f << 13);
+  float r;
+  memcpy(&r, &u, 4);
+  return r;
+}
+
+// host tensor (bf16 / f16 / f32) -> device bf16, viewed as (rows, cols) row-major, optionally zero-padded
+int upload_tensor(aha_model* m, const aha_tensor_view* t, const std::vector<int64_t>& shape, void** out,
+                  int64_t pad_rows_to, int64_t pad_cols_to) {
+  int64_t n = 1;
+  for (auto s : shape) n *= s;
+  int64_t tn = 1;
+  for (int i = 0; i < t->ndim; ++i) tn *= t->shape[i];
+  if (tn != n) {
+    std::string got;
+    for (int i = 0; i < t->ndim; ++i) got += (i ? "," : "") + std::to_string(t->shape[i]);
+    std::string want;
+    for (size_t i = 0; i < shape.size(); ++i) want += (i ? "," : "") + std::to_string(shape[i]);
+    set_error(std::string("tensor ") + t->name + " has shape (" + got + "), expected (" + want + ")");
+    return AHA_ERR_SHAPE;
+  }
+  const int64_t cols = shape.back();
+  const int64_t rows = n / cols;
+  const int64_t prow = std::max(rows, pad_rows_to), pcol = std::max(cols, pad_cols_to);
+  std::vector<uint16_t> tmp;
+  const void* src = t->data;
+  if (t->dtype == AHA_F32) {
+    tmp.resize(n);
+    const float* f = (const float*)t->data;
+    for (int64_t i = 0; i < n; ++i) tmp[i] = f32_to_bf16_host(f[i]);
+    src = tmp.data();
+  } else if (t->dtype == AHA_F16) {
+    tmp.resize(n);
+    const uint16_t* h = (const uint16_t*)t->data;
+    for (int64_t i = 0; i < n; ++i) tmp[i] = f32_to_bf16_host(f16_to_f32_host(h[i]));
+    src = tmp.data();
+  } else if (t->dtype != AHA_BF16) {
+    set_error(std::string("tensor ") + t->name + ": unsupported dtype");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  void* d = nullptr;
+  const bool padded = prow != rows || pcol != cols;
+  int rc = dev_alloc(m, (size_t)prow * pcol * 2, &d, padded);
+  if (rc) return rc;
+  if (!padded) AHA_HIP_CHECK(hipMemcpy(d, src, (size_t)n * 2, hipMemcpyHostToDevice));
+  else {
+    AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    AHA_HIP_CHECK(hipMemcpy2D(d, (size_t)pcol * 2, src, (size_t)cols * 2, (size_t)cols * 2, (size_t)rows, hipMemcpyHostToDevice));
+  }
+  *out = d;
+  return AHA_OK;
+}
+
+static int need(const aha_tensor_view* w, size_t nw, const std::string& name, const aha_tensor_view** out) {
+  *out = find_tensor(w, nw, name);
+  if (!*out) {
+    set_error("missing weight tensor: " + name);
+    return AHA_ERR_MISSING_WEIGHT;
+  }
+  return AHA_OK;
+}
+
+// copy `rows` rows of a host bf16-convertible tensor into dst rows [row0, row0+rows) of a device (.., cols) bf16 matrix
+static int upload_rows_into(aha_model* m, const aha_tensor_view* t, int64_t rows, int64_t cols, void* dst, int64_t row0) {
+  int64_t tn = 1;
+  for (int i = 0; i < t->ndim; ++i) tn *= t->shape[i];
+  if (tn != rows * cols) {
+    set_error(std::string("tensor ") + t->name + " has " + std::to_string(tn) + " elements, expected " + std::to_string(rows * cols));
+    return AHA_ERR_SHAPE;
+  }
+  std::vector<uint16_t> tmp;
+  const void* src = t->data;
+  if (t->dtype == AHA_F32) {
+    tmp.resize(tn);
+    for (int64_t i = 0; i < tn; ++i) tmp[i] = f32_to_bf16_host(((const float*)t->data)[i]);
+    src = tmp.data();
+  } else if (t->dtype == AHA_F16) {
+    tmp.resize(tn);
+    for (int64_t i = 0; i < tn; ++i) tmp[i] = f32_to_bf16_host(f16_to_f32_host(((const uint16_t*)t->data)[i]));
+    src = tmp.data();
+  } else if (t->dtype != AHA_BF16) {
+    set_error(std::string("tensor ") + t->name + ": unsupported dtype");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  AHA_HIP_CHECK(hipMemcpy((char*)dst + (size_t)row0 * cols * 2, src, (size_t)tn * 2, hipMemcpyHostToDevice));
+  return AHA_OK;
+}
+
+// gate/up -> one (2I, H) matrix of alternating 16-row blocks: [gate 0..15 | up 0..15 | gate 16..31 | up 16..31 | ...]
+static int upload_gate_up(aha_model* m, const aha_tensor_view* g, const aha_tensor_view* u, int64_t I, int64_t H, void** out) {
+  if (I % 16) {
+    set_error("intermediate_size must be a multiple of 16");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  void* d = nullptr;
+  int rc = dev_alloc(m, (size_t)2 * I * H * 2, &d);
+  if (rc) return rc;
+  for (int which = 0; which < 2; ++which) {
+    const aha_tensor_view* t = which ? u : g;
+    int64_t tn = 1;
+    for (int i = 0; i < t->ndim; ++i) tn *= t->shape[i];
+    if (tn != I * H) {
+      set_error(std::string("tensor ") + t->name + " has wrong size");
+      return AHA_ERR_SHAPE;
+    }
+    std::vector<uint16_t> tmp;
+    const void* src = t->data;
+    if (t->dtype == AHA_F32) {
+      tmp.resize(tn);
+      for (int64_t i = 0; i < tn; ++i) tmp[i] = f32_to_bf16_host(((const float*)t->data)[i]);
+      src = tmp.data();
+    } else if (t->dtype == AHA_F16) {
+      tmp.resize(tn);
+      for (int64_t i = 0; i < tn; ++i) tmp[i] = f32_to_bf16_host(f16_to_f32_host(((const uint16_t*)t->data)[i]));
+      src = tmp.data();
+    } else if (t->dtype != AHA_BF16) {
+      set_error("unsupported dtype");
+      return AHA_ERR_UNSUPPORTED;
+    }
+    const size_t blk = (size_t)16 * H * 2;
+    AHA_HIP_CHECK(hipMemcpy2D((char*)d + which * blk, 2 * blk, src, blk, blk, (size_t)(I / 16), hipMemcpyHostToDevice));
+  }
+  *out = d;
+  return AHA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// paged KV cache
+static int alloc_slab(aha_model* m) {
+  void* p = nullptr;
+  const size_t bytes = (size_t)m->layer_stride * m->desc.num_hidden_layers;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    set_error("KV slab hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? AHA_ERR_OOM : AHA_ERR_HIP;
+  }
+  // pages must never hold NaN bit patterns: masked P (= 0) still multiplies the V slots of the page tail
+  AHA_HIP_CHECK(hipMemsetAsync(p, 0, bytes, m->stream));
+  m->slabs.push_back(p);
+  std::vector<uint64_t> pages(m->pages_per_slab);
+  for (size_t i = 0; i < m->pages_per_slab; ++i) pages[i] = (uint64_t)(uintptr_t)p + i * m->page_bytes;
+  if (m->scramble_pages) {
+    uint64_t s = 0x9e3779b97f4a7c15ull * (m->slabs.size() + 1);
+    for (size_t i = pages.size(); i > 1; --i) {
+      s = s * 6364136223846793005ull + 1442695040888963407ull;
+      std::swap(pages[i - 1], pages[(s >> 33) % i]);
+    }
+  }
+  // free list is popped from the back
+  for (size_t i = pages.size(); i > 0; --i) m->free_pages.push_back(pages[i - 1]);
+  return AHA_OK;
+}
+
+int model_ensure_pages(aha_model* m, size_t tokens) {
+  const size_t needp = (tokens + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS;
+  if (needp <= m->n_pages) return AHA_OK;
+  if (needp > m->page_table_cap) {
+    size_t cap = std::max<size_t>(1024, m->page_table_cap);
+    while (cap < needp) cap *= 2;
+    uint64_t* nd = nullptr;
+    AHA_HIP_CHECK(hipMalloc((void**)&nd, cap * sizeof(uint64_t)));
+    AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (m->d_page_ptrs) AHA_HIP_CHECK(hipFree(m->d_page_ptrs));
+    m->d_page_ptrs = nd;
+    m->page_table_cap = cap;
+    if (m->n_pages)
+      AHA_HIP_CHECK(hipMemcpy(m->d_page_ptrs, m->h_page_ptrs.data(), m->n_pages * sizeof(uint64_t), hipMemcpyHostToDevice));
+  }
+  const size_t first_new = m->n_pages;
+  while (m->n_pages < needp) {
+    if (m->free_pages.empty()) {
+      int rc = alloc_slab(m);
+      if (rc) return rc;
+    }
+    const uint64_t p = m->free_pages.back();
+    m->free_pages.pop_back();
+    if (m->h_page_ptrs.size() <= m->n_pages) m->h_page_ptrs.resize(m->n_pages + 1);
+    m->h_page_ptrs[m->n_pages++] = p;
+  }
+  AHA_HIP_CHECK(hipMemcpyAsync(m->d_page_ptrs + first_new, m->h_page_ptrs.data() + first_new,
+                               (m->n_pages - first_new) * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
+  // h_page_ptrs is pageable: the async copy above is staged synchronously by the runtime, so the vector may be reused
+  return AHA_OK;
+}
+
+KvLayer model_kv_layer(aha_model* m, int layer) {
+  KvLayer kv;
+  kv.page_ptrs = m->d_page_ptrs;
+  kv.layer_off = (uint64_t)layer * m->layer_stride;
+  kv.kvh = m->desc.num_key_value_heads;
+  kv.d = m->desc.head_dim;
+  return kv;
+}
+
+int model_clear_cache(aha_model* m) {
+  // QKNormAttention::clear_kv_cache (modules.rs:581-583): the cache becomes empty; pages go back to the pool
+  for (size_t i = m->n_pages; i > 0; --i) m->free_pages.push_back(m->h_page_ptrs[i - 1]);
+  m->n_pages = 0;
+  m->cache_len = 0;
+  m->rope_delta = 0;
+  m->rope_delta_valid = false;
+  return AHA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view* w, size_t nw, aha_model** out) {
+  if (!ctx || !desc || !out || (!w && nw)) {
+    set_error("model_create: null argument");
+    return AHA_ERR_INVALID;
+  }
+  const aha_model_desc& c = *desc;
+  if (c.head_dim != 128) {
+    set_error("only head_dim == 128 is supported by the decoder kernels (Qwen3 family)");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  if (c.num_attention_heads % c.num_key_value_heads || c.num_attention_heads / c.num_key_value_heads > 16) {
+    set_error("unsupported GQA group size");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  if (c.hidden_size % 8 || c.intermediate_size % 16) {
+    set_error("hidden_size must be a multiple of 8 and intermediate_size of 16");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  AHA_HIP_CHECK(hipSetDevice(ctx->device));
+  aha_model* m = new aha_model();
+  m->ctx = ctx;
+  m->desc = c;
+  m->stream = ctx->stream;
+  int rc = AHA_OK;
+  auto fail = [&](int code) {
+    model_destroy(m);
+    return code;
+  };
+  const int H = c.hidden_size, I = c.intermediate_size, d = c.head_dim;
+  const int nq = c.num_attention_heads * d, nkv = c.num_key_value_heads * d;
+
+  // name prefixes: Qwen3 "model." optional (qwen3/model.rs:105-109); Qwen3-VL "model.language_model." (qwen3vl/model.rs:847-870)
+  std::string pre;
+  if (c.arch == AHA_ARCH_QWEN3VL) pre = "model.language_model.";
+  else pre = find_tensor(w, nw, "model.embed_tokens.weight") ? "model." : "";
+
+  const aha_tensor_view* t = nullptr;
+  if ((rc = need(w, nw, pre + "embed_tokens.weight", &t))) return fail(rc);
+  if ((rc = upload_tensor(m, t, {c.vocab_size, H}, &m->embed))) return fail(rc);
+  if (c.tie_word_embeddings) m->lm_head = m->embed;
+  else {
+    // HF stores lm_head at top level; the reference's Qwen3 (non-VL) branch would look it up under the prefix
+    // (qwen3/model.rs:124) -- accept either.
+    t = find_tensor(w, nw, "lm_head.weight");
+    if (!t) t = find_tensor(w, nw, pre + "lm_head.weight");
+    if (!t) {
+      set_error("missing weight tensor: lm_head.weight");
+      return fail(AHA_ERR_MISSING_WEIGHT);
+    }
+    if ((rc = upload_tensor(m, t, {c.vocab_size, H}, &m->lm_head))) return fail(rc);
+  }
+  if ((rc = need(w, nw, pre + "norm.weight", &t))) return fail(rc);
+  if ((rc = upload_tensor(m, t, {H}, &m->final_norm))) return fail(rc);
+
+  m->layers.resize(c.num_hidden_layers);
+  for (int li = 0; li < c.num_hidden_layers; ++li) {
+    const std::string p = pre + "layers." + std::to_string(li) + ".";
+    LayerWeights& L = m->layers[li];
+    const aha_tensor_view *tq, *tk, *tv, *tg, *tu;
+    if ((rc = need(w, nw, p + "self_attn.q_proj.weight", &tq))) return fail(rc);
+    if ((rc = need(w, nw, p + "self_attn.k_proj.weight", &tk))) return fail(rc);
+    if ((rc = need(w, nw, p + "self_attn.v_proj.weight", &tv))) return fail(rc);
+    if ((rc = dev_alloc(m, (size_t)(nq + 2 * nkv) * H * 2, &L.wqkv))) return fail(rc);
+    if ((rc = upload_rows_into(m, tq, nq, H, L.wqkv, 0))) return fail(rc);
+    if ((rc = upload_rows_into(m, tk, nkv, H, L.wqkv, nq))) return fail(rc);
+    if ((rc = upload_rows_into(m, tv, nkv, H, L.wqkv, nq + nkv))) return fail(rc);
+    if ((rc = need(w, nw, p + "self_attn.o_proj.weight", &t))) return fail(rc);
+    if ((rc = upload_tensor(m, t, {H, nq}, &L.wo))) return fail(rc);
+    if ((rc = need(w, nw, p + "mlp.gate_proj.weight", &tg))) return fail(rc);
+    if ((rc = need(w, nw, p + "mlp.up_proj.weight", &tu))) return fail(rc);
+    if ((rc = upload_gate_up(m, tg, tu, I, H, &L.wgu))) return fail(rc);
+    if ((rc = need(w, nw, p + "mlp.down_proj.weight", &t))) return fail(rc);
+    if ((rc = upload_tensor(m, t, {H, I}, &L.wdown))) return fail(rc);
+    if ((rc = need(w, nw, p + "input_layernorm.weight", &t))) return fail(rc);
+    if ((rc = upload_tensor(m, t, {H}, &L.in_norm))) return fail(rc);
+    if ((rc = need(w, nw, p + "post_attention_layernorm.weight", &t))) return fail(rc);
+    if ((rc = upload_tensor(m, t, {H}, &L.post_norm))) return fail(rc);
+    if ((rc = need(w, nw, p + "self_attn.q_norm.weight", &t))) return fail(rc);
+    if ((rc = upload_tensor(m, t, {d}, &L.q_norm))) return fail(rc);
+    if ((rc = need(w, nw, p + "self_attn.k_norm.weight", &t))) return fail(rc);
+    if ((rc = upload_tensor(m, t, {d}, &L.k_norm))) return fail(rc);
+  }
+
+  // rope constants.  inv_freq_i = 1 / theta^(2i/d) in f32 with powf (rope.rs:7-13); the M-RoPE axis of slot i follows
+  // apply_interleaved_mrope (rope.rs:454-476): H overwrites i = 1,4,.. < 3*sec[1], W overwrites i = 2,5,.. < 3*sec[2].
+  {
+    std::vector<float> inv(d / 2);
+    std::vector<int32_t> axis(d / 2, 0);
+    for (int i = 0; i < d / 2; ++i) {
+      inv[i] = 1.0f / powf(c.rope_theta, (float)(2 * i) / (float)d);
+      if (c.mrope_section[0] + c.mrope_section[1] + c.mrope_section[2] > 0) {
+        if (i % 3 == 1 && i < 3 * c.mrope_section[1]) axis[i] = 1;
+        if (i % 3 == 2 && i < 3 * c.mrope_section[2]) axis[i] = 2;
+      }
+    }
+    void* p;
+    if ((rc = dev_alloc(m, inv.size() * 4, &p))) return fail(rc);
+    m->d_inv_freq = (float*)p;
+    if ((rc = dev_alloc(m, axis.size() * 4, &p))) return fail(rc);
+    m->d_axis_map = (int32_t*)p;
+    hipMemcpy(m->d_inv_freq, inv.data(), inv.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(m->d_axis_map, axis.data(), axis.size() * 4, hipMemcpyHostToDevice);
+    // `attn_weights * scaling` is a Candle affine op: the f64 scalar is cast to the tensor dtype first [unverified],
+    // so the effective scale is bf16(1/sqrt(d)) (modules.rs:476,783; oracle/qwen3.py attn_scale)
+    const float s = 1.0f / sqrtf((float)d);
+    uint32_t u;
+    memcpy(&u, &s, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    memcpy(&m->attn_scale, &u, 4);
+  }
+
+  // KV pages
+  m->page_bytes = (uint64_t)2 * c.num_key_value_heads * KV_PAGE_TOKENS * d * 2;
+  m->pages_per_slab = 64;
+  m->layer_stride = m->pages_per_slab * m->page_bytes;
+  if (c.kv_reserve_tokens > 0) {
+    if ((rc = model_ensure_pages(m, c.kv_reserve_tokens))) return fail(rc);
+    model_clear_cache(m);
+  }
+
+  // step state + decode scratch
+  void* p;
+  if ((rc = dev_alloc(m, sizeof(StepState), &p, true))) return fail(rc);
+  m->d_state = (StepState*)p;
+  AHA_HIP_CHECK(hipHostMalloc((void**)&m->h_state, sizeof(StepState)));
+  AHA_HIP_CHECK(hipHostMalloc((void**)&m->h_logits, (size_t)c.vocab_size * 4));
+  m->token_log_cap = 1 << 16;
+  if ((rc = dev_alloc(m, m->token_log_cap * 4, &p))) return fail(rc);
+  m->d_token_log = (uint32_t*)p;
+  if ((rc = dev_alloc(m, (size_t)H * 2, &m->d_x))) return fail(rc);
+  if ((rc = dev_alloc(m, (size_t)(nq + 2 * nkv) * 2, &m->d_qkv))) return fail(rc);
+  if ((rc = dev_alloc(m, (size_t)nq * 2, &m->d_q))) return fail(rc);
+  if ((rc = dev_alloc(m, (size_t)nq * 2, &m->d_attn))) return fail(rc);
+  if ((rc = dev_alloc(m, (size_t)I * 2, &m->d_act))) return fail(rc);
+  if ((rc = dev_alloc(m, (size_t)H * 2, &m->d_hlast, true))) return fail(rc);
+  if ((rc = dev_alloc(m, (size_t)c.vocab_size * 4, &p))) return fail(rc);
+  m->d_logits = (float*)p;
+  const int nt = std::max(gemv_num_tiles(c.vocab_size, H), 256);
+  if ((rc = dev_alloc(m, (size_t)nt * 4, &p))) return fail(rc);
+  m->d_blk_max = (float*)p;
+  if ((rc = dev_alloc(m, (size_t)nt * 4, &p))) return fail(rc);
+  m->d_blk_idx = (uint32_t*)p;
+  if ((rc = dev_alloc(m, (size_t)m->max_nsplit * 4 * c.num_attention_heads * d * 4, &p))) return fail(rc);
+  m->d_part_o = (float*)p;
+  if ((rc = dev_alloc(m, (size_t)m->max_nsplit * 4 * c.num_attention_heads * 2 * 4, &p))) return fail(rc);
+  m->d_part_ml = (float*)p;
+
+  if (c.arch == AHA_ARCH_QWEN3VL) {
+    if ((rc = vision_create(m, w, nw))) return fail(rc);
+  }
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  *out = m;
+  return AHA_OK;
+}
+
+void model_destroy(aha_model* m) {
+  if (!m) return;
+  hipStreamSynchronize(m->stream);
+  for (auto& r : m->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  vision_destroy(m);
+  for (void* p : m->owned) hipFree(p);
+  for (void* p : m->pf_owned) hipFree(p);
+  for (void* p : m->slabs) hipFree(p);
+  if (m->d_page_ptrs) hipFree(m->d_page_ptrs);
+  if (m->h_state) hipHostFree(m->h_state);
+  if (m->h_logits) hipHostFree(m->h_logits);
+  delete m;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static int ensure_prefill_scratch(aha_model* m, size_t S) {
+  if (S <= m->pf_cap) return AHA_OK;
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  for (void* p : m->pf_owned) hipFree(p);
+  m->pf_owned.clear();
+  m->pf_cap = 0;
+  const aha_model_desc& c = m->desc;
+  const size_t cap = (S + 255) / 256 * 256;
+  const size_t H = c.hidden_size, I = c.intermediate_size, nq = (size_t)c.num_attention_heads * c.head_dim,
+               nkv = (size_t)c.num_key_value_heads * c.head_dim;
+  auto al = [&](size_t bytes, void** out) -> int {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      set_error(std::string("prefill scratch hipMalloc failed: ") + hipGetErrorString(e));
+      return e == hipErrorOutOfMemory ? AHA_ERR_OOM : AHA_ERR_HIP;
+    }
+    m->pf_owned.push_back(p);
+    *out = p;
+    return AHA_OK;
+  };
+  int rc;
+  if ((rc = al(cap * 4, (void**)&m->p_ids))) return rc;
+  if ((rc = al(cap * 3 * 4, (void**)&m->p_pos))) return rc;
+  if ((rc = al(cap * H * 2, &m->p_x))) return rc;
+  if ((rc = al(cap * H * 2, &m->p_h))) return rc;
+  if ((rc = al(cap * (nq + 2 * nkv) * 2, &m->p_qkv))) return rc;
+  if ((rc = al(cap * nq * 2, &m->p_q))) return rc;
+  if ((rc = al(cap * nq * 2, &m->p_attn))) return rc;
+  if ((rc = al(cap * I * 2, &m->p_act))) return rc;
+  m->pf_cap = cap;
+  return AHA_OK;
+}
+
+static int push_state(aha_model* m, uint32_t token, const int64_t pos[3], size_t kv_start, size_t kv_len) {
+  StepState* s = m->h_state;
+  s->token = token;
+  for (int i = 0; i < 3; ++i) s->pos[i] = (int32_t)pos[i];
+  s->kv_start = (int32_t)kv_start;
+  s->kv_len = (int32_t)kv_len;
+  s->next_token = 0;
+  s->step = 0;
+  AHA_HIP_CHECK(hipMemcpyAsync(m->d_state, s, sizeof(StepState), hipMemcpyHostToDevice, m->stream));
+  return AHA_OK;
+}
+
+// final RMSNorm (qwen3/model.rs:186) fused into the lm_head matvec of the LAST position only (model.rs:187,142),
+// f32 logits + argmax partials -> d_state->next_token
+static void enqueue_lm_head(aha_model* m, const void* x_last) {
+  const aha_model_desc& c = m->desc;
+  GemvArgs g{};
+  g.W = m->lm_head;
+  g.x = x_last;
+  g.norm_w = m->final_norm;
+  g.eps = c.rms_norm_eps;
+  g.N = c.vocab_size;
+  g.K = c.hidden_size;
+  g.y_f32 = m->d_logits;
+  g.blk_max = m->d_blk_max;
+  g.blk_idx = m->d_blk_idx;
+  g.h_out = m->d_hlast;
+  {
+    ProfScope ps(m, "gemv", (double)c.vocab_size * c.hidden_size * 2 + c.hidden_size * 2 + c.vocab_size * 4.0, 2.0 * c.vocab_size * c.hidden_size);
+    launch_gemv(g, GEMV_LOGITS, m->stream);
+  }
+  {
+    ProfScope ps(m, "argmax", 0, 0);
+    launch_argmax_partials(m->d_blk_max, m->d_blk_idx, gemv_num_tiles(c.vocab_size, c.hidden_size), &m->d_state->next_token, m->stream);
+  }
+}
+
+static int fetch_outputs(aha_model* m, float* logits_out, uint32_t* argmax_out) {
+  const aha_model_desc& c = m->desc;
+  if (logits_out) AHA_HIP_CHECK(hipMemcpyAsync(m->h_logits, m->d_logits, (size_t)c.vocab_size * 4, hipMemcpyDeviceToHost, m->stream));
+  AHA_HIP_CHECK(hipMemcpyAsync(&m->h_state->next_token, &m->d_state->next_token, 4, hipMemcpyDeviceToHost, m->stream));
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  if (logits_out) memcpy(logits_out, m->h_logits, (size_t)c.vocab_size * 4);
+  if (argmax_out) *argmax_out = m->h_state->next_token;
+  return AHA_OK;
+}
+
+// ---- decode: one token through all layers; every length-dependent value is read from d_state on the device ----
+__global__ void embed_state_kernel(const bf16_t* __restrict__ table, const StepState* __restrict__ st, bf16_t* __restrict__ out, int H) {
+  const u32x4_t* src = reinterpret_cast<const u32x4_t*>(table + (size_t)st->token * H);
+  u32x4_t* dst = reinterpret_cast<u32x4_t*>(out);
+  for (int i = threadIdx.x + blockIdx.x * blockDim.x; i < H / 8; i += blockDim.x * gridDim.x) dst[i] = src[i];
+}
+__global__ void advance_state_kernel(StepState* st, uint32_t* token_log) {
+  const uint32_t t = st->next_token;
+  token_log[st->step] = t;
+  st->step += 1;
+  st->token = t;
+  st->pos[0] += 1;
+  st->pos[1] += 1;
+  st->pos[2] += 1;
+  st->kv_start += 1;
+  st->kv_len += 1;
+}
+
+static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
+  const aha_model_desc& c = m->desc;
+  const int H = c.hidden_size, I = c.intermediate_size, d = c.head_dim, nh = c.num_attention_heads, kvh = c.num_key_value_heads;
+  const int nq = nh * d, nkv = kvh * d;
+  hipStream_t st = m->stream;
+  {
+    ProfScope ps(m, "elem", H * 4.0, 0);
+    hipLaunchKernelGGL(embed_state_kernel, dim3(1), dim3(256), 0, st, (const bf16_t*)m->embed, m->d_state, (bf16_t*)m->d_x, H);
+  }
+  const int npages = (int)((kv_len_after + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS);
+  int nsplit = (npages + 3) / 4;
+  nsplit = std::max(1, std::min(nsplit, m->max_nsplit));
+  for (int li = 0; li < c.num_hidden_layers; ++li) {
+    const LayerWeights& L = m->layers[li];
+    {  // h = RMSNorm(x); qkv = h Wqkv^T                      (qwen3/model.rs:79, modules.rs:538-552)
+      GemvArgs g{};
+      g.W = L.wqkv; g.x = m->d_x; g.norm_w = L.in_norm; g.eps = c.rms_norm_eps; g.y = m->d_qkv; g.N = nq + 2 * nkv; g.K = H;
+      ProfScope ps(m, "gemv", (double)g.N * g.K * 2 + g.K * 4.0 + g.N * 2.0, 2.0 * g.N * g.K);
+      launch_gemv(g, GEMV_STORE, st);
+    }
+    {  // q/k norm + rope + append                            (modules.rs:544-566)
+      RopeArgs r{};
+      r.qkv = m->d_qkv; r.ld = nq + 2 * nkv; r.q_norm_w = L.q_norm; r.k_norm_w = L.k_norm;
+      r.pos = m->d_state->pos; r.pos_ld = 1; r.inv_freq = m->d_inv_freq; r.axis_map = m->d_axis_map;
+      r.q_out = m->d_q; r.kv = model_kv_layer(m, li); r.kv_start = &m->d_state->kv_start;
+      r.S = 1; r.nh = nh; r.kvh = kvh; r.d = d; r.eps = c.rms_norm_eps;
+      ProfScope ps(m, "elem", (nq + 2 * nkv) * 4.0, 0);
+      launch_qknorm_rope(r, st);
+    }
+    {  // attention over the paged cache                       (modules.rs:567-574, 757-813)
+      AttnDecodeArgs a{};
+      a.q = m->d_q; a.kv = model_kv_layer(m, li); a.kv_len = &m->d_state->kv_len; a.part_o = m->d_part_o; a.part_ml = m->d_part_ml;
+      a.o = m->d_attn; a.nh = nh; a.kvh = kvh; a.d = d; a.nsplit = nsplit; a.scale = m->attn_scale;
+      ProfScope ps(m, "attn_decode", (double)kv_len_after * 2 * nkv * 2 + nq * 4.0, 4.0 * kv_len_after * nq);
+      launch_attn_decode(a, st);
+    }
+    {  // x = x + attn Wo^T                                    (modules.rs:577, qwen3/model.rs:81)
+      GemvArgs g{};
+      g.W = L.wo; g.x = m->d_attn; g.residual = m->d_x; g.y = m->d_x; g.N = H; g.K = nq;
+      ProfScope ps(m, "gemv", (double)g.N * g.K * 2 + g.K * 2.0 + g.N * 4.0, 2.0 * g.N * g.K);
+      launch_gemv(g, GEMV_RESIDUAL, st);
+    }
+    {  // act = silu(h Wg^T) * (h Wu^T), h = RMSNorm(x)        (qwen3/model.rs:83, modules.rs:81-84)
+      GemvArgs g{};
+      g.W = L.wgu; g.W2 = nullptr; g.x = m->d_x; g.norm_w = L.post_norm; g.eps = c.rms_norm_eps; g.y = m->d_act; g.N = I; g.K = H;
+      ProfScope ps(m, "gemv", (double)2 * I * H * 2 + H * 4.0 + I * 2.0, 4.0 * I * H);
+      launch_gemv(g, GEMV_SILU_MUL, st);
+    }
+    {  // x = x + act Wd^T                                     (modules.rs:85, qwen3/model.rs:86)
+      GemvArgs g{};
+      g.W = L.wdown; g.x = m->d_act; g.residual = m->d_x; g.y = m->d_x; g.N = H; g.K = I;
+      ProfScope ps(m, "gemv", (double)g.N * g.K * 2 + g.K * 2.0 + g.N * 4.0, 2.0 * g.N * g.K);
+      launch_gemv(g, GEMV_RESIDUAL, st);
+    }
+  }
+  enqueue_lm_head(m, m->d_x);
+}
+
+int model_forward_step(aha_model* m, uint32_t token, size_t offset, float* logits_out, uint32_t* argmax_out) {
+  const aha_model_desc& c = m->desc;
+  if (token >= (uint32_t)c.vocab_size) {
+    set_error("token id out of range");
+    return AHA_ERR_INVALID;
+  }
+  AHA_HIP_CHECK(hipSetDevice(m->ctx->device));
+  int rc = model_ensure_pages(m, m->cache_len + 1);
+  if (rc) return rc;
+  // rope position: seqlen_offset (+ rope_delta for Qwen3-VL, qwen3vl/model.rs:1235-1264); cache slot: current length
+  int64_t p = (int64_t)offset + m->rope_delta;
+  if (c.arch == AHA_ARCH_QWEN3VL && !m->rope_delta_valid) {
+    // first forward after clear_cache: get_rope_index on the ids alone -> position 0, delta 0 (model.rs:1229-1236)
+    p = 0;
+    m->rope_delta = 0;
+    m->rope_delta_valid = true;
+  }
+  const int64_t pos[3] = {p, p, p};
+  if ((rc = push_state(m, token, pos, m->cache_len, m->cache_len + 1))) return rc;
+  enqueue_decode_step(m, m->cache_len + 1);
+  m->cache_len += 1;
+  AHA_HIP_CHECK(hipGetLastError());
+  return fetch_outputs(m, logits_out, argmax_out);
+}
+
+int model_decode_greedy(aha_model* m, uint32_t first_token, size_t offset, size_t max_new, uint32_t* out) {
+  const aha_model_desc& c = m->desc;
+  if (max_new == 0) return 0;
+  if (first_token >= (uint32_t)c.vocab_size) {
+    set_error("token id out of range");
+    return AHA_ERR_INVALID;
+  }
+  AHA_HIP_CHECK(hipSetDevice(m->ctx->device));
+  int rc = model_ensure_pages(m, m->cache_len + max_new);
+  if (rc) return rc;
+  const int64_t p = (int64_t)offset + m->rope_delta;
+  const int64_t pos[3] = {p, p, p};
+  if ((rc = push_state(m, first_token, pos, m->cache_len, m->cache_len + 1))) return rc;
+  size_t produced = 0;
+  const size_t chunk = 32;  // host looks for an eos id every `chunk` tokens; nothing else crosses PCIe
+  bool stop = false;
+  while (produced < max_new && !stop) {
+    const size_t n = std::min(chunk, max_new - produced);
+    if (n > m->token_log_cap) return AHA_ERR_INVALID;
+    m->h_state->step = 0;
+    AHA_HIP_CHECK(hipMemcpyAsync(&m->d_state->step, &m->h_state->step, 4, hipMemcpyHostToDevice, m->stream));
+    for (size_t i = 0; i < n; ++i) {
+      enqueue_decode_step(m, m->cache_len + i + 1);
+      hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(1), 0, m->stream, m->d_state, m->d_token_log);
+    }
+    AHA_HIP_CHECK(hipGetLastError());
+    AHA_HIP_CHECK(hipMemcpyAsync(out + produced, m->d_token_log, n * 4, hipMemcpyDeviceToHost, m->stream));
+    AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    size_t used = n;
+    for (size_t i = 0; i < n && !stop; ++i)
+      for (int e = 0; e < c.n_stop_tokens; ++e)
+        if (out[produced + i] == c.stop_tokens[e]) {
+          used = i + 1;
+          stop = true;
+          break;
+        }
+    m->cache_len += used;  // inputs consumed: first_token and the first used-1 generated tokens of this chunk
+    produced += used;
+  }
+  return (int)produced;
+}
+
+// ---- prefill ---------------------------------------------------------------------------------------------------
+int model_forward_initial(aha_model* m, const uint32_t* ids, size_t n, size_t offset, const aha_mm_input* mm,
+                          float* logits_out, uint32_t* argmax_out) {
+  const aha_model_desc& c = m->desc;
+  if (!ids || n == 0) {
+    set_error("forward_initial: empty input_ids");
+    return AHA_ERR_INVALID;
+  }
+  for (size_t i = 0; i < n; ++i)
+    if (ids[i] >= (uint32_t)c.vocab_size) {
+      set_error("token id out of range at position " + std::to_string(i));
+      return AHA_ERR_INVALID;
+    }
+  if (n == 1 && !mm) return model_forward_step(m, ids[0], offset, logits_out, argmax_out);
+  AHA_HIP_CHECK(hipSetDevice(m->ctx->device));
+  const int S = (int)n;
+  const int H = c.hidden_size, I = c.intermediate_size, d = c.head_dim, nh = c.num_attention_heads, kvh = c.num_key_value_heads;
+  const int nq = nh * d, nkv = kvh * d;
+  hipStream_t st = m->stream;
+  int rc;
+  if ((rc = ensure_prefill_scratch(m, n))) return rc;
+  if ((rc = model_ensure_pages(m, m->cache_len + n))) return rc;
+
+  // positions: 1-D arange(offset, offset+S) on all three rows (rope.rs:599-604), or get_rope_index for Qwen3-VL
+  std::vector<int32_t> pos(3 * (size_t)S);
+  const bool has_image = mm && mm->n_images > 0 && m->vision;
+  if (c.arch == AHA_ARCH_QWEN3VL) {
+    if ((rc = vl_rope_index(m, ids, n, offset, has_image ? mm : nullptr, pos.data()))) return rc;
+  } else {
+    for (int a = 0; a < 3; ++a)
+      for (int i = 0; i < S; ++i) pos[(size_t)a * S + i] = (int32_t)(offset + i);
+  }
+  AHA_HIP_CHECK(hipMemcpyAsync(m->p_ids, ids, n * 4, hipMemcpyHostToDevice, st));
+  AHA_HIP_CHECK(hipMemcpyAsync(m->p_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, st));
+  const int64_t p0[3] = {pos[0], pos[S], pos[2 * (size_t)S]};
+  if ((rc = push_state(m, ids[n - 1], p0, m->cache_len, m->cache_len + n))) return rc;
+  AHA_HIP_CHECK(hipStreamSynchronize(st));  // pos / ids are pageable host memory
+
+  {
+    ProfScope ps(m, "elem", (double)S * H * 4, 0);
+    launch_embed_gather(m->embed, m->p_ids, m->p_x, S, H, st);
+  }
+  if (has_image) {
+    // ViT -> masked_scatter of image embeds into the <|image_pad|> rows (qwen3vl/model.rs:1166-1190)
+    if ((rc = vision_forward_and_scatter(m, ids, n, mm, m->p_x))) return rc;
+  }
+  const int kv_off = (int)m->cache_len;
+  for (int li = 0; li < c.num_hidden_layers; ++li) {
+    const LayerWeights& L = m->layers[li];
+    {
+      ProfScope ps(m, "elem", (double)S * H * 4, 0);
+      launch_rmsnorm_rows(m->p_x, L.in_norm, m->p_h, S, H, H, H, c.rms_norm_eps, st);
+    }
+    {
+      GemmArgs g{};
+      g.A = m->p_h; g.W = L.wqkv; g.C = m->p_qkv; g.M = S; g.N = nq + 2 * nkv; g.K = H; g.lda = H; g.ldw = H; g.ldc = g.N; g.act = ACT_NONE;
+      ProfScope ps(m, "gemm", ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N) * 2, 2.0 * g.M * g.N * g.K);
+      launch_gemm(g, st);
+    }
+    {
+      RopeArgs r{};
+      r.qkv = m->p_qkv; r.ld = nq + 2 * nkv; r.q_norm_w = L.q_norm; r.k_norm_w = L.k_norm;
+      r.pos = m->p_pos; r.pos_ld = S; r.inv_freq = m->d_inv_freq; r.axis_map = m->d_axis_map;
+      r.q_out = m->p_q; r.kv = model_kv_layer(m, li); r.kv_start = &m->d_state->kv_start;
+      r.S = S; r.nh = nh; r.kvh = kvh; r.d = d; r.eps = c.rms_norm_eps;
+      ProfScope ps(m, "elem", (double)S * (nq + 2 * nkv) * 4, 0);
+      launch_qknorm_rope(r, st);
+    }
+    {
+      AttnPrefillArgs a{};
+      a.q = m->p_q; a.kv = model_kv_layer(m, li); a.o = m->p_attn; a.S = S; a.nh = nh; a.kvh = kvh; a.d = d;
+      a.kv_offset = kv_off; a.kv_total = kv_off + S; a.causal = 1; a.scale = m->attn_scale;
+      const double Lk = kv_off + S;
+      ProfScope ps(m, "attn_prefill", (double)S * nq * 4 + Lk * nkv * 4, 4.0 * S * (kv_off + 0.5 * S) * nq);
+      launch_attn_prefill(a, st);
+    }
+    {
+      GemmArgs g{};
+      g.A = m->p_attn; g.W = L.wo; g.C = m->p_x; g.residual = m->p_x; g.M = S; g.N = H; g.K = nq; g.lda = nq; g.ldw = nq; g.ldc = H; g.act = ACT_NONE;
+      ProfScope ps(m, "gemm", ((double)g.M * g.K + (double)g.N * g.K + 2.0 * g.M * g.N) * 2, 2.0 * g.M * g.N * g.K);
+      launch_gemm(g, st);
+    }
+    {
+      ProfScope ps(m, "elem", (double)S * H * 4, 0);
+      launch_rmsnorm_rows(m->p_x, L.post_norm, m->p_h, S, H, H, H, c.rms_norm_eps, st);
+    }
+    {
+      GemmArgs g{};
+      g.A = m->p_h; g.W = L.wgu; g.C = m->p_act; g.M = S; g.N = 2 * I; g.K = H; g.lda = H; g.ldw = H; g.ldc = I; g.act = ACT_SILU_MUL_PAIRS;
+      ProfScope ps(m, "gemm", ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * I) * 2, 2.0 * g.M * g.N * g.K);
+      launch_gemm(g, st);
+    }
+    {
+      GemmArgs g{};
+      g.A = m->p_act; g.W = L.wdown; g.C = m->p_x; g.residual = m->p_x; g.M = S; g.N = H; g.K = I; g.lda = I; g.ldw = I; g.ldc = H; g.act = ACT_NONE;
+      ProfScope ps(m, "gemm", ((double)g.M * g.K + (double)g.N * g.K + 2.0 * g.M * g.N) * 2, 2.0 * g.M * g.N * g.K);
+      launch_gemm(g, st);
+    }
+    if (has_image) {
+      // DeepStack: add visual feature k to the visual rows after decoder layer k (qwen3vl/model.rs:806-822)
+      if ((rc = vision_deepstack_add(m, li, m->p_x))) return rc;
+    }
+  }
+  enqueue_lm_head(m, (const char*)m->p_x + (size_t)(S - 1) * H * 2);
+  m->cache_len += n;
+  AHA_HIP_CHECK(hipGetLastError());
+  return fetch_outputs(m, logits_out, argmax_out);
+}
+
+}  // namespace aha

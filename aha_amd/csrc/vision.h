@@ -1,0 +1,16 @@
+// Qwen3-VL specific host pieces: M-RoPE position bookkeeping (M2), the vision tower (V1-V7) and the visual-token
+// scatter / DeepStack adds (M3).  SURVEY.md section 8a.
+#pragma once
+#include "model.h"
+
+namespace aha {
+
+int vision_create(aha_model* m, const aha_tensor_view* w, size_t nw);
+void vision_destroy(aha_model* m);
+// get_rope_index (/root/reference/src/models/qwen3vl/model.rs:901-1133): fills pos (3, n) rows T,H,W and sets
+// m->rope_delta.  mm == nullptr => text only: rows = arange(n) + offset, delta 0.
+int vl_rope_index(aha_model* m, const uint32_t* ids, size_t n, size_t offset, const aha_mm_input* mm, int32_t* pos);
+int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, const aha_mm_input* mm, void* x);
+int vision_deepstack_add(aha_model* m, int layer, void* x);
+
+}  // namespace aha

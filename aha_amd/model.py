@@ -1,0 +1,230 @@
+"""Host-side mirror of the reference's operator interface for this path, on top of the C ABI.
+
+  HipInferenceModel.forward_initial / forward_step / clear_cache / stop_token_ids
+      == trait InferenceModel                (/root/reference/src/models/common/mod.rs:25-45)
+  generate_generic(...)                      == generate_generic with Sampling::ArgMax when temperature < 1e-7
+                                             (/root/reference/src/models/common/generate.rs:70-159, sample.rs:7-37)
+Same names, same argument meaning, errors raised as exceptions where the reference returns Err(anyhow!).
+Everything numeric happens inside libaha_hip.so; this file only marshals buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MmInput, ModelDesc, TensorView, check, lib
+from .configs import Qwen3Config, Qwen3VLConfig
+
+_DT = {torch.bfloat16: _lib.AHA_BF16, torch.float16: _lib.AHA_F16, torch.float32: _lib.AHA_F32}
+
+
+class HipContext:
+    def __init__(self, device: int = 0):
+        self.handle = C.c_void_p()
+        check(lib().aha_hip_init(device, C.byref(self.handle)))
+        self.device = device
+
+    def close(self):
+        if self.handle:
+            lib().aha_hip_shutdown(self.handle)
+            self.handle = C.c_void_p()
+
+
+@dataclass
+class MultiModalData:
+    """data_vec = [pixel_values, image_grid_thw, None, None, cache_position] (qwen3vl/generate.rs:79-101)."""
+    pixel_values: torch.Tensor      # (n_patches, C*T*P*P) bf16 or f32, processor row order
+    image_grid_thw: np.ndarray      # (n_images, 3) uint32
+
+
+def make_desc(cfg, kv_reserve_tokens: int = 0) -> ModelDesc:
+    d = ModelDesc()
+    if isinstance(cfg, Qwen3VLConfig):
+        t, v = cfg.text, cfg.vision
+        d.arch = _lib.AHA_ARCH_QWEN3VL
+        d.vis_depth, d.vis_hidden_size, d.vis_num_heads = v.depth, v.hidden_size, v.num_heads
+        d.vis_intermediate_size, d.vis_in_channels, d.vis_patch_size = v.intermediate_size, v.in_channels, v.patch_size
+        d.vis_temporal_patch_size, d.vis_spatial_merge_size = v.temporal_patch_size, v.spatial_merge_size
+        d.vis_out_hidden_size, d.vis_num_position_embeddings = v.out_hidden_size, v.num_position_embeddings
+        for i, x in enumerate(v.deepstack_visual_indexes):
+            d.vis_deepstack_indexes[i] = x
+        d.vis_num_deepstack = len(v.deepstack_visual_indexes)
+        d.image_token_id, d.video_token_id = cfg.image_token_id, cfg.video_token_id
+        d.vision_start_token_id, d.vision_end_token_id = cfg.vision_start_token_id, cfg.vision_end_token_id
+        tie = cfg.tie_word_embeddings
+    else:
+        t = cfg
+        d.arch = _lib.AHA_ARCH_QWEN3
+        tie = cfg.tie_word_embeddings
+    d.hidden_size, d.intermediate_size, d.num_hidden_layers = t.hidden_size, t.intermediate_size, t.num_hidden_layers
+    d.num_attention_heads, d.num_key_value_heads, d.head_dim = t.num_attention_heads, t.num_key_value_heads, t.head_dim
+    d.vocab_size = t.vocab_size
+    d.rms_norm_eps, d.rope_theta = t.rms_norm_eps, t.rope_theta
+    d.tie_word_embeddings = int(tie)
+    ms = t.mrope_section or [0, 0, 0]
+    for i in range(3):
+        d.mrope_section[i] = ms[i]
+    d.kv_reserve_tokens = kv_reserve_tokens
+    eos = list(t.eos_token_ids)[:8]
+    d.n_stop_tokens = len(eos)
+    for i, e in enumerate(eos):
+        d.stop_tokens[i] = e
+    return d
+
+
+class HipInferenceModel:
+    """One model instance on one GPU (== XxxGenerateModel::init's model object, qwen3/generate.rs:22-50)."""
+
+    def __init__(self, cfg, weights: Dict[str, torch.Tensor], ctx: Optional[HipContext] = None, device: int = 0,
+                 kv_reserve_tokens: int = 0):
+        self.cfg = cfg
+        self.text_cfg: Qwen3Config = cfg.text if isinstance(cfg, Qwen3VLConfig) else cfg
+        self._own_ctx = ctx is None
+        self.ctx = ctx or HipContext(device)
+        self.handle = C.c_void_p()
+        desc = make_desc(cfg, kv_reserve_tokens)
+        views = (TensorView * len(weights))()
+        keep = []
+        for i, (name, t) in enumerate(weights.items()):
+            t = t.detach().contiguous()
+            if t.dtype not in _DT:
+                raise TypeError(f"{name}: unsupported dtype {t.dtype}")
+            keep.append(t)
+            views[i].name = name.encode()
+            views[i].data = t.data_ptr()
+            views[i].dtype = _DT[t.dtype]
+            views[i].ndim = t.dim()
+            for j, s in enumerate(t.shape):
+                views[i].shape[j] = s
+        check(lib().aha_hip_model_create(self.ctx.handle, C.byref(desc), views, len(weights), C.byref(self.handle)))
+        del keep
+        self.vocab = self.text_cfg.vocab_size
+        self._logits = np.empty(self.vocab, dtype=np.float32)
+
+    # -- InferenceModel ------------------------------------------------------------------------------------------
+    def forward_initial(self, input_ids: Sequence[int], seqlen_offset: int, data: Optional[MultiModalData] = None,
+                        want_logits: bool = True):
+        ids = np.ascontiguousarray(np.asarray(input_ids, dtype=np.uint32).reshape(-1))
+        am = C.c_uint32()
+        mm_ref = None
+        if data is not None:
+            pv = data.pixel_values.detach().contiguous()
+            grid = np.ascontiguousarray(np.asarray(data.image_grid_thw, dtype=np.uint32).reshape(-1, 3))
+            mm = MmInput()
+            mm.pixel_values = pv.data_ptr()
+            mm.pixel_dtype = _DT[pv.dtype]
+            mm.n_patches = pv.shape[0]
+            mm.image_grid_thw = grid.ctypes.data_as(C.POINTER(C.c_uint32))
+            mm.n_images = grid.shape[0]
+            mm_ref = C.byref(mm)
+        lp = self._logits.ctypes.data_as(C.POINTER(C.c_float)) if want_logits else None
+        check(lib().aha_hip_forward_initial(self.handle, ids.ctypes.data_as(C.POINTER(C.c_uint32)), ids.size,
+                                            seqlen_offset, mm_ref, lp, C.byref(am)))
+        return (self._logits.copy() if want_logits else None), int(am.value)
+
+    def forward_step(self, token: int, seqlen_offset: int, want_logits: bool = True):
+        am = C.c_uint32()
+        lp = self._logits.ctypes.data_as(C.POINTER(C.c_float)) if want_logits else None
+        check(lib().aha_hip_forward_step(self.handle, int(token), seqlen_offset, lp, C.byref(am)))
+        return (self._logits.copy() if want_logits else None), int(am.value)
+
+    def clear_cache(self):
+        check(lib().aha_hip_clear_cache(self.handle))
+
+    def stop_token_ids(self) -> List[int]:
+        buf = (C.c_uint32 * 8)()
+        n = check(lib().aha_hip_stop_token_ids(self.handle, buf, 8))
+        return [int(buf[i]) for i in range(n)]
+
+    # -- extensions ----------------------------------------------------------------------------------------------
+    def decode_greedy(self, first_token: int, seqlen_offset: int, max_new: int) -> List[int]:
+        buf = (C.c_uint32 * max(max_new, 1))()
+        n = check(lib().aha_hip_decode_greedy(self.handle, int(first_token), seqlen_offset, max_new, buf))
+        return [int(buf[i]) for i in range(n)]
+
+    def cache_len(self) -> int:
+        return int(lib().aha_hip_cache_len(self.handle))
+
+    def set_profiling(self, on: bool):
+        check(lib().aha_hip_set_profiling(self.handle, int(on)))
+
+    def get_profile(self, kernel_class: str):
+        ms, n, b, f = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        check(lib().aha_hip_get_profile(self.handle, kernel_class.encode(), C.byref(ms), C.byref(n), C.byref(b), C.byref(f)))
+        return {"ms": ms.value, "launches": n.value, "bytes": b.value, "flops": f.value}
+
+    def debug_scramble_pages(self, on: bool = True):
+        check(lib().aha_hip_debug_scramble_pages(self.handle, int(on)))
+
+    def debug_last_hidden(self) -> np.ndarray:
+        out = np.empty(self.text_cfg.hidden_size, dtype=np.float32)
+        check(lib().aha_hip_debug_last_hidden(self.handle, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+        return out
+
+    def debug_image_embeds(self, which: int, rows: int) -> np.ndarray:
+        out = np.empty((rows, self.text_cfg.hidden_size), dtype=np.float32)
+        check(lib().aha_hip_debug_image_embeds(self.handle, which, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+        return out
+
+    def close(self):
+        if self.handle:
+            lib().aha_hip_model_destroy(self.handle)
+            self.handle = C.c_void_p()
+        if self._own_ctx:
+            self.ctx.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class Usage:
+    """utils/response_utils.rs:225-255 / params/shared.rs:3-28 timing fields."""
+    prompt_tokens: int
+    prompt_secs: float
+    completion_tokens: int
+    completion_secs: float
+
+    @property
+    def completion_tps(self) -> float:
+        return self.completion_tokens / self.completion_secs if self.completion_secs > 0 else float("nan")
+
+
+def generate_generic(model: HipInferenceModel, input_ids: Sequence[int], max_tokens: int,
+                     data: Optional[MultiModalData] = None, device_loop: bool = False):
+    """generate_generic (common/generate.rs:115-159) with temperature 0 => Sampling::ArgMax (sample.rs:13-37).
+
+    Returns (generated token ids, Usage).  ``device_loop`` uses the aha_hip_decode_greedy extension for the decode
+    loop (no per-token host round trip); the token sequence is identical by construction.
+    """
+    eos = set(model.stop_token_ids())
+    generated: List[int] = []
+    seqlen_offset, seq_len = 0, len(input_ids)
+    t0 = time.perf_counter()
+    _, tok = model.forward_initial(input_ids, seqlen_offset, data, want_logits=False)
+    generated.append(tok)
+    prompt_secs = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    if device_loop and max_tokens > 1:
+        seqlen_offset += seq_len
+        generated += model.decode_greedy(tok, seqlen_offset, max_tokens - 1)
+    else:
+        for _ in range(1, max_tokens):
+            seqlen_offset += seq_len
+            seq_len = 1
+            _, tok = model.forward_step(tok, seqlen_offset, want_logits=False)
+            generated.append(tok)
+            if tok in eos:
+                break
+    completion_secs = time.perf_counter() - t0
+    model.clear_cache()
+    return generated, Usage(len(input_ids), prompt_secs, len(generated), completion_secs)

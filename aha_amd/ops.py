@@ -1,0 +1,123 @@
+"""Op-level entry points of the C ABI on torch device tensors (torch is only the allocator / stream provider here).
+
+Each function is one kernel family of SURVEY.md section 8a; the parity tests compare them with oracle/ on the same
+seeded inputs.  All tensors must live on the GPU and be contiguous bf16 unless stated otherwise.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda or not t.is_contiguous():
+            raise ValueError("op inputs must be contiguous GPU tensors")
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    _chk(x, w)
+    y = torch.empty_like(x)
+    rows = x.numel() // x.shape[-1]
+    check(lib().aha_hip_rmsnorm(_ptr(x), _ptr(w), _ptr(y), rows, x.shape[-1], eps, _stream()))
+    return y
+
+
+def gemv(W: torch.Tensor, x: torch.Tensor, norm_w: Optional[torch.Tensor] = None, eps: float = 1e-6,
+         residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(W, x, norm_w, residual)
+    N, K = W.shape
+    y = torch.empty(N, dtype=torch.bfloat16, device=x.device)
+    check(lib().aha_hip_gemv(_ptr(W), _ptr(x), _ptr(y), N, K, _ptr(norm_w), eps, _ptr(residual), _stream()))
+    return y
+
+
+def gemv_gate_up(Wg: torch.Tensor, Wu: torch.Tensor, x: torch.Tensor, norm_w: Optional[torch.Tensor] = None,
+                 eps: float = 1e-6) -> torch.Tensor:
+    _chk(Wg, Wu, x, norm_w)
+    I, K = Wg.shape
+    y = torch.empty(I, dtype=torch.bfloat16, device=x.device)
+    check(lib().aha_hip_gemv_gate_up(_ptr(Wg), _ptr(Wu), _ptr(x), _ptr(y), I, K, _ptr(norm_w), eps, _stream()))
+    return y
+
+
+def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
+         residual: Optional[torch.Tensor] = None, act: int = _lib.ACT_NONE) -> torch.Tensor:
+    _chk(A, W, bias, residual)
+    M, K = A.shape
+    N = W.shape[0]
+    n_out = N // 2 if act == _lib.ACT_SILU_MUL_PAIRS else N
+    Cm = torch.empty(M, n_out, dtype=torch.bfloat16, device=A.device)
+    check(lib().aha_hip_gemm(_ptr(A), _ptr(W), _ptr(Cm), M, N, K, K, W.shape[1], n_out, _ptr(bias), _ptr(residual),
+                             act, _stream()))
+    return Cm
+
+
+def interleave_gate_up(Wg: torch.Tensor, Wu: torch.Tensor) -> torch.Tensor:
+    """The model loader's fused layout: 16-row blocks alternating gate / up (csrc/model.hip upload_gate_up)."""
+    I, K = Wg.shape
+    return torch.stack([Wg.reshape(I // 16, 16, K), Wu.reshape(I // 16, 16, K)], dim=1).reshape(2 * I, K).contiguous()
+
+
+def qknorm_rope(qkv: torch.Tensor, q_norm_w: torch.Tensor, k_norm_w: torch.Tensor, pos: torch.Tensor,
+                axis_map: torch.Tensor, nh: int, kvh: int, d: int, eps: float, theta: float):
+    """qkv (S, (nh+2kvh)*d) bf16; pos (3,S) int32; axis_map (d/2) int32 -> q (S,nh*d), k (S,kvh*d), v (S,kvh*d)."""
+    _chk(qkv, q_norm_w, k_norm_w, pos, axis_map)
+    S = qkv.shape[0]
+    q = torch.empty(S, nh * d, dtype=torch.bfloat16, device=qkv.device)
+    k = torch.empty(S, kvh * d, dtype=torch.bfloat16, device=qkv.device)
+    v = torch.empty(S, kvh * d, dtype=torch.bfloat16, device=qkv.device)
+    check(lib().aha_hip_qknorm_rope(_ptr(qkv), _ptr(q_norm_w), _ptr(k_norm_w), _ptr(pos), _ptr(axis_map), _ptr(q),
+                                    _ptr(k), _ptr(v), S, nh, kvh, d, eps, theta, _stream()))
+    return q, k, v
+
+
+def attn_decode(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, nh: int, kvh: int, d: int,
+                scale: Optional[float] = None) -> torch.Tensor:
+    """q (nh*d); k, v (L, kvh*d) token-major -> o (nh*d)."""
+    _chk(q, k, v)
+    L = k.shape[0]
+    scale = bf16_scale(d) if scale is None else scale
+    o = torch.empty(nh * d, dtype=torch.bfloat16, device=q.device)
+    check(lib().aha_hip_attn_decode(_ptr(q), _ptr(k), _ptr(v), _ptr(o), nh, kvh, d, L, scale, _stream()))
+    return o
+
+
+def attn_prefill(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, nh: int, kvh: int, d: int, kv_offset: int = 0,
+                 causal: bool = True, scale: Optional[float] = None) -> torch.Tensor:
+    """q (S, nh*d); k, v (L, kvh*d) token-major, L = kv_offset + S when causal -> o (S, nh*d)."""
+    _chk(q, k, v)
+    S, L = q.shape[0], k.shape[0]
+    scale = bf16_scale(d) if scale is None else scale
+    o = torch.empty(S, nh * d, dtype=torch.bfloat16, device=q.device)
+    check(lib().aha_hip_attn_prefill(_ptr(q), _ptr(k), _ptr(v), _ptr(o), S, L, nh, kvh, d, kv_offset, int(causal),
+                                     scale, _stream()))
+    return o
+
+
+def argmax(x: torch.Tensor) -> int:
+    _chk(x)
+    assert x.dtype == torch.float32
+    out = torch.zeros(1, dtype=torch.int32, device=x.device)
+    check(lib().aha_hip_argmax(_ptr(x), x.numel(), _ptr(out), _stream()))
+    return int(out.item()) & 0xFFFFFFFF
+
+
+def bf16_scale(d: int) -> float:
+    """1/sqrt(d) rounded to bf16: the scalar of Candle's `attn_weights * scaling` affine op is cast to the tensor dtype."""
+    return float(torch.tensor(1.0 / math.sqrt(d), dtype=torch.float32).bfloat16().float())

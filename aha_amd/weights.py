@@ -1,0 +1,93 @@
+"""Synthetic checkpoints with the exact tensor names the reference looks up.
+
+Names follow SURVEY.md Appendix C:
+  * Qwen3      -- /root/reference/src/models/qwen3/model.rs:104-134, common/modules.rs:482-513,66-71
+  * Qwen3-VL   -- /root/reference/src/models/qwen3vl/model.rs:847-870 (visual.*, language_model.*, lm_head)
+Distribution is BASELINE.md section 4: N(0, 0.02^2) matrices/embeddings/biases, norm weights 1 + N(0, 0.02^2),
+stored bf16.  There is no network, hence no real checkpoint; shapes are those of the named architecture.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from .configs import Qwen3Config, Qwen3VLConfig
+
+
+def _randn(gen, shape, std=0.02, mean=0.0, dtype=torch.bfloat16):
+    t = torch.empty(shape, dtype=torch.float32)
+    t.normal_(mean, std, generator=gen)
+    return t.to(dtype)
+
+
+def qwen3_text_weights(cfg: Qwen3Config, seed: int = 0, prefix: str = "model.",
+                       lm_head_name: str = "lm_head.weight", dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+    gen = torch.Generator().manual_seed(seed)
+    w: Dict[str, torch.Tensor] = {}
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    w[f"{prefix}embed_tokens.weight"] = _randn(gen, (cfg.vocab_size, H), dtype=dtype)
+    for i in range(cfg.num_hidden_layers):
+        p = f"{prefix}layers.{i}."
+        w[p + "input_layernorm.weight"] = _randn(gen, (H,), mean=1.0, dtype=dtype)
+        w[p + "self_attn.q_proj.weight"] = _randn(gen, (cfg.q_dim, H), dtype=dtype)
+        w[p + "self_attn.k_proj.weight"] = _randn(gen, (cfg.kv_dim, H), dtype=dtype)
+        w[p + "self_attn.v_proj.weight"] = _randn(gen, (cfg.kv_dim, H), dtype=dtype)
+        w[p + "self_attn.o_proj.weight"] = _randn(gen, (H, cfg.q_dim), dtype=dtype)
+        w[p + "self_attn.q_norm.weight"] = _randn(gen, (cfg.head_dim,), mean=1.0, dtype=dtype)
+        w[p + "self_attn.k_norm.weight"] = _randn(gen, (cfg.head_dim,), mean=1.0, dtype=dtype)
+        w[p + "post_attention_layernorm.weight"] = _randn(gen, (H,), mean=1.0, dtype=dtype)
+        w[p + "mlp.gate_proj.weight"] = _randn(gen, (I, H), dtype=dtype)
+        w[p + "mlp.up_proj.weight"] = _randn(gen, (I, H), dtype=dtype)
+        w[p + "mlp.down_proj.weight"] = _randn(gen, (H, I), dtype=dtype)
+    w[f"{prefix}norm.weight"] = _randn(gen, (H,), mean=1.0, dtype=dtype)
+    if not cfg.tie_word_embeddings:
+        w[lm_head_name] = _randn(gen, (cfg.vocab_size, H), dtype=dtype)
+    return w
+
+
+def qwen3vl_vision_weights(cfg: Qwen3VLConfig, seed: int = 100, prefix: str = "model.visual.",
+                           dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+    v = cfg.vision
+    gen = torch.Generator().manual_seed(seed)
+    w: Dict[str, torch.Tensor] = {}
+    D = v.hidden_size
+    w[prefix + "patch_embed.proj.weight"] = _randn(
+        gen, (D, v.in_channels, v.temporal_patch_size, v.patch_size, v.patch_size), dtype=dtype)
+    w[prefix + "patch_embed.proj.bias"] = _randn(gen, (D,), dtype=dtype)
+    w[prefix + "pos_embed.weight"] = _randn(gen, (v.num_position_embeddings, D), dtype=dtype)
+    for i in range(v.depth):
+        p = f"{prefix}blocks.{i}."
+        for n in ("norm1", "norm2"):
+            w[p + n + ".weight"] = _randn(gen, (D,), mean=1.0, dtype=dtype)
+            w[p + n + ".bias"] = _randn(gen, (D,), dtype=dtype)
+        w[p + "attn.qkv.weight"] = _randn(gen, (3 * D, D), dtype=dtype)
+        w[p + "attn.qkv.bias"] = _randn(gen, (3 * D,), dtype=dtype)
+        w[p + "attn.proj.weight"] = _randn(gen, (D, D), dtype=dtype)
+        w[p + "attn.proj.bias"] = _randn(gen, (D,), dtype=dtype)
+        w[p + "mlp.linear_fc1.weight"] = _randn(gen, (v.intermediate_size, D), dtype=dtype)
+        w[p + "mlp.linear_fc1.bias"] = _randn(gen, (v.intermediate_size,), dtype=dtype)
+        w[p + "mlp.linear_fc2.weight"] = _randn(gen, (D, v.intermediate_size), dtype=dtype)
+        w[p + "mlp.linear_fc2.bias"] = _randn(gen, (D,), dtype=dtype)
+    M = D * v.spatial_merge_size ** 2
+
+    def merger(p, postshuffle):
+        nd = M if postshuffle else D
+        w[p + "norm.weight"] = _randn(gen, (nd,), mean=1.0, dtype=dtype)
+        w[p + "norm.bias"] = _randn(gen, (nd,), dtype=dtype)
+        w[p + "linear_fc1.weight"] = _randn(gen, (M, M), dtype=dtype)
+        w[p + "linear_fc1.bias"] = _randn(gen, (M,), dtype=dtype)
+        w[p + "linear_fc2.weight"] = _randn(gen, (v.out_hidden_size, M), dtype=dtype)
+        w[p + "linear_fc2.bias"] = _randn(gen, (v.out_hidden_size,), dtype=dtype)
+
+    merger(prefix + "merger.", False)
+    for k in range(len(v.deepstack_visual_indexes)):
+        merger(f"{prefix}deepstack_merger_list.{k}.", True)
+    return w
+
+
+def qwen3vl_weights(cfg: Qwen3VLConfig, seed: int = 0, dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+    w = qwen3_text_weights(cfg.text, seed=seed, prefix="model.language_model.",
+                           lm_head_name="lm_head.weight", dtype=dtype)
+    w.update(qwen3vl_vision_weights(cfg, seed=seed + 100, dtype=dtype))
+    return w

@@ -1,0 +1,163 @@
+/* aha_hip.h -- C ABI of the MI355X-native backend for aha's Qwen3 / Qwen3-VL hot path.
+ *
+ * The reference (jhqxxx/aha v0.2.6) has no FFI or backend trait; its only seam for this path is the Rust trait
+ *   InferenceModel { forward_initial, forward_step, clear_cache, stop_token_ids }
+ *     -- /root/reference/src/models/common/mod.rs:25-45
+ * driven by generate_generic -- /root/reference/src/models/common/generate.rs:115-159.
+ * The model-level entry points below are exactly what a Rust `impl InferenceModel for HipQwen3` would bind
+ * (INTEGRATION.md shows the shim).  The op-level entry points exist for unit parity tests of each kernel against
+ * the oracle; they take DEVICE pointers and a hipStream_t (passed as void*).
+ *
+ * Conventions: every function returns 0 on success or a negative aha_status; the message of the last error on the
+ * calling thread is available from aha_hip_last_error().  The library never aborts and never throws across the ABI.
+ * Handles are NOT thread-safe (same contract as the reference: `&mut self`, server holds a write lock per request,
+ * /root/reference/src/server/api.rs:117).  Host buffers passed in stay owned by the caller; weights are copied to HBM.
+ */
+#ifndef AHA_HIP_H
+#define AHA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct aha_ctx aha_ctx;
+typedef struct aha_model aha_model;
+
+enum aha_status {
+  AHA_OK = 0,
+  AHA_ERR_INVALID = -1,        /* bad argument / null handle */
+  AHA_ERR_HIP = -2,            /* a HIP runtime call failed */
+  AHA_ERR_OOM = -3,
+  AHA_ERR_SHAPE = -4,          /* tensor shape does not match the model description */
+  AHA_ERR_MISSING_WEIGHT = -5, /* a tensor name the reference looks up is absent */
+  AHA_ERR_UNSUPPORTED = -6,
+  AHA_ERR_STATE = -7           /* e.g. seqlen_offset does not equal the current cache length */
+};
+
+enum aha_dtype { AHA_BF16 = 0, AHA_F16 = 1, AHA_F32 = 2, AHA_U32 = 3, AHA_U8 = 4 };
+enum aha_arch { AHA_ARCH_QWEN3 = 0, AHA_ARCH_QWEN3VL = 1 };
+
+/* Mirrors Qwen3Config (/root/reference/src/models/qwen3/config.rs:4-27), Qwen3VLTextConfig / Qwen3VLVisionConfig /
+ * Qwen3VLConfig (/root/reference/src/models/qwen3vl/config.rs:59-133).  Vision fields are ignored for AHA_ARCH_QWEN3. */
+typedef struct aha_model_desc {
+  int32_t arch;
+  int32_t hidden_size, intermediate_size, num_hidden_layers;
+  int32_t num_attention_heads, num_key_value_heads, head_dim, vocab_size;
+  float rms_norm_eps, rope_theta;
+  int32_t tie_word_embeddings;
+  int32_t mrope_section[3];        /* {0,0,0} => plain 1-D RoPE (rope.rs:583-612); else interleaved M-RoPE (rope.rs:454-476) */
+  /* vision tower (Qwen3VLVisionConfig) */
+  int32_t vis_depth, vis_hidden_size, vis_num_heads, vis_intermediate_size, vis_in_channels, vis_patch_size,
+      vis_temporal_patch_size, vis_spatial_merge_size, vis_out_hidden_size, vis_num_position_embeddings;
+  int32_t vis_deepstack_indexes[8];
+  int32_t vis_num_deepstack;
+  /* token ids (Qwen3VLConfig) */
+  int32_t image_token_id, video_token_id, vision_start_token_id, vision_end_token_id;
+  /* KV-cache sizing hint (tokens).  The cache is paged and grows on demand; this only pre-reserves pages. */
+  int32_t kv_reserve_tokens;
+  int32_t n_stop_tokens;
+  uint32_t stop_tokens[8];         /* generation_config.json eos_token_id list (qwen3/generate.rs:36-43) */
+} aha_model_desc;
+
+/* One checkpoint tensor: HF name, host pointer (e.g. into an mmapped safetensors file), dtype, shape. */
+typedef struct aha_tensor_view {
+  const char* name;
+  const void* data;
+  int32_t dtype;
+  int32_t ndim;
+  int64_t shape[5];
+} aha_tensor_view;
+
+/* MultiModalData for Qwen3-VL (/root/reference/src/models/qwen3vl/generate.rs:79-101: data_vec =
+ * [pixel_values, image_grid_thw, None, None, cache_position]).  pixel_values is the processor output
+ * (N_patches, C*T*P*P) in merge-window row order (/root/reference/src/models/qwen3vl/processor.rs:174-227). */
+typedef struct aha_mm_input {
+  const void* pixel_values;     /* host, (n_patches, patch_dim) */
+  int32_t pixel_dtype;          /* AHA_BF16 or AHA_F32 */
+  int64_t n_patches;
+  const uint32_t* image_grid_thw; /* host, (n_images, 3) */
+  int32_t n_images;
+} aha_mm_input;
+
+/* ---- lifecycle ---------------------------------------------------------------------------------------------- */
+int aha_hip_init(int device, aha_ctx** out);
+void aha_hip_shutdown(aha_ctx* ctx);
+const char* aha_hip_last_error(void);
+const char* aha_hip_version(void);
+
+/* Replaces XxxGenerateModel::init's VarBuilder::from_mmaped_safetensors + Qwen3Model::new
+ * (/root/reference/src/models/qwen3/generate.rs:22-50, qwen3/model.rs:104-134). */
+int aha_hip_model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view* weights, size_t n_weights,
+                         aha_model** out);
+void aha_hip_model_destroy(aha_model* m);
+
+/* ---- InferenceModel (common/mod.rs:25-45) ------------------------------------------------------------------- */
+/* forward_initial(&mut self, input_ids, seqlen_offset, data) -> logits (1,1,V).
+ * logits_out (V floats, host, may be NULL) receives the last position's logits as f32 exactly as the generic loop
+ * reads them (generate.rs:75).  argmax_out (may be NULL) receives the first maximal index (Sampling::ArgMax). */
+int aha_hip_forward_initial(aha_model* m, const uint32_t* input_ids, size_t n_ids, size_t seqlen_offset,
+                            const aha_mm_input* mm, float* logits_out, uint32_t* argmax_out);
+/* forward_step(&mut self, input_ids (1,1), seqlen_offset) -> logits (1,1,V). */
+int aha_hip_forward_step(aha_model* m, uint32_t token, size_t seqlen_offset, float* logits_out, uint32_t* argmax_out);
+/* clear_cache(&mut self) */
+int aha_hip_clear_cache(aha_model* m);
+/* stop_token_ids(&self) -> Vec<u32>: writes up to cap ids, returns the count (>=0) or a negative status. */
+int aha_hip_stop_token_ids(const aha_model* m, uint32_t* out, size_t cap);
+
+/* Extension (not in the reference): device-resident greedy loop = generate_generic with temperature 0
+ * (generate.rs:115-159) without a host round trip per token.  Must follow a forward_initial/forward_step call;
+ * first_token is the token sampled from that call.  Writes up to max_new tokens; stops after an eos id.
+ * Returns the number of tokens written or a negative status. */
+int aha_hip_decode_greedy(aha_model* m, uint32_t first_token, size_t seqlen_offset, size_t max_new, uint32_t* tokens_out);
+
+/* ---- introspection used by bench.py / tests ------------------------------------------------------------------ */
+size_t aha_hip_cache_len(const aha_model* m);
+/* Per-kernel-class HIP-event timing of subsequent forward calls (adds one event pair per launch).  0 = off. */
+int aha_hip_set_profiling(aha_model* m, int enable);
+/* name: e.g. "gemv", "gemm", "attn_decode", "attn_prefill".  Returns accumulated ms and launch count since enable. */
+int aha_hip_get_profile(aha_model* m, const char* kernel_class, double* total_ms, int64_t* launches, double* bytes,
+                        double* flops);
+/* Debug knob for the paged-KV property tests: 1 => hand out physical pages in a scrambled order. */
+int aha_hip_debug_scramble_pages(aha_model* m, int enable);
+/* Copies the last hidden state before lm_head (hidden_size floats) / the image embeddings of the last
+ * forward_initial (rows x out_hidden floats) to the host, for parity tests of intermediate tensors. */
+int aha_hip_debug_last_hidden(aha_model* m, float* out, size_t n);
+int aha_hip_debug_image_embeds(aha_model* m, int which /*0=merged, 1..=deepstack k*/, float* out, size_t n);
+
+/* ---- op-level entry points (device pointers; stream = hipStream_t as void*, NULL = default stream) ---------- */
+/* D3: y = x / sqrt(mean(x^2)+eps) * w over the last dim (qwen3/model.rs:79,83,186; modules.rs:512-513). bf16. */
+int aha_hip_rmsnorm(const void* x, const void* w, void* y, int64_t rows, int32_t dim, float eps, void* stream);
+/* D4/D8 decode: y[n] = sum_k x[k] W[n,k]  (candle_nn::Linear, batch 1).  W (N,K) bf16 row-major, x (K) bf16.
+ * norm_w != NULL fuses y = Linear(RMSNorm(x; norm_w, eps)); residual != NULL fuses y = residual + Linear(..). */
+int aha_hip_gemv(const void* W, const void* x, void* y, int32_t N, int32_t K, const void* norm_w, float eps,
+                 const void* residual, void* stream);
+/* D8 decode: y[j] = silu(gate_j . h) * (up_j . h), h = RMSNorm(x) if norm_w else x.  Wg, Wu (I,K) bf16. */
+int aha_hip_gemv_gate_up(const void* Wg, const void* Wu, const void* x, void* y, int32_t I, int32_t K,
+                         const void* norm_w, float eps, void* stream);
+/* D4/D8/V1 prefill: C[M,N] = A[M,K] . W[N,K]^T (+bias[N]) (+residual[M,N]); bf16 in/out, f32 accumulate (MFMA).
+ * act: 0 none, 1 gelu_pytorch_tanh, 2 gelu (erf), 3 silu. lda/ldw/ldc in elements. K % 32 == 0. */
+int aha_hip_gemm(const void* A, const void* W, void* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw,
+                 int32_t ldc, const void* bias, const void* residual, int32_t act, void* stream);
+/* D5/M1: q/k RMSNorm over head_dim + rotary embedding (rope.rs:96-132) on a fused qkv activation (S, (nh+2kvh)*d).
+ * pos: int32 (3,S) rows T,H,W (all equal for 1-D RoPE).  axis_map: int32[d/2], frequency slot -> row of pos.
+ * Writes q_out (S, nh*d) and k_out / v_out (S, kvh*d) contiguous (op-level variant without the paged cache). */
+int aha_hip_qknorm_rope(const void* qkv, const void* q_norm_w, const void* k_norm_w, const int32_t* pos,
+                        const int32_t* axis_map, void* q_out, void* k_out, void* v_out, int32_t S, int32_t nh,
+                        int32_t kvh, int32_t d, float eps, float theta, void* stream);
+/* D6/D7 decode attention over a contiguous (kvh, L, d) K/V (op-level variant): o (nh*d) bf16. */
+int aha_hip_attn_decode(const void* q, const void* k, const void* v, void* o, int32_t nh, int32_t kvh, int32_t d,
+                        int32_t L, float scale, void* stream);
+/* D7 prefill attention, causal with q position i attending to k positions <= kv_offset + i; q (S, nh*d),
+ * k/v (L, kvh*d) token-major, L = kv_offset + S.  causal = 0 gives full (ViT) attention. */
+int aha_hip_attn_prefill(const void* q, const void* k, const void* v, void* o, int32_t S, int32_t L, int32_t nh,
+                         int32_t kvh, int32_t d, int32_t kv_offset, int32_t causal, float scale, void* stream);
+/* D11 greedy: first maximal index of an f32 vector. */
+int aha_hip_argmax(const float* x, int64_t n, uint32_t* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AHA_HIP_H */

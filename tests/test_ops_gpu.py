@@ -1,0 +1,235 @@
+"""-m gpu: every HIP kernel family against the oracle restatement on the same seeded inputs (through the C ABI).
+
+Tolerances (bf16 model dtype): a HIP op may differ from the oracle's op-granular bf16 result by at most a few bf16
+ulps of the output (f32 accumulation order, f32 vs bf16-rounded softmax probabilities); each test states its bound.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qwen3 as oq
+from oracle.numerics import Numerics
+
+pytestmark = pytest.mark.gpu
+NM = Numerics("bf16")
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rnd(shape, seed, std=1.0, mean=0.0):
+    g = torch.Generator().manual_seed(seed)
+    return bf(torch.randn(shape, generator=g) * std + mean)
+
+
+def ulp_bf16(x):
+    """bf16 ulp at |x| (f32 tensor)."""
+    e = torch.floor(torch.log2(x.abs().clamp_min(1e-30)))
+    return torch.pow(2.0, e - 7)
+
+
+def assert_close_ulps(got, ref, ulps, frac_exact=None, what=""):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    tol = ulps * ulp_bf16(ref).clamp_min(2.0 ** -24)
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} elements off by more than {ulps} bf16 ulp; max diff {float((got-ref).abs().max())}"
+    if frac_exact is not None:
+        fe = float((got == ref).float().mean())
+        assert fe >= frac_exact, f"{what}: only {fe:.4f} of elements bit-identical (< {frac_exact})"
+
+
+@pytest.mark.parametrize("rows,dim", [(1, 1024), (7, 4096), (33, 512), (5, 128), (3, 1152)])
+def test_rmsnorm(gpu, rows, dim):
+    from aha_amd import ops
+    x, w = rnd((rows, dim), 1), rnd((dim,), 2, 0.02, 1.0)
+    ref = oq.rms_norm(NM, x.float(), w.float(), 1e-6)
+    got = ops.rmsnorm(x.to(gpu), w.to(gpu), 1e-6)
+    assert_close_ulps(got, ref, 1, 0.99, "rmsnorm")
+
+
+@pytest.mark.parametrize("N,K", [(4096, 1024), (1024, 3072), (6144, 4096), (4096, 12288), (1000, 512), (152, 264)])
+@pytest.mark.parametrize("fuse_norm,residual", [(False, False), (True, False), (False, True)])
+def test_gemv(gpu, N, K, fuse_norm, residual):
+    from aha_amd import ops
+    W, x = rnd((N, K), 3, 0.02), rnd((K,), 4)
+    nw = rnd((K,), 5, 0.02, 1.0) if fuse_norm else None
+    res = rnd((N,), 6) if residual else None
+    h = oq.rms_norm(NM, x.float(), nw.float(), 1e-6) if fuse_norm else x.float()
+    ref = NM.linear(h[None], W.float())[0]
+    if residual:
+        ref = NM.r(res.float() + ref)
+    got = ops.gemv(W.to(gpu), x.to(gpu), None if nw is None else nw.to(gpu), 1e-6, None if res is None else res.to(gpu))
+    assert_close_ulps(got, ref, 1, 0.98, "gemv")
+
+
+@pytest.mark.parametrize("I,K", [(3072, 1024), (12288, 4096), (1024, 512)])
+def test_gemv_gate_up(gpu, I, K):
+    from aha_amd import ops
+    Wg, Wu, x, nw = rnd((I, K), 7, 0.02), rnd((I, K), 8, 0.02), rnd((K,), 9), rnd((K,), 10, 0.02, 1.0)
+    h = oq.rms_norm(NM, x.float(), nw.float(), 1e-6)
+    lhs = NM.r(oq.silu(NM.linear(h[None], Wg.float())))
+    ref = NM.r(lhs * NM.linear(h[None], Wu.float()))[0]
+    got = ops.gemv_gate_up(Wg.to(gpu), Wu.to(gpu), x.to(gpu), nw.to(gpu), 1e-6)
+    assert_close_ulps(got, ref, 2, 0.97, "gemv_gate_up")
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 384, 1024), (1542, 512, 4096), (37, 1152, 1536), (64, 4352, 1152), (65, 136, 72)])
+def test_gemm_plain(gpu, M, N, K):
+    from aha_amd import ops
+    A, W = rnd((M, K), 11), rnd((N, K), 12, 0.02)
+    ref = NM.linear(A.float(), W.float())
+    got = ops.gemm(A.to(gpu), W.to(gpu))
+    assert_close_ulps(got, ref, 1, 0.98, "gemm")
+
+
+def test_gemm_transpose_detect(gpu):
+    """A = I against an asymmetric W: catches swapped C rows/cols (cdna guide: always A=I-check with asymmetric B)."""
+    from aha_amd import ops
+    K = 128
+    A = bf(torch.eye(K))
+    W = bf(torch.arange(192 * K, dtype=torch.float32).reshape(192, K) % 251 - 100.0)
+    got = ops.gemm(A.to(gpu), W.to(gpu)).float().cpu()
+    assert torch.equal(got, W.float().t())
+
+
+@pytest.mark.parametrize("act", ["gelu_tanh", "gelu_erf", "silu", "none"])
+def test_gemm_bias_act_residual(gpu, act):
+    from aha_amd import ops, _lib
+    M, N, K = 150, 640, 1152
+    A, W, b, res = rnd((M, K), 13), rnd((N, K), 14, 0.02), rnd((N,), 15, 0.5), rnd((M, N), 16)
+    y = NM.linear(A.float(), W.float(), b.float())
+    if act == "gelu_tanh":
+        y = NM.r(torch.nn.functional.gelu(y, approximate="tanh")); code = _lib.ACT_GELU_TANH
+    elif act == "gelu_erf":
+        y = NM.r(torch.nn.functional.gelu(y)); code = _lib.ACT_GELU_ERF
+    elif act == "silu":
+        y = NM.r(oq.silu(y)); code = _lib.ACT_SILU
+    else:
+        code = _lib.ACT_NONE
+    ref = NM.r(res.float() + y)
+    got = ops.gemm(A.to(gpu), W.to(gpu), b.to(gpu), res.to(gpu), code)
+    assert_close_ulps(got, ref, 2, 0.97, f"gemm+bias+{act}+res")
+
+
+def test_gemm_gate_up_pairs(gpu):
+    from aha_amd import ops, _lib
+    M, I, K = 130, 1024, 512
+    A, Wg, Wu = rnd((M, K), 17), rnd((I, K), 18, 0.05), rnd((I, K), 19, 0.05)
+    lhs = NM.r(oq.silu(NM.linear(A.float(), Wg.float())))
+    ref = NM.r(lhs * NM.linear(A.float(), Wu.float()))
+    Wf = ops.interleave_gate_up(Wg, Wu)
+    got = ops.gemm(A.to(gpu), Wf.to(gpu), act=_lib.ACT_SILU_MUL_PAIRS)
+    assert got.shape == (M, I)
+    assert_close_ulps(got, ref, 2, 0.97, "gemm gate/up pairs")
+
+
+def _rope_ref(qkv, qw, kw, pos, axis_map, nh, kvh, d, eps, theta):
+    S = qkv.shape[0]
+    q = qkv[:, : nh * d].float().reshape(1, S, nh, d)
+    k = qkv[:, nh * d: (nh + kvh) * d].float().reshape(1, S, kvh, d)
+    v = qkv[:, (nh + kvh) * d:]
+    q = oq.rms_norm(NM, q, qw.float(), eps).transpose(1, 2)
+    k = oq.rms_norm(NM, k, kw.float(), eps).transpose(1, 2)
+    inv = oq.compute_default_rope_parameters(d, theta)
+    p = pos.float()  # (3,S)
+    fr = p[:, :, None] * inv[None, None, :]           # (3,S,d/2)
+    g = torch.gather(fr, 0, axis_map.long()[None, None, :].expand(1, S, d // 2))[0]
+    emb = torch.cat([g, g], -1)
+    q, k = oq.apply_rotary_pos_emb(NM, q, k, emb.cos()[None], emb.sin()[None])
+    return q.transpose(1, 2).reshape(S, nh * d), k.transpose(1, 2).reshape(S, kvh * d), v
+
+
+@pytest.mark.parametrize("mrope", [False, True])
+def test_qknorm_rope(gpu, mrope):
+    from aha_amd import ops
+    S, nh, kvh, d, theta = 77, 4, 2, 128, 1e6
+    qkv = rnd((S, (nh + 2 * kvh) * d), 20)
+    qw, kw = rnd((d,), 21, 0.02, 1.0), rnd((d,), 22, 0.02, 1.0)
+    g = torch.Generator().manual_seed(23)
+    if mrope:
+        pos = torch.randint(0, 5000, (3, S), generator=g, dtype=torch.int32)
+        axis = torch.zeros(d // 2, dtype=torch.int32)
+        for i in range(d // 2):
+            if i % 3 == 1 and i < 60: axis[i] = 1
+            if i % 3 == 2 and i < 60: axis[i] = 2
+    else:
+        pos = (torch.arange(S, dtype=torch.int32) + 1234)[None].repeat(3, 1).contiguous()
+        axis = torch.zeros(d // 2, dtype=torch.int32)
+    rq, rk, rv = _rope_ref(qkv, qw, kw, pos, axis, nh, kvh, d, 1e-6, theta)
+    q, k, v = ops.qknorm_rope(qkv.to(gpu), qw.to(gpu), kw.to(gpu), pos.to(gpu), axis.to(gpu), nh, kvh, d, 1e-6, theta)
+    assert torch.equal(v.cpu(), rv), "v must pass through bit-exact"
+    # cos/sin of f32 angles up to ~5e3 rad: device sinf/cosf vs torch differ by <= 1 ulp f32 -> rare bf16 flips
+    assert_close_ulps(q, rq, 2, 0.97, "q rope")
+    assert_close_ulps(k, rk, 2, 0.97, "k rope")
+
+
+def _attn_ref(q, k, v, nh, kvh, d, causal, kv_offset):
+    S, L = q.shape[0], k.shape[0]
+    qq = q.float().reshape(1, S, nh, d).transpose(1, 2)
+    kk = k.float().reshape(1, L, kvh, d).transpose(1, 2)
+    vv = v.float().reshape(1, L, kvh, d).transpose(1, 2)
+    mask = None
+    if causal:
+        i = torch.arange(S)[:, None] + kv_offset
+        j = torch.arange(L)[None, :]
+        mask = torch.zeros(S, L).masked_fill(j > i, float("-inf"))[None, None]
+    o = oq.eager_attention_forward(NM, qq, kk, vv, nh // kvh, mask, oq.attn_scale(NM, d))
+    return o.reshape(S, nh * d)
+
+
+@pytest.mark.parametrize("L", [1, 63, 64, 65, 200, 1000, 4133])
+@pytest.mark.parametrize("nh,kvh", [(16, 8), (32, 8), (4, 4)])
+def test_attn_decode(gpu, L, nh, kvh):
+    from aha_amd import ops
+    d = 128
+    q, k, v = rnd((1, nh * d), 30), rnd((L, kvh * d), 31), rnd((L, kvh * d), 32)
+    ref = _attn_ref(q, k, v, nh, kvh, d, False, 0)[0]
+    got = ops.attn_decode(q[0].contiguous().to(gpu), k.to(gpu), v.to(gpu), nh, kvh, d)
+    # unrounded-f32 P vs the oracle's bf16-rounded P: <= 1 ulp of the output plus accumulation order
+    assert_close_ulps(got, ref, 3, None, "attn_decode")
+    assert float((got.float().cpu() - ref).abs().max()) < 0.02
+
+
+def test_attn_decode_peaky(gpu):
+    """Forces large score spreads (online-softmax rescale path) -- one key dominates late in the sequence."""
+    from aha_amd import ops
+    nh, kvh, d, L = 8, 2, 128, 700
+    q, k, v = rnd((1, nh * d), 33), rnd((L, kvh * d), 34, 0.3), rnd((L, kvh * d), 35)
+    k[650] = (q[0, :d] * 2.0).repeat(kvh)  # spike for head 0 (and correlated for others) in a late page
+    ref = _attn_ref(q, k, v, nh, kvh, d, False, 0)[0]
+    got = ops.attn_decode(q[0].contiguous().to(gpu), k.to(gpu), v.to(gpu), nh, kvh, d)
+    assert_close_ulps(got, ref, 3, None, "attn_decode peaky")
+
+
+@pytest.mark.parametrize("S,off", [(1, 0), (5, 0), (64, 0), (65, 0), (130, 0), (300, 0), (17, 100), (64, 64), (100, 333)])
+@pytest.mark.parametrize("nh,kvh", [(4, 2), (8, 2)])
+def test_attn_prefill_causal(gpu, S, off, nh, kvh):
+    from aha_amd import ops
+    d, L = 128, S + off
+    q, k, v = rnd((S, nh * d), 40), rnd((L, kvh * d), 41), rnd((L, kvh * d), 42)
+    ref = _attn_ref(q, k, v, nh, kvh, d, True, off)
+    got = ops.attn_prefill(q.to(gpu), k.to(gpu), v.to(gpu), nh, kvh, d, off, True)
+    assert_close_ulps(got, ref, 3, None, "attn_prefill")
+
+
+def test_attn_prefill_full(gpu):
+    from aha_amd import ops
+    S, nh, kvh, d = 150, 4, 4, 128
+    q, k, v = rnd((S, nh * d), 43), rnd((S, kvh * d), 44), rnd((S, kvh * d), 45)
+    ref = _attn_ref(q, k, v, nh, kvh, d, False, 0)
+    got = ops.attn_prefill(q.to(gpu), k.to(gpu), v.to(gpu), nh, kvh, d, 0, False)
+    assert_close_ulps(got, ref, 3, None, "attn_prefill full")
+
+
+def test_argmax_first_max(gpu):
+    from aha_amd import ops
+    x = torch.randn(151936, generator=torch.Generator().manual_seed(50))
+    x[77777] = 9.0
+    x[1234] = 9.0     # tie -> first index wins (candle argmax / Sampling::ArgMax)
+    assert ops.argmax(x.to(gpu)) == 1234
+    x2 = torch.full((5000,), -3.0)
+    assert ops.argmax(x2.to(gpu)) == 0
