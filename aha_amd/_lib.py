@@ -40,7 +40,7 @@ class ModelDesc(C.Structure):
 
 class TensorView(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("dtype", C.c_int32), ("ndim", C.c_int32),
-                ("shape", C.c_int64 * 5)]
+                ("shape", C.c_int64 * 5), ("on_device", C.c_int32)]
 
 
 class MmInput(C.Structure):

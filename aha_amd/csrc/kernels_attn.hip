@@ -236,18 +236,51 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
 }
 
 // merge the per-unit partials: o = sum_u e^{m_u - M} o_u / sum_u e^{m_u - M} l_u  -> bf16 (the P.V matmul output tensor)
+// One block per head; nunits <= 256.  The per-unit weights e^{m_u - M} are computed once (one unit per thread) and
+// shared through LDS; the weighted sum over units then runs 8 independent loads deep per thread.
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnDecodeArgs a, int nunits) {
-  const int head = blockIdx.x, d = threadIdx.x;
-  float M = -INFINITY;
-  for (int u = 0; u < nunits; ++u) M = fmaxf(M, a.part_ml[((int64_t)u * a.nh + head) * 2]);
-  float acc = 0.f, lsum = 0.f;
-  for (int u = 0; u < nunits; ++u) {
-    const float mu = a.part_ml[((int64_t)u * a.nh + head) * 2];
-    if (mu == -INFINITY) continue;
-    const float w = __expf(mu - M);
-    acc += w * a.part_o[((int64_t)u * a.nh + head) * 128 + d];
-    lsum += w * a.part_ml[((int64_t)u * a.nh + head) * 2 + 1];
+  __shared__ float sw[256];
+  __shared__ float red[4];
+  const int head = blockIdx.x, d = threadIdx.x, lane = d & 63, wave = d >> 6;
+  float mu[2], lu[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int u = d + i * 128;
+    mu[i] = -INFINITY;
+    lu[i] = 0.f;
+    if (u < nunits) {
+      const float2 ml = *reinterpret_cast<const float2*>(a.part_ml + ((int64_t)u * a.nh + head) * 2);
+      mu[i] = ml.x;
+      lu[i] = ml.y;
+    }
   }
+  float M = wave_max(fmaxf(mu[0], mu[1]));
+  if (lane == 0) red[wave] = M;
+  __syncthreads();
+  M = fmaxf(red[0], red[1]);
+  float lsum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float w = (mu[i] == -INFINITY) ? 0.f : __expf(mu[i] - M);
+    sw[d + i * 128] = w;
+    lsum += w * lu[i];
+  }
+  lsum = wave_sum(lsum);
+  if (lane == 0) red[2 + wave] = lsum;
+  __syncthreads();
+  lsum = red[2] + red[3];
+  const float* po = a.part_o + (int64_t)head * 128 + d;
+  const int64_t ustride = (int64_t)a.nh * 128;
+  float acc = 0.f;
+  int u = 0;
+  for (; u + 8 <= nunits; u += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = po[(u + j) * ustride];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += sw[u + j] * v[j];
+  }
+  for (; u < nunits; ++u) acc += sw[u] * po[u * ustride];
   ((bf16_t*)a.o)[head * 128 + d] = f2bf(acc / lsum);
 }
 

@@ -37,6 +37,52 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a) {
   const int nchunks = (K + 511) >> 9;  // K % 8 == 0; the tail of the last chunk is zero-filled
   float* red = xs + (nchunks << 9);
 
+  // ---- flattened work list: this block's tiles x the chunk groups of a tile ---------------------------------------
+  constexpr int ROWS_PER_TILE = GEMV_WAVES * R;
+  constexpr int NW = (EPI == GEMV_SILU_MUL) ? 2 : 1;
+  const int n_out = N;  // for SILU_MUL a "row" runs over the I outputs; the wave streams gate row j and up row j together
+  const int ntiles = (n_out + ROWS_PER_TILE - 1) / ROWS_PER_TILE;
+  const int gpt = (nchunks + U - 1) / U;                                  // chunk groups per tile
+  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int ngroups = my_tiles * gpt;
+  const bf16_t* Wb = (const bf16_t*)a.W;
+  const bf16_t* W2b = (const bf16_t*)a.W2;
+
+  // issue the R*U*NW 16-byte loads of work item gi (no dependence on x: they go out BEFORE the prologue)
+  auto issue = [&](int gi, u32x4_t (&buf)[U][NW][R]) {
+    const int tile = blockIdx.x + (gi / gpt) * gridDim.x;
+    const int c0 = (gi % gpt) * U;
+    const int row0 = tile * ROWS_PER_TILE + wave * R;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = min(row0 + r, n_out - 1);  // clamp: out-of-range rows are computed but never stored
+      const bf16_t* p0;
+      const bf16_t* p1 = nullptr;
+      if (NW == 2) {
+        if (W2b != nullptr) {  // separate gate / up matrices (op-level entry point)
+          p0 = Wb + (size_t)row * K;
+          p1 = W2b + (size_t)row * K;
+        } else {  // the model's fused matrix: 16-row blocks alternating gate / up
+          const size_t fr = (size_t)(row >> 4) * 32 + (row & 15);
+          p0 = Wb + fr * K;
+          p1 = Wb + (fr + 16) * K;
+        }
+      } else {
+        p0 = Wb + (size_t)row * K;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = ((c0 + u) << 9) + lane * 8;
+        const bool ok = (c0 + u < nchunks) && (k < K);
+        buf[u][0][r] = ok ? ld_nt16(p0 + k) : u32x4_t{0u, 0u, 0u, 0u};
+        if (NW == 2) buf[u][NW - 1][r] = ok ? ld_nt16(p1 + k) : u32x4_t{0u, 0u, 0u, 0u};
+      }
+    }
+  };
+
+  u32x4_t bufA[U][NW][R], bufB[U][NW][R];
+  if (ngroups > 0) issue(0, bufA);
+
   // ---- prologue: h = x, or h = bf16(RMSNorm(x) * norm_w) (qwen3/model.rs:79,83,186) ------------------------
   {
     const bf16_t* x = (const bf16_t*)a.x;
@@ -80,77 +126,44 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a) {
     __syncthreads();
   }
 
-  // ---- main: grid-stride over tiles of GEMV_WAVES*R rows -----------------------------------------------------
-  constexpr int ROWS_PER_TILE = GEMV_WAVES * R;
-  // for SILU_MUL a "row" index runs over the I outputs; the wave streams gate row j and up row j together
-  const int n_out = N;
-  const int ntiles = (n_out + ROWS_PER_TILE - 1) / ROWS_PER_TILE;
-  constexpr int NW = (EPI == GEMV_SILU_MUL) ? 2 : 1;
+  // ---- main: consume item g while item g+1 is in flight (two named register buffers, static indexing) ------------
   float tile_best = -INFINITY;
   uint32_t tile_best_i = 0xffffffffu;
+  float acc[NW][R];
+#pragma unroll
+  for (int m = 0; m < NW; ++m)
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int row0 = tile * ROWS_PER_TILE + wave * R;
-    const bf16_t* wp[NW][R];
+  auto consume = [&](int gi, u32x4_t (&buf)[U][NW][R]) {
+    const int c0 = (gi % gpt) * U;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int row = min(row0 + r, n_out - 1);  // clamp: out-of-range rows are computed but never stored
-      if (NW == 2) {
-        if (a.W2 != nullptr) {  // separate gate / up matrices (op-level entry point)
-          wp[0][r] = (const bf16_t*)a.W + (size_t)row * K + lane * 8;
-          wp[NW - 1][r] = (const bf16_t*)a.W2 + (size_t)row * K + lane * 8;
-        } else {  // the model's fused matrix: 16-row blocks alternating gate / up
-          const size_t fr = (size_t)(row >> 4) * 32 + (row & 15);
-          wp[0][r] = (const bf16_t*)a.W + fr * K + lane * 8;
-          wp[NW - 1][r] = (const bf16_t*)a.W + (fr + 16) * K + lane * 8;
-        }
-      } else {
-        wp[0][r] = (const bf16_t*)a.W + (size_t)row * K + lane * 8;
-      }
-    }
-    float acc[NW][R];
-#pragma unroll
-    for (int m = 0; m < NW; ++m)
-#pragma unroll
-      for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
-
-    for (int c0 = 0; c0 < nchunks; c0 += U) {
-      u32x4_t wv[U][NW][R];
-#pragma unroll
-      for (int u = 0; u < U; ++u)
+    for (int u = 0; u < U; ++u) {
+      if (c0 + u < nchunks) {
+        const float4 xlo = *reinterpret_cast<const float4*>(xs + ((c0 + u) << 9) + (lane << 2));
+        const float4 xhi = *reinterpret_cast<const float4*>(xs + ((c0 + u) << 9) + 256 + (lane << 2));
 #pragma unroll
         for (int m = 0; m < NW; ++m)
 #pragma unroll
-          for (int r = 0; r < R; ++r)
-            if (c0 + u < nchunks) {
-              wv[u][m][r] = u32x4_t{0u, 0u, 0u, 0u};
-              if (((c0 + u) << 9) + lane * 8 < K) wv[u][m][r] = ld_nt16(wp[m][r] + ((size_t)(c0 + u) << 9));
-            }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (c0 + u < nchunks) {
-          const float4 xlo = *reinterpret_cast<const float4*>(xs + ((c0 + u) << 9) + (lane << 2));
-          const float4 xhi = *reinterpret_cast<const float4*>(xs + ((c0 + u) << 9) + 256 + (lane << 2));
-#pragma unroll
-          for (int m = 0; m < NW; ++m)
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-              const u32x4_t w = wv[u][m][r];
-              float s = acc[m][r];
-              s = fmaf(lo_bf(w[0]), xlo.x, s); s = fmaf(hi_bf(w[0]), xlo.y, s);
-              s = fmaf(lo_bf(w[1]), xlo.z, s); s = fmaf(hi_bf(w[1]), xlo.w, s);
-              s = fmaf(lo_bf(w[2]), xhi.x, s); s = fmaf(hi_bf(w[2]), xhi.y, s);
-              s = fmaf(lo_bf(w[3]), xhi.z, s); s = fmaf(hi_bf(w[3]), xhi.w, s);
-              acc[m][r] = s;
-            }
-        }
+          for (int r = 0; r < R; ++r) {
+            const u32x4_t w = buf[u][m][r];
+            float s = acc[m][r];
+            s = fmaf(lo_bf(w[0]), xlo.x, s); s = fmaf(hi_bf(w[0]), xlo.y, s);
+            s = fmaf(lo_bf(w[1]), xlo.z, s); s = fmaf(hi_bf(w[1]), xlo.w, s);
+            s = fmaf(lo_bf(w[2]), xhi.x, s); s = fmaf(hi_bf(w[2]), xhi.y, s);
+            s = fmaf(lo_bf(w[3]), xhi.z, s); s = fmaf(hi_bf(w[3]), xhi.w, s);
+            acc[m][r] = s;
+          }
       }
     }
+    if (gi % gpt != gpt - 1) return;
+    // last chunk group of the tile: reduce across the wave and run the epilogue
+    const int tile = blockIdx.x + (gi / gpt) * gridDim.x;
+    const int row0 = tile * ROWS_PER_TILE + wave * R;
 #pragma unroll
     for (int m = 0; m < NW; ++m)
 #pragma unroll
       for (int r = 0; r < R; ++r) acc[m][r] = wave_sum(acc[m][r]);
-
     if (lane == 0) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -172,6 +185,17 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a) {
         }
       }
     }
+#pragma unroll
+    for (int m = 0; m < NW; ++m)
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
+  };
+
+  for (int g = 0; g < ngroups; g += 2) {
+    if (g + 1 < ngroups) issue(g + 1, bufB);
+    consume(g, bufA);
+    if (g + 2 < ngroups) issue(g + 2, bufA);
+    if (g + 1 < ngroups) consume(g + 1, bufB);
   }
   if (EPI == GEMV_LOGITS) {
     // per-block argmax partial: 4 wave leaders -> slot blockIdx.x
@@ -209,7 +233,8 @@ GemvPlan plan_gemv(int N, int K, GemvEpi epi) {
   int Up = 1;
   while (Up * 2 <= U) Up *= 2;
   const int ntiles = (N + 4 * R - 1) / (4 * R);
-  int grid = ntiles < 2048 ? ntiles : 2048;
+  // persistent blocks: two register buffers of R*U*NW loads => ~2 blocks (8 waves) per CU on 256 CUs
+  int grid = ntiles < 512 ? ntiles : 512;
   return {R, Up, grid};
 }
 

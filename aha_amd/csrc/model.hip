@@ -129,6 +129,10 @@ int upload_tensor(aha_model* m, const aha_tensor_view* t, const std::vector<int6
   const int64_t prow = std::max(rows, pad_rows_to), pcol = std::max(cols, pad_cols_to);
   std::vector<uint16_t> tmp;
   const void* src = t->data;
+  if (t->on_device && t->dtype != AHA_BF16) {
+    set_error(std::string("tensor ") + t->name + ": device-resident weights must be bf16");
+    return AHA_ERR_UNSUPPORTED;
+  }
   if (t->dtype == AHA_F32) {
     tmp.resize(n);
     const float* f = (const float*)t->data;
@@ -147,10 +151,10 @@ int upload_tensor(aha_model* m, const aha_tensor_view* t, const std::vector<int6
   const bool padded = prow != rows || pcol != cols;
   int rc = dev_alloc(m, (size_t)prow * pcol * 2, &d, padded);
   if (rc) return rc;
-  if (!padded) AHA_HIP_CHECK(hipMemcpy(d, src, (size_t)n * 2, hipMemcpyHostToDevice));
+  if (!padded) AHA_HIP_CHECK(hipMemcpy(d, src, (size_t)n * 2, hipMemcpyDefault));
   else {
     AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
-    AHA_HIP_CHECK(hipMemcpy2D(d, (size_t)pcol * 2, src, (size_t)cols * 2, (size_t)cols * 2, (size_t)rows, hipMemcpyHostToDevice));
+    AHA_HIP_CHECK(hipMemcpy2D(d, (size_t)pcol * 2, src, (size_t)cols * 2, (size_t)cols * 2, (size_t)rows, hipMemcpyDefault));
   }
   *out = d;
   return AHA_OK;
@@ -175,6 +179,10 @@ static int upload_rows_into(aha_model* m, const aha_tensor_view* t, int64_t rows
   }
   std::vector<uint16_t> tmp;
   const void* src = t->data;
+  if (t->on_device && t->dtype != AHA_BF16) {
+    set_error(std::string("tensor ") + t->name + ": device-resident weights must be bf16");
+    return AHA_ERR_UNSUPPORTED;
+  }
   if (t->dtype == AHA_F32) {
     tmp.resize(tn);
     for (int64_t i = 0; i < tn; ++i) tmp[i] = f32_to_bf16_host(((const float*)t->data)[i]);
@@ -187,7 +195,7 @@ static int upload_rows_into(aha_model* m, const aha_tensor_view* t, int64_t rows
     set_error(std::string("tensor ") + t->name + ": unsupported dtype");
     return AHA_ERR_UNSUPPORTED;
   }
-  AHA_HIP_CHECK(hipMemcpy((char*)dst + (size_t)row0 * cols * 2, src, (size_t)tn * 2, hipMemcpyHostToDevice));
+  AHA_HIP_CHECK(hipMemcpy((char*)dst + (size_t)row0 * cols * 2, src, (size_t)tn * 2, hipMemcpyDefault));
   return AHA_OK;
 }
 
@@ -210,6 +218,10 @@ static int upload_gate_up(aha_model* m, const aha_tensor_view* g, const aha_tens
     }
     std::vector<uint16_t> tmp;
     const void* src = t->data;
+    if (t->on_device && t->dtype != AHA_BF16) {
+      set_error(std::string("tensor ") + t->name + ": device-resident weights must be bf16");
+      return AHA_ERR_UNSUPPORTED;
+    }
     if (t->dtype == AHA_F32) {
       tmp.resize(tn);
       for (int64_t i = 0; i < tn; ++i) tmp[i] = f32_to_bf16_host(((const float*)t->data)[i]);
@@ -223,7 +235,7 @@ static int upload_gate_up(aha_model* m, const aha_tensor_view* g, const aha_tens
       return AHA_ERR_UNSUPPORTED;
     }
     const size_t blk = (size_t)16 * H * 2;
-    AHA_HIP_CHECK(hipMemcpy2D((char*)d + which * blk, 2 * blk, src, blk, blk, (size_t)(I / 16), hipMemcpyHostToDevice));
+    AHA_HIP_CHECK(hipMemcpy2D((char*)d + which * blk, 2 * blk, src, blk, blk, (size_t)(I / 16), hipMemcpyDefault));
   }
   *out = d;
   return AHA_OK;

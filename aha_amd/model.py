@@ -102,6 +102,7 @@ class HipInferenceModel:
             views[i].ndim = t.dim()
             for j, s in enumerate(t.shape):
                 views[i].shape[j] = s
+            views[i].on_device = int(t.is_cuda)
         check(lib().aha_hip_model_create(self.ctx.handle, C.byref(desc), views, len(weights), C.byref(self.handle)))
         del keep
         self.vocab = self.text_cfg.vocab_size

@@ -16,14 +16,20 @@ from .configs import Qwen3Config, Qwen3VLConfig
 
 
 def _randn(gen, shape, std=0.02, mean=0.0, dtype=torch.bfloat16):
-    t = torch.empty(shape, dtype=torch.float32)
+    # gen.device decides where the tensor is made: CPU generators give the reproducible fixtures the oracle shares;
+    # a CUDA generator lets bench.py build a full-size checkpoint in HBM in seconds (passed to the ABI on_device).
+    t = torch.empty(shape, dtype=torch.float32, device=gen.device)
     t.normal_(mean, std, generator=gen)
     return t.to(dtype)
 
 
-def qwen3_text_weights(cfg: Qwen3Config, seed: int = 0, prefix: str = "model.",
+def _gen(seed: int, device="cpu") -> torch.Generator:
+    return torch.Generator(device=device).manual_seed(seed)
+
+
+def qwen3_text_weights(cfg: Qwen3Config, seed: int = 0, prefix: str = "model.", device="cpu",
                        lm_head_name: str = "lm_head.weight", dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
-    gen = torch.Generator().manual_seed(seed)
+    gen = _gen(seed, device)
     w: Dict[str, torch.Tensor] = {}
     H, I = cfg.hidden_size, cfg.intermediate_size
     w[f"{prefix}embed_tokens.weight"] = _randn(gen, (cfg.vocab_size, H), dtype=dtype)
@@ -46,10 +52,10 @@ def qwen3_text_weights(cfg: Qwen3Config, seed: int = 0, prefix: str = "model.",
     return w
 
 
-def qwen3vl_vision_weights(cfg: Qwen3VLConfig, seed: int = 100, prefix: str = "model.visual.",
+def qwen3vl_vision_weights(cfg: Qwen3VLConfig, seed: int = 100, prefix: str = "model.visual.", device="cpu",
                            dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
     v = cfg.vision
-    gen = torch.Generator().manual_seed(seed)
+    gen = _gen(seed, device)
     w: Dict[str, torch.Tensor] = {}
     D = v.hidden_size
     w[prefix + "patch_embed.proj.weight"] = _randn(
@@ -86,8 +92,8 @@ def qwen3vl_vision_weights(cfg: Qwen3VLConfig, seed: int = 100, prefix: str = "m
     return w
 
 
-def qwen3vl_weights(cfg: Qwen3VLConfig, seed: int = 0, dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+def qwen3vl_weights(cfg: Qwen3VLConfig, seed: int = 0, dtype=torch.bfloat16, device="cpu") -> Dict[str, torch.Tensor]:
     w = qwen3_text_weights(cfg.text, seed=seed, prefix="model.language_model.",
-                           lm_head_name="lm_head.weight", dtype=dtype)
-    w.update(qwen3vl_vision_weights(cfg, seed=seed + 100, dtype=dtype))
+                           lm_head_name="lm_head.weight", dtype=dtype, device=device)
+    w.update(qwen3vl_vision_weights(cfg, seed=seed + 100, dtype=dtype, device=device))
     return w

@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- decode tokens/s (+ prefill tok/s) of the Qwen3-VL-8B hot path on MI355X, through the C ABI.
+
+  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one greedy decode token (one pass of the decoder stack + lm_head over the paged KV cache) of the
+configuration BASELINE.json's metric is quoted on: Qwen3-VL-"7B" (= 8B) with one 1024x1024
+image + a 512-token prompt.  Weights are synthetic (random init of that architecture, bf16, built directly in HBM);
+inputs are synthetic and resident in HBM when the timed region starts.  Prefill is run once before the timed region
+and reported as prefill_tok_s.  Decode stays single-GPU (BASELINE.json north_star): with N > 1 every rank serves its
+own request (independent replicas, no data-path collective) => "scaling": "weak".
+
+Extra objects on the JSON line: roofline (dominant kernel = the batch-1 weight-streaming matvec, HIP-event timed over
+K further steps) and cpu_baseline (the oracle restatement timed on the host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_PEAK_TFLOPS = 2500.0  # bf16 dense
+
+
+def build_workload(name: str):
+    from aha_amd import configs
+    if name == "qwen3vl8b":
+        return configs.qwen3vl_8b(), dict(image=1024, prompt=512)
+    if name == "qwen3vl8b-text":
+        return configs.qwen3vl_8b(), dict(image=0, prompt=1542)
+    if name == "qwen3-0.6b":
+        return configs.qwen3_0_6b(), dict(image=0, prompt=2048)
+    if name == "tiny":
+        return configs.tiny_qwen3(layers=2, hidden=512, heads=4, kv_heads=2, inter=1024, vocab=2048), dict(image=0, prompt=96)
+    raise SystemExit(f"unknown workload {name}")
+
+
+def decode_bytes_per_token(cfg, L):
+    """layer weights + lm_head + KV read/write, bf16."""
+    t = cfg.text if hasattr(cfg, "text") else cfg
+    H, I = t.hidden_size, t.intermediate_size
+    per_layer = (t.q_dim + 2 * t.kv_dim) * H + H * t.q_dim + 3 * I * H
+    w = (t.num_hidden_layers * per_layer + t.vocab_size * H) * 2
+    kv = t.num_hidden_layers * 2 * t.kv_dim * 2
+    return w + kv * L + kv
+
+
+def cpu_baseline(cfg, sample_secs=20.0):
+    """Oracle restatement timed on the host cores: one decoder layer at full width + lm_head, extrapolated to the
+    full depth ("port"; the Candle reference cannot be built here -- BASELINE.md section 2)."""
+    import copy
+    import torch
+    from aha_amd.weights import qwen3_text_weights
+    from oracle.numerics import Numerics
+    from oracle.qwen3 import OracleQwen3
+    t = cfg.text if hasattr(cfg, "text") else cfg
+    one = copy.deepcopy(t)
+    one.num_hidden_layers = 1
+    one.mrope_section = None
+    one.tie_word_embeddings = True   # lm_head timed through the (tied) embedding: same shape
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    w = qwen3_text_weights(one, seed=0)
+    o = OracleQwen3(one, w, Numerics("bf16"))
+    ids = torch.randint(0, one.vocab_size, (32,), generator=torch.Generator().manual_seed(0)).tolist()
+    o.forward(ids, 0)
+    # time the single layer (hidden -> hidden) and the lm_head separately over decode steps
+    n, t_layer, t_head = 0, 0.0, 0.0
+    t_start = time.perf_counter()
+    pos = len(ids)
+    while time.perf_counter() - t_start < sample_secs and n < 64:
+        t0 = time.perf_counter()
+        h = o.forward_hidden([5], None, pos)
+        t1 = time.perf_counter()
+        o.nm.linear(h, o.lm_head)
+        t2 = time.perf_counter()
+        t_layer += t1 - t0
+        t_head += t2 - t1
+        n += 1
+        pos += 1
+    per_tok = t.num_hidden_layers * (t_layer / n) + t_head / n
+    return {"value": round(1.0 / per_tok, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"oracle restatement (torch-CPU, bf16 rounding points), {n} decode steps of 1 of "
+                      f"{t.num_hidden_layers} layers at full width + lm_head, extrapolated x{t.num_hidden_layers}; "
+                      "Candle CPU reference not buildable here"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default=os.environ.get("AHA_BENCH_WORKLOAD", "qwen3vl8b"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-loop", action="store_true", help="drive decode with forward_step (one host sync per token)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+
+    import __graft_entry__
+    __graft_entry__.build()
+    from aha_amd import weights as W
+    from aha_amd.model import HipInferenceModel, MultiModalData
+
+    cfg, wl = build_workload(args.workload)
+    is_vl = hasattr(cfg, "text")
+    tcfg = cfg.text if is_vl else cfg
+    dev = f"cuda:{local_rank}"
+    t0 = time.perf_counter()
+    if is_vl:
+        w = W.qwen3vl_weights(cfg, seed=rank, device=dev) if wl["image"] else \
+            W.qwen3_text_weights(tcfg, seed=rank, prefix="model.language_model.", device=dev)
+    else:
+        w = W.qwen3_text_weights(tcfg, seed=rank, device=dev)
+    torch.cuda.synchronize()
+    model = HipInferenceModel(cfg, w, device=local_rank, kv_reserve_tokens=4096)
+    del w
+    torch.cuda.empty_cache()
+    t_load = time.perf_counter() - t0
+
+    # synthetic request (cfg 3): template + <|vision_start|> + image pads + <|vision_end|> + text
+    g = torch.Generator().manual_seed(3 + rank)
+    data = None
+    if wl["image"]:
+        from aha_amd.vision_host import synthetic_image_request
+        ids, data = synthetic_image_request(cfg, wl["image"], wl["prompt"], g)
+    else:
+        ids = torch.randint(0, min(tcfg.vocab_size, 151643), (wl["prompt"],), generator=g).tolist()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- prefill (reported, outside the K timed steps) ----
+    model.forward_initial(ids, 0, data, want_logits=False)  # warm
+    model.clear_cache()
+    barrier()
+    t0 = time.perf_counter()
+    _, tok = model.forward_initial(ids, 0, data, want_logits=False)
+    t_prefill = time.perf_counter() - t0
+    off = len(ids)
+
+    # ---- decode: W warmup steps, then exactly K timed steps ----
+    def run_steps(n, tok, off):
+        if args.host_loop:
+            for _ in range(n):
+                _, tok = model.forward_step(tok, off, want_logits=False)
+                off += 1
+            return tok, off
+        out = model.decode_greedy(tok, off, n)
+        assert len(out) == n
+        return out[-1], off + n
+
+    tok, off = run_steps(args.warmup, tok, off)
+    barrier()
+    t0 = time.perf_counter()
+    tok, off = run_steps(args.steps, tok, off)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    kv_mid = off - args.steps // 2
+
+    # ---- roofline of the dominant kernel (weight-streaming matvec), HIP events on the model's stream ----
+    model.set_profiling(True)
+    tok, off = run_steps(args.steps, tok, off)
+    prof = {k: model.get_profile(k) for k in ("gemv", "attn_decode", "elem", "argmax")}
+    model.set_profiling(False)
+    gv = prof["gemv"]
+    achieved = gv["bytes"] / (gv["ms"] * 1e-3) / 1e9 if gv["ms"] > 0 else 0.0
+    roof = {"bound": "hbm", "kernel": "gemv_kernel (batch-1 weight streaming, all projections + lm_head)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "launches": gv["launches"], "avg_us": round(1e3 * gv["ms"] / max(gv["launches"], 1), 2),
+            "algorithmic_bytes_per_launch": round(gv["bytes"] / max(gv["launches"], 1))}
+    ad = prof["attn_decode"]
+    attn_gbs = ad["bytes"] / (ad["ms"] * 1e-3) / 1e9 if ad["ms"] > 0 else 0.0
+
+    if rank == 0:
+        step_bytes = decode_bytes_per_token(cfg, kv_mid)
+        line = {
+            "metric": "decode tokens/s (greedy, batch 1) -- Qwen3-VL-8B, 1x1024^2 image + 512-token prompt; prefill tok/s alongside",
+            "value": round(world * args.steps / dt, 3), "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": args.workload, "prompt_tokens": len(ids), "image": wl["image"],
+                       "kv_len_mid": kv_mid, "replicas": world,
+                       "loop": "host forward_step" if args.host_loop else "device-resident greedy loop"},
+            "prefill_tok_s": round(len(ids) / t_prefill, 1), "prefill_ms": round(1e3 * t_prefill, 2),
+            "decode_step_hbm_frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            "attn_decode_GBs": round(attn_gbs, 1),
+            "load_s": round(t_load, 1),
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
+    model.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -62,13 +62,15 @@ typedef struct aha_model_desc {
   uint32_t stop_tokens[8];         /* generation_config.json eos_token_id list (qwen3/generate.rs:36-43) */
 } aha_model_desc;
 
-/* One checkpoint tensor: HF name, host pointer (e.g. into an mmapped safetensors file), dtype, shape. */
+/* One checkpoint tensor: HF name, pointer (host memory, e.g. an mmapped safetensors file; or, when on_device != 0,
+ * device memory of the same GPU -- bf16 only), dtype, shape. */
 typedef struct aha_tensor_view {
   const char* name;
   const void* data;
   int32_t dtype;
   int32_t ndim;
   int64_t shape[5];
+  int32_t on_device;
 } aha_tensor_view;
 
 /* MultiModalData for Qwen3-VL (/root/reference/src/models/qwen3vl/generate.rs:79-101: data_vec =

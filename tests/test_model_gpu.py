@@ -19,9 +19,12 @@ from oracle.qwen3 import OracleQwen3, greedy_generate
 
 pytestmark = pytest.mark.gpu
 
-# |logit_hip - logit_oracle| bound, in units of the oracle logits' std: bf16 activations through L layers differ by
-# accumulation order / unrounded softmax probabilities; measured ~0.005 on these configs, bound set at 0.03.
-LOGIT_TOL_STD = 0.03
+# Logit tolerance.  Both sides materialise bf16 tensors at the same op boundaries; they differ in f32 accumulation
+# order and in the (unrounded, f32) softmax probabilities, which flips an occasional bf16 rounding upstream.  Bound:
+#   max |logit_hip - logit_oracle| <= 0.05 * std(oracle logits)   and   rms <= 0.02 * std
+# (one bf16 ulp of a logit of size ~2 std is already 0.008-0.016 std-units on these models).
+LOGIT_TOL_STD = 0.05
+LOGIT_RMS_STD = 0.02
 
 
 def make(cfg_kw=None, seed=0):
@@ -40,7 +43,7 @@ def tiny(gpu):
     from aha_amd.model import HipInferenceModel
     cfg, w = make()
     m = HipInferenceModel(cfg, w)
-    o = OracleQwen3(cfg, w, Numerics("bf16"))
+    o = OracleQwen3(cfg, w, Numerics("bf16", matmul_f64=True))
     yield cfg, w, m, o
     m.close()
 
@@ -48,9 +51,12 @@ def tiny(gpu):
 def check_logits(got, ref, what):
     ref = ref.reshape(-1).float().numpy()
     std = float(ref.std())
-    err = float(np.abs(got - ref).max())
+    diff = np.abs(got - ref)
+    err = float(diff.max())
     assert np.isfinite(got).all(), what
+    rms = float(np.sqrt((diff ** 2).mean()))
     assert err <= LOGIT_TOL_STD * std, f"{what}: max|dlogit| {err:.5f} > {LOGIT_TOL_STD} * std {std:.4f}"
+    assert rms <= LOGIT_RMS_STD * std, f"{what}: rms dlogit {rms:.5f} > {LOGIT_RMS_STD} * std {std:.4f}"
     return err / std
 
 
@@ -69,6 +75,7 @@ def test_decode_teacher_forced(tiny):
     """Feed the ORACLE's greedy tokens to both; compare logits each step and the argmax where the margin is decisive."""
     cfg, w, m, o = tiny
     ids = ids_for(cfg, 50, 7)
+    o.clear_cache()
     toks, logits = greedy_generate(o, ids, 40, return_logits=True)
     m.clear_cache()
     got, am = m.forward_initial(ids, 0)
@@ -178,7 +185,7 @@ def test_gqa_8b_shape_slice(gpu):
     cfg = tiny_qwen3(layers=1, hidden=4096, heads=32, kv_heads=8, inter=12288, vocab=2048, tie=False)
     w = qwen3_text_weights(cfg, seed=3)
     m = HipInferenceModel(cfg, w)
-    o = OracleQwen3(cfg, w, Numerics("bf16"))
+    o = OracleQwen3(cfg, w, Numerics("bf16", matmul_f64=True))
     ids = ids_for(cfg, 97, 29)
     got, _ = m.forward_initial(ids, 0)
     check_logits(got, o.forward(ids, 0), "8B-width prefill")
