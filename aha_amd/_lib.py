@@ -81,6 +81,8 @@ SIGNATURES = {
     "aha_hip_attn_prefill": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_float, _P]),
     "aha_hip_argmax": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "aha_hip_image_to_patches": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float),
+                                           C.POINTER(C.c_float), _P]),
 }
 
 _lib = None

@@ -329,6 +329,17 @@ int aha_hip_attn_prefill(const void* q, const void* k, const void* v, void* o, i
   API_GUARD_END
 }
 
+int aha_hip_image_to_patches(const uint8_t* img_hwc, void* out, int32_t H, int32_t W, int32_t patch, int32_t merge,
+                             const float mean[3], const float std[3], void* stream) {
+  if (!img_hwc || !out || !mean || !std || patch <= 0 || merge <= 0 || H % (patch * merge) || W % (patch * merge)) {
+    set_error("image_to_patches: H and W must be multiples of patch*merge");
+    return AHA_ERR_INVALID;
+  }
+  launch_image_to_patches(img_hwc, out, H, W, patch, merge, mean, std, (hipStream_t)stream);
+  AHA_HIP_CHECK(hipGetLastError());
+  return AHA_OK;
+}
+
 int aha_hip_argmax(const float* x, int64_t n, uint32_t* out_dev, void* stream) {
   API_GUARD_BEGIN
   if (!x || !out_dev || n <= 0) {
@@ -351,9 +362,13 @@ int aha_hip_argmax(const float* x, int64_t n, uint32_t* out_dev, void* stream) {
 }
 
 int aha_hip_debug_image_embeds(aha_model* m, int which, float* out, size_t n) {
-  (void)m; (void)which; (void)out; (void)n;
-  set_error("vision tower not built");
-  return AHA_ERR_UNSUPPORTED;
+  API_GUARD_BEGIN
+  if (!m || !out) {
+    set_error("null argument");
+    return AHA_ERR_INVALID;
+  }
+  return vision_debug_embeds(m, which, out, n);
+  API_GUARD_END
 }
 
 }  // extern "C"

@@ -102,3 +102,28 @@ struct GemmArgs {
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 
 }  // namespace aha
+
+// ---- Qwen3-VL vision tower (kernels_vit.hip) -----------------------------------------------------------------------
+namespace aha {
+constexpr int VIT_DQK = 96;  // ViT head_dim 72: Q/K rows zero-padded to 3 MFMA k-steps
+constexpr int VIT_DV = 80;   //                   V block zero-padded to 5 16-row sub-tiles
+void launch_layernorm_rows(const void* x, const void* w, const void* b, void* y, int64_t rows, int dim, float eps,
+                           hipStream_t st);
+// x[n,:] += bilinear pos-embed: sum_i table[idx[i][n],:] * wt[i][n]  (4 corners), every op rounded as the reference
+void launch_pos_embed_add(void* x, const void* table, const int32_t* idx, const float* wt, int64_t N, int D,
+                          hipStream_t st);
+struct VitRopeArgs {
+  const void* qkv;          // (N, 3*nh*hd) bf16: [q heads | k heads | v heads]
+  const int32_t* rowcol;    // (N, 2) patch (row, col)
+  const float* inv_freq;    // (hd/4)
+  const int32_t* page_of;   // (N) page index of token n
+  const int32_t* slot_of;   // (N) slot (0..63) of token n inside its page
+  void* q_out;              // (N, nh, VIT_DQK) bf16, zero padded
+  KvLayer kv;               // pages: K block [nh][64][VIT_DQK], V block [nh][VIT_DV][64]
+  int N, nh, hd;
+};
+void launch_vit_rope_pack(const VitRopeArgs& a, hipStream_t st);
+void launch_scatter_rows(void* dst, const void* src, const int32_t* rows, int64_t n, int D, int add, hipStream_t st);
+void launch_image_to_patches(const uint8_t* img, void* out, int H, int W, int patch, int merge, const float* mean,
+                             const float* stdv, hipStream_t st);
+}  // namespace aha

@@ -78,11 +78,15 @@ __device__ __forceinline__ void softmax_tile(f32x4_t (&st)[4], float scale, Vali
   }
 }
 
-constexpr int K_ROW_BYTES = 128 * 2 + 16;            // padded LDS row of the K tile (bank-conflict-free b128 reads)
 constexpr int V_ROW_BYTES = KV_PAGE_TOKENS * 2 + 16;  // padded LDS row of the V^T tile
 
 // ---- prefill: 4 waves x 16 q rows per block, K / V^T page staged in LDS and shared by the 4 waves --------------
+// DQK = padded head dim of Q/K rows (multiple of 32), DV = padded head dim of the V block (multiple of 16).
+// Text decoder: 128/128.  ViT (head_dim 72): 96/80, pad lanes are zero in Q, K and V (csrc/kernels_vit.hip).
+template <int DQK, int DV>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
+  constexpr int KS = DQK / 32, DS = DV / 16;
+  constexpr int K_ROW_BYTES = DQK * 2 + 16;  // padded LDS row of the K tile (bank-conflict-free b128 reads)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ks = smem;
   char* vs = smem + KV_PAGE_TOKENS * K_ROW_BYTES;
@@ -91,10 +95,10 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
   const int kvhd = head / (a.nh / a.kvh);
   const int q0 = blockIdx.x * 64 + wave * 16;
   const int qrow = min(q0 + c, a.S - 1);
-  const bf16_t* qp = (const bf16_t*)a.q + ((int64_t)qrow * a.nh + head) * 128;
-  bf16x8_t qf[4];
+  const bf16_t* qp = (const bf16_t*)a.q + ((int64_t)qrow * a.nh + head) * DQK;
+  bf16x8_t qf[KS];
 #pragma unroll
-  for (int k4 = 0; k4 < 4; ++k4) qf[k4] = as_frag(ld16(qp + k4 * 32 + G * 8));
+  for (int k4 = 0; k4 < KS; ++k4) qf[k4] = as_frag(ld16(qp + k4 * 32 + G * 8));
 
   const int qpos = a.kv_offset + q0 + c;  // cache position of this lane's q row
   const int blk_last_q = min(blockIdx.x * 64 + 63, a.S - 1);
@@ -103,21 +107,28 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
   const int wave_last_tok = a.causal ? a.kv_offset + q0 + 15 : a.kv_total - 1;
 
   float m = -INFINITY, l = 0.f;
-  f32x4_t o[8];
+  f32x4_t o[DS];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < DS; ++i) o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   for (int tile = 0; tile < ntiles; ++tile) {
     __syncthreads();  // everyone is done with the previous tile
     {
       const char* base = reinterpret_cast<const char*>(a.kv.page_ptrs[tile] + a.kv.layer_off);
-      const char* kb = base + (size_t)kvhd * KV_PAGE_TOKENS * 256;
-      const char* vb = base + (size_t)a.kvh * KV_PAGE_TOKENS * 256 + (size_t)kvhd * 128 * (KV_PAGE_TOKENS * 2);
+      const char* kb = base + (size_t)kvhd * KV_PAGE_TOKENS * (DQK * 2);
+      const char* vb = base + (size_t)a.kvh * KV_PAGE_TOKENS * (DQK * 2) + (size_t)kvhd * DV * (KV_PAGE_TOKENS * 2);
+      constexpr int KP = KV_PAGE_TOKENS * DQK / 8, VP = DV * KV_PAGE_TOKENS / 8, SPR = DQK / 8;  // 16-byte pieces
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int p = tid + i * 256;  // 1024 16-byte pieces per 16-KiB tile
-        *reinterpret_cast<u32x4_t*>(ks + (p >> 4) * K_ROW_BYTES + (p & 15) * 16) = ld16(kb + (size_t)p * 16);
-        *reinterpret_cast<u32x4_t*>(vs + (p >> 3) * V_ROW_BYTES + (p & 7) * 16) = ld16(vb + (size_t)p * 16);
+      for (int i = 0; i < (KP + 255) / 256; ++i) {
+        const int p = tid + i * 256;
+        if (KP % 256 == 0 || p < KP)
+          *reinterpret_cast<u32x4_t*>(ks + (p / SPR) * K_ROW_BYTES + (p % SPR) * 16) = ld16(kb + (size_t)p * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < (VP + 255) / 256; ++i) {
+        const int p = tid + i * 256;
+        if (VP % 256 == 0 || p < VP)
+          *reinterpret_cast<u32x4_t*>(vs + (p >> 3) * V_ROW_BYTES + (p & 7) * 16) = ld16(vb + (size_t)p * 16);
       }
     }
     __syncthreads();
@@ -129,7 +140,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
     for (int sub = 0; sub < 4; ++sub) {
       st[sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
+      for (int k4 = 0; k4 < KS; ++k4) {
         const bf16x8_t kf = as_frag(*reinterpret_cast<const u32x4_t*>(ks + (sub * 16 + c) * K_ROW_BYTES + (k4 * 32 + G * 8) * 2));
         st[sub] = mfma16(kf, qf[k4], st[sub]);
       }
@@ -139,7 +150,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
     const int lim = a.causal ? min(qpos, a.kv_total - 1) : a.kv_total - 1;
     softmax_tile(st, a.scale, [&](int t) { return t0 + t <= lim; }, G, m, l, alpha, pf);
 #pragma unroll
-    for (int ds = 0; ds < 8; ++ds) {
+    for (int ds = 0; ds < DS; ++ds) {
       o[ds] *= alpha;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -151,13 +162,15 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
   l = group_sum(l);
   if (q0 + c < a.S) {
     const float inv = 1.0f / l;
-    bf16_t* op = (bf16_t*)a.o + ((int64_t)(q0 + c) * a.nh + head) * 128;
+    bf16_t* op = (bf16_t*)a.o + ((int64_t)(q0 + c) * a.nh + head) * a.d;  // a.d = real head dim of the output rows
 #pragma unroll
-    for (int ds = 0; ds < 8; ++ds) {
-      uint2 w;
-      w.x = pack_bf(o[ds][0] * inv, o[ds][1] * inv);
-      w.y = pack_bf(o[ds][2] * inv, o[ds][3] * inv);
-      *reinterpret_cast<uint2*>(op + ds * 16 + G * 4) = w;
+    for (int ds = 0; ds < DS; ++ds) {
+      if (ds * 16 + G * 4 < a.d) {  // head dims come in multiples of 4, so a 4-wide group is all-in or all-out
+        uint2 w;
+        w.x = pack_bf(o[ds][0] * inv, o[ds][1] * inv);
+        w.y = pack_bf(o[ds][2] * inv, o[ds][3] * inv);
+        *reinterpret_cast<uint2*>(op + ds * 16 + G * 4) = w;
+      }
     }
   }
 }
@@ -288,8 +301,14 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnDecodeArgs
 
 void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st) {
   if (a.S <= 0) return;
-  const size_t lds = KV_PAGE_TOKENS * K_ROW_BYTES + 128 * V_ROW_BYTES;
-  hipLaunchKernelGGL(attn_prefill_kernel, dim3((a.S + 63) / 64, a.nh), dim3(256), lds, st, a);
+  dim3 grid((a.S + 63) / 64, a.nh), block(256);
+  if (a.d == 128) {
+    const size_t lds = KV_PAGE_TOKENS * (128 * 2 + 16) + 128 * V_ROW_BYTES;
+    hipLaunchKernelGGL((attn_prefill_kernel<128, 128>), grid, block, lds, st, a);
+  } else {  // head_dim 72 (Qwen3-VL ViT): Q/K rows padded to 96, V block to 80
+    const size_t lds = KV_PAGE_TOKENS * (96 * 2 + 16) + 80 * V_ROW_BYTES;
+    hipLaunchKernelGGL((attn_prefill_kernel<96, 80>), grid, block, lds, st, a);
+  }
 }
 
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {

@@ -12,5 +12,6 @@ void vision_destroy(aha_model* m);
 int vl_rope_index(aha_model* m, const uint32_t* ids, size_t n, size_t offset, const aha_mm_input* mm, int32_t* pos);
 int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, const aha_mm_input* mm, void* x);
 int vision_deepstack_add(aha_model* m, int layer, void* x);
+int vision_debug_embeds(aha_model* m, int which, float* out, size_t n);
 
 }  // namespace aha

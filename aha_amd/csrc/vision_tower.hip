@@ -1,25 +1,419 @@
-// Qwen3-VL vision tower (V1-V7) -- placeholder until the ViT kernels land: text-only Qwen3-VL works, images are refused.
+// Qwen3-VL vision tower on the GPU (SURVEY.md section 8a V1-V7 + the M3 scatter / DeepStack adds).
+//   create   <- Qwen3VLVisionModel::new            /root/reference/src/models/qwen3vl/model.rs:385-431
+//   forward  <- Qwen3VLVisionModel::forward        /root/reference/src/models/qwen3vl/model.rs:692-740
+//   scatter  <- Qwen3VLModel::forward              /root/reference/src/models/qwen3vl/model.rs:1150-1168 (masked_scatter_dim0)
+//   deepstack<- Qwen3VLTextModel::forward          /root/reference/src/models/qwen3vl/model.rs:806-822 (mask_index_add)
+// Index-heavy pieces (bilinear corner indices/weights, patch (row,col), segment -> page mapping) are plain host integer
+// code, built exactly as the reference builds them; every tensor op runs in a HIP kernel.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "common.h"
 #include "vision.h"
 
 namespace aha {
 
-struct VisionModel {};
+struct VisBlockW {
+  void *n1w, *n1b, *n2w, *n2b, *qkv_w, *qkv_b, *proj_w, *proj_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+};
+struct MergerW {
+  void *nw, *nb, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+};
 
-int vision_create(aha_model* m, const aha_tensor_view* w, size_t nw) {
-  (void)w;
-  (void)nw;
-  m->vision = nullptr;
+struct VisionModel {
+  int D = 0, nh = 0, hd = 0, I = 0, depth = 0, merge = 0, out = 0, G = 0, patch_dim = 0, M4 = 0;
+  void *patch_w = nullptr, *patch_b = nullptr, *pos_table = nullptr;
+  float* d_inv_freq = nullptr;
+  std::vector<VisBlockW> blocks;
+  MergerW merger{};
+  std::vector<MergerW> ds_mergers;
+  std::vector<int> ds_idx;
+  float scale = 0.f;
+  // scratch (grown on demand)
+  size_t cap = 0;
+  std::vector<void*> owned;
+  void *pix = nullptr, *x = nullptr, *h = nullptr, *qkv = nullptr, *q = nullptr, *attn = nullptr, *mlp = nullptr, *mh = nullptr;
+  int32_t *d_idx = nullptr, *d_rowcol = nullptr, *d_page_of = nullptr, *d_slot_of = nullptr, *d_vis_rows = nullptr;
+  float* d_wt = nullptr;
+  void* page_store = nullptr;
+  uint64_t* d_page_ptrs = nullptr;
+  uint64_t page_bytes = 0;
+  void* merged = nullptr;
+  std::vector<void*> deep;
+  int64_t n_merged = 0;
+};
+
+static int vneed(const aha_tensor_view* w, size_t nw, const std::string& name, const aha_tensor_view** out) {
+  *out = find_tensor(w, nw, name);
+  if (!*out) {
+    set_error("missing weight tensor: " + name);
+    return AHA_ERR_MISSING_WEIGHT;
+  }
   return AHA_OK;
 }
+
+int vision_create(aha_model* m, const aha_tensor_view* w, size_t nw) {
+  const aha_model_desc& c = m->desc;
+  const std::string pre = "model.visual.";
+  if (!find_tensor(w, nw, pre + "patch_embed.proj.weight")) {
+    m->vision = nullptr;  // text-only checkpoint: images will be refused at forward time
+    return AHA_OK;
+  }
+  if (c.vis_hidden_size % c.vis_num_heads || c.vis_hidden_size / c.vis_num_heads != 72) {
+    set_error("vision tower: only head_dim 72 is supported (Qwen3-VL ViT)");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  VisionModel* v = new VisionModel();
+  m->vision = v;
+  v->D = c.vis_hidden_size; v->nh = c.vis_num_heads; v->hd = v->D / v->nh; v->I = c.vis_intermediate_size;
+  v->depth = c.vis_depth; v->merge = c.vis_spatial_merge_size; v->out = c.vis_out_hidden_size;
+  v->G = (int)sqrtf((float)c.vis_num_position_embeddings);
+  v->patch_dim = c.vis_in_channels * c.vis_temporal_patch_size * c.vis_patch_size * c.vis_patch_size;
+  v->M4 = v->D * v->merge * v->merge;
+  if (v->out != c.hidden_size) {
+    set_error("vision out_hidden_size must equal the text hidden_size");
+    return AHA_ERR_SHAPE;
+  }
+  for (int i = 0; i < c.vis_num_deepstack; ++i) v->ds_idx.push_back(c.vis_deepstack_indexes[i]);
+  int rc;
+  const aha_tensor_view* t;
+#define LOAD(name, shape, dst)                          \
+  if ((rc = vneed(w, nw, name, &t))) return rc;         \
+  if ((rc = upload_tensor(m, t, shape, &(dst)))) return rc;
+  using S = std::vector<int64_t>;
+  LOAD(pre + "patch_embed.proj.weight", (S{v->D, v->patch_dim}), v->patch_w);  // flatten(1,4) (model.rs:44-58)
+  LOAD(pre + "patch_embed.proj.bias", (S{v->D}), v->patch_b);
+  LOAD(pre + "pos_embed.weight", (S{c.vis_num_position_embeddings, v->D}), v->pos_table);
+  v->blocks.resize(v->depth);
+  for (int i = 0; i < v->depth; ++i) {
+    const std::string p = pre + "blocks." + std::to_string(i) + ".";
+    VisBlockW& b = v->blocks[i];
+    LOAD(p + "norm1.weight", (S{v->D}), b.n1w);
+    LOAD(p + "norm1.bias", (S{v->D}), b.n1b);
+    LOAD(p + "norm2.weight", (S{v->D}), b.n2w);
+    LOAD(p + "norm2.bias", (S{v->D}), b.n2b);
+    LOAD(p + "attn.qkv.weight", (S{3 * v->D, v->D}), b.qkv_w);
+    LOAD(p + "attn.qkv.bias", (S{3 * v->D}), b.qkv_b);
+    LOAD(p + "attn.proj.weight", (S{v->D, v->D}), b.proj_w);
+    LOAD(p + "attn.proj.bias", (S{v->D}), b.proj_b);
+    LOAD(p + "mlp.linear_fc1.weight", (S{v->I, v->D}), b.fc1_w);
+    LOAD(p + "mlp.linear_fc1.bias", (S{v->I}), b.fc1_b);
+    LOAD(p + "mlp.linear_fc2.weight", (S{v->D, v->I}), b.fc2_w);
+    LOAD(p + "mlp.linear_fc2.bias", (S{v->D}), b.fc2_b);
+  }
+  auto load_merger = [&](const std::string& p, bool post, MergerW& mw) -> int {
+    const int64_t nd = post ? v->M4 : v->D;
+    LOAD(p + "norm.weight", (S{nd}), mw.nw);
+    LOAD(p + "norm.bias", (S{nd}), mw.nb);
+    LOAD(p + "linear_fc1.weight", (S{v->M4, v->M4}), mw.fc1_w);
+    LOAD(p + "linear_fc1.bias", (S{v->M4}), mw.fc1_b);
+    LOAD(p + "linear_fc2.weight", (S{v->out, v->M4}), mw.fc2_w);
+    LOAD(p + "linear_fc2.bias", (S{v->out}), mw.fc2_b);
+    return AHA_OK;
+  };
+  if ((rc = load_merger(pre + "merger.", false, v->merger))) return rc;
+  v->ds_mergers.resize(v->ds_idx.size());
+  for (size_t k = 0; k < v->ds_idx.size(); ++k)
+    if ((rc = load_merger(pre + "deepstack_merger_list." + std::to_string(k) + ".", true, v->ds_mergers[k]))) return rc;
+#undef LOAD
+  // Qwen2_5VisionRotaryEmbedding::new(head_dim/2, 10000): inv_freq_j = 1/10000^(2j/(hd/2)), j < hd/4 (rope.rs:428-433)
+  {
+    const int half = v->hd / 2;
+    std::vector<float> inv(half / 2);
+    for (int j = 0; j < half / 2; ++j) inv[j] = 1.0f / powf(10000.0f, (float)(2 * j) / (float)half);
+    void* p;
+    if ((rc = dev_alloc(m, inv.size() * 4, &p))) return rc;
+    v->d_inv_freq = (float*)p;
+    AHA_HIP_CHECK(hipMemcpy(v->d_inv_freq, inv.data(), inv.size() * 4, hipMemcpyHostToDevice));
+    const float s = 1.0f / sqrtf((float)v->hd);  // scaling cast to bf16 by the affine op (see model.hip attn_scale)
+    uint32_t u;
+    memcpy(&u, &s, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    memcpy(&v->scale, &u, 4);
+  }
+  v->page_bytes = (uint64_t)v->nh * KV_PAGE_TOKENS * VIT_DQK * 2 + (uint64_t)v->nh * VIT_DV * KV_PAGE_TOKENS * 2;
+  return AHA_OK;
+}
+
+static void vision_free_scratch(VisionModel* v) {
+  for (void* p : v->owned) hipFree(p);
+  v->owned.clear();
+  v->cap = 0;
+}
+
 void vision_destroy(aha_model* m) {
+  if (!m->vision) return;
+  vision_free_scratch(m->vision);
   delete m->vision;
   m->vision = nullptr;
 }
-int vision_forward_and_scatter(aha_model* m, const uint32_t*, size_t, const aha_mm_input*, void*) {
-  (void)m;
-  set_error("vision tower not built");
-  return AHA_ERR_UNSUPPORTED;
+
+static int vision_ensure_scratch(aha_model* m, size_t N, size_t npages) {
+  VisionModel* v = m->vision;
+  if (N <= v->cap) return AHA_OK;
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  vision_free_scratch(v);
+  const size_t cap = (N + 255) / 256 * 256, pcap = npages + cap / KV_PAGE_TOKENS + 64;
+  auto al = [&](size_t bytes, void** out, bool zero = false) -> int {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      set_error(std::string("vision scratch hipMalloc failed: ") + hipGetErrorString(e));
+      return e == hipErrorOutOfMemory ? AHA_ERR_OOM : AHA_ERR_HIP;
+    }
+    if (zero) hipMemsetAsync(p, 0, bytes, m->stream);
+    v->owned.push_back(p);
+    *out = p;
+    return AHA_OK;
+  };
+  int rc;
+  const size_t D = v->D, n4 = cap / (v->merge * v->merge);
+  if ((rc = al(cap * v->patch_dim * 2, &v->pix))) return rc;
+  if ((rc = al(cap * D * 2, &v->x))) return rc;
+  if ((rc = al(cap * D * 2, &v->h))) return rc;
+  if ((rc = al(cap * 3 * D * 2, &v->qkv))) return rc;
+  if ((rc = al(cap * v->nh * VIT_DQK * 2, &v->q))) return rc;
+  if ((rc = al(cap * D * 2, &v->attn))) return rc;
+  if ((rc = al(cap * (size_t)v->I * 2, &v->mlp))) return rc;
+  if ((rc = al(n4 * v->M4 * 2, &v->mh))) return rc;
+  if ((rc = al(cap * 4 * 4, (void**)&v->d_idx))) return rc;
+  if ((rc = al(cap * 4 * 4, (void**)&v->d_wt))) return rc;
+  if ((rc = al(cap * 2 * 4, (void**)&v->d_rowcol))) return rc;
+  if ((rc = al(cap * 4, (void**)&v->d_page_of))) return rc;
+  if ((rc = al(cap * 4, (void**)&v->d_slot_of))) return rc;
+  if ((rc = al(n4 * 4, (void**)&v->d_vis_rows))) return rc;
+  if ((rc = al(pcap * v->page_bytes, &v->page_store, true))) return rc;  // zero: pad slots of tail pages must stay finite
+  if ((rc = al(pcap * 8, (void**)&v->d_page_ptrs))) return rc;
+  {
+    std::vector<uint64_t> ptrs(pcap);
+    for (size_t i = 0; i < pcap; ++i) ptrs[i] = (uint64_t)(uintptr_t)v->page_store + i * v->page_bytes;
+    AHA_HIP_CHECK(hipMemcpy(v->d_page_ptrs, ptrs.data(), pcap * 8, hipMemcpyHostToDevice));
+  }
+  if ((rc = al(n4 * v->out * 2, &v->merged))) return rc;
+  v->deep.assign(v->ds_idx.size(), nullptr);
+  for (size_t k = 0; k < v->ds_idx.size(); ++k)
+    if ((rc = al(n4 * v->out * 2, &v->deep[k]))) return rc;
+  v->cap = cap;
+  return AHA_OK;
 }
-int vision_deepstack_add(aha_model*, int, void*) { return AHA_OK; }
+
+static inline uint16_t f2bf_host(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+static void vgemm(aha_model* m, const void* A, const void* W, void* C, int M, int N, int K, const void* bias,
+                  const void* residual, int act) {
+  GemmArgs g{};
+  g.A = A; g.W = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N; g.bias = bias; g.residual = residual; g.act = act;
+  ProfScope ps(m, "gemm", ((double)M * K + (double)N * K + (double)M * N * (residual ? 2 : 1)) * 2, 2.0 * M * N * K);
+  launch_gemm(g, m->stream);
+}
+
+// Qwen3VLVisionPatchMerger::forward (model.rs:167-184): LN (before or after the 2x2 regroup), fc1 + erf-GELU, fc2
+static void run_merger(aha_model* m, const MergerW& w, bool post, const void* x, int64_t N, void* out) {
+  VisionModel* v = m->vision;
+  const int64_t n4 = N / (v->merge * v->merge);
+  {
+    ProfScope ps(m, "elem", (double)N * v->D * 4, 0);
+    if (post) launch_layernorm_rows(x, w.nw, w.nb, v->h, n4, v->M4, 1e-6f, m->stream);
+    else launch_layernorm_rows(x, w.nw, w.nb, v->h, N, v->D, 1e-6f, m->stream);
+  }
+  vgemm(m, v->h, w.fc1_w, v->mh, (int)n4, v->M4, v->M4, w.fc1_b, nullptr, ACT_GELU_ERF);
+  vgemm(m, v->mh, w.fc2_w, out, (int)n4, v->out, v->M4, w.fc2_b, nullptr, ACT_NONE);
+}
+
+int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, const aha_mm_input* mm, void* x_text) {
+  VisionModel* v = m->vision;
+  const aha_model_desc& c = m->desc;
+  if (!v) {
+    set_error("this model was created without vision tower weights (model.visual.*)");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  if (!mm->pixel_values || !mm->image_grid_thw || mm->n_images <= 0) {
+    set_error("forward_initial: image input without pixel_values / image_grid_thw");
+    return AHA_ERR_INVALID;
+  }
+  const int ms = v->merge;
+  // ---- host index construction ------------------------------------------------------------------------------
+  int64_t N = 0;
+  for (int i = 0; i < mm->n_images; ++i) {
+    const uint32_t* g = mm->image_grid_thw + 3 * i;
+    if (g[1] % ms || g[2] % ms || g[0] == 0) {
+      set_error("image_grid_thw: h and w must be multiples of spatial_merge_size");
+      return AHA_ERR_SHAPE;
+    }
+    N += (int64_t)g[0] * g[1] * g[2];
+  }
+  if (N != mm->n_patches) {
+    set_error("pixel_values has " + std::to_string(mm->n_patches) + " rows, image_grid_thw describes " + std::to_string(N));
+    return AHA_ERR_SHAPE;
+  }
+  const int64_t n4 = N / (ms * ms);
+  std::vector<int32_t> vis_rows;
+  for (size_t i = 0; i < n; ++i)
+    if (ids[i] == (uint32_t)c.image_token_id) vis_rows.push_back((int32_t)i);
+  if ((int64_t)vis_rows.size() != n4) {  // model.rs:1158-1164
+    set_error("n_image_token num: " + std::to_string(vis_rows.size()) + " not equal to image_embed len: " + std::to_string(n4));
+    return AHA_ERR_SHAPE;
+  }
+  std::vector<int32_t> idx(4 * N), rowcol(2 * N), page_of(N), slot_of(N);
+  std::vector<float> wt(4 * N);
+  struct Seg { int64_t start, len, page0; };
+  std::vector<Seg> segs;
+  int64_t off = 0, pages = 0;
+  const float Gm1 = (float)(v->G - 1);
+  for (int im = 0; im < mm->n_images; ++im) {
+    const uint32_t* g = mm->image_grid_thw + 3 * im;
+    const int t = g[0], h = g[1], w = g[2];
+    // linspace(0, G-1, h) in f32 (tensor_utils.rs:354-365), floor by u32 truncation, ceil clamped (model.rs:520-548)
+    auto lin = [&](int steps, std::vector<float>& val, std::vector<int>& fl, std::vector<int>& ce) {
+      val.resize(steps); fl.resize(steps); ce.resize(steps);
+      const float step = steps > 1 ? (Gm1 - 0.0f) / (float)(steps - 1) : 0.f;
+      for (int i = 0; i < steps; ++i) {
+        val[i] = steps > 1 ? 0.0f + (float)i * step : 0.0f;
+        fl[i] = (int)(uint32_t)val[i];
+        ce[i] = std::min(fl[i] + 1, v->G - 1);
+      }
+    };
+    std::vector<float> hv, wv;
+    std::vector<int> hf, hc, wf, wc;
+    lin(h, hv, hf, hc);
+    lin(w, wv, wf, wc);
+    for (int ti = 0; ti < t; ++ti) {
+      segs.push_back({off + (int64_t)ti * h * w, (int64_t)h * w, pages});
+      for (int bh = 0; bh < h / ms; ++bh)
+        for (int bw = 0; bw < w / ms; ++bw)
+          for (int ih = 0; ih < ms; ++ih)
+            for (int iw = 0; iw < ms; ++iw) {
+              const int y = bh * ms + ih, xq = bw * ms + iw;
+              const int64_t local = (((int64_t)bh * (w / ms) + bw) * ms + ih) * ms + iw;
+              const int64_t nn = off + (int64_t)ti * h * w + local;
+              const float dh = hv[y] - (float)hf[y], dw = wv[xq] - (float)wf[xq];
+              idx[0 * N + nn] = hf[y] * v->G + wf[xq];
+              idx[1 * N + nn] = hf[y] * v->G + wc[xq];
+              idx[2 * N + nn] = hc[y] * v->G + wf[xq];
+              idx[3 * N + nn] = hc[y] * v->G + wc[xq];
+              wt[0 * N + nn] = (1.0f - dh) * (1.0f - dw);
+              wt[1 * N + nn] = (1.0f - dh) * dw;
+              wt[2 * N + nn] = dh * (1.0f - dw);
+              wt[3 * N + nn] = dh * dw;
+              rowcol[2 * nn] = y;
+              rowcol[2 * nn + 1] = xq;
+              page_of[nn] = (int32_t)(pages + local / KV_PAGE_TOKENS);
+              slot_of[nn] = (int32_t)(local % KV_PAGE_TOKENS);
+            }
+      pages += ((int64_t)h * w + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS;
+    }
+    off += (int64_t)t * h * w;
+  }
+  int rc;
+  if ((rc = vision_ensure_scratch(m, (size_t)N, (size_t)pages))) return rc;
+  hipStream_t st = m->stream;
+  // ---- uploads ---------------------------------------------------------------------------------------------------
+  if (mm->pixel_dtype == AHA_BF16) {
+    AHA_HIP_CHECK(hipMemcpyAsync(v->pix, mm->pixel_values, (size_t)N * v->patch_dim * 2, hipMemcpyDefault, st));
+  } else if (mm->pixel_dtype == AHA_F32) {
+    std::vector<uint16_t> tmp((size_t)N * v->patch_dim);
+    const float* f = (const float*)mm->pixel_values;
+    for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = f2bf_host(f[i]);
+    AHA_HIP_CHECK(hipMemcpy(v->pix, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+  } else {
+    set_error("pixel_values must be bf16 or f32");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  AHA_HIP_CHECK(hipMemcpyAsync(v->d_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, st));
+  AHA_HIP_CHECK(hipMemcpyAsync(v->d_wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice, st));
+  AHA_HIP_CHECK(hipMemcpyAsync(v->d_rowcol, rowcol.data(), rowcol.size() * 4, hipMemcpyHostToDevice, st));
+  AHA_HIP_CHECK(hipMemcpyAsync(v->d_page_of, page_of.data(), page_of.size() * 4, hipMemcpyHostToDevice, st));
+  AHA_HIP_CHECK(hipMemcpyAsync(v->d_slot_of, slot_of.data(), slot_of.size() * 4, hipMemcpyHostToDevice, st));
+  AHA_HIP_CHECK(hipMemcpyAsync(v->d_vis_rows, vis_rows.data(), vis_rows.size() * 4, hipMemcpyHostToDevice, st));
+  AHA_HIP_CHECK(hipStreamSynchronize(st));  // host vectors are pageable
+
+  // ---- V1 patch embed + V2 position embedding ----------------------------------------------------------------------
+  vgemm(m, v->pix, v->patch_w, v->x, (int)N, v->D, v->patch_dim, v->patch_b, nullptr, ACT_NONE);
+  {
+    ProfScope ps(m, "elem", (double)N * v->D * 2 * 6, 0);
+    launch_pos_embed_add(v->x, v->pos_table, v->d_idx, v->d_wt, N, v->D, st);
+  }
+  KvLayer kv{};
+  kv.page_ptrs = v->d_page_ptrs;
+  kv.layer_off = 0;
+  kv.kvh = v->nh;
+  kv.d = v->hd;
+  for (int li = 0; li < v->depth; ++li) {
+    const VisBlockW& b = v->blocks[li];
+    {
+      ProfScope ps(m, "elem", (double)N * v->D * 4, 0);
+      launch_layernorm_rows(v->x, b.n1w, b.n1b, v->h, N, v->D, 1e-6f, st);
+    }
+    vgemm(m, v->h, b.qkv_w, v->qkv, (int)N, 3 * v->D, v->D, b.qkv_b, nullptr, ACT_NONE);
+    {
+      VitRopeArgs r{};
+      r.qkv = v->qkv; r.rowcol = v->d_rowcol; r.inv_freq = v->d_inv_freq; r.page_of = v->d_page_of; r.slot_of = v->d_slot_of;
+      r.q_out = v->q; r.kv = kv; r.N = (int)N; r.nh = v->nh; r.hd = v->hd;
+      ProfScope ps(m, "elem", (double)N * v->D * 3 * 4, 0);
+      launch_vit_rope_pack(r, st);
+    }
+    for (const Seg& s : segs) {  // block-diagonal attention: one launch per (image, frame) segment (model.rs:258-273)
+      AttnPrefillArgs a{};
+      a.q = (const char*)v->q + (size_t)s.start * v->nh * VIT_DQK * 2;
+      a.kv = kv;
+      a.kv.page_ptrs = v->d_page_ptrs + s.page0;
+      a.o = (char*)v->attn + (size_t)s.start * v->D * 2;
+      a.S = (int)s.len; a.nh = v->nh; a.kvh = v->nh; a.d = v->hd; a.kv_offset = 0; a.kv_total = (int)s.len; a.causal = 0;
+      a.scale = v->scale;
+      ProfScope ps(m, "attn_vit", (double)s.len * v->D * 8, 4.0 * s.len * s.len * v->D);
+      launch_attn_prefill(a, st);
+    }
+    vgemm(m, v->attn, b.proj_w, v->x, (int)N, v->D, v->D, b.proj_b, v->x, ACT_NONE);
+    {
+      ProfScope ps(m, "elem", (double)N * v->D * 4, 0);
+      launch_layernorm_rows(v->x, b.n2w, b.n2b, v->h, N, v->D, 1e-6f, st);
+    }
+    vgemm(m, v->h, b.fc1_w, v->mlp, (int)N, v->I, v->D, b.fc1_b, nullptr, ACT_GELU_TANH);
+    vgemm(m, v->mlp, b.fc2_w, v->x, (int)N, v->D, v->I, b.fc2_b, v->x, ACT_NONE);
+    for (size_t k = 0; k < v->ds_idx.size(); ++k)
+      if (v->ds_idx[k] == li) run_merger(m, v->ds_mergers[k], true, v->x, N, v->deep[k]);
+  }
+  run_merger(m, v->merger, false, v->x, N, v->merged);
+  v->n_merged = n4;
+  {
+    ProfScope ps(m, "elem", (double)n4 * v->out * 4, 0);
+    launch_scatter_rows(x_text, v->merged, v->d_vis_rows, n4, v->out, 0, st);
+  }
+  AHA_HIP_CHECK(hipGetLastError());
+  return AHA_OK;
+}
+
+int vision_deepstack_add(aha_model* m, int layer, void* x) {
+  VisionModel* v = m->vision;
+  if (!v || layer >= (int)v->deep.size()) return AHA_OK;
+  ProfScope ps(m, "elem", (double)v->n_merged * v->out * 6, 0);
+  launch_scatter_rows(x, v->deep[layer], v->d_vis_rows, v->n_merged, v->out, 1, m->stream);
+  return AHA_OK;
+}
+
+int vision_debug_embeds(aha_model* m, int which, float* out, size_t n) {
+  VisionModel* v = m->vision;
+  if (!v || which < 0 || which > (int)v->deep.size() || n != (size_t)v->n_merged * v->out) {
+    set_error("debug_image_embeds: no image embeddings of that shape");
+    return AHA_ERR_INVALID;
+  }
+  std::vector<uint16_t> tmp(n);
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  AHA_HIP_CHECK(hipMemcpy(tmp.data(), which == 0 ? v->merged : v->deep[which - 1], n * 2, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) {
+    const uint32_t u = (uint32_t)tmp[i] << 16;
+    memcpy(&out[i], &u, 4);
+  }
+  return AHA_OK;
+}
 
 }  // namespace aha

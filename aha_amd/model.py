@@ -103,6 +103,8 @@ class HipInferenceModel:
             for j, s in enumerate(t.shape):
                 views[i].shape[j] = s
             views[i].on_device = int(t.is_cuda)
+        if any(t.is_cuda for t in keep):
+            torch.cuda.synchronize()
         check(lib().aha_hip_model_create(self.ctx.handle, C.byref(desc), views, len(weights), C.byref(self.handle)))
         del keep
         self.vocab = self.text_cfg.vocab_size
@@ -116,6 +118,8 @@ class HipInferenceModel:
         mm_ref = None
         if data is not None:
             pv = data.pixel_values.detach().contiguous()
+            if pv.is_cuda:  # produced on torch's stream; the library copies on its own stream
+                torch.cuda.current_stream(pv.device).synchronize()
             grid = np.ascontiguousarray(np.asarray(data.image_grid_thw, dtype=np.uint32).reshape(-1, 3))
             mm = MmInput()
             mm.pixel_values = pv.data_ptr()

@@ -121,3 +121,17 @@ def argmax(x: torch.Tensor) -> int:
 def bf16_scale(d: int) -> float:
     """1/sqrt(d) rounded to bf16: the scalar of Candle's `attn_weights * scaling` affine op is cast to the tensor dtype."""
     return float(torch.tensor(1.0 / math.sqrt(d), dtype=torch.float32).bfloat16().float())
+
+
+def image_to_patches(img_u8_hwc: torch.Tensor, patch: int = 16, merge: int = 2, mean=(0.5, 0.5, 0.5),
+                     std=(0.5, 0.5, 0.5)) -> torch.Tensor:
+    """V0: (H, W, 3) uint8 GPU tensor -> (N, 3*2*patch*patch) bf16 pixel_values rows (frame duplicated, merge order)."""
+    import ctypes as C
+    _chk(img_u8_hwc)
+    assert img_u8_hwc.dtype == torch.uint8 and img_u8_hwc.dim() == 3 and img_u8_hwc.shape[2] == 3
+    H, W = int(img_u8_hwc.shape[0]), int(img_u8_hwc.shape[1])
+    out = torch.empty((H // patch) * (W // patch), 6 * patch * patch, dtype=torch.bfloat16, device=img_u8_hwc.device)
+    m = (C.c_float * 3)(*mean)
+    s = (C.c_float * 3)(*std)
+    check(lib().aha_hip_image_to_patches(_ptr(img_u8_hwc), _ptr(out), H, W, patch, merge, m, s, _stream()))
+    return out

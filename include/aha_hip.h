@@ -156,6 +156,11 @@ int aha_hip_attn_decode(const void* q, const void* k, const void* v, void* o, in
  * k/v (L, kvh*d) token-major, L = kv_offset + S.  causal = 0 gives full (ViT) attention. */
 int aha_hip_attn_prefill(const void* q, const void* k, const void* v, void* o, int32_t S, int32_t L, int32_t nh,
                          int32_t kvh, int32_t d, int32_t kv_offset, int32_t causal, float scale, void* stream);
+/* V0: one RGB8 image (H, W, 3) in device memory, H and W multiples of patch*merge -> the processor's pixel_values rows
+ * ((H/patch)*(W/patch), 3*2*patch*patch) bf16 in merge-window order with the frame duplicated to T = 2
+ * (/root/reference/src/models/qwen3vl/processor.rs:174-251; img_transform, /root/reference/src/utils/img_utils.rs:272-293). */
+int aha_hip_image_to_patches(const uint8_t* img_hwc, void* out, int32_t H, int32_t W, int32_t patch, int32_t merge,
+                             const float mean[3], const float std[3], void* stream);
 /* D11 greedy: first maximal index of an f32 vector. */
 int aha_hip_argmax(const float* x, int64_t n, uint32_t* out_dev, void* stream);
 

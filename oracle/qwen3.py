@@ -180,14 +180,18 @@ class OracleQwen3:
         ids = torch.as_tensor(np.asarray(input_ids, dtype=np.int64)).reshape(1, -1)
         return self.embed[ids]
 
-    def forward_hidden(self, input_ids=None, inputs_embeds=None, seqlen_offset: int = 0, all_positions=False):
-        """Qwen3Model::forward_hidden, qwen3/model.rs:146-189."""
+    def forward_hidden(self, input_ids=None, inputs_embeds=None, seqlen_offset: int = 0, all_positions=False,
+                       cos_sin=None, after_layer=None):
+        """Qwen3Model::forward_hidden, qwen3/model.rs:146-189.  ``cos_sin`` / ``after_layer`` let the Qwen3-VL text
+        model (qwen3vl/model.rs:775-828: M-RoPE tables, DeepStack adds) reuse the same layer code."""
         x = inputs_embeds if inputs_embeds is not None else self.embed_tokens(input_ids)
         s = x.shape[1]
         mask = None if s <= 1 else prepare_causal_attention_mask(s)   # offset hard-coded 0 (model.rs:168-173)
-        cos, sin = rope_cos_sin(self.inv_freq, seqlen_offset, s)
+        cos, sin = cos_sin if cos_sin is not None else rope_cos_sin(self.inv_freq, seqlen_offset, s)
         for li in range(self.cfg.num_hidden_layers):
             x = self.decoder_layer(li, x, cos, sin, mask)
+            if after_layer is not None:
+                x = after_layer(li, x)
         x = rms_norm(self.nm, x, self.w[self.p + "norm.weight"], self.cfg.rms_norm_eps)
         return x if all_positions else x[:, s - 1:s, :]
 
