@@ -1,0 +1,47 @@
+"""Multi-GPU plumbing for the one part of the path that shards without a collective: independent requests.
+
+BASELINE.json north_star: decode stays single-GPU (weights 15 GB << 288 GB), so N GPUs serve N independent requests
+(replicas, "scaling": "weak"); only the timing is combined across ranks (max over ranks, as the bench contract asks).
+The ViT (per-image) and long-context TP prefill (RCCL reduce-scatter / all-gather) are SURVEY.md section 8(e) rows
+for a later round; `shard_units` is the partitioning they will share.
+One process per GPU; `torch.distributed` backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Tuple
+
+
+def shard_units(n_units: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block partition of n_units independent units (requests / images) over ranks: [start, end)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    base, rem = divmod(n_units, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def init_process_group(backend: str = "nccl", device=None):
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if dist.is_initialized():
+        return dist
+    kw = {}
+    if backend == "nccl" and device is not None:
+        kw["device_id"] = device
+    dist.init_process_group(backend, **kw)
+    return dist
+
+
+def aggregate_throughput(units_this_rank: float, secs_this_rank: float, device="cpu") -> Tuple[float, float]:
+    """Whole-job throughput = (sum over ranks of units) / (max over ranks of seconds).  Returns (value, max_secs)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return units_this_rank / secs_this_rank, secs_this_rank
+    t = torch.tensor([secs_this_rank], dtype=torch.float64, device=device)
+    u = torch.tensor([units_this_rank], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(u.item()) / float(t.item()), float(t.item())

@@ -1,0 +1,106 @@
+"""Generates the golden fixtures under tests/golden/ -- run in the BUILD container only (needs `transformers`).
+
+The reference (Rust, Candle) cannot be executed here and holds no golden vectors of its own, so
+these fixtures come from an INDEPENDENT implementation of the same architectures: HF transformers 5.15
+Qwen3ForCausalLM / Qwen3VLForConditionalGeneration in f32, eager attention, with our seeded synthetic checkpoints
+(tensor names identical to the ones the reference looks up).  They pin the oracle's architecture (op graph, M-RoPE,
+get_rope_index, ViT, DeepStack); they do NOT pin Candle's rounding behaviour -- see oracle/numerics.py.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from aha_amd.configs import tiny_qwen3, tiny_qwen3vl  # noqa: E402
+from aha_amd.weights import qwen3_text_weights, qwen3vl_weights  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def qwen3_case():
+    from transformers import Qwen3Config as HFC, Qwen3ForCausalLM
+    cfg = tiny_qwen3()
+    w = qwen3_text_weights(cfg, seed=0, dtype=torch.float32)
+    hf = HFC(hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size, num_hidden_layers=cfg.num_hidden_layers,
+             num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+             vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta, tie_word_embeddings=True,
+             attention_bias=False, max_position_embeddings=4096)
+    hf._attn_implementation = "eager"
+    m = Qwen3ForCausalLM(hf).eval()
+    sd = dict(w)
+    sd["lm_head.weight"] = w["model.embed_tokens.weight"]
+    assert not m.load_state_dict(sd, strict=False).missing_keys
+    ids = torch.randint(0, cfg.vocab_size, (1, 37), generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        out = m(ids, use_cache=True)
+        logits = [out.logits[0, -1].numpy()]
+        toks = [int(out.logits[0, -1].argmax())]
+        past = out.past_key_values
+        for t in range(5):
+            out = m(torch.tensor([[toks[-1]]]), past_key_values=past, use_cache=True)
+            past = out.past_key_values
+            logits.append(out.logits[0, -1].numpy())
+            toks.append(int(out.logits[0, -1].argmax()))
+    np.savez_compressed(os.path.join(OUT, "qwen3_tiny_f32.npz"), ids=ids[0].numpy().astype(np.int64),
+                        logits=np.stack(logits).astype(np.float32), tokens=np.asarray(toks, dtype=np.int64), seed=0)
+
+
+def qwen3vl_case():
+    from transformers.models.qwen3_vl import Qwen3VLConfig as HFC, Qwen3VLForConditionalGeneration
+    from oracle.numerics import Numerics
+    from oracle.qwen3vl import process_images
+    cfg = tiny_qwen3vl()
+    w = qwen3vl_weights(cfg, seed=0, dtype=torch.float32)
+    t, v = cfg.text, cfg.vision
+    hf = HFC(
+        text_config=dict(hidden_size=t.hidden_size, intermediate_size=t.intermediate_size, num_hidden_layers=t.num_hidden_layers,
+                         num_attention_heads=t.num_attention_heads, num_key_value_heads=t.num_key_value_heads, head_dim=t.head_dim,
+                         vocab_size=t.vocab_size, rms_norm_eps=t.rms_norm_eps, rope_theta=t.rope_theta,
+                         rope_scaling=dict(rope_type="default", mrope_section=[24, 20, 20], mrope_interleaved=True),
+                         max_position_embeddings=4096, attention_bias=False, tie_word_embeddings=False),
+        vision_config=dict(depth=v.depth, hidden_size=v.hidden_size, num_heads=v.num_heads, intermediate_size=v.intermediate_size,
+                           in_channels=3, patch_size=16, temporal_patch_size=2, spatial_merge_size=2,
+                           out_hidden_size=v.out_hidden_size, num_position_embeddings=v.num_position_embeddings,
+                           deepstack_visual_indexes=v.deepstack_visual_indexes, hidden_act="gelu_pytorch_tanh"),
+        image_token_id=cfg.image_token_id, video_token_id=cfg.video_token_id,
+        vision_start_token_id=cfg.vision_start_token_id, vision_end_token_id=cfg.vision_end_token_id, tie_word_embeddings=False)
+    hf.text_config._attn_implementation = "eager"
+    hf.vision_config._attn_implementation = "eager"
+    hf._attn_implementation = "eager"
+    m = Qwen3VLForConditionalGeneration(hf).eval().float()
+    r = m.load_state_dict(w, strict=False)
+    assert not r.missing_keys and not r.unexpected_keys
+    g = np.random.default_rng(3)
+    imgs = [g.integers(0, 256, size=(96, 64, 3), dtype=np.uint8), g.integers(0, 256, size=(64, 128, 3), dtype=np.uint8)]
+    pv, grid = process_images(Numerics("f32"), imgs)
+    ids = [5, 6, 7]
+    for gi in grid.tolist():
+        ids += [cfg.vision_start_token_id] + [cfg.image_token_id] * (gi[0] * gi[1] * gi[2] // 4) + [cfg.vision_end_token_id, 9]
+    ids += [int(x) for x in g.integers(0, 1900, size=11)]
+    mmt = torch.tensor([[1 if t_ == cfg.image_token_id else 0 for t_ in ids]])
+    with torch.no_grad():
+        out = m(input_ids=torch.tensor([ids]), pixel_values=pv, image_grid_thw=torch.tensor(grid.astype(np.int64)),
+                mm_token_type_ids=mmt, use_cache=True)
+        logits = [out.logits[0, -1].numpy()]
+        toks = [int(out.logits[0, -1].argmax())]
+        past = out.past_key_values
+        for t_ in range(4):
+            out = m(input_ids=torch.tensor([[toks[-1]]]), past_key_values=past, use_cache=True,
+                    cache_position=torch.tensor([len(ids) + t_]))
+            past = out.past_key_values
+            logits.append(out.logits[0, -1].numpy())
+            toks.append(int(out.logits[0, -1].argmax()))
+    np.savez_compressed(os.path.join(OUT, "qwen3vl_tiny_f32.npz"), ids=np.asarray(ids, dtype=np.int64),
+                        img0=imgs[0], img1=imgs[1], grid=grid, logits=np.stack(logits).astype(np.float32),
+                        tokens=np.asarray(toks, dtype=np.int64), seed=0)
+
+
+if __name__ == "__main__":
+    qwen3_case()
+    qwen3vl_case()
+    print("wrote", [f for f in os.listdir(OUT) if f.endswith(".npz")])

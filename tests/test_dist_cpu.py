@@ -1,0 +1,40 @@
+"""CPU (-m "not gpu"): the N > 1 path with world_size 2 over gloo -- request sharding and the bench aggregation
+(sum of units / max of seconds), exactly the code bench.py runs over RCCL."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from aha_amd import parallel
+    dist = parallel.init_process_group("gloo")
+    a, b = parallel.shard_units(5, world, rank)
+    units = float(b - a) * 10.0            # e.g. tokens produced by this rank's requests
+    secs = 1.0 + rank                      # rank 1 is the slow one
+    value, tmax = parallel.aggregate_throughput(units, secs)
+    out.put((rank, a, b, value, tmax))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_replicas_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, a0, b0, v0, t0), (r1, a1, b1, v1, t1) = res
+    assert (a0, b0, a1, b1) == (0, 3, 3, 5)
+    assert t0 == t1 == 2.0                       # max over ranks
+    assert abs(v0 - 50.0 / 2.0) < 1e-9 and v0 == v1   # whole-job units / slowest rank's time

@@ -1,0 +1,129 @@
+"""CPU (-m "not gpu"): the oracle restatement against the committed golden fixtures (tests/golden/*.npz, produced by
+tests/golden/make_golden.py from HF transformers -- an independent implementation of the same architectures), plus
+properties of the restatement itself."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from aha_amd.configs import tiny_qwen3, tiny_qwen3vl
+from aha_amd.weights import qwen3_text_weights, qwen3vl_weights
+from oracle import qwen3 as oq
+from oracle import qwen3vl as ov
+from oracle.numerics import Numerics
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_qwen3_oracle_matches_golden_f32():
+    g = np.load(os.path.join(GOLD, "qwen3_tiny_f32.npz"))
+    cfg = tiny_qwen3()
+    w = qwen3_text_weights(cfg, seed=int(g["seed"]), dtype=torch.float32)
+    o = oq.OracleQwen3(cfg, w, Numerics("f32"))
+    ids = g["ids"].tolist()
+    lg = o.forward(ids, 0).reshape(-1).numpy()
+    assert np.abs(lg - g["logits"][0]).max() < 2e-5
+    toks = g["tokens"].tolist()
+    assert int(np.argmax(lg)) == toks[0]
+    off = len(ids)
+    for t in range(len(toks) - 1):
+        lg = o.forward_step([toks[t]], off).reshape(-1).numpy()
+        assert np.abs(lg - g["logits"][t + 1]).max() < 2e-5
+        assert int(np.argmax(lg)) == toks[t + 1]
+        off += 1
+    o.clear_cache()
+    assert oq.greedy_generate(o, ids, len(toks)) == toks
+
+
+def test_qwen3vl_oracle_matches_golden_f32():
+    g = np.load(os.path.join(GOLD, "qwen3vl_tiny_f32.npz"))
+    cfg = tiny_qwen3vl()
+    w = qwen3vl_weights(cfg, seed=int(g["seed"]), dtype=torch.float32)
+    nm = Numerics("f32")
+    o = ov.OracleQwen3VL(cfg, w, nm)
+    pv, grid = ov.process_images(nm, [g["img0"], g["img1"]])
+    assert np.array_equal(grid, g["grid"])
+    ids = g["ids"].tolist()
+    lg = o.forward_initial(ids, 0, (pv, grid)).reshape(-1).numpy()
+    assert np.abs(lg - g["logits"][0]).max() < 3e-5
+    toks = g["tokens"].tolist()
+    off = len(ids)
+    for t in range(len(toks) - 1):
+        lg = o.forward_step([toks[t]], off).reshape(-1).numpy()
+        assert np.abs(lg - g["logits"][t + 1]).max() < 3e-5, t
+        assert int(np.argmax(lg)) == toks[t + 1]
+        off += 1
+
+
+def test_decode_equals_prefill_suffix_and_gqa_mapping():
+    cfg = tiny_qwen3(layers=2, hidden=256, heads=4, kv_heads=2, inter=512, vocab=512)
+    w = qwen3_text_weights(cfg, seed=2, dtype=torch.float32)
+    o = oq.OracleQwen3(cfg, w, Numerics("f32"))
+    ids = torch.randint(0, 512, (29,), generator=torch.Generator().manual_seed(4)).tolist()
+    full = o.forward(ids, 0).reshape(-1)
+    o.clear_cache()
+    o.forward(ids[:20], 0)
+    for t in range(20, 29):
+        step = o.forward([ids[t]], t).reshape(-1)
+    assert (step - full).abs().max() < 1e-5
+    # repeat_kv: q head i reads kv head i // g (tensor_utils.rs:108-124)
+    x = torch.arange(2 * 3 * 4, dtype=torch.float32).reshape(1, 2, 3, 4)
+    r = oq.repeat_kv(x, 3)
+    assert r.shape == (1, 6, 3, 4) and all(torch.equal(r[0, i], x[0, i // 3]) for i in range(6))
+
+
+def test_bf16_rounding_points_are_small_but_real():
+    cfg = tiny_qwen3(layers=2, hidden=256, heads=4, kv_heads=2, inter=512, vocab=512)
+    w = qwen3_text_weights(cfg, seed=2)
+    ids = list(range(40))
+    a = oq.OracleQwen3(cfg, w, Numerics("bf16")).forward(ids, 0).reshape(-1)
+    b = oq.OracleQwen3(cfg, w, Numerics("f32")).forward(ids, 0).reshape(-1)
+    c = oq.OracleQwen3(cfg, w, Numerics("bf16", matmul_f64=True)).forward(ids, 0).reshape(-1)
+    d = oq.OracleQwen3(cfg, w, Numerics("bf16", rmsnorm_in_T=True)).forward(ids, 0).reshape(-1)
+    std = float(b.std())
+    assert 0 < float((a - b).abs().max()) < 0.1 * std          # bf16 rounding points matter ...
+    assert float((a - c).abs().max()) < 0.05 * std              # ... accumulation order barely does
+    assert float((a - d).abs().max()) < 0.08 * std              # candle-CPU sub-op rounding of rms_norm: same class
+    assert torch.equal(a, torch.tensor(a).bfloat16().float())   # logits are materialised in bf16
+
+
+def test_rope_tables():
+    inv = oq.compute_default_rope_parameters(128, 1e6)
+    assert inv.shape == (64,) and float(inv[0]) == 1.0 and abs(float(inv[32]) - 1e-3) < 1e-9
+    cos, sin = oq.rope_cos_sin(inv, 5, 3)
+    assert cos.shape == (3, 128) and torch.equal(cos[:, :64], cos[:, 64:])
+    # interleaved M-RoPE: slot i uses axis [T,H,W][i % 3] for i < 60, T for 60..63 (rope.rs:454-476)
+    pos = np.stack([np.full(4, 7), np.full(4, 11), np.full(4, 13)])
+    c, _ = ov.mrope_cos_sin(inv, pos, [24, 20, 20])
+    for i in range(64):
+        p = [7, 11, 13][i % 3] if i < 60 else 7
+        assert abs(float(c[0, 0, i]) - float(torch.cos(torch.tensor(np.float32(p)) * inv[i]))) < 1e-6
+
+
+def test_get_rope_index_examples():
+    cfg = tiny_qwen3vl()
+    ids = [1, 2, cfg.vision_start_token_id] + [cfg.image_token_id] * 6 + [cfg.vision_end_token_id, 3, 4]
+    pos, delta = ov.get_rope_index(ids, np.array([[1, 4, 6]], dtype=np.uint32), cfg)
+    assert pos[:, :3].tolist() == [[0, 1, 2]] * 3
+    assert pos[0, 3:9].tolist() == [3] * 6 and pos[1, 3:9].tolist() == [3, 3, 3, 4, 4, 4] and pos[2, 3:9].tolist() == [3, 4, 5] * 2
+    assert pos[:, 9:].tolist() == [[6, 7, 8]] * 3 and delta == 9 - len(ids)
+    p2, d2 = ov.get_rope_index([1, 2, 3], None, cfg)
+    assert p2.tolist() == [[0, 1, 2]] * 3 and d2 == 0
+
+
+def test_patch_order_and_pos_embed_indices():
+    nm = Numerics("f32")
+    img = np.arange(64 * 96 * 3, dtype=np.int64).reshape(64, 96, 3) % 251
+    pv, grid = ov.process_images(nm, [img.astype(np.uint8)])
+    assert tuple(grid[0]) == (1, 4, 6) and pv.shape == (24, 1536)
+    # row 1 is the patch to the RIGHT of row 0 inside the first 2x2 window; row 2 is BELOW row 0 (processor.rs:199-216)
+    x = ov.img_transform(nm, img.astype(np.uint8))
+    assert torch.equal(pv[1, :256].reshape(16, 16), x[0, 0:16, 16:32])
+    assert torch.equal(pv[2, :256].reshape(16, 16), x[0, 16:32, 0:16])
+    assert torch.equal(pv[0, 256:512], pv[0, :256])      # duplicated frame
+    cfg = tiny_qwen3vl()
+    v = ov.OracleVision(cfg, qwen3vl_weights(cfg, seed=0, dtype=torch.float32), nm)
+    idx, wt = v.pos_embed_indices(grid)
+    assert idx.shape == (4, 24) and np.allclose(wt.sum(0), 1.0, atol=1e-6)
+    assert idx.min() >= 0 and idx.max() < cfg.vision.num_position_embeddings
