@@ -30,6 +30,7 @@ struct GemvArgs {
   void* h_out;           // optional (K) bf16: block 0 also writes the normalised input (debug / last hidden)
   int N, K;
   float eps;
+  int cached;            // 0 (default): non-temporal weight loads (streamed once); 1: default cache policy
 };
 void launch_gemv(const GemvArgs& a, GemvEpi epi, hipStream_t st);
 int gemv_num_tiles(int N, int K);  // number of (max,idx) partials GEMV_LOGITS writes

@@ -10,6 +10,8 @@
 //   * epilogues fuse the reference's next op: residual add (qwen3/model.rs:81,86), silu(gate)*up
 //     (modules.rs:81-87), f32 logits + argmax partials (generate.rs:75-84)
 // Rounding points follow the reference's op boundaries: Linear output -> bf16, then each further op -> bf16.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -74,8 +76,8 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a) {
       for (int u = 0; u < U; ++u) {
         const int k = ((c0 + u) << 9) + lane * 8;
         const bool ok = (c0 + u < nchunks) && (k < K);
-        buf[u][0][r] = ok ? ld_nt16(p0 + k) : u32x4_t{0u, 0u, 0u, 0u};
-        if (NW == 2) buf[u][NW - 1][r] = ok ? ld_nt16(p1 + k) : u32x4_t{0u, 0u, 0u, 0u};
+        buf[u][0][r] = ok ? (a.cached ? ld16(p0 + k) : ld_nt16(p0 + k)) : u32x4_t{0u, 0u, 0u, 0u};
+        if (NW == 2) buf[u][NW - 1][r] = ok ? (a.cached ? ld16(p1 + k) : ld_nt16(p1 + k)) : u32x4_t{0u, 0u, 0u, 0u};
       }
     }
   };
@@ -234,7 +236,25 @@ GemvPlan plan_gemv(int N, int K, GemvEpi epi) {
   while (Up * 2 <= U) Up *= 2;
   const int ntiles = (N + 4 * R - 1) / (4 * R);
   // persistent blocks: two register buffers of R*U*NW loads => ~2 blocks (8 waves) per CU on 256 CUs
-  int grid = ntiles < 512 ? ntiles : 512;
+  int gmax = 512;
+  // tuning knobs for scripts/bench_gemv.py (not used by the product path unless set)
+  static const char* e_grid = getenv("AHA_GEMV_GRID");
+  static const char* e_r = getenv("AHA_GEMV_R");
+  static const char* e_u = getenv("AHA_GEMV_U");
+  if (e_grid) gmax = atoi(e_grid);
+  if (e_r) {
+    R = atoi(e_r);
+    if (nw == 2 && R > 2) R = 2;
+  }
+  if (e_u) Up = atoi(e_u);
+  if (e_r || e_u) {
+    if (Up > nchunks) Up = nchunks;
+    int q = 1;
+    while (q * 2 <= Up) q *= 2;
+    Up = q;
+  }
+  const int ntiles2 = (N + 4 * R - 1) / (4 * R);
+  int grid = ntiles2 < gmax ? ntiles2 : gmax;
   return {R, Up, grid};
 }
 
@@ -257,7 +277,10 @@ static void launch_gemv_epi(const GemvArgs& a, const GemvPlan& p, hipStream_t st
 #undef GV
 }
 
-void launch_gemv(const GemvArgs& a, GemvEpi epi, hipStream_t st) {
+void launch_gemv(const GemvArgs& a_in, GemvEpi epi, hipStream_t st) {
+  GemvArgs a = a_in;
+  static const char* e_cached = getenv("AHA_GEMV_CACHED");
+  if (e_cached) a.cached = atoi(e_cached);
   const GemvPlan p = plan_gemv(a.N, a.K, epi);
   switch (epi) {
     case GEMV_STORE: launch_gemv_epi<GEMV_STORE>(a, p, st); break;
