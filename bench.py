@@ -194,6 +194,16 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "launches": gv["launches"], "avg_us": round(1e3 * gv["ms"] / max(gv["launches"], 1), 2),
             "algorithmic_bytes_per_launch": round(gv["bytes"] / max(gv["launches"], 1))}
+    # HBM traffic of the same kernel class from the PMC passes (rocprofv3 cannot run inside this process): the committed
+    # summary profiles/r01_pmc_traffic_gemv.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes).
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_gemv.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("workload") == args.workload:
+            roof["traffic"] = round(pmc["traffic_bytes_per_launch"])
+            roof["traffic_source"] = "profiles/r01_pmc_traffic_gemv.json"
+    except (OSError, KeyError, ValueError):
+        pass
     ad = prof["attn_decode"]
     attn_gbs = ad["bytes"] / (ad["ms"] * 1e-3) / 1e9 if ad["ms"] > 0 else 0.0
 
