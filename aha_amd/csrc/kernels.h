@@ -31,6 +31,11 @@ struct GemvArgs {
   int N, K;
   float eps;
   int cached;            // 0 (default): non-temporal weight loads (streamed once); 1: default cache policy
+  // optional: x is the attention output still split over comb_n KV splits (attn_decode_fused_kernel); the prologue
+  // merges them: x[h*128+d] = bf16( sum_s e^{m_s-M} o_s[h][d] / sum_s e^{m_s-M} l_s )   (K == comb_nh*128)
+  const float* comb_o;   // (comb_n, comb_nh, 128) f32
+  const float* comb_ml;  // (comb_n, comb_nh, 2) f32
+  int comb_n, comb_nh;
 };
 void launch_gemv(const GemvArgs& a, GemvEpi epi, hipStream_t st);
 int gemv_num_tiles(int N, int K);  // number of (max,idx) partials GEMV_LOGITS writes
@@ -76,6 +81,25 @@ struct AttnDecodeArgs {
   float scale;
 };
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t st);
+
+// Fused decode step of the attention block: q/k norm + rope + KV append + split-KV attention (kernels_attn.hip).
+// Leaves nsplit un-normalised partials per head; the o_proj matvec merges them in its prologue (GemvArgs::comb_*).
+struct AttnDecodeFusedArgs {
+  const void* qkv;          // ((nh+2kvh)*128) bf16: output of the fused QKV matvec
+  const void* q_norm_w;     // (128) bf16
+  const void* k_norm_w;
+  const int32_t* pos;       // (3) rope positions T,H,W of the token
+  const float* inv_freq;    // (64)
+  const int32_t* axis_map;  // (64)
+  KvLayer kv;
+  const int32_t* kv_start;  // device scalar: cache slot of the token
+  const int32_t* kv_len;    // device scalar: cache length after the append (= kv_start + 1)
+  float* part_o;            // (nsplit, nh, 128) f32
+  float* part_ml;           // (nsplit, nh, 2) f32
+  int nh, kvh, nsplit;
+  float eps, scale;
+};
+void launch_attn_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t st);
 
 struct AttnPrefillArgs {
   const void* q;           // (S, nh*d) bf16

@@ -96,6 +96,7 @@ struct aha_model {
   float* d_part_o = nullptr;
   float* d_part_ml = nullptr;
   int max_nsplit = 64;
+  bool decode_fused = true;  // attention block of a decode step in one launch (kernels_attn.hip attn_decode_fused_kernel)
   float* h_logits = nullptr;  // pinned
   // prefill scratch (grown on demand)
   size_t pf_cap = 0;

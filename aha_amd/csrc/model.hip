@@ -7,6 +7,7 @@
 #include "model.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -343,6 +344,7 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
   m->ctx = ctx;
   m->desc = c;
   m->stream = ctx->stream;
+  if (const char* e = getenv("AHA_DECODE_FUSED")) m->decode_fused = atoi(e) != 0;
   int rc = AHA_OK;
   auto fail = [&](int code) {
     model_destroy(m);
@@ -610,27 +612,46 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
       ProfScope ps(m, "gemv", (double)g.N * g.K * 2 + g.K * 4.0 + g.N * 2.0, 2.0 * g.N * g.K);
       launch_gemv(g, GEMV_STORE, st);
     }
-    {  // q/k norm + rope + append                            (modules.rs:544-566)
-      RopeArgs r{};
-      r.qkv = m->d_qkv; r.ld = nq + 2 * nkv; r.q_norm_w = L.q_norm; r.k_norm_w = L.k_norm;
-      r.pos = m->d_state->pos; r.pos_ld = 1; r.inv_freq = m->d_inv_freq; r.axis_map = m->d_axis_map;
-      r.q_out = m->d_q; r.kv = model_kv_layer(m, li); r.kv_start = &m->d_state->kv_start;
-      r.S = 1; r.nh = nh; r.kvh = kvh; r.d = d; r.eps = c.rms_norm_eps;
-      ProfScope ps(m, "elem", (nq + 2 * nkv) * 4.0, 0);
-      launch_qknorm_rope(r, st);
-    }
-    {  // attention over the paged cache                       (modules.rs:567-574, 757-813)
-      AttnDecodeArgs a{};
-      a.q = m->d_q; a.kv = model_kv_layer(m, li); a.kv_len = &m->d_state->kv_len; a.part_o = m->d_part_o; a.part_ml = m->d_part_ml;
-      a.o = m->d_attn; a.nh = nh; a.kvh = kvh; a.d = d; a.nsplit = nsplit; a.scale = m->attn_scale;
-      ProfScope ps(m, "attn_decode", (double)kv_len_after * 2 * nkv * 2 + nq * 4.0, 4.0 * kv_len_after * nq);
-      launch_attn_decode(a, st);
-    }
-    {  // x = x + attn Wo^T                                    (modules.rs:577, qwen3/model.rs:81)
-      GemvArgs g{};
-      g.W = L.wo; g.x = m->d_attn; g.residual = m->d_x; g.y = m->d_x; g.N = H; g.K = nq;
-      ProfScope ps(m, "gemv", (double)g.N * g.K * 2 + g.K * 2.0 + g.N * 4.0, 2.0 * g.N * g.K);
-      launch_gemv(g, GEMV_RESIDUAL, st);
+    if (m->decode_fused) {
+      {  // q/k norm + rope + KV append + attention over the paged cache, one launch   (modules.rs:544-574, 757-813)
+        AttnDecodeFusedArgs a{};
+        a.qkv = m->d_qkv; a.q_norm_w = L.q_norm; a.k_norm_w = L.k_norm; a.pos = m->d_state->pos; a.inv_freq = m->d_inv_freq;
+        a.axis_map = m->d_axis_map; a.kv = model_kv_layer(m, li); a.kv_start = &m->d_state->kv_start; a.kv_len = &m->d_state->kv_len;
+        a.part_o = m->d_part_o; a.part_ml = m->d_part_ml; a.nh = nh; a.kvh = kvh; a.nsplit = nsplit; a.eps = c.rms_norm_eps;
+        a.scale = m->attn_scale;
+        ProfScope ps(m, "attn_decode", (double)kv_len_after * 2 * nkv * 2 + (nq + 2 * nkv) * 2.0 + nsplit * nq * 4.0, 4.0 * kv_len_after * nq);
+        launch_attn_decode_fused(a, st);
+      }
+      {  // x = x + attn Wo^T, attn = merge of the KV-split partials in the prologue  (modules.rs:577, qwen3/model.rs:81)
+        GemvArgs g{};
+        g.W = L.wo; g.x = m->d_attn; g.residual = m->d_x; g.y = m->d_x; g.N = H; g.K = nq;
+        g.comb_o = m->d_part_o; g.comb_ml = m->d_part_ml; g.comb_n = nsplit; g.comb_nh = nh;
+        ProfScope ps(m, "gemv", (double)g.N * g.K * 2 + g.K * 2.0 + g.N * 4.0, 2.0 * g.N * g.K);
+        launch_gemv(g, GEMV_RESIDUAL, st);
+      }
+    } else {  // three-launch variant (A/B knob AHA_DECODE_FUSED=0)
+      {  // q/k norm + rope + append                            (modules.rs:544-566)
+        RopeArgs r{};
+        r.qkv = m->d_qkv; r.ld = nq + 2 * nkv; r.q_norm_w = L.q_norm; r.k_norm_w = L.k_norm;
+        r.pos = m->d_state->pos; r.pos_ld = 1; r.inv_freq = m->d_inv_freq; r.axis_map = m->d_axis_map;
+        r.q_out = m->d_q; r.kv = model_kv_layer(m, li); r.kv_start = &m->d_state->kv_start;
+        r.S = 1; r.nh = nh; r.kvh = kvh; r.d = d; r.eps = c.rms_norm_eps;
+        ProfScope ps(m, "elem", (nq + 2 * nkv) * 4.0, 0);
+        launch_qknorm_rope(r, st);
+      }
+      {  // attention over the paged cache                       (modules.rs:567-574, 757-813)
+        AttnDecodeArgs a{};
+        a.q = m->d_q; a.kv = model_kv_layer(m, li); a.kv_len = &m->d_state->kv_len; a.part_o = m->d_part_o; a.part_ml = m->d_part_ml;
+        a.o = m->d_attn; a.nh = nh; a.kvh = kvh; a.d = d; a.nsplit = nsplit; a.scale = m->attn_scale;
+        ProfScope ps(m, "attn_decode", (double)kv_len_after * 2 * nkv * 2 + nq * 4.0, 4.0 * kv_len_after * nq);
+        launch_attn_decode(a, st);
+      }
+      {  // x = x + attn Wo^T                                    (modules.rs:577, qwen3/model.rs:81)
+        GemvArgs g{};
+        g.W = L.wo; g.x = m->d_attn; g.residual = m->d_x; g.y = m->d_x; g.N = H; g.K = nq;
+        ProfScope ps(m, "gemv", (double)g.N * g.K * 2 + g.K * 2.0 + g.N * 4.0, 2.0 * g.N * g.K);
+        launch_gemv(g, GEMV_RESIDUAL, st);
+      }
     }
     {  // act = silu(h Wg^T) * (h Wu^T), h = RMSNorm(x)        (qwen3/model.rs:83, modules.rs:81-84)
       GemvArgs g{};
