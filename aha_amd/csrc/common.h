@@ -13,20 +13,27 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even f32 -> bf16 (what a Candle op does when it materialises a bf16 tensor)
+// round-to-nearest-even f32 -> bf16 (what a Candle op does when it materialises a bf16 tensor).  The cast lowers to
+// the gfx950 hardware conversion v_cvt_pk_bf16_f32 (RNE), 1 VALU op instead of ~6 integer ops: the softmax of the
+// attention kernels is VALU-bound, so this matters.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 __device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  const __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
 }
 // value of f after a round trip through bf16
+// (through the bit pattern on purpose: `(float)(__bf16)f` may be elided under clang's bf16 excess-precision rules)
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 
 // low / high bf16 of a packed dword as f32
 __device__ __forceinline__ float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-__device__ __forceinline__ uint32_t pack_bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ uint32_t pack_bf(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  const bf16x2_t p = __builtin_convertvector(v, bf16x2_t);
+  return __builtin_bit_cast(uint32_t, p);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -13,6 +13,8 @@
 //                         B = P^T (col = q c,    k = the two S^T fragments of token sub-tiles 2kk, 2kk+1, in registers)
 //                         C[reg] = O[q c][dim G*4+reg]
 // so no operand ever needs a transpose or a cross-lane shuffle; see v_slot() in common.h for the V slot permutation.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -56,6 +58,8 @@ __device__ __forceinline__ void softmax_tile(f32x4_t (&st)[4], float scale, Vali
   const float m_new = fmaxf(m, tmax);
   const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: keep everything at zero
   alpha = __expf(m - m_use);                               // m = -inf -> 0
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float m2 = m_use * LOG2E;
   float psum = 0.f;
   uint32_t pk[2][4];
 #pragma unroll
@@ -63,7 +67,7 @@ __device__ __forceinline__ void softmax_tile(f32x4_t (&st)[4], float scale, Vali
     float p[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      p[r] = __expf(st[sub][r] - m_use);
+      p[r] = __builtin_amdgcn_exp2f(fmaf(st[sub][r], LOG2E, -m2));  // e^(s - m): one fma + one v_exp_f32
       psum += p[r];
     }
     pk[sub >> 1][(sub & 1) * 2 + 0] = pack_bf(p[0], p[1]);
@@ -80,96 +84,148 @@ __device__ __forceinline__ void softmax_tile(f32x4_t (&st)[4], float scale, Vali
 
 constexpr int V_ROW_BYTES = KV_PAGE_TOKENS * 2 + 16;  // padded LDS row of the V^T tile
 
-// ---- prefill: 4 waves x 16 q rows per block, K / V^T page staged in LDS and shared by the 4 waves --------------
+// ---- prefill: 4 waves x QT*16 q rows per block, K / V^T page staged in LDS and shared by the 4 waves ---------------
 // DQK = padded head dim of Q/K rows (multiple of 32), DV = padded head dim of the V block (multiple of 16).
 // Text decoder: 128/128.  ViT (head_dim 72): 96/80, pad lanes are zero in Q, K and V (csrc/kernels_vit.hip).
-template <int DQK, int DV>
+// QT q sub-tiles per wave share every K / V^T fragment read from LDS (LDS reads per MFMA 1 -> 1/QT) and every
+// global->LDS staging pass is amortised over 64*QT query rows.
+template <int DQK, int DV, int QT>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
   constexpr int KS = DQK / 32, DS = DV / 16;
   constexpr int K_ROW_BYTES = DQK * 2 + 16;  // padded LDS row of the K tile (bank-conflict-free b128 reads)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* ks = smem;
-  char* vs = smem + KV_PAGE_TOKENS * K_ROW_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x [K tile | V^T tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, c = lane & 15;
   const int head = blockIdx.y;
   const int kvhd = head / (a.nh / a.kvh);
-  const int q0 = blockIdx.x * 64 + wave * 16;
-  const int qrow = min(q0 + c, a.S - 1);
-  const bf16_t* qp = (const bf16_t*)a.q + ((int64_t)qrow * a.nh + head) * DQK;
-  bf16x8_t qf[KS];
+  const int qb = blockIdx.x * (64 * QT);       // first q row of the block
+  const int q0 = qb + wave * (16 * QT);        // first q row of the wave
+  bf16x8_t qf[QT][KS];
 #pragma unroll
-  for (int k4 = 0; k4 < KS; ++k4) qf[k4] = as_frag(ld16(qp + k4 * 32 + G * 8));
-
-  const int qpos = a.kv_offset + q0 + c;  // cache position of this lane's q row
-  const int blk_last_q = min(blockIdx.x * 64 + 63, a.S - 1);
+  for (int t = 0; t < QT; ++t) {
+    const int qrow = min(q0 + t * 16 + c, a.S - 1);
+    const bf16_t* qp = (const bf16_t*)a.q + ((int64_t)qrow * a.nh + head) * DQK;
+#pragma unroll
+    for (int k4 = 0; k4 < KS; ++k4) qf[t][k4] = as_frag(ld16(qp + k4 * 32 + G * 8));
+  }
+  const int blk_last_q = min(qb + 64 * QT - 1, a.S - 1);
   const int last_tok = a.causal ? min(a.kv_offset + blk_last_q, a.kv_total - 1) : a.kv_total - 1;
   const int ntiles = last_tok / KV_PAGE_TOKENS + 1;
-  const int wave_last_tok = a.causal ? a.kv_offset + q0 + 15 : a.kv_total - 1;
 
-  float m = -INFINITY, l = 0.f;
-  f32x4_t o[DS];
+  float m[QT], l[QT];
+  f32x4_t o[QT][DS];
 #pragma unroll
-  for (int i = 0; i < DS; ++i) o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < QT; ++t) {
+    m[t] = -INFINITY;
+    l[t] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DS; ++i) o[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
 
-  for (int tile = 0; tile < ntiles; ++tile) {
-    __syncthreads();  // everyone is done with the previous tile
-    {
-      const char* base = reinterpret_cast<const char*>(a.kv.page_ptrs[tile] + a.kv.layer_off);
-      const char* kb = base + (size_t)kvhd * KV_PAGE_TOKENS * (DQK * 2);
-      const char* vb = base + (size_t)a.kvh * KV_PAGE_TOKENS * (DQK * 2) + (size_t)kvhd * DV * (KV_PAGE_TOKENS * 2);
-      constexpr int KP = KV_PAGE_TOKENS * DQK / 8, VP = DV * KV_PAGE_TOKENS / 8, SPR = DQK / 8;  // 16-byte pieces
+  // Software pipeline over KV pages: the next page travels global -> registers while the MFMAs of the current one run
+  // from LDS, and is written to the other LDS buffer afterwards (one barrier per page).
+  constexpr int KP = KV_PAGE_TOKENS * DQK / 8, VP = DV * KV_PAGE_TOKENS / 8, SPR = DQK / 8;  // 16-byte pieces
+  constexpr int KI = (KP + 255) / 256, VI = (VP + 255) / 256;
+  constexpr int STAGE_BYTES = KV_PAGE_TOKENS * K_ROW_BYTES + DV * V_ROW_BYTES;
+  u32x4_t rk[KI], rv[VI];
+  auto gload = [&](int tile) {
+    const char* base = reinterpret_cast<const char*>(a.kv.page_ptrs[tile] + a.kv.layer_off);
+    const char* kb = base + (size_t)kvhd * KV_PAGE_TOKENS * (DQK * 2);
+    const char* vb = base + (size_t)a.kvh * KV_PAGE_TOKENS * (DQK * 2) + (size_t)kvhd * DV * (KV_PAGE_TOKENS * 2);
 #pragma unroll
-      for (int i = 0; i < (KP + 255) / 256; ++i) {
-        const int p = tid + i * 256;
-        if (KP % 256 == 0 || p < KP)
-          *reinterpret_cast<u32x4_t*>(ks + (p / SPR) * K_ROW_BYTES + (p % SPR) * 16) = ld16(kb + (size_t)p * 16);
-      }
-#pragma unroll
-      for (int i = 0; i < (VP + 255) / 256; ++i) {
-        const int p = tid + i * 256;
-        if (VP % 256 == 0 || p < VP)
-          *reinterpret_cast<u32x4_t*>(vs + (p >> 3) * V_ROW_BYTES + (p & 7) * 16) = ld16(vb + (size_t)p * 16);
-      }
+    for (int i = 0; i < KI; ++i) {
+      const int p = tid + i * 256;
+      if (KP % 256 == 0 || p < KP) rk[i] = ld16(kb + (size_t)p * 16);
     }
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+      const int p = tid + i * 256;
+      if (VP % 256 == 0 || p < VP) rv[i] = ld16(vb + (size_t)p * 16);
+    }
+  };
+  auto lstore = [&](int stage) {
+    char* ksw = smem + stage * STAGE_BYTES;
+    char* vsw = ksw + KV_PAGE_TOKENS * K_ROW_BYTES;
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const int p = tid + i * 256;
+      if (KP % 256 == 0 || p < KP) *reinterpret_cast<u32x4_t*>(ksw + (p / SPR) * K_ROW_BYTES + (p % SPR) * 16) = rk[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+      const int p = tid + i * 256;
+      if (VP % 256 == 0 || p < VP) *reinterpret_cast<u32x4_t*>(vsw + (p >> 3) * V_ROW_BYTES + (p & 7) * 16) = rv[i];
+    }
+  };
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; ++tile) {
+    if (tile + 1 < ntiles) gload(tile + 1);
+    const char* ks = smem + (tile & 1) * STAGE_BYTES;
+    const char* vs = ks + KV_PAGE_TOKENS * K_ROW_BYTES;
     const int t0 = tile * KV_PAGE_TOKENS;
-    if (t0 > wave_last_tok) continue;  // wave-uniform: this wave's 16 rows see nothing of the tile
-
-    f32x4_t st[4];
+    // wave-uniform activity of each q sub-tile (causal: its 16 rows may see nothing of this tile)
+    bool act[QT];
+    bool any = false;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      act[t] = !a.causal || t0 <= a.kv_offset + q0 + t * 16 + 15;
+      any |= act[t];
+    }
+    if (any) {
+    f32x4_t st[QT][4];
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
-      st[sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < QT; ++t) st[t][sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k4 = 0; k4 < KS; ++k4) {
         const bf16x8_t kf = as_frag(*reinterpret_cast<const u32x4_t*>(ks + (sub * 16 + c) * K_ROW_BYTES + (k4 * 32 + G * 8) * 2));
-        st[sub] = mfma16(kf, qf[k4], st[sub]);
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+          if (act[t]) st[t][sub] = mfma16(kf, qf[t][k4], st[t][sub]);
       }
     }
-    float alpha;
-    bf16x8_t pf[2];
-    const int lim = a.causal ? min(qpos, a.kv_total - 1) : a.kv_total - 1;
-    softmax_tile(st, a.scale, [&](int t) { return t0 + t <= lim; }, G, m, l, alpha, pf);
+    float alpha[QT];
+    bf16x8_t pf[QT][2];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      if (!act[t]) continue;
+      const int qpos = a.kv_offset + q0 + t * 16 + c;  // cache position of this lane's q row
+      const int lim = a.causal ? min(qpos, a.kv_total - 1) : a.kv_total - 1;
+      softmax_tile(st[t], a.scale, [&](int tk) { return t0 + tk <= lim; }, G, m[t], l[t], alpha[t], pf[t]);
+#pragma unroll
+      for (int ds = 0; ds < DS; ++ds) o[t][ds] *= alpha[t];
+    }
 #pragma unroll
     for (int ds = 0; ds < DS; ++ds) {
-      o[ds] *= alpha;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const bf16x8_t vf = as_frag(*reinterpret_cast<const u32x4_t*>(vs + (ds * 16 + c) * V_ROW_BYTES + (kk * 32 + G * 8) * 2));
-        o[ds] = mfma16(vf, pf[kk], o[ds]);
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+          if (act[t]) o[t][ds] = mfma16(vf, pf[t][kk], o[t][ds]);
       }
     }
+    }  // any
+    if (tile + 1 < ntiles) lstore((tile + 1) & 1);
+    __syncthreads();
   }
-  l = group_sum(l);
-  if (q0 + c < a.S) {
-    const float inv = 1.0f / l;
-    bf16_t* op = (bf16_t*)a.o + ((int64_t)(q0 + c) * a.nh + head) * a.d;  // a.d = real head dim of the output rows
 #pragma unroll
-    for (int ds = 0; ds < DS; ++ds) {
-      if (ds * 16 + G * 4 < a.d) {  // head dims come in multiples of 4, so a 4-wide group is all-in or all-out
-        uint2 w;
-        w.x = pack_bf(o[ds][0] * inv, o[ds][1] * inv);
-        w.y = pack_bf(o[ds][2] * inv, o[ds][3] * inv);
-        *reinterpret_cast<uint2*>(op + ds * 16 + G * 4) = w;
+  for (int t = 0; t < QT; ++t) {
+    const float lt = group_sum(l[t]);
+    const int qr = q0 + t * 16 + c;
+    if (qr < a.S) {
+      const float inv = 1.0f / lt;
+      bf16_t* op = (bf16_t*)a.o + ((int64_t)qr * a.nh + head) * a.d;  // a.d = real head dim of the output rows
+#pragma unroll
+      for (int ds = 0; ds < DS; ++ds) {
+        if (ds * 16 + G * 4 < a.d) {  // head dims come in multiples of 4, so a 4-wide group is all-in or all-out
+          uint2 w;
+          w.x = pack_bf(o[t][ds][0] * inv, o[t][ds][1] * inv);
+          w.y = pack_bf(o[t][ds][2] * inv, o[t][ds][3] * inv);
+          *reinterpret_cast<uint2*>(op + ds * 16 + G * 4) = w;
+        }
       }
     }
   }
@@ -462,13 +518,21 @@ void launch_attn_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t st) {
 
 void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st) {
   if (a.S <= 0) return;
-  dim3 grid((a.S + 63) / 64, a.nh), block(256);
+  static const int qt_env = [] {
+    const char* e = getenv("AHA_ATTN_QT");
+    return e ? atoi(e) : 0;
+  }();
+  // 2 q sub-tiles per wave (128 rows per block) once there are enough rows to fill the chip that way
+  const int qt = qt_env ? qt_env : 1;  // measured: QT=2 loses to QT=1 (fewer resident blocks per CU)
+  dim3 grid((a.S + 64 * qt - 1) / (64 * qt), a.nh), block(256);
   if (a.d == 128) {
-    const size_t lds = KV_PAGE_TOKENS * (128 * 2 + 16) + 128 * V_ROW_BYTES;
-    hipLaunchKernelGGL((attn_prefill_kernel<128, 128>), grid, block, lds, st, a);
+    const size_t lds = 2 * (KV_PAGE_TOKENS * (128 * 2 + 16) + 128 * V_ROW_BYTES);
+    if (qt == 2) hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 2>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 1>), grid, block, lds, st, a);
   } else {  // head_dim 72 (Qwen3-VL ViT): Q/K rows padded to 96, V block to 80
-    const size_t lds = KV_PAGE_TOKENS * (96 * 2 + 16) + 80 * V_ROW_BYTES;
-    hipLaunchKernelGGL((attn_prefill_kernel<96, 80>), grid, block, lds, st, a);
+    const size_t lds = 2 * (KV_PAGE_TOKENS * (96 * 2 + 16) + 80 * V_ROW_BYTES);
+    if (qt == 2) hipLaunchKernelGGL((attn_prefill_kernel<96, 80, 2>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((attn_prefill_kernel<96, 80, 1>), grid, block, lds, st, a);
   }
 }
 

@@ -4,10 +4,17 @@
 //
 // Both operands are K-contiguous (activations row-major, candle_nn::Linear weights (out,in) row-major), which is the
 // natural MFMA feed on CDNA: every fragment is a 16-byte run of one row.  v_mfma_f32_16x16x32_bf16, 128x128x64 block
-// tile, 4 waves (2x2, 64x64 each), LDS double buffer, XOR-swizzled 16-byte slots (conflict-free ds_read_b128).
+// tile, 4 waves (2x2, 64x64 each), XOR-swizzled 16-byte LDS slots (conflict-free ds_read_b128).
+// Two staging variants:
+//   gemm_glds_kernel (default): global_load_lds_dwordx4 straight into a 32-KiB LDS tile (no VGPR round trip, no
+//       ds_write pass); the swizzle is applied on the per-lane SOURCE address because the DMA destination is
+//       lane-linear; 32 KiB LDS and ~110 VGPRs let 4 blocks share a CU, which is what overlaps load and MFMA.
+//   gemm_kernel (AHA_GEMM_GLDS=0): register-staged double buffer, kept for A/B.
 // The MFMA is issued as W-fragment x A-fragment so that each lane ends up with 4 consecutive output columns of one row:
 // bias / activation / gate*up pairing / residual are then lane-local and the store is 8 bytes.
 // Rounding points follow the reference op boundaries (Linear matmul -> bf16, + bias -> bf16, act -> bf16, + residual -> bf16).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -17,6 +24,9 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * BK * 2;  // 16 KiB per operand per stage
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 __device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
@@ -37,93 +47,37 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
-template <int ACT, bool HAS_BIAS, bool HAS_RES>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A tile | W tile]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, c = lane & 15;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs, so give each XCD a contiguous run of
-  // tiles (which share A row panels / W column panels in its private L2).  Bijective for any grid size.
+// XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs, so give each XCD a contiguous run of tiles
+// (which share A row panels / W column panels in its private L2).  Bijective for any grid size.
+__device__ __forceinline__ void tile_of_block(const GemmArgs& a, int& m0, int& n0) {
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN, nwg = ntm * ntn;
   int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  // within an XCD's run walk N fastest in groups of 8 column tiles so the A panel stays hot
-  const int tn = bid % ntn, tm = bid / ntn;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  m0 = (bid / ntn) * BM;
+  n0 = (bid % ntn) * BN;
+}
 
-  const bf16_t* A = (const bf16_t*)a.A;
-  const bf16_t* W = (const bf16_t*)a.W;
-  const int nk = (a.K + BK - 1) / BK;
-
-  // staging assignment: 1024 16-byte pieces per operand tile, 4 per thread; piece p -> row p>>3, slot p&7
-  const bf16_t* ga[4];
-  const bf16_t* gw[4];
-  int lds_off[4];
+// one K tile of MFMA work from an LDS stage: acc[ni][mi] += W-frag(ni) x A-frag(mi)
+__device__ __forceinline__ void mma_tile(const char* sa, const char* sw, int wm, int wn, int G, int c, f32x4_t (&acc)[4][4]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int p = tid + i * 256, row = p >> 3, slot = p & 7;
-    ga[i] = A + (int64_t)min(m0 + row, a.M - 1) * a.lda + slot * 8;
-    gw[i] = W + (int64_t)min(n0 + row, a.N - 1) * a.ldw + slot * 8;
-    lds_off[i] = swz(row, slot);
-  }
-  const int kslot = (tid & 7) * 8;  // k offset of this thread's pieces inside a K tile
-
-  u32x4_t ra[4], rw[4];
-  auto gload = [&](int kt) {
-    const int k = kt * BK + kslot;
-    const bool ok = k < a.K;
+  for (int ks = 0; ks < 2; ++ks) {
+    bf16x8_t af[4], wf[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ra[i] = ok ? ld16(ga[i] + kt * BK) : u32x4_t{0u, 0u, 0u, 0u};
-      rw[i] = ok ? ld16(gw[i] + kt * BK) : u32x4_t{0u, 0u, 0u, 0u};
+      af[i] = as_frag(*reinterpret_cast<const u32x4_t*>(sa + swz(wm * 64 + i * 16 + c, ks * 4 + G)));
+      wf[i] = as_frag(*reinterpret_cast<const u32x4_t*>(sw + swz(wn * 64 + i * 16 + c, ks * 4 + G)));
     }
-  };
-  auto lstore = [&](int stage) {
-    char* sa = smem + stage * 2 * TILE_BYTES;
-    char* sw = sa + TILE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<u32x4_t*>(sa + lds_off[i]) = ra[i];
-      *reinterpret_cast<u32x4_t*>(sw + lds_off[i]) = rw[i];
-    }
-  };
-
-  f32x4_t acc[4][4];  // [ni][mi]
+    for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-    const char* sa = smem + cur * 2 * TILE_BYTES;
-    const char* sw = sa + TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t af[4], wf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[i] = as_frag(*reinterpret_cast<const u32x4_t*>(sa + swz(wm * 64 + i * 16 + c, ks * 4 + G)));
-        wf[i] = as_frag(*reinterpret_cast<const u32x4_t*>(sw + swz(wn * 64 + i * 16 + c, ks * 4 + G)));
-      }
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(wf[ni], af[mi], acc[ni][mi]);
-    }
-    if (kt + 1 < nk) lstore(cur ^ 1);
-    __syncthreads();
+      for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(wf[ni], af[mi], acc[ni][mi]);
   }
+}
 
-  // ---- epilogue: lane holds C[m = .. + c][n = .. + G*4 + 0..3] ----------------------------------------------
+// ---- epilogue: lane holds C[m = .. + c][n = .. + G*4 + 0..3] -------------------------------------------------------
+template <int ACT, bool HAS_BIAS, bool HAS_RES>
+__device__ __forceinline__ void epilogue(const GemmArgs& a, f32x4_t (&acc)[4][4], int m0, int n0, int wm, int wn, int G, int c) {
   bf16_t* C = (bf16_t*)a.C;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
@@ -184,27 +138,161 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
   }
 }
 
+// ---- variant 1: direct-to-LDS staging -------------------------------------------------------------------------------
+// Per K tile each wave issues 4 + 4 global_load_lds_dwordx4 (1 KiB each: 8 rows x 128 B of the LDS image).  Lane i of
+// round j writes LDS row (j*4+wave)*8 + i/8, slot position i%8; it therefore READS logical slot (i%8) ^ f(row) from
+// global memory (source-side swizzle), and the fragment reads apply the same XOR.  K tails / nothing-to-load lanes
+// point at a 16-byte zero block.
+template <int ACT, bool HAS_BIAS, bool HAS_RES>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs a, const void* zeros) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [A tile | W tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, c = lane & 15;
+  const int wm = wave >> 1, wn = wave & 1;
+  int m0, n0;
+  tile_of_block(a, m0, n0);
+  const bf16_t* A = (const bf16_t*)a.A;
+  const bf16_t* W = (const bf16_t*)a.W;
+  const int nk = (a.K + BK - 1) / BK;
+
+  const bf16_t* ga[4];
+  const bf16_t* gw[4];
+  int kofs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (j * 4 + wave) * 8 + (lane >> 3);
+    const int s = (lane & 7) ^ ((row >> 1) & 7);  // logical k-slot this lane fetches
+    kofs[j] = s * 8;
+    ga[j] = A + (int64_t)min(m0 + row, a.M - 1) * a.lda + s * 8;
+    gw[j] = W + (int64_t)min(n0 + row, a.N - 1) * a.ldw + s * 8;
+  }
+  char* sa = smem;
+  char* sw = smem + TILE_BYTES;
+
+  f32x4_t acc[4][4];  // [ni][mi]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = kt * BK + kofs[j] < a.K;
+      const void* pa = ok ? (const void*)(ga[j] + kt * BK) : zeros;
+      const void* pw = ok ? (const void*)(gw[j] + kt * BK) : zeros;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)pa, (lds_ptr_t)(sa + (j * 4 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)pw, (lds_ptr_t)(sw + (j * 4 + wave) * 1024), 16, 0, 0);
+    }
+    __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
+    mma_tile(sa, sw, wm, wn, G, c, acc);
+    __syncthreads();
+  }
+  epilogue<ACT, HAS_BIAS, HAS_RES>(a, acc, m0, n0, wm, wn, G, c);
+}
+
+// ---- variant 2: register-staged double buffer ----------------------------------------------------------------------
+template <int ACT, bool HAS_BIAS, bool HAS_RES>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A tile | W tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, c = lane & 15;
+  const int wm = wave >> 1, wn = wave & 1;
+  int m0, n0;
+  tile_of_block(a, m0, n0);
+  const bf16_t* A = (const bf16_t*)a.A;
+  const bf16_t* W = (const bf16_t*)a.W;
+  const int nk = (a.K + BK - 1) / BK;
+
+  // staging assignment: 1024 16-byte pieces per operand tile, 4 per thread; piece p -> row p>>3, slot p&7
+  const bf16_t* ga[4];
+  const bf16_t* gw[4];
+  int lds_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = tid + i * 256, row = p >> 3, slot = p & 7;
+    ga[i] = A + (int64_t)min(m0 + row, a.M - 1) * a.lda + slot * 8;
+    gw[i] = W + (int64_t)min(n0 + row, a.N - 1) * a.ldw + slot * 8;
+    lds_off[i] = swz(row, slot);
+  }
+  const int kslot = (tid & 7) * 8;  // k offset of this thread's pieces inside a K tile
+
+  u32x4_t ra[4], rw[4];
+  auto gload = [&](int kt) {
+    const bool ok = kt * BK + kslot < a.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = ok ? ld16(ga[i] + kt * BK) : u32x4_t{0u, 0u, 0u, 0u};
+      rw[i] = ok ? ld16(gw[i] + kt * BK) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+  };
+  auto lstore = [&](int stage) {
+    char* sa = smem + stage * 2 * TILE_BYTES;
+    char* sw = sa + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<u32x4_t*>(sa + lds_off[i]) = ra[i];
+      *reinterpret_cast<u32x4_t*>(sw + lds_off[i]) = rw[i];
+    }
+  };
+
+  f32x4_t acc[4][4];  // [ni][mi]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const char* sa = smem + cur * 2 * TILE_BYTES;
+    mma_tile(sa, sa + TILE_BYTES, wm, wn, G, c, acc);
+    if (kt + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+  }
+  epilogue<ACT, HAS_BIAS, HAS_RES>(a, acc, m0, n0, wm, wn, G, c);
+}
+
+const void* zero_block() {
+  static void* z = nullptr;
+  if (!z) {
+    hipMalloc(&z, 256);
+    hipMemset(z, 0, 256);
+  }
+  return z;
+}
+
+template <int ACT, bool B, bool R>
+void launch_one(const GemmArgs& a, dim3 grid, bool glds, hipStream_t st) {
+  if (glds) hipLaunchKernelGGL((gemm_glds_kernel<ACT, B, R>), grid, dim3(256), 2 * TILE_BYTES, st, a, zero_block());
+  else hipLaunchKernelGGL((gemm_kernel<ACT, B, R>), grid, dim3(256), 4 * TILE_BYTES, st, a);
+}
+
 template <int ACT>
-void launch_act(const GemmArgs& a, dim3 grid, hipStream_t st) {
-  const size_t lds = 4 * TILE_BYTES;
-  if (a.bias && a.residual) hipLaunchKernelGGL((gemm_kernel<ACT, true, true>), grid, dim3(256), lds, st, a);
-  else if (a.bias) hipLaunchKernelGGL((gemm_kernel<ACT, true, false>), grid, dim3(256), lds, st, a);
-  else if (a.residual) hipLaunchKernelGGL((gemm_kernel<ACT, false, true>), grid, dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((gemm_kernel<ACT, false, false>), grid, dim3(256), lds, st, a);
+void launch_act(const GemmArgs& a, dim3 grid, bool glds, hipStream_t st) {
+  if (a.bias && a.residual) launch_one<ACT, true, true>(a, grid, glds, st);
+  else if (a.bias) launch_one<ACT, true, false>(a, grid, glds, st);
+  else if (a.residual) launch_one<ACT, false, true>(a, grid, glds, st);
+  else launch_one<ACT, false, false>(a, grid, glds, st);
 }
 
 }  // namespace
 
 void launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0) return;
+  static const bool glds = [] {
+    const char* e = getenv("AHA_GEMM_GLDS");
+    return e ? atoi(e) != 0 : true;
+  }();
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
   dim3 grid(ntm * ntn);
   switch (a.act) {
-    case ACT_NONE: launch_act<ACT_NONE>(a, grid, st); break;
-    case ACT_GELU_TANH: launch_act<ACT_GELU_TANH>(a, grid, st); break;
-    case ACT_GELU_ERF: launch_act<ACT_GELU_ERF>(a, grid, st); break;
-    case ACT_SILU: launch_act<ACT_SILU>(a, grid, st); break;
-    case ACT_SILU_MUL_PAIRS: hipLaunchKernelGGL((gemm_kernel<ACT_SILU_MUL_PAIRS, false, false>), grid, dim3(256), 4 * TILE_BYTES, st, a); break;
+    case ACT_NONE: launch_act<ACT_NONE>(a, grid, glds, st); break;
+    case ACT_GELU_TANH: launch_act<ACT_GELU_TANH>(a, grid, glds, st); break;
+    case ACT_GELU_ERF: launch_act<ACT_GELU_ERF>(a, grid, glds, st); break;
+    case ACT_SILU: launch_act<ACT_SILU>(a, grid, glds, st); break;
+    case ACT_SILU_MUL_PAIRS: launch_one<ACT_SILU_MUL_PAIRS, false, false>(a, grid, glds, st); break;
   }
 }
 
