@@ -129,3 +129,47 @@ def tiny_qwen3vl(text_layers: int = 3, depth: int = 3) -> Qwen3VLConfig:
                               deepstack_visual_indexes=[0, 1, 2][:depth])
     return Qwen3VLConfig(text=text, vision=vis, image_token_id=2000, video_token_id=2001,
                          vision_start_token_id=2002, vision_end_token_id=2003)
+
+
+# ---- Qwen3-ASR (reference: Qwen3ASRAudioConfig / ThinkerConfig, /root/reference/src/models/qwen3_asr/config.rs) ----------
+
+@dataclass
+class Qwen3ASRAudioConfig:
+    d_model: int = 896
+    encoder_layers: int = 18
+    encoder_attention_heads: int = 14
+    encoder_ffn_dim: int = 3584
+    num_mel_bins: int = 128
+    downsample_hidden_size: int = 480
+    output_dim: int = 1024
+    n_window: int = 50
+    n_window_infer: int = 800
+    conv_chunksize: int = 500
+    activation_function: str = "gelu"
+
+    @property
+    def head_dim(self) -> int:
+        return self.d_model // self.encoder_attention_heads
+
+
+@dataclass
+class Qwen3ASRConfig:
+    text: Qwen3Config
+    audio: Qwen3ASRAudioConfig
+    audio_token_id: int = 151676
+    audio_start_token_id: int = 151669
+    audio_end_token_id: int = 151670
+
+
+def qwen3_asr_0_6b() -> Qwen3ASRConfig:
+    """BASELINE cfg 4.  Audio dims are the published Qwen3-ASR-0.6B values as recalled in SURVEY.md section 8 -- flagged
+    [unverified] there (no config.json on disk); text tower = Qwen3-0.6B dims."""
+    t = qwen3_0_6b()
+    return Qwen3ASRConfig(text=t, audio=Qwen3ASRAudioConfig())
+
+
+def tiny_qwen3_asr(layers: int = 2) -> Qwen3ASRConfig:
+    text = tiny_qwen3(layers=2, hidden=256, heads=4, kv_heads=2, inter=512, vocab=2048, tie=True)
+    aud = Qwen3ASRAudioConfig(d_model=128, encoder_layers=layers, encoder_attention_heads=2, encoder_ffn_dim=256,
+                              downsample_hidden_size=32, output_dim=256)
+    return Qwen3ASRConfig(text=text, audio=aud, audio_token_id=2000, audio_start_token_id=2001, audio_end_token_id=2002)

@@ -97,3 +97,39 @@ def qwen3vl_weights(cfg: Qwen3VLConfig, seed: int = 0, dtype=torch.bfloat16, dev
                            lm_head_name="lm_head.weight", dtype=dtype, device=device)
     w.update(qwen3vl_vision_weights(cfg, seed=seed + 100, dtype=dtype, device=device))
     return w
+
+
+def qwen3_asr_weights(cfg, seed: int = 0, dtype=torch.bfloat16, device="cpu") -> Dict[str, torch.Tensor]:
+    """Names the reference looks up for Qwen3-ASR (qwen3_asr/model.rs:42-70,102-169,238-256,316-334)."""
+    w = qwen3_text_weights(cfg.text, seed=seed, prefix="thinker.model.", lm_head_name="thinker.lm_head.weight",
+                           dtype=dtype, device=device)
+    a = cfg.audio
+    gen = _gen(seed + 200, device)
+    p = "thinker.audio_tower."
+    D, H = a.d_model, a.downsample_hidden_size
+    w[p + "conv2d1.weight"] = _randn(gen, (H, 1, 3, 3), std=0.2, dtype=dtype)
+    w[p + "conv2d1.bias"] = _randn(gen, (H,), dtype=dtype)
+    for n in ("conv2d2", "conv2d3"):
+        w[p + n + ".weight"] = _randn(gen, (H, H, 3, 3), dtype=dtype)
+        w[p + n + ".bias"] = _randn(gen, (H,), dtype=dtype)
+    fdim = H * ((((a.num_mel_bins + 1) // 2 + 1) // 2 + 1) // 2)
+    w[p + "conv_out.weight"] = _randn(gen, (D, fdim), dtype=dtype)
+    for i in range(a.encoder_layers):
+        q = f"{p}layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            w[q + f"self_attn.{n}.weight"] = _randn(gen, (D, D), dtype=dtype)
+            w[q + f"self_attn.{n}.bias"] = _randn(gen, (D,), dtype=dtype)
+        for n in ("self_attn_layer_norm", "final_layer_norm"):
+            w[q + n + ".weight"] = _randn(gen, (D,), mean=1.0, dtype=dtype)
+            w[q + n + ".bias"] = _randn(gen, (D,), dtype=dtype)
+        w[q + "fc1.weight"] = _randn(gen, (a.encoder_ffn_dim, D), dtype=dtype)
+        w[q + "fc1.bias"] = _randn(gen, (a.encoder_ffn_dim,), dtype=dtype)
+        w[q + "fc2.weight"] = _randn(gen, (D, a.encoder_ffn_dim), dtype=dtype)
+        w[q + "fc2.bias"] = _randn(gen, (D,), dtype=dtype)
+    w[p + "ln_post.weight"] = _randn(gen, (D,), mean=1.0, dtype=dtype)
+    w[p + "ln_post.bias"] = _randn(gen, (D,), dtype=dtype)
+    w[p + "proj1.weight"] = _randn(gen, (D, D), dtype=dtype)
+    w[p + "proj1.bias"] = _randn(gen, (D,), dtype=dtype)
+    w[p + "proj2.weight"] = _randn(gen, (a.output_dim, D), dtype=dtype)
+    w[p + "proj2.bias"] = _randn(gen, (a.output_dim,), dtype=dtype)
+    return w
