@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libaha_hip.so")
 
 AHA_BF16, AHA_F16, AHA_F32, AHA_U32, AHA_U8 = 0, 1, 2, 3, 4
-AHA_ARCH_QWEN3, AHA_ARCH_QWEN3VL = 0, 1
+AHA_ARCH_QWEN3, AHA_ARCH_QWEN3VL, AHA_ARCH_QWEN3ASR = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU, ACT_SILU_MUL_PAIRS = 0, 1, 2, 3, 4
 
 
@@ -35,6 +35,10 @@ class ModelDesc(C.Structure):
         ("kv_reserve_tokens", C.c_int32),
         ("n_stop_tokens", C.c_int32),
         ("stop_tokens", C.c_uint32 * 8),
+        ("aud_d_model", C.c_int32), ("aud_encoder_layers", C.c_int32), ("aud_attention_heads", C.c_int32),
+        ("aud_ffn_dim", C.c_int32), ("aud_num_mel_bins", C.c_int32), ("aud_downsample_hidden_size", C.c_int32),
+        ("aud_output_dim", C.c_int32), ("aud_n_window", C.c_int32),
+        ("audio_token_id", C.c_int32),
     ]
 
 
@@ -45,7 +49,9 @@ class TensorView(C.Structure):
 
 class MmInput(C.Structure):
     _fields_ = [("pixel_values", C.c_void_p), ("pixel_dtype", C.c_int32), ("n_patches", C.c_int64),
-                ("image_grid_thw", C.POINTER(C.c_uint32)), ("n_images", C.c_int32)]
+                ("image_grid_thw", C.POINTER(C.c_uint32)), ("n_images", C.c_int32),
+                ("audio_features", C.POINTER(C.c_float)), ("n_frames", C.c_int64),
+                ("audio_samples", C.POINTER(C.c_float)), ("n_samples", C.c_int64)]
 
 
 # every symbol include/aha_hip.h declares: name -> (restype, argtypes)
@@ -81,6 +87,8 @@ SIGNATURES = {
     "aha_hip_attn_prefill": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_float, _P]),
     "aha_hip_argmax": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "aha_hip_logmel": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "aha_hip_debug_audio_embeds": (C.c_int, [_P, C.POINTER(C.c_float), C.c_size_t]),
     "aha_hip_image_to_patches": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float),
                                            C.POINTER(C.c_float), _P]),
 }

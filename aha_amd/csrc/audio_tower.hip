@@ -1,0 +1,498 @@
+// Qwen3-ASR audio tower on the GPU and the audio-token scatter (A3).
+//   create   <- Qwen3ASRAudioEncoder::new             /root/reference/src/models/qwen3_asr/model.rs:102-169
+//   forward  <- Qwen3ASRAudioEncoder::forward         /root/reference/src/models/qwen3_asr/model.rs:171-226
+//   frontend <- WhisperFeatureExtractor               /root/reference/src/models/feature_extractor/feature_extraction_whisper.rs:93-115
+//   scatter  <- Qwen3ASRThinker::forward              /root/reference/src/models/qwen3_asr/model.rs:336-361
+// Window / mel filter bank / twiddle tables are host-built exactly as the reference builds them (f32 arithmetic, f64 for
+// the Hann window) and uploaded once; every tensor op runs in a HIP kernel.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "audio.h"
+#include "common.h"
+
+namespace aha {
+
+struct AudLayerW {
+  void *ln1w, *ln1b, *qkv_w, *qkv_b, *out_w, *out_b, *ln2w, *ln2b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+};
+
+struct AudioModel {
+  int D = 0, nh = 0, hd = 0, ffn = 0, layers = 0, mels = 0, H = 0, out = 0, nwin = 0, fq = 0;
+  void *c1w = nullptr, *c1b = nullptr, *c2w = nullptr, *c2b = nullptr, *c3w = nullptr, *c3b = nullptr, *conv_out = nullptr;
+  std::vector<AudLayerW> L;
+  void *lnp_w = nullptr, *lnp_b = nullptr, *p1w = nullptr, *p1b = nullptr, *p2w = nullptr, *p2b = nullptr;
+  float *d_window = nullptr, *d_twid = nullptr, *d_melfb = nullptr;
+  float scale = 0.f;
+  // scratch
+  size_t cap_frames = 0;
+  std::vector<void*> owned;
+  float *d_samples = nullptr, *d_feat = nullptr, *d_fmax = nullptr;
+  void *col = nullptr, *act_a = nullptr, *act_b = nullptr, *tok = nullptr, *x = nullptr, *h = nullptr, *qkv = nullptr, *attn = nullptr,
+       *mlp = nullptr, *embeds = nullptr;
+  int32_t* d_rows = nullptr;
+  void* page_store = nullptr;
+  uint64_t* d_page_ptrs = nullptr;
+  uint64_t page_bytes = 0;
+  int64_t n_tok = 0;
+};
+
+static int aneed(const aha_tensor_view* w, size_t nw, const std::string& name, const aha_tensor_view** out) {
+  *out = find_tensor(w, nw, name);
+  if (!*out) {
+    set_error("missing weight tensor: " + name);
+    return AHA_ERR_MISSING_WEIGHT;
+  }
+  return AHA_OK;
+}
+
+static inline uint16_t f2bf_h(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf2f_h(uint16_t b) {
+  const uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static int host_bf16(const aha_tensor_view* t, std::vector<uint16_t>& out) {
+  int64_t n = 1;
+  for (int i = 0; i < t->ndim; ++i) n *= t->shape[i];
+  out.resize(n);
+  if (t->on_device) {
+    if (t->dtype != AHA_BF16) {
+      set_error("device-resident weights must be bf16");
+      return AHA_ERR_UNSUPPORTED;
+    }
+    AHA_HIP_CHECK(hipMemcpy(out.data(), t->data, n * 2, hipMemcpyDeviceToHost));
+  } else if (t->dtype == AHA_BF16) memcpy(out.data(), t->data, n * 2);
+  else if (t->dtype == AHA_F32)
+    for (int64_t i = 0; i < n; ++i) out[i] = f2bf_h(((const float*)t->data)[i]);
+  else {
+    set_error(std::string("tensor ") + t->name + ": unsupported dtype for the audio tower");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  return AHA_OK;
+}
+
+// conv weight (Cout, Cin, 3, 3) -> GEMM weight (Cout, Kpad) with K ordered (kh, kw, cin) to match im2col_nhwc
+static int upload_conv(aha_model* m, const aha_tensor_view* t, int cout, int cin, int kpad, void** out) {
+  std::vector<uint16_t> src;
+  int rc = host_bf16(t, src);
+  if (rc) return rc;
+  if ((int64_t)src.size() != (int64_t)cout * cin * 9) {
+    set_error(std::string("tensor ") + t->name + " has the wrong number of elements");
+    return AHA_ERR_SHAPE;
+  }
+  std::vector<uint16_t> dst((size_t)cout * kpad, 0);
+  for (int o = 0; o < cout; ++o)
+    for (int c = 0; c < cin; ++c)
+      for (int k = 0; k < 9; ++k) dst[(size_t)o * kpad + (size_t)k * cin + c] = src[((size_t)o * cin + c) * 9 + k];
+  if ((rc = dev_alloc(m, dst.size() * 2, out))) return rc;
+  AHA_HIP_CHECK(hipMemcpy(*out, dst.data(), dst.size() * 2, hipMemcpyHostToDevice));
+  return AHA_OK;
+}
+
+// ---- host tables of the Whisper frontend ---------------------------------------------------------------------------------
+static float hz2mel(float f) {  // audio_utils.rs:1157-1175, Slaney
+  float mels = 3.0f * f / 200.0f;
+  if (f >= 1000.0f) mels = 15.0f + logf(f / 1000.0f) * (27.0f / logf(6.4f));
+  return mels;
+}
+static float mel2hz(float m) {  // audio_utils.rs:1177-1195
+  float fr = 200.0f * m / 3.0f;
+  if (m >= 15.0f) fr = 1000.0f * expf((logf(6.4f) / 27.0f) * (m - 15.0f));
+  return fr;
+}
+static std::vector<float> linspace_f(float a, float b, int n) {  // tensor_utils.rs:354-365
+  std::vector<float> v(n);
+  if (n == 1) {
+    v[0] = a;
+    return v;
+  }
+  const float step = (b - a) / (float)(n - 1);
+  for (int i = 0; i < n; ++i) v[i] = a + (float)i * step;
+  return v;
+}
+
+int audio_create(aha_model* m, const aha_tensor_view* w, size_t nw) {
+  const aha_model_desc& c = m->desc;
+  const std::string pre = "thinker.audio_tower.";
+  if (c.aud_d_model % c.aud_attention_heads || c.aud_d_model / c.aud_attention_heads != 64) {
+    set_error("audio tower: only head_dim 64 is supported (Qwen3-ASR encoder)");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  if (c.aud_downsample_hidden_size % 8 || c.aud_num_mel_bins != 128) {
+    set_error("audio tower: downsample_hidden_size must be a multiple of 8 and num_mel_bins 128");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  AudioModel* a = new AudioModel();
+  m->audio = a;
+  a->D = c.aud_d_model; a->nh = c.aud_attention_heads; a->hd = 64; a->ffn = c.aud_ffn_dim; a->layers = c.aud_encoder_layers;
+  a->mels = c.aud_num_mel_bins; a->H = c.aud_downsample_hidden_size; a->out = c.aud_output_dim; a->nwin = c.aud_n_window;
+  a->fq = (((a->mels + 1) / 2 + 1) / 2 + 1) / 2;
+  if (a->out != c.hidden_size) {
+    set_error("audio output_dim must equal the text hidden_size");
+    return AHA_ERR_SHAPE;
+  }
+  int rc;
+  const aha_tensor_view* t;
+  using S = std::vector<int64_t>;
+#define LOADA(name, shape, dst)                  \
+  if ((rc = aneed(w, nw, name, &t))) return rc;  \
+  if ((rc = upload_tensor(m, t, shape, &(dst)))) return rc;
+  if ((rc = aneed(w, nw, pre + "conv2d1.weight", &t))) return rc;
+  if ((rc = upload_conv(m, t, a->H, 1, 16, &a->c1w))) return rc;
+  LOADA(pre + "conv2d1.bias", (S{a->H}), a->c1b);
+  if ((rc = aneed(w, nw, pre + "conv2d2.weight", &t))) return rc;
+  if ((rc = upload_conv(m, t, a->H, a->H, 9 * a->H, &a->c2w))) return rc;
+  LOADA(pre + "conv2d2.bias", (S{a->H}), a->c2b);
+  if ((rc = aneed(w, nw, pre + "conv2d3.weight", &t))) return rc;
+  if ((rc = upload_conv(m, t, a->H, a->H, 9 * a->H, &a->c3w))) return rc;
+  LOADA(pre + "conv2d3.bias", (S{a->H}), a->c3b);
+  LOADA(pre + "conv_out.weight", (S{a->D, (int64_t)a->H * a->fq}), a->conv_out);
+  a->L.resize(a->layers);
+  for (int i = 0; i < a->layers; ++i) {
+    const std::string p = pre + "layers." + std::to_string(i) + ".";
+    AudLayerW& L = a->L[i];
+    LOADA(p + "self_attn_layer_norm.weight", (S{a->D}), L.ln1w);
+    LOADA(p + "self_attn_layer_norm.bias", (S{a->D}), L.ln1b);
+    // fused q|k|v projection: rows and bias concatenated (three Linear with bias, modules.rs:208-210)
+    if ((rc = dev_alloc(m, (size_t)3 * a->D * a->D * 2, &L.qkv_w))) return rc;
+    if ((rc = dev_alloc(m, (size_t)3 * a->D * 2, &L.qkv_b))) return rc;
+    const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+    for (int j = 0; j < 3; ++j) {
+      std::vector<uint16_t> tmp;
+      if ((rc = aneed(w, nw, p + "self_attn." + names[j] + ".weight", &t))) return rc;
+      if ((rc = host_bf16(t, tmp))) return rc;
+      if ((int64_t)tmp.size() != (int64_t)a->D * a->D) { set_error("audio q/k/v weight shape"); return AHA_ERR_SHAPE; }
+      AHA_HIP_CHECK(hipMemcpy((char*)L.qkv_w + (size_t)j * a->D * a->D * 2, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+      if ((rc = aneed(w, nw, p + "self_attn." + names[j] + ".bias", &t))) return rc;
+      if ((rc = host_bf16(t, tmp))) return rc;
+      if ((int64_t)tmp.size() != a->D) { set_error("audio q/k/v bias shape"); return AHA_ERR_SHAPE; }
+      AHA_HIP_CHECK(hipMemcpy((char*)L.qkv_b + (size_t)j * a->D * 2, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+    }
+    LOADA(p + "self_attn.out_proj.weight", (S{a->D, a->D}), L.out_w);
+    LOADA(p + "self_attn.out_proj.bias", (S{a->D}), L.out_b);
+    LOADA(p + "final_layer_norm.weight", (S{a->D}), L.ln2w);
+    LOADA(p + "final_layer_norm.bias", (S{a->D}), L.ln2b);
+    LOADA(p + "fc1.weight", (S{a->ffn, a->D}), L.fc1_w);
+    LOADA(p + "fc1.bias", (S{a->ffn}), L.fc1_b);
+    LOADA(p + "fc2.weight", (S{a->D, a->ffn}), L.fc2_w);
+    LOADA(p + "fc2.bias", (S{a->D}), L.fc2_b);
+  }
+  LOADA(pre + "ln_post.weight", (S{a->D}), a->lnp_w);
+  LOADA(pre + "ln_post.bias", (S{a->D}), a->lnp_b);
+  LOADA(pre + "proj1.weight", (S{a->D, a->D}), a->p1w);
+  LOADA(pre + "proj1.bias", (S{a->D}), a->p1b);
+  LOADA(pre + "proj2.weight", (S{a->out, a->D}), a->p2w);
+  LOADA(pre + "proj2.bias", (S{a->out}), a->p2b);
+#undef LOADA
+  // frontend tables
+  {
+    std::vector<float> win(400), tw(800), fb((size_t)201 * 128);
+    for (int j = 0; j < 400; ++j) {
+      const double i = (double)(1 - 400 + 2 * j);                       // audio_utils.rs:1071-1080 (symmetric Hann, f64)
+      win[j] = (float)(0.5 + 0.5 * cos(M_PI * i / 399.0));
+      tw[2 * j] = (float)cos(2.0 * M_PI * j / 400.0);
+      tw[2 * j + 1] = (float)(-sin(2.0 * M_PI * j / 400.0));           // sign is irrelevant for the power spectrum
+    }
+    const std::vector<float> melpts = linspace_f(hz2mel(0.0f), hz2mel(8000.0f), 130);
+    std::vector<float> filt(130);
+    for (int i = 0; i < 130; ++i) filt[i] = mel2hz(melpts[i]);
+    const std::vector<float> fft = linspace_f(0.0f, 8000.0f, 201);
+    for (int k = 0; k < 201; ++k)
+      for (int j = 0; j < 128; ++j) {                                   // audio_utils.rs:1197-1216, 1281-1290
+        const float down = -1.0f * (filt[j] - fft[k]) / (filt[j + 1] - filt[j]);
+        const float up = (filt[j + 2] - fft[k]) / (filt[j + 2] - filt[j + 1]);
+        const float tri = std::max(std::min(down, up), 0.0f);
+        fb[(size_t)k * 128 + j] = tri * (2.0f / (filt[j + 2] - filt[j]));
+      }
+    void* p;
+    if ((rc = dev_alloc(m, win.size() * 4, &p))) return rc;
+    a->d_window = (float*)p;
+    if ((rc = dev_alloc(m, tw.size() * 4, &p))) return rc;
+    a->d_twid = (float*)p;
+    if ((rc = dev_alloc(m, fb.size() * 4, &p))) return rc;
+    a->d_melfb = (float*)p;
+    AHA_HIP_CHECK(hipMemcpy(a->d_window, win.data(), win.size() * 4, hipMemcpyHostToDevice));
+    AHA_HIP_CHECK(hipMemcpy(a->d_twid, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
+    AHA_HIP_CHECK(hipMemcpy(a->d_melfb, fb.data(), fb.size() * 4, hipMemcpyHostToDevice));
+  }
+  a->scale = 0.125f;  // 1/sqrt(64), exactly representable in bf16
+  a->page_bytes = (uint64_t)2 * a->nh * KV_PAGE_TOKENS * a->hd * 2;
+  return AHA_OK;
+}
+
+static void audio_free_scratch(AudioModel* a) {
+  for (void* p : a->owned) hipFree(p);
+  a->owned.clear();
+  a->cap_frames = 0;
+}
+void audio_destroy(aha_model* m) {
+  if (!m->audio) return;
+  audio_free_scratch(m->audio);
+  delete m->audio;
+  m->audio = nullptr;
+}
+
+static int audio_ensure_scratch(aha_model* m, size_t frames, size_t samples) {
+  AudioModel* a = m->audio;
+  if (frames <= a->cap_frames) return AHA_OK;
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  audio_free_scratch(a);
+  const size_t cap = (frames + 999) / 1000 * 1000;
+  const size_t C = (cap + 99) / 100, win = 2 * (size_t)a->nwin;
+  auto al = [&](size_t bytes, void** out, bool zero = false) -> int {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+      set_error(std::string("audio scratch hipMalloc failed: ") + hipGetErrorString(e));
+      return e == hipErrorOutOfMemory ? AHA_ERR_OOM : AHA_ERR_HIP;
+    }
+    if (zero) hipMemsetAsync(p, 0, bytes, m->stream);
+    a->owned.push_back(p);
+    *out = p;
+    return AHA_OK;
+  };
+  int rc;
+  const size_t H = a->H, r1 = C * 64 * ((win + 1) / 2), r2 = C * 32 * 25, r3 = C * 16 * 13, ntok = C * 13;
+  (void)samples;
+  if ((rc = al((cap * 160 + 1024) * 4, (void**)&a->d_samples))) return rc;
+  if ((rc = al((size_t)a->mels * cap * 4, (void**)&a->d_feat))) return rc;
+  if ((rc = al(cap * 4, (void**)&a->d_fmax))) return rc;
+  if ((rc = al(std::max(r1 * 16, std::max(r2, r3) * 9 * H) * 2, &a->col))) return rc;
+  if ((rc = al(r1 * H * 2, &a->act_a))) return rc;
+  if ((rc = al(r2 * H * 2, &a->act_b))) return rc;
+  if ((rc = al(ntok * H * a->fq * 2, &a->tok))) return rc;
+  if ((rc = al(ntok * a->D * 2, &a->x))) return rc;
+  if ((rc = al(ntok * a->D * 2, &a->h))) return rc;
+  if ((rc = al(ntok * 3 * a->D * 2, &a->qkv))) return rc;
+  if ((rc = al(ntok * a->D * 2, &a->attn))) return rc;
+  if ((rc = al(ntok * a->ffn * 2, &a->mlp))) return rc;
+  if ((rc = al(ntok * a->out * 2, &a->embeds))) return rc;
+  if ((rc = al(ntok * 4, (void**)&a->d_rows))) return rc;
+  const size_t pcap = ntok / KV_PAGE_TOKENS + 2;
+  if ((rc = al(pcap * a->page_bytes, &a->page_store, true))) return rc;
+  if ((rc = al(pcap * 8, (void**)&a->d_page_ptrs))) return rc;
+  std::vector<uint64_t> ptrs(pcap);
+  for (size_t i = 0; i < pcap; ++i) ptrs[i] = (uint64_t)(uintptr_t)a->page_store + i * a->page_bytes;
+  AHA_HIP_CHECK(hipMemcpy(a->d_page_ptrs, ptrs.data(), pcap * 8, hipMemcpyHostToDevice));
+  a->cap_frames = cap;
+  return AHA_OK;
+}
+
+static void agemm(aha_model* m, const void* A, const void* W, void* C, int M, int N, int K, const void* bias, const void* residual,
+                  int act) {
+  GemmArgs g{};
+  g.A = A; g.W = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N; g.bias = bias; g.residual = residual; g.act = act;
+  ProfScope ps(m, "gemm", ((double)M * K + (double)N * K + (double)M * N * (residual ? 2 : 1)) * 2, 2.0 * M * N * K);
+  launch_gemm(g, m->stream);
+}
+
+static int get_out_len(int n) {  // get_feat_extract_output_lengths, processor.rs:187-195
+  const int r = n % 100;
+  if (r > 0) {
+    const int f = (r - 1) / 2 + 1;
+    return ((f - 1) / 2 + 1 - 1) / 2 + 1 + (n / 100) * 13;
+  }
+  return (n / 100) * 13;
+}
+
+int audio_logmel_device(aha_model* m, const float* d_samples, int64_t n_samples, float* d_out, float* d_fmax, int F) {
+  AudioModel* a = m->audio;
+  ProfScope ps(m, "logmel", (double)n_samples * 4 + (double)128 * F * 4, 2.0 * F * 201 * 400 * 2);
+  launch_logmel(d_samples, n_samples, a->d_window, a->d_twid, a->d_melfb, d_out, d_fmax, F, m->stream);
+  return AHA_OK;
+}
+
+int audio_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, const aha_mm_input* mm, void* x_text) {
+  AudioModel* a = m->audio;
+  const aha_model_desc& c = m->desc;
+  if (!a) {
+    set_error("this model has no audio tower");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = m->stream;
+  int64_t F;
+  int rc;
+  if (mm->audio_samples && mm->n_samples > 0) {
+    if (mm->n_samples < 401) {
+      set_error("audio too short for the reflect padding (need > 400 samples)");
+      return AHA_ERR_INVALID;
+    }
+    F = mm->n_samples / 160;  // (L + 400 - 400) / 160 + 1 frames, last one dropped
+    if ((rc = audio_ensure_scratch(m, (size_t)F, (size_t)mm->n_samples))) return rc;
+    AHA_HIP_CHECK(hipMemcpyAsync(a->d_samples, mm->audio_samples, (size_t)mm->n_samples * 4, hipMemcpyDefault, st));
+    if ((rc = audio_logmel_device(m, a->d_samples, mm->n_samples, a->d_feat, a->d_fmax, (int)F))) return rc;
+  } else if (mm->audio_features && mm->n_frames > 0) {
+    F = mm->n_frames;
+    if ((rc = audio_ensure_scratch(m, (size_t)F, 0))) return rc;
+    AHA_HIP_CHECK(hipMemcpyAsync(a->d_feat, mm->audio_features, (size_t)a->mels * F * 4, hipMemcpyDefault, st));
+  } else {
+    set_error("forward_initial: audio input without features or samples");
+    return AHA_ERR_INVALID;
+  }
+  const int win = 2 * a->nwin;  // 100 frames per chunk
+  const int C = (int)((F + win - 1) / win);
+  int n_tok = 0;
+  for (int i = 0; i < C; ++i) n_tok += get_out_len((int)std::min<int64_t>(win, F - (int64_t)i * win));
+  std::vector<int32_t> rows;
+  for (size_t i = 0; i < n; ++i)
+    if (ids[i] == (uint32_t)c.audio_token_id) rows.push_back((int32_t)i);
+  if ((int)rows.size() != n_tok) {  // qwen3_asr/model.rs:349-355
+    set_error("n_audio_tokens num: " + std::to_string(rows.size()) + " not equal to audio_feature len: " + std::to_string(n_tok));
+    return AHA_ERR_SHAPE;
+  }
+  AHA_HIP_CHECK(hipMemcpyAsync(a->d_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
+  AHA_HIP_CHECK(hipStreamSynchronize(st));
+
+  // conv stack: (C,1,128,100) -> (C,H,64,50) -> (C,H,32,25) -> (C,H,16,13), each conv + bias + tanh-GELU (model.rs:196-204)
+  const int H = a->H;
+  {
+    ProfScope ps(m, "elem", (double)C * 64 * 50 * 32, 0);
+    launch_audio_im2col1(a->d_feat, a->col, (int)F, C, a->mels, win, st);
+  }
+  agemm(m, a->col, a->c1w, a->act_a, C * 64 * 50, H, 16, a->c1b, nullptr, ACT_GELU_TANH);
+  {
+    ProfScope ps(m, "elem", (double)C * 32 * 25 * 9 * H * 4, 0);
+    launch_im2col_nhwc(a->act_a, a->col, C, 64, 50, H, st);
+  }
+  agemm(m, a->col, a->c2w, a->act_b, C * 32 * 25, H, 9 * H, a->c2b, nullptr, ACT_GELU_TANH);
+  {
+    ProfScope ps(m, "elem", (double)C * 16 * 13 * 9 * H * 4, 0);
+    launch_im2col_nhwc(a->act_b, a->col, C, 32, 25, H, st);
+  }
+  agemm(m, a->col, a->c3w, a->act_a, C * 16 * 13, H, 9 * H, a->c3b, nullptr, ACT_GELU_TANH);
+  {
+    ProfScope ps(m, "elem", (double)C * 13 * H * a->fq * 4, 0);
+    launch_audio_tokens_gather(a->act_a, a->tok, C, a->fq, 13, H, st);
+  }
+  agemm(m, a->tok, a->conv_out, a->x, C * 13, a->D, H * a->fq, nullptr, nullptr, ACT_NONE);
+  {
+    ProfScope ps(m, "elem", (double)C * 13 * a->D * 4, 0);
+    launch_sinus_pe_add(a->x, (int64_t)C * 13, a->D, 13, st);
+  }
+  // the first n_tok rows are the audio tokens (narrow(0, 0, feature_len_after_cnn), model.rs:213-215)
+  KvLayer kv{};
+  kv.page_ptrs = a->d_page_ptrs;
+  kv.layer_off = 0;
+  kv.kvh = a->nh;
+  kv.d = a->hd;
+  const int D = a->D;
+  for (int li = 0; li < a->layers; ++li) {
+    const AudLayerW& L = a->L[li];
+    {
+      ProfScope ps(m, "elem", (double)n_tok * D * 4, 0);
+      launch_layernorm_rows(a->x, L.ln1w, L.ln1b, a->h, n_tok, D, 1e-5f, st);
+    }
+    agemm(m, a->h, L.qkv_w, a->qkv, n_tok, 3 * D, D, L.qkv_b, nullptr, ACT_NONE);
+    {
+      ProfScope ps(m, "elem", (double)n_tok * D * 8, 0);
+      launch_kv_pack_generic(a->qkv, 3 * D, D, 2 * D, kv, n_tok, a->nh, a->hd, st);
+    }
+    {  // global (unmasked, unwindowed) attention over all audio tokens (model.rs:218-220)
+      AttnPrefillArgs q{};
+      q.q = a->qkv; q.q_ld = 3 * D; q.kv = kv; q.o = a->attn; q.S = n_tok; q.nh = a->nh; q.kvh = a->nh; q.d = a->hd;
+      q.kv_offset = 0; q.kv_total = n_tok; q.causal = 0; q.scale = a->scale;
+      ProfScope ps(m, "attn_audio", (double)n_tok * D * 8, 4.0 * n_tok * n_tok * D);
+      launch_attn_prefill(q, st);
+    }
+    agemm(m, a->attn, L.out_w, a->x, n_tok, D, D, L.out_b, a->x, ACT_NONE);
+    {
+      ProfScope ps(m, "elem", (double)n_tok * D * 4, 0);
+      launch_layernorm_rows(a->x, L.ln2w, L.ln2b, a->h, n_tok, D, 1e-5f, st);
+    }
+    agemm(m, a->h, L.fc1_w, a->mlp, n_tok, a->ffn, D, L.fc1_b, nullptr, ACT_GELU_ERF);
+    agemm(m, a->mlp, L.fc2_w, a->x, n_tok, D, a->ffn, L.fc2_b, a->x, ACT_NONE);
+  }
+  {
+    ProfScope ps(m, "elem", (double)n_tok * D * 4, 0);
+    launch_layernorm_rows(a->x, a->lnp_w, a->lnp_b, a->h, n_tok, D, 1e-5f, st);
+  }
+  agemm(m, a->h, a->p1w, a->mlp, n_tok, D, D, a->p1b, nullptr, ACT_GELU_ERF);
+  agemm(m, a->mlp, a->p2w, a->embeds, n_tok, a->out, D, a->p2b, nullptr, ACT_NONE);
+  a->n_tok = n_tok;
+  {
+    ProfScope ps(m, "elem", (double)n_tok * a->out * 4, 0);
+    launch_scatter_rows(x_text, a->embeds, a->d_rows, n_tok, a->out, 0, st);
+  }
+  AHA_HIP_CHECK(hipGetLastError());
+  return AHA_OK;
+}
+
+int audio_debug_embeds(aha_model* m, float* out, size_t n) {
+  AudioModel* a = m->audio;
+  if (!a || n != (size_t)a->n_tok * a->out) {
+    set_error("debug_audio_embeds: no audio embeddings of that shape");
+    return AHA_ERR_INVALID;
+  }
+  std::vector<uint16_t> tmp(n);
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  AHA_HIP_CHECK(hipMemcpy(tmp.data(), a->embeds, n * 2, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) out[i] = bf2f_h(tmp[i]);
+  return AHA_OK;
+}
+
+// op-level frontend (aha_hip_logmel): tables built on the fly
+int logmel_standalone(const float* d_samples, int64_t n_samples, float* d_out, hipStream_t st) {
+  aha_model fake;
+  aha_ctx ctx;
+  fake.ctx = &ctx;
+  fake.stream = st;
+  fake.desc = aha_model_desc{};
+  fake.desc.aud_d_model = 128; fake.desc.aud_attention_heads = 2; fake.desc.aud_num_mel_bins = 128;
+  fake.desc.aud_downsample_hidden_size = 8;
+  // only the tables are needed: build them through a minimal AudioModel
+  AudioModel* a = new AudioModel();
+  fake.audio = a;
+  int rc = AHA_OK;
+  {
+    std::vector<float> win(400), tw(800), fb((size_t)201 * 128);
+    for (int j = 0; j < 400; ++j) {
+      const double i = (double)(1 - 400 + 2 * j);
+      win[j] = (float)(0.5 + 0.5 * cos(M_PI * i / 399.0));
+      tw[2 * j] = (float)cos(2.0 * M_PI * j / 400.0);
+      tw[2 * j + 1] = (float)(-sin(2.0 * M_PI * j / 400.0));
+    }
+    const std::vector<float> melpts = linspace_f(hz2mel(0.0f), hz2mel(8000.0f), 130);
+    std::vector<float> filt(130);
+    for (int i = 0; i < 130; ++i) filt[i] = mel2hz(melpts[i]);
+    const std::vector<float> fft = linspace_f(0.0f, 8000.0f, 201);
+    for (int k = 0; k < 201; ++k)
+      for (int j = 0; j < 128; ++j) {
+        const float down = -1.0f * (filt[j] - fft[k]) / (filt[j + 1] - filt[j]);
+        const float up = (filt[j + 2] - fft[k]) / (filt[j + 2] - filt[j + 1]);
+        fb[(size_t)k * 128 + j] = std::max(std::min(down, up), 0.0f) * (2.0f / (filt[j + 2] - filt[j]));
+      }
+    void *pw = nullptr, *pt = nullptr, *pf = nullptr, *pm = nullptr;
+    const int F = (int)(n_samples / 160);
+    if ((rc = dev_alloc(&fake, win.size() * 4, &pw)) || (rc = dev_alloc(&fake, tw.size() * 4, &pt)) ||
+        (rc = dev_alloc(&fake, fb.size() * 4, &pf)) || (rc = dev_alloc(&fake, (size_t)F * 4 + 16, &pm))) {
+      for (void* p : fake.owned) hipFree(p);
+      delete a;
+      return rc;
+    }
+    hipMemcpy(pw, win.data(), win.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(pt, tw.data(), tw.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(pf, fb.data(), fb.size() * 4, hipMemcpyHostToDevice);
+    launch_logmel(d_samples, n_samples, (float*)pw, (float*)pt, (float*)pf, d_out, (float*)pm, F, st);
+    hipError_t e = hipGetLastError();
+    hipStreamSynchronize(st);
+    for (void* p : fake.owned) hipFree(p);
+    delete a;
+    if (e != hipSuccess) {
+      set_error(std::string("logmel launch failed: ") + hipGetErrorString(e));
+      return AHA_ERR_HIP;
+    }
+  }
+  return AHA_OK;
+}
+
+}  // namespace aha

@@ -7,6 +7,7 @@
 
 #include "common.h"
 #include "model.h"
+#include "audio.h"
 #include "vision.h"
 
 namespace aha {
@@ -338,6 +339,26 @@ int aha_hip_image_to_patches(const uint8_t* img_hwc, void* out, int32_t H, int32
   launch_image_to_patches(img_hwc, out, H, W, patch, merge, mean, std, (hipStream_t)stream);
   AHA_HIP_CHECK(hipGetLastError());
   return AHA_OK;
+}
+
+int aha_hip_logmel(const float* samples, int64_t n_samples, float* out, void* stream) {
+  API_GUARD_BEGIN
+  if (!samples || !out || n_samples < 401) {
+    set_error("logmel: need more than 400 samples");
+    return AHA_ERR_INVALID;
+  }
+  return logmel_standalone(samples, n_samples, out, (hipStream_t)stream);
+  API_GUARD_END
+}
+
+int aha_hip_debug_audio_embeds(aha_model* m, float* out, size_t n) {
+  API_GUARD_BEGIN
+  if (!m || !out) {
+    set_error("null argument");
+    return AHA_ERR_INVALID;
+  }
+  return audio_debug_embeds(m, out, n);
+  API_GUARD_END
 }
 
 int aha_hip_argmax(const float* x, int64_t n, uint32_t* out_dev, void* stream) {

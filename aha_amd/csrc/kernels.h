@@ -110,6 +110,7 @@ struct AttnPrefillArgs {
   int kv_total;            // number of valid cache tokens
   int causal;
   float scale;
+  int64_t q_ld;            // elements between consecutive q rows; 0 => nh * padded head dim
 };
 void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st);
 
@@ -151,4 +152,15 @@ void launch_vit_rope_pack(const VitRopeArgs& a, hipStream_t st);
 void launch_scatter_rows(void* dst, const void* src, const int32_t* rows, int64_t n, int D, int add, hipStream_t st);
 void launch_image_to_patches(const uint8_t* img, void* out, int H, int W, int patch, int merge, const float* mean,
                              const float* stdv, hipStream_t st);
+}  // namespace aha
+
+// ---- Qwen3-ASR audio path (kernels_audio.hip) ----------------------------------------------------------------------
+namespace aha {
+void launch_logmel(const float* x, int64_t L, const float* window, const float* twid, const float* melfb, float* out,
+                   float* frame_max, int F, hipStream_t st);
+void launch_audio_im2col1(const float* feat, void* out, int F, int C, int Hin, int Win, hipStream_t st);
+void launch_im2col_nhwc(const void* in, void* out, int B, int Hin, int Win, int Cin, hipStream_t st);
+void launch_audio_tokens_gather(const void* in, void* out, int B, int Fq, int T, int Cc, hipStream_t st);
+void launch_sinus_pe_add(void* x, int64_t rows, int d, int T, hipStream_t st);
+void launch_kv_pack_generic(const void* src, int64_t ld, int k_off, int v_off, KvLayer kv, int N, int nh, int hd, hipStream_t st);
 }  // namespace aha

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     const int qrow = min(q0 + t * 16 + c, a.S - 1);
-    const bf16_t* qp = (const bf16_t*)a.q + ((int64_t)qrow * a.nh + head) * DQK;
+    const bf16_t* qp = (const bf16_t*)a.q + (int64_t)qrow * (a.q_ld ? a.q_ld : (int64_t)a.nh * DQK) + (int64_t)head * DQK;
 #pragma unroll
     for (int k4 = 0; k4 < KS; ++k4) qf[t][k4] = as_frag(ld16(qp + k4 * 32 + G * 8));
   }
@@ -523,12 +523,15 @@ void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st) {
     return e ? atoi(e) : 0;
   }();
   // 2 q sub-tiles per wave (128 rows per block) once there are enough rows to fill the chip that way
-  const int qt = qt_env ? qt_env : 1;  // measured: QT=2 loses to QT=1 (fewer resident blocks per CU)
+  const int qt = (qt_env && a.d != 64) ? qt_env : 1;  // measured: QT=2 loses to QT=1 (fewer resident blocks per CU)
   dim3 grid((a.S + 64 * qt - 1) / (64 * qt), a.nh), block(256);
   if (a.d == 128) {
     const size_t lds = 2 * (KV_PAGE_TOKENS * (128 * 2 + 16) + 128 * V_ROW_BYTES);
     if (qt == 2) hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 2>), grid, block, lds, st, a);
     else hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 1>), grid, block, lds, st, a);
+  } else if (a.d == 64) {  // Qwen3-ASR audio encoder
+    const size_t lds = 2 * (KV_PAGE_TOKENS * (64 * 2 + 16) + 64 * V_ROW_BYTES);
+    hipLaunchKernelGGL((attn_prefill_kernel<64, 64, 1>), grid, block, lds, st, a);
   } else {  // head_dim 72 (Qwen3-VL ViT): Q/K rows padded to 96, V block to 80
     const size_t lds = 2 * (KV_PAGE_TOKENS * (96 * 2 + 16) + 80 * V_ROW_BYTES);
     if (qt == 2) hipLaunchKernelGGL((attn_prefill_kernel<96, 80, 2>), grid, block, lds, st, a);

@@ -52,6 +52,7 @@ struct StepState {
 struct ProfRec { int cls; hipEvent_t e0, e1; double bytes, flops; };
 
 struct VisionModel;  // vision.h
+struct AudioModel;   // audio.h
 
 }  // namespace aha
 
@@ -106,6 +107,8 @@ struct aha_model {
   std::vector<void*> pf_owned;
   // vision tower (Qwen3-VL)
   aha::VisionModel* vision = nullptr;
+  // audio tower (Qwen3-ASR)
+  aha::AudioModel* audio = nullptr;
   // profiling
   bool profiling = false;
   std::vector<aha::ProfRec> prof;

@@ -13,6 +13,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "audio.h"
 #include "vision.h"
 
 namespace aha {
@@ -356,6 +357,7 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
   // name prefixes: Qwen3 "model." optional (qwen3/model.rs:105-109); Qwen3-VL "model.language_model." (qwen3vl/model.rs:847-870)
   std::string pre;
   if (c.arch == AHA_ARCH_QWEN3VL) pre = "model.language_model.";
+  else if (c.arch == AHA_ARCH_QWEN3ASR) pre = "thinker.model.";  // qwen3_asr/model.rs:318,378
   else pre = find_tensor(w, nw, "model.embed_tokens.weight") ? "model." : "";
 
   const aha_tensor_view* t = nullptr;
@@ -365,7 +367,7 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
   else {
     // HF stores lm_head at top level; the reference's Qwen3 (non-VL) branch would look it up under the prefix
     // (qwen3/model.rs:124) -- accept either.
-    t = find_tensor(w, nw, "lm_head.weight");
+    t = find_tensor(w, nw, c.arch == AHA_ARCH_QWEN3ASR ? "thinker.lm_head.weight" : "lm_head.weight");
     if (!t) t = find_tensor(w, nw, pre + "lm_head.weight");
     if (!t) {
       set_error("missing weight tensor: lm_head.weight");
@@ -473,6 +475,9 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
   if (c.arch == AHA_ARCH_QWEN3VL) {
     if ((rc = vision_create(m, w, nw))) return fail(rc);
   }
+  if (c.arch == AHA_ARCH_QWEN3ASR) {
+    if ((rc = audio_create(m, w, nw))) return fail(rc);
+  }
   AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
   *out = m;
   return AHA_OK;
@@ -483,6 +488,7 @@ void model_destroy(aha_model* m) {
   hipStreamSynchronize(m->stream);
   for (auto& r : m->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   vision_destroy(m);
+  audio_destroy(m);
   for (void* p : m->owned) hipFree(p);
   for (void* p : m->pf_owned) hipFree(p);
   for (void* p : m->slabs) hipFree(p);
@@ -749,6 +755,11 @@ int model_forward_initial(aha_model* m, const uint32_t* ids, size_t n, size_t of
       set_error("token id out of range at position " + std::to_string(i));
       return AHA_ERR_INVALID;
     }
+  const bool has_audio = mm && ((mm->audio_features && mm->n_frames > 0) || (mm->audio_samples && mm->n_samples > 0));
+  if (has_audio && (c.arch != AHA_ARCH_QWEN3ASR || !m->audio)) {
+    set_error("audio input given but this model has no audio tower");
+    return AHA_ERR_UNSUPPORTED;
+  }
   if (n == 1 && !mm) return model_forward_step(m, ids[0], offset, logits_out, argmax_out);
   AHA_HIP_CHECK(hipSetDevice(m->ctx->device));
   const int S = (int)n;
@@ -785,6 +796,10 @@ int model_forward_initial(aha_model* m, const uint32_t* ids, size_t n, size_t of
   if (has_image) {
     // ViT -> masked_scatter of image embeds into the <|image_pad|> rows (qwen3vl/model.rs:1166-1190)
     if ((rc = vision_forward_and_scatter(m, ids, n, mm, m->p_x))) return rc;
+  }
+  if (has_audio) {
+    // audio tower -> masked_scatter into the <|audio_pad|> rows (qwen3_asr/model.rs:343-358)
+    if ((rc = audio_forward_and_scatter(m, ids, n, mm, m->p_x))) return rc;
   }
   const int kv_off = (int)m->cache_len;
   for (int li = 0; li < c.num_hidden_layers; ++li) {

@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 from ._lib import MmInput, ModelDesc, TensorView, check, lib
-from .configs import Qwen3Config, Qwen3VLConfig
+from .configs import Qwen3ASRConfig, Qwen3Config, Qwen3VLConfig
 
 _DT = {torch.bfloat16: _lib.AHA_BF16, torch.float16: _lib.AHA_F16, torch.float32: _lib.AHA_F32}
 
@@ -39,8 +39,11 @@ class HipContext:
 @dataclass
 class MultiModalData:
     """data_vec = [pixel_values, image_grid_thw, None, None, cache_position] (qwen3vl/generate.rs:79-101)."""
-    pixel_values: torch.Tensor      # (n_patches, C*T*P*P) bf16 or f32, processor row order
-    image_grid_thw: np.ndarray      # (n_images, 3) uint32
+    pixel_values: Optional[torch.Tensor] = None    # (n_patches, C*T*P*P) bf16 or f32, processor row order
+    image_grid_thw: Optional[np.ndarray] = None    # (n_images, 3) uint32
+    # Qwen3-ASR: data_vec = [input_features] (qwen3_asr/generate.rs:100-125): log-mel (128, F) f32, or raw 16 kHz samples
+    audio_features: Optional[np.ndarray] = None
+    audio_samples: Optional[np.ndarray] = None
 
 
 def make_desc(cfg, kv_reserve_tokens: int = 0) -> ModelDesc:
@@ -58,6 +61,14 @@ def make_desc(cfg, kv_reserve_tokens: int = 0) -> ModelDesc:
         d.image_token_id, d.video_token_id = cfg.image_token_id, cfg.video_token_id
         d.vision_start_token_id, d.vision_end_token_id = cfg.vision_start_token_id, cfg.vision_end_token_id
         tie = cfg.tie_word_embeddings
+    elif isinstance(cfg, Qwen3ASRConfig):
+        t, a = cfg.text, cfg.audio
+        d.arch = _lib.AHA_ARCH_QWEN3ASR
+        d.aud_d_model, d.aud_encoder_layers, d.aud_attention_heads = a.d_model, a.encoder_layers, a.encoder_attention_heads
+        d.aud_ffn_dim, d.aud_num_mel_bins, d.aud_downsample_hidden_size = a.encoder_ffn_dim, a.num_mel_bins, a.downsample_hidden_size
+        d.aud_output_dim, d.aud_n_window = a.output_dim, a.n_window
+        d.audio_token_id = cfg.audio_token_id
+        tie = t.tie_word_embeddings
     else:
         t = cfg
         d.arch = _lib.AHA_ARCH_QWEN3
@@ -84,7 +95,7 @@ class HipInferenceModel:
     def __init__(self, cfg, weights: Dict[str, torch.Tensor], ctx: Optional[HipContext] = None, device: int = 0,
                  kv_reserve_tokens: int = 0):
         self.cfg = cfg
-        self.text_cfg: Qwen3Config = cfg.text if isinstance(cfg, Qwen3VLConfig) else cfg
+        self.text_cfg: Qwen3Config = cfg.text if isinstance(cfg, (Qwen3VLConfig, Qwen3ASRConfig)) else cfg
         self._own_ctx = ctx is None
         self.ctx = ctx or HipContext(device)
         self.handle = C.c_void_p()
@@ -117,16 +128,25 @@ class HipInferenceModel:
         am = C.c_uint32()
         mm_ref = None
         if data is not None:
-            pv = data.pixel_values.detach().contiguous()
-            if pv.is_cuda:  # produced on torch's stream; the library copies on its own stream
-                torch.cuda.current_stream(pv.device).synchronize()
-            grid = np.ascontiguousarray(np.asarray(data.image_grid_thw, dtype=np.uint32).reshape(-1, 3))
             mm = MmInput()
-            mm.pixel_values = pv.data_ptr()
-            mm.pixel_dtype = _DT[pv.dtype]
-            mm.n_patches = pv.shape[0]
-            mm.image_grid_thw = grid.ctypes.data_as(C.POINTER(C.c_uint32))
-            mm.n_images = grid.shape[0]
+            if data.pixel_values is not None:
+                pv = data.pixel_values.detach().contiguous()
+                if pv.is_cuda:  # produced on torch's stream; the library copies on its own stream
+                    torch.cuda.current_stream(pv.device).synchronize()
+                grid = np.ascontiguousarray(np.asarray(data.image_grid_thw, dtype=np.uint32).reshape(-1, 3))
+                mm.pixel_values = pv.data_ptr()
+                mm.pixel_dtype = _DT[pv.dtype]
+                mm.n_patches = pv.shape[0]
+                mm.image_grid_thw = grid.ctypes.data_as(C.POINTER(C.c_uint32))
+                mm.n_images = grid.shape[0]
+            if data.audio_features is not None:
+                af = np.ascontiguousarray(np.asarray(data.audio_features, dtype=np.float32))
+                mm.audio_features = af.ctypes.data_as(C.POINTER(C.c_float))
+                mm.n_frames = af.shape[1]
+            if data.audio_samples is not None:
+                au = np.ascontiguousarray(np.asarray(data.audio_samples, dtype=np.float32).reshape(-1))
+                mm.audio_samples = au.ctypes.data_as(C.POINTER(C.c_float))
+                mm.n_samples = au.size
             mm_ref = C.byref(mm)
         lp = self._logits.ctypes.data_as(C.POINTER(C.c_float)) if want_logits else None
         check(lib().aha_hip_forward_initial(self.handle, ids.ctypes.data_as(C.POINTER(C.c_uint32)), ids.size,
@@ -175,6 +195,11 @@ class HipInferenceModel:
     def debug_image_embeds(self, which: int, rows: int) -> np.ndarray:
         out = np.empty((rows, self.text_cfg.hidden_size), dtype=np.float32)
         check(lib().aha_hip_debug_image_embeds(self.handle, which, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+        return out
+
+    def debug_audio_embeds(self, rows: int) -> np.ndarray:
+        out = np.empty((rows, self.text_cfg.hidden_size), dtype=np.float32)
+        check(lib().aha_hip_debug_audio_embeds(self.handle, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
         return out
 
     def close(self):

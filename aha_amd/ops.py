@@ -135,3 +135,12 @@ def image_to_patches(img_u8_hwc: torch.Tensor, patch: int = 16, merge: int = 2, 
     s = (C.c_float * 3)(*std)
     check(lib().aha_hip_image_to_patches(_ptr(img_u8_hwc), _ptr(out), H, W, patch, merge, m, s, _stream()))
     return out
+
+
+def logmel(samples: torch.Tensor) -> torch.Tensor:
+    """A0: 16 kHz mono f32 samples on the GPU -> Whisper log-mel features (128, n_samples // 160) f32."""
+    _chk(samples)
+    assert samples.dtype == torch.float32 and samples.dim() == 1
+    out = torch.empty(128, samples.numel() // 160, dtype=torch.float32, device=samples.device)
+    check(lib().aha_hip_logmel(_ptr(samples), samples.numel(), _ptr(out), _stream()))
+    return out

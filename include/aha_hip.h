@@ -38,7 +38,7 @@ enum aha_status {
 };
 
 enum aha_dtype { AHA_BF16 = 0, AHA_F16 = 1, AHA_F32 = 2, AHA_U32 = 3, AHA_U8 = 4 };
-enum aha_arch { AHA_ARCH_QWEN3 = 0, AHA_ARCH_QWEN3VL = 1 };
+enum aha_arch { AHA_ARCH_QWEN3 = 0, AHA_ARCH_QWEN3VL = 1, AHA_ARCH_QWEN3ASR = 2 };
 
 /* Mirrors Qwen3Config (/root/reference/src/models/qwen3/config.rs:4-27), Qwen3VLTextConfig / Qwen3VLVisionConfig /
  * Qwen3VLConfig (/root/reference/src/models/qwen3vl/config.rs:59-133).  Vision fields are ignored for AHA_ARCH_QWEN3. */
@@ -60,6 +60,10 @@ typedef struct aha_model_desc {
   int32_t kv_reserve_tokens;
   int32_t n_stop_tokens;
   uint32_t stop_tokens[8];         /* generation_config.json eos_token_id list (qwen3/generate.rs:36-43) */
+  /* audio tower (Qwen3ASRAudioConfig, /root/reference/src/models/qwen3_asr/config.rs:24-96); AHA_ARCH_QWEN3ASR only */
+  int32_t aud_d_model, aud_encoder_layers, aud_attention_heads, aud_ffn_dim, aud_num_mel_bins,
+      aud_downsample_hidden_size, aud_output_dim, aud_n_window;
+  int32_t audio_token_id;
 } aha_model_desc;
 
 /* One checkpoint tensor: HF name, pointer (host memory, e.g. an mmapped safetensors file; or, when on_device != 0,
@@ -82,6 +86,13 @@ typedef struct aha_mm_input {
   int64_t n_patches;
   const uint32_t* image_grid_thw; /* host, (n_images, 3) */
   int32_t n_images;
+  /* Qwen3-ASR (MultiModalData = [input_features], /root/reference/src/models/qwen3_asr/generate.rs:100-125): either the
+   * Whisper log-mel features (num_mel_bins, n_frames) f32, or raw 16 kHz mono samples from which the library computes
+   * them on the GPU (WhisperFeatureExtractor, feature_extraction_whisper.rs:93-115).  Host pointers. */
+  const float* audio_features;
+  int64_t n_frames;
+  const float* audio_samples;
+  int64_t n_samples;
 } aha_mm_input;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------------------- */
@@ -161,6 +172,12 @@ int aha_hip_attn_prefill(const void* q, const void* k, const void* v, void* o, i
  * (/root/reference/src/models/qwen3vl/processor.rs:174-251; img_transform, /root/reference/src/utils/img_utils.rs:272-293). */
 int aha_hip_image_to_patches(const uint8_t* img_hwc, void* out, int32_t H, int32_t W, int32_t patch, int32_t merge,
                              const float mean[3], const float std[3], void* stream);
+/* A0: Whisper log-mel frontend on the GPU (extract_fbank_features, feature_extraction_whisper.rs:93-115): n_samples f32
+ * device samples -> out (128, n_samples/160) f32 device (n_fft 400, hop 160, symmetric Hann, Slaney mel, log10, max-8 clamp,
+ * (x+4)/4).  n_samples must be >= 401. */
+int aha_hip_logmel(const float* samples, int64_t n_samples, float* out, void* stream);
+/* Debug: audio embeddings of the last forward_initial (rows x output_dim floats). */
+int aha_hip_debug_audio_embeds(aha_model* m, float* out, size_t n);
 /* D11 greedy: first maximal index of an f32 vector. */
 int aha_hip_argmax(const float* x, int64_t n, uint32_t* out_dev, void* stream);
 

@@ -104,3 +104,38 @@ if __name__ == "__main__":
     qwen3_case()
     qwen3vl_case()
     print("wrote", [f for f in os.listdir(OUT) if f.endswith(".npz")])
+
+
+def qwen3_asr_encoder_case():
+    """HF Qwen3ASREncoder (upstream behaviour) on our seeded audio-tower weights, <= 8 s so one attention window."""
+    from transformers.models.qwen3_asr import Qwen3ASREncoderConfig, Qwen3ASREncoder
+    from aha_amd.configs import tiny_qwen3_asr
+    from aha_amd.weights import qwen3_asr_weights
+    cfg = tiny_qwen3_asr()
+    a = cfg.audio
+    w = qwen3_asr_weights(cfg, seed=0, dtype=torch.float32)
+    hc = Qwen3ASREncoderConfig(num_mel_bins=128, d_model=a.d_model, encoder_layers=a.encoder_layers,
+                               encoder_attention_heads=a.encoder_attention_heads, encoder_ffn_dim=a.encoder_ffn_dim,
+                               output_dim=a.output_dim, downsample_hidden_size=a.downsample_hidden_size, n_window=50,
+                               n_window_infer=800)
+    hc._attn_implementation = "eager"
+    m = Qwen3ASREncoder(hc).eval()
+    sd = {k[len("thinker.audio_tower."):]: v for k, v in w.items() if k.startswith("thinker.audio_tower.")}
+    r = m.load_state_dict(sd, strict=False)
+    assert not r.missing_keys
+    F = 430
+    feats = np.random.default_rng(7).normal(0, 1, (128, F)).astype(np.float32)
+    Fp = ((F + 99) // 100) * 100
+    x = torch.zeros(1, 128, Fp)
+    x[0, :, :F] = torch.from_numpy(feats)
+    mask = torch.zeros(1, Fp, dtype=torch.long)
+    mask[0, :F] = 1
+    with torch.no_grad():
+        out = m(x, input_features_mask=mask).last_hidden_state
+    np.savez_compressed(os.path.join(OUT, "qwen3_asr_encoder_tiny_f32.npz"), feats=feats,
+                        ln_post=out.reshape(-1, a.d_model).numpy().astype(np.float32), seed=0)
+
+
+if __name__ == "__main__":
+    qwen3_asr_encoder_case()
+    print("wrote qwen3_asr_encoder_tiny_f32.npz")

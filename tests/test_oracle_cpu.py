@@ -127,3 +127,38 @@ def test_patch_order_and_pos_embed_indices():
     idx, wt = v.pos_embed_indices(grid)
     assert idx.shape == (4, 24) and np.allclose(wt.sum(0), 1.0, atol=1e-6)
     assert idx.min() >= 0 and idx.max() < cfg.vision.num_position_embeddings
+
+
+def test_asr_logmel_matches_torch_stft():
+    """A0 restatement vs an independent STFT (torch.stft) fed the same symmetric Hann window and the same padding."""
+    from oracle import qwen3_asr as oa
+    wave = np.clip(np.random.default_rng(4).normal(0, 0.1, 40000), -1, 1).astype(np.float32)
+    lm = oa.log_mel(wave)
+    y = torch.from_numpy(oa.pad_reflect_last_dim(wave, 200, 200)).double()
+    st = torch.stft(y, 400, 160, window=torch.from_numpy(oa.create_hann_window(400)).double(), center=False, return_complex=True)
+    mel = torch.from_numpy(oa.mel_filter_bank()).double().t() @ (st.abs() ** 2)[:, :-1]
+    lg = torch.log10(mel.clamp_min(1e-10))
+    ref = ((torch.maximum(lg, lg.max() - 8.0) + 4) / 4).float().numpy()
+    assert lm.shape == (128, 250) and np.abs(lm - ref).max() < 5e-6
+    # the right-pad quirk (tensor_utils.rs:525-549): mirrors x[L-400:L-200], and differs from a true reflection
+    x = np.arange(1000, dtype=np.float32)
+    p = oa.pad_reflect_last_dim(x, 200, 200)
+    assert p[:3].tolist() == [200, 199, 198] and p[-1] == 600 and p[1200] == 799
+    assert [oa.get_feat_extract_output_lengths(n) for n in (100, 3000, 37, 1, 101)] == [13, 390, 5, 1, 14]
+
+
+def test_asr_encoder_matches_golden_f32():
+    """Audio encoder restatement (with the reference's three deviations switched to upstream) vs HF Qwen3ASREncoder."""
+    from aha_amd.configs import tiny_qwen3_asr
+    from aha_amd.weights import qwen3_asr_weights
+    from oracle import qwen3_asr as oa
+    g = np.load(os.path.join(GOLD, "qwen3_asr_encoder_tiny_f32.npz"))
+    cfg = tiny_qwen3_asr()
+    w = qwen3_asr_weights(cfg, seed=int(g["seed"]), dtype=torch.float32)
+    sw = oa.AsrSwitches(global_attention=False, pe_reference=False, conv_gelu_tanh=False)
+    enc = oa.OracleAudioEncoder(cfg.audio, w, Numerics("f32"), sw=sw)
+    out = enc.forward(torch.from_numpy(g["feats"]), upto="ln_post").numpy()
+    assert out.shape == g["ln_post"].shape and np.abs(out - g["ln_post"]).max() < 2e-5
+    # and the reference's own behaviour differs measurably (so the switches are live)
+    ref = oa.OracleAudioEncoder(cfg.audio, w, Numerics("f32")).forward(torch.from_numpy(g["feats"]), upto="ln_post").numpy()
+    assert np.abs(ref - g["ln_post"]).max() > 1e-3
