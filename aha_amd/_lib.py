@@ -51,7 +51,8 @@ class MmInput(C.Structure):
     _fields_ = [("pixel_values", C.c_void_p), ("pixel_dtype", C.c_int32), ("n_patches", C.c_int64),
                 ("image_grid_thw", C.POINTER(C.c_uint32)), ("n_images", C.c_int32),
                 ("audio_features", C.POINTER(C.c_float)), ("n_frames", C.c_int64),
-                ("audio_samples", C.POINTER(C.c_float)), ("n_samples", C.c_int64)]
+                ("audio_samples", C.POINTER(C.c_float)), ("n_samples", C.c_int64),
+                ("image_embeds", C.c_void_p), ("n_image_tokens", C.c_int64)]
 
 
 # every symbol include/aha_hip.h declares: name -> (restype, argtypes)
@@ -88,6 +89,7 @@ SIGNATURES = {
                                        C.c_int32, C.c_int32, C.c_float, _P]),
     "aha_hip_argmax": (C.c_int, [_P, C.c_int64, _P, _P]),
     "aha_hip_logmel": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "aha_hip_vision_encode": (C.c_int, [_P, C.POINTER(MmInput), _P, C.POINTER(C.c_int64)]),
     "aha_hip_debug_audio_embeds": (C.c_int, [_P, C.POINTER(C.c_float), C.c_size_t]),
     "aha_hip_image_to_patches": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float),
                                            C.POINTER(C.c_float), _P]),

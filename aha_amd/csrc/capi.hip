@@ -341,6 +341,16 @@ int aha_hip_image_to_patches(const uint8_t* img_hwc, void* out, int32_t H, int32
   return AHA_OK;
 }
 
+int aha_hip_vision_encode(aha_model* m, const aha_mm_input* mm, void* out_dev, int64_t* n_tokens) {
+  API_GUARD_BEGIN
+  if (!m || !mm) {
+    set_error("null argument");
+    return AHA_ERR_INVALID;
+  }
+  return vision_encode(m, mm, out_dev, n_tokens);
+  API_GUARD_END
+}
+
 int aha_hip_logmel(const float* samples, int64_t n_samples, float* out, void* stream) {
   API_GUARD_BEGIN
   if (!samples || !out || n_samples < 401) {

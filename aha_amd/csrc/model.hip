@@ -772,7 +772,7 @@ int model_forward_initial(aha_model* m, const uint32_t* ids, size_t n, size_t of
 
   // positions: 1-D arange(offset, offset+S) on all three rows (rope.rs:599-604), or get_rope_index for Qwen3-VL
   std::vector<int32_t> pos(3 * (size_t)S);
-  const bool has_image = mm && mm->n_images > 0;
+  const bool has_image = mm && (mm->n_images > 0 || mm->image_embeds);
   if (has_image && (c.arch != AHA_ARCH_QWEN3VL || !m->vision)) {
     set_error("image input given but this model has no vision tower (arch / model.visual.* weights)");
     return AHA_ERR_UNSUPPORTED;

@@ -13,5 +13,6 @@ int vl_rope_index(aha_model* m, const uint32_t* ids, size_t n, size_t offset, co
 int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, const aha_mm_input* mm, void* x);
 int vision_deepstack_add(aha_model* m, int layer, void* x);
 int vision_debug_embeds(aha_model* m, int which, float* out, size_t n);
+int vision_encode(aha_model* m, const aha_mm_input* mm, void* out_dev, int64_t* n_tokens);
 
 }  // namespace aha

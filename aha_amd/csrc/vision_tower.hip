@@ -236,11 +236,37 @@ int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, cons
     set_error("this model was created without vision tower weights (model.visual.*)");
     return AHA_ERR_UNSUPPORTED;
   }
+  const int ms = v->merge;
+  if (mm->image_embeds) {
+    // Embeddings computed elsewhere (another rank's share of the images, gathered over RCCL -- aha_amd/parallel.py):
+    // layout (1 + n_deepstack, n_image_tokens, out_hidden) bf16 in device memory.  Skip the tower, keep the scatter.
+    const int64_t n4 = mm->n_image_tokens;
+    std::vector<int32_t> rows;
+    for (size_t i = 0; i < n; ++i)
+      if (ids[i] == (uint32_t)c.image_token_id) rows.push_back((int32_t)i);
+    if ((int64_t)rows.size() != n4 || n4 <= 0) {
+      set_error("n_image_token num: " + std::to_string(rows.size()) + " not equal to image_embed len: " + std::to_string(n4));
+      return AHA_ERR_SHAPE;
+    }
+    int rc0 = vision_ensure_scratch(m, (size_t)n4 * ms * ms, 0);
+    if (rc0) return rc0;
+    hipStream_t s0 = m->stream;
+    const size_t bytes = (size_t)n4 * v->out * 2;
+    AHA_HIP_CHECK(hipMemcpyAsync(v->merged, mm->image_embeds, bytes, hipMemcpyDefault, s0));
+    for (size_t k = 0; k < v->deep.size(); ++k)
+      AHA_HIP_CHECK(hipMemcpyAsync(v->deep[k], (const char*)mm->image_embeds + (k + 1) * bytes, bytes, hipMemcpyDefault, s0));
+    AHA_HIP_CHECK(hipMemcpyAsync(v->d_vis_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, s0));
+    AHA_HIP_CHECK(hipStreamSynchronize(s0));
+    v->n_merged = n4;
+    launch_scatter_rows(x_text, v->merged, v->d_vis_rows, n4, v->out, 0, s0);
+    AHA_HIP_CHECK(hipGetLastError());
+    return AHA_OK;
+  }
   if (!mm->pixel_values || !mm->image_grid_thw || mm->n_images <= 0) {
     set_error("forward_initial: image input without pixel_values / image_grid_thw");
     return AHA_ERR_INVALID;
   }
-  const int ms = v->merge;
+  const bool encode_only = ids == nullptr;
   // ---- host index construction ------------------------------------------------------------------------------
   int64_t N = 0;
   for (int i = 0; i < mm->n_images; ++i) {
@@ -259,7 +285,7 @@ int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, cons
   std::vector<int32_t> vis_rows;
   for (size_t i = 0; i < n; ++i)
     if (ids[i] == (uint32_t)c.image_token_id) vis_rows.push_back((int32_t)i);
-  if ((int64_t)vis_rows.size() != n4) {  // model.rs:1158-1164
+  if (!encode_only && (int64_t)vis_rows.size() != n4) {  // model.rs:1158-1164
     set_error("n_image_token num: " + std::to_string(vis_rows.size()) + " not equal to image_embed len: " + std::to_string(n4));
     return AHA_ERR_SHAPE;
   }
@@ -384,11 +410,33 @@ int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, cons
   }
   run_merger(m, v->merger, false, v->x, N, v->merged);
   v->n_merged = n4;
-  {
+  if (!encode_only) {
     ProfScope ps(m, "elem", (double)n4 * v->out * 4, 0);
     launch_scatter_rows(x_text, v->merged, v->d_vis_rows, n4, v->out, 0, st);
   }
   AHA_HIP_CHECK(hipGetLastError());
+  return AHA_OK;
+}
+
+// V1-V7 only: encode the images of `mm` and copy (merged, deepstack 0..K-1) to out_dev, (1+K, n_tokens, out) bf16
+int vision_encode(aha_model* m, const aha_mm_input* mm, void* out_dev, int64_t* n_tokens) {
+  VisionModel* v = m->vision;
+  if (!v) {
+    set_error("this model was created without vision tower weights (model.visual.*)");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  aha_mm_input local = *mm;
+  local.image_embeds = nullptr;
+  int rc = vision_forward_and_scatter(m, nullptr, 0, &local, nullptr);
+  if (rc) return rc;
+  const size_t bytes = (size_t)v->n_merged * v->out * 2;
+  if (out_dev) {
+    AHA_HIP_CHECK(hipMemcpyAsync(out_dev, v->merged, bytes, hipMemcpyDefault, m->stream));
+    for (size_t k = 0; k < v->deep.size(); ++k)
+      AHA_HIP_CHECK(hipMemcpyAsync((char*)out_dev + (k + 1) * bytes, v->deep[k], bytes, hipMemcpyDefault, m->stream));
+  }
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  if (n_tokens) *n_tokens = v->n_merged;
   return AHA_OK;
 }
 

@@ -44,6 +44,8 @@ class MultiModalData:
     # Qwen3-ASR: data_vec = [input_features] (qwen3_asr/generate.rs:100-125): log-mel (128, F) f32, or raw 16 kHz samples
     audio_features: Optional[np.ndarray] = None
     audio_samples: Optional[np.ndarray] = None
+    # image-parallel ViT: embeddings already computed (vision_encode, gathered over RCCL): (1+K, n_tokens, H) bf16 on the GPU
+    image_embeds: Optional[torch.Tensor] = None
 
 
 def make_desc(cfg, kv_reserve_tokens: int = 0) -> ModelDesc:
@@ -139,6 +141,15 @@ class HipInferenceModel:
                 mm.n_patches = pv.shape[0]
                 mm.image_grid_thw = grid.ctypes.data_as(C.POINTER(C.c_uint32))
                 mm.n_images = grid.shape[0]
+            if data.image_embeds is not None:
+                ie = data.image_embeds.detach().contiguous()
+                assert ie.is_cuda and ie.dtype == torch.bfloat16 and ie.dim() == 3
+                torch.cuda.current_stream(ie.device).synchronize()
+                grid = np.ascontiguousarray(np.asarray(data.image_grid_thw, dtype=np.uint32).reshape(-1, 3))
+                mm.image_embeds = ie.data_ptr()
+                mm.n_image_tokens = ie.shape[1]
+                mm.image_grid_thw = grid.ctypes.data_as(C.POINTER(C.c_uint32))
+                mm.n_images = grid.shape[0]
             if data.audio_features is not None:
                 af = np.ascontiguousarray(np.asarray(data.audio_features, dtype=np.float32))
                 mm.audio_features = af.ctypes.data_as(C.POINTER(C.c_float))
@@ -195,6 +206,24 @@ class HipInferenceModel:
     def debug_image_embeds(self, which: int, rows: int) -> np.ndarray:
         out = np.empty((rows, self.text_cfg.hidden_size), dtype=np.float32)
         check(lib().aha_hip_debug_image_embeds(self.handle, which, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+        return out
+
+    def vision_encode(self, data: "MultiModalData") -> torch.Tensor:
+        """ViT only (aha_hip_vision_encode): -> (1 + n_deepstack, n_tokens, hidden) bf16 on this model's GPU."""
+        pv = data.pixel_values.detach().contiguous()
+        if pv.is_cuda:
+            torch.cuda.current_stream(pv.device).synchronize()
+        grid = np.ascontiguousarray(np.asarray(data.image_grid_thw, dtype=np.uint32).reshape(-1, 3))
+        mm = MmInput()
+        mm.pixel_values, mm.pixel_dtype, mm.n_patches = pv.data_ptr(), _DT[pv.dtype], pv.shape[0]
+        mm.image_grid_thw, mm.n_images = grid.ctypes.data_as(C.POINTER(C.c_uint32)), grid.shape[0]
+        m2 = self.cfg.vision.spatial_merge_size ** 2
+        n_tok = int(sum(int(g[0]) * int(g[1]) * int(g[2]) for g in grid) // m2)
+        k = 1 + len(self.cfg.vision.deepstack_visual_indexes)
+        out = torch.empty(k, n_tok, self.text_cfg.hidden_size, dtype=torch.bfloat16, device=f"cuda:{self.ctx.device}")
+        nt = C.c_int64()
+        check(lib().aha_hip_vision_encode(self.handle, C.byref(mm), out.data_ptr(), C.byref(nt)))
+        assert nt.value == n_tok
         return out
 
     def debug_audio_embeds(self, rows: int) -> np.ndarray:

@@ -45,3 +45,34 @@ def aggregate_throughput(units_this_rank: float, secs_this_rank: float, device="
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(u.item()) / float(t.item()), float(t.item())
+
+
+def encode_images_sharded(encode_fn, per_image_inputs: List, tokens_per_image: List[int], world: int, rank: int):
+    """Image-parallel ViT: images are independent units (block-diagonal attention per image,
+    /root/reference/src/models/qwen3vl/model.rs:258-273), so rank r encodes images shard_units(n, world, r) and ONE
+    all_gather moves the embeddings.  ``encode_fn(list_of_inputs) -> (K, n_local_tokens, H)`` tensor (device for nccl,
+    CPU for gloo); returns (K, total_tokens, H) in image order on every rank.  Ragged shards are padded to the largest
+    shard for the collective and trimmed afterwards."""
+    import torch
+    import torch.distributed as dist
+    n = len(per_image_inputs)
+    a, b = shard_units(n, world, rank)
+    local = encode_fn(per_image_inputs[a:b]) if b > a else None
+    if world == 1 or not dist.is_initialized():
+        return local
+    counts = [sum(tokens_per_image[slice(*shard_units(n, world, r))]) for r in range(world)]
+    mx = max(counts)
+    ref = local
+    if ref is None:  # this rank has no image: it still takes part in the collective
+        shapes = [None] * world
+        dist.all_gather_object(shapes, None)
+        kh = next(s for s in shapes if s is not None)
+        buf = torch.zeros(kh[0], mx, kh[1], dtype=kh[2], device=kh[3])
+    else:
+        shapes = [None] * world
+        dist.all_gather_object(shapes, (local.shape[0], local.shape[2], local.dtype, str(local.device)))
+        buf = torch.zeros(local.shape[0], mx, local.shape[2], dtype=local.dtype, device=local.device)
+        buf[:, : local.shape[1]] = local
+    outs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    return torch.cat([o[:, :c] for o, c in zip(outs, counts) if c > 0], dim=1)

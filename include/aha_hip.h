@@ -93,6 +93,11 @@ typedef struct aha_mm_input {
   int64_t n_frames;
   const float* audio_samples;
   int64_t n_samples;
+  /* Qwen3-VL, image-parallel ViT: embeddings already computed (by aha_hip_vision_encode, possibly on
+   * other GPUs and all-gathered): device pointer to (1 + n_deepstack, n_image_tokens, hidden) bf16.  When set,
+   * pixel_values is ignored (image_grid_thw is still needed for the M-RoPE positions). */
+  const void* image_embeds;
+  int64_t n_image_tokens;
 } aha_mm_input;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------------------- */
@@ -125,6 +130,11 @@ int aha_hip_stop_token_ids(const aha_model* m, uint32_t* out, size_t cap);
  * first_token is the token sampled from that call.  Writes up to max_new tokens; stops after an eos id.
  * Returns the number of tokens written or a negative status. */
 int aha_hip_decode_greedy(aha_model* m, uint32_t first_token, size_t seqlen_offset, size_t max_new, uint32_t* tokens_out);
+
+/* Extension for the image-parallel ViT (each GPU encodes its share of the images, embeddings are all-gathered over RCCL):
+ * runs only the vision tower on `mm` and writes (1 + n_deepstack, n_tokens, hidden) bf16 to out_dev (device memory, may be
+ * NULL to query n_tokens). */
+int aha_hip_vision_encode(aha_model* m, const aha_mm_input* mm, void* out_dev, int64_t* n_tokens);
 
 /* ---- introspection used by bench.py / tests ------------------------------------------------------------------ */
 size_t aha_hip_cache_len(const aha_model* m);

@@ -38,3 +38,37 @@ def test_two_rank_replicas_gloo():
     assert (a0, b0, a1, b1) == (0, 3, 3, 5)
     assert t0 == t1 == 2.0                       # max over ranks
     assert abs(v0 - 50.0 / 2.0) < 1e-9 and v0 == v1   # whole-job units / slowest rank's time
+
+
+def _gather_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from aha_amd import parallel
+    dist = parallel.init_process_group("gloo")
+    toks = [3, 5, 2]                                   # three images with different token counts, two ranks
+    def encode(imgs):                                  # stand-in for HipInferenceModel.vision_encode
+        return torch.cat([torch.full((2, toks[i], 4), float(i)) + torch.arange(toks[i]).float()[None, :, None] / 10 for i in imgs], 1)
+    res = parallel.encode_images_sharded(encode, [0, 1, 2], toks, world, rank)
+    out.put((rank, res.shape, res[0, :, 0].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_image_parallel_gather_gloo():
+    """Image-parallel ViT plumbing: ragged shards, one all_gather, image order preserved on every rank."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [0.0, 0.1, 0.2, 1.0, 1.1, 1.2, 1.3, 1.4, 2.0, 2.1]
+    for rank, shape, col in res:
+        assert tuple(shape) == (2, 10, 4)
+        assert all(abs(a - b) < 1e-6 for a, b in zip(col, want))

@@ -33,7 +33,7 @@ def test_struct_layout_matches_header(hip_lib):
     from aha_amd import _lib
     # aha_tensor_view: ptr, ptr, i32, i32, i64[5], i32 (+pad) ; aha_mm_input: ptr, i32, i64, ptr, i32 (+pad)
     assert ctypes.sizeof(_lib.TensorView) == 8 + 8 + 4 + 4 + 40 + 8
-    assert ctypes.sizeof(_lib.MmInput) == 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
+    assert ctypes.sizeof(_lib.MmInput) == 8 * 11
     assert ctypes.sizeof(_lib.ModelDesc) % 4 == 0 and _lib.ModelDesc.stop_tokens.offset > _lib.ModelDesc.kv_reserve_tokens.offset
 
 

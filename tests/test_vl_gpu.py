@@ -136,3 +136,19 @@ def test_rope_index_matches_oracle():
     assert pos[:, :3].tolist() == [[0, 1, 2]] * 3
     assert pos[0, 3:9].tolist() == [3] * 6 and pos[1, 3:9].tolist() == [3, 3, 3, 4, 4, 4] and pos[2, 3:9].tolist() == [3, 4, 5] * 2
     assert pos[:, 9:].tolist() == [[6, 7, 8]] * 3 and delta == 9 - len(ids)
+
+
+def test_vision_encode_then_precomputed_embeds(vl, gpu):
+    """aha_hip_vision_encode + forward_initial(image_embeds=...) (the image-parallel path on one GPU) must reproduce the
+    fused forward bit for bit."""
+    from aha_amd.model import MultiModalData
+    cfg, m, o = vl
+    imgs, pv, grid, ids = make_request(cfg, [(160, 96), (64, 128)], 6, 23)
+    m.clear_cache()
+    a, _ = m.forward_initial(ids, 0, MultiModalData(pv.to(torch.bfloat16), grid))
+    emb = m.vision_encode(MultiModalData(pv.to(torch.bfloat16), grid))
+    assert emb.shape[0] == 1 + len(cfg.vision.deepstack_visual_indexes)
+    m.clear_cache()
+    b, _ = m.forward_initial(ids, 0, MultiModalData(image_grid_thw=grid, image_embeds=emb))
+    assert np.array_equal(a, b)
+    m.clear_cache()
