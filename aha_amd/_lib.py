@@ -39,6 +39,7 @@ class ModelDesc(C.Structure):
         ("aud_ffn_dim", C.c_int32), ("aud_num_mel_bins", C.c_int32), ("aud_downsample_hidden_size", C.c_int32),
         ("aud_output_dim", C.c_int32), ("aud_n_window", C.c_int32),
         ("audio_token_id", C.c_int32),
+        ("tp_rank", C.c_int32), ("tp_size", C.c_int32),
     ]
 
 
@@ -57,6 +58,8 @@ class MmInput(C.Structure):
 
 # every symbol include/aha_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
+
 SIGNATURES = {
     "aha_hip_init": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "aha_hip_shutdown": (None, [_P]),
@@ -89,6 +92,10 @@ SIGNATURES = {
                                        C.c_int32, C.c_int32, C.c_float, _P]),
     "aha_hip_argmax": (C.c_int, [_P, C.c_int64, _P, _P]),
     "aha_hip_logmel": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "aha_hip_set_allreduce": (C.c_int, [_P, _P, _P]),
+    "aha_hip_tp_unique_id": (C.c_int, [_P]),
+    "aha_hip_tp_init_rccl": (C.c_int, [_P, _P]),
+    "aha_hip_debug_allreduce": (C.c_int, [_P, _P, C.c_size_t]),
     "aha_hip_vision_encode": (C.c_int, [_P, C.POINTER(MmInput), _P, C.POINTER(C.c_int64)]),
     "aha_hip_debug_audio_embeds": (C.c_int, [_P, C.POINTER(C.c_float), C.c_size_t]),
     "aha_hip_image_to_patches": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float),

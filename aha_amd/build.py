@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libaha_hip.so")
-SOURCES = ["kernels_elem.hip", "kernels_gemv.hip", "kernels_attn.hip", "kernels_gemm.hip", "kernels_vit.hip", "kernels_audio.hip", "audio_tower.hip", "model.hip",
+SOURCES = ["kernels_elem.hip", "kernels_gemv.hip", "kernels_attn.hip", "kernels_gemm.hip", "kernels_vit.hip", "kernels_audio.hip", "audio_tower.hip", "tp_rccl.hip", "model.hip",
            "vision.hip", "vision_tower.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value",
          "-Wno-unused-result"]
@@ -57,7 +57,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(compile_one, srcs))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lrccl",
+           "-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")

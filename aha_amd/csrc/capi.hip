@@ -341,6 +341,46 @@ int aha_hip_image_to_patches(const uint8_t* img_hwc, void* out, int32_t H, int32
   return AHA_OK;
 }
 
+int aha_hip_set_allreduce(aha_model* m, aha_allreduce_fn fn, void* user) {
+  if (!m) {
+    set_error("null model");
+    return AHA_ERR_INVALID;
+  }
+  m->allreduce_cb = fn;
+  m->allreduce_user = user;
+  return AHA_OK;
+}
+int aha_hip_tp_unique_id(void* out128) {
+  API_GUARD_BEGIN
+  if (!out128) return AHA_ERR_INVALID;
+  return tp_unique_id(out128);
+  API_GUARD_END
+}
+int aha_hip_tp_init_rccl(aha_model* m, const void* unique_id128) {
+  API_GUARD_BEGIN
+  if (!m || !unique_id128) return AHA_ERR_INVALID;
+  return tp_init_rccl(m, unique_id128);
+  API_GUARD_END
+}
+
+int aha_hip_debug_allreduce(aha_model* m, void* buf, size_t count) {
+  API_GUARD_BEGIN
+  if (!m || !buf) return AHA_ERR_INVALID;
+  int rc;
+  if (m->rccl_comm) {
+    rc = rccl_allreduce(m, (float*)buf, count);
+  } else if (m->allreduce_cb) {
+    rc = m->allreduce_cb(buf, count, m->allreduce_user) ? AHA_ERR_STATE : AHA_OK;
+  } else {
+    set_error("no all-reduce installed");
+    return AHA_ERR_STATE;
+  }
+  if (rc) return rc;
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  return AHA_OK;
+  API_GUARD_END
+}
+
 int aha_hip_vision_encode(aha_model* m, const aha_mm_input* mm, void* out_dev, int64_t* n_tokens) {
   API_GUARD_BEGIN
   if (!m || !mm) {

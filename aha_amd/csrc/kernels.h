@@ -15,7 +15,8 @@ struct KvLayer {
   int kvh, d;
 };
 
-enum GemvEpi { GEMV_STORE = 0, GEMV_RESIDUAL = 1, GEMV_SILU_MUL = 2, GEMV_LOGITS = 3 };
+// GEMV_PARTIAL_F32: tensor-parallel row-split projection -- y_f32[n] = un-rounded f32 partial sum over this rank's K slice
+enum GemvEpi { GEMV_STORE = 0, GEMV_RESIDUAL = 1, GEMV_SILU_MUL = 2, GEMV_LOGITS = 3, GEMV_PARTIAL_F32 = 4 };
 
 struct GemvArgs {
   const void* W;         // (N,K) bf16 row-major; for GEMV_SILU_MUL the gate matrix (I,K)
@@ -114,7 +115,8 @@ struct AttnPrefillArgs {
 };
 void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st);
 
-enum GemmAct { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_SILU_MUL_PAIRS = 4 };
+// ACT_PARTIAL_F32: tensor-parallel row-split projection -- C is (M,N) f32, the un-rounded partial sums over this rank's K slice
+enum GemmAct { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_SILU_MUL_PAIRS = 4, ACT_PARTIAL_F32 = 5 };
 struct GemmArgs {
   const void* A;  // (M,K) bf16, row stride lda
   const void* W;  // (N,K) bf16, row stride ldw
@@ -126,6 +128,8 @@ struct GemmArgs {
   int act;
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
+// x[i] = bf16(x[i] + bf16(sum[i])): Linear output tensor (all-reduced f32 partials) -> bf16, then the residual add -> bf16
+void launch_residual_add_f32(void* x, const float* sum, int64_t n, hipStream_t st);
 
 }  // namespace aha
 

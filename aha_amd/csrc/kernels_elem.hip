@@ -231,3 +231,21 @@ void launch_argmax_f32(const float* x, int64_t n, float* ws_max, uint32_t* ws_id
 }
 
 }  // namespace aha
+
+// ---- tensor-parallel seam: x = bf16(x + bf16(sum)) after the all-reduce of f32 partial projections ---------------------
+namespace aha {
+__global__ __launch_bounds__(256) void residual_add_f32_kernel(bf16_t* __restrict__ x, const float* __restrict__ s, int64_t n) {
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 256 * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(s + i);
+    uint2 xv = *reinterpret_cast<const uint2*>(x + i);
+    xv.x = pack_bf(lo_bf(xv.x) + rbf(v.x), hi_bf(xv.x) + rbf(v.y));
+    xv.y = pack_bf(lo_bf(xv.y) + rbf(v.z), hi_bf(xv.y) + rbf(v.w));
+    *reinterpret_cast<uint2*>(x + i) = xv;
+  }
+}
+void launch_residual_add_f32(void* x, const float* sum, int64_t n, hipStream_t st) {
+  if (n <= 0) return;
+  const int64_t blocks = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(residual_add_f32_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, (bf16_t*)x, sum, n);
+}
+}  // namespace aha

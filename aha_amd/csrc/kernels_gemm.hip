@@ -83,7 +83,15 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x4_t (&acc)[4][4]
   for (int mi = 0; mi < 4; ++mi) {
     const int m = m0 + wm * 64 + mi * 16 + c;
     if (m >= a.M) continue;
-    if (ACT == ACT_SILU_MUL_PAIRS) {
+    if (ACT == ACT_PARTIAL_F32) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wn * 64 + ni * 16 + G * 4;
+        if (n >= a.N) continue;
+        *reinterpret_cast<float4*>((float*)a.C + (int64_t)m * a.ldc + n) =
+            make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
+      }
+    } else if (ACT == ACT_SILU_MUL_PAIRS) {
       // W rows come in 16-row blocks: gate rows j..j+15 then up rows j..j+15 (the model loader interleaves them)
 #pragma unroll
       for (int np = 0; np < 2; ++np) {
@@ -293,6 +301,7 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
     case ACT_GELU_ERF: launch_act<ACT_GELU_ERF>(a, grid, glds, st); break;
     case ACT_SILU: launch_act<ACT_SILU>(a, grid, glds, st); break;
     case ACT_SILU_MUL_PAIRS: launch_one<ACT_SILU_MUL_PAIRS, false, false>(a, grid, glds, st); break;
+    case ACT_PARTIAL_F32: launch_one<ACT_PARTIAL_F32, false, false>(a, grid, glds, st); break;
   }
 }
 

@@ -215,7 +215,9 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a) {
         const int row = row0 + r;
         if (row < n_out) {
           const float lin = rbf(acc[0][r]);  // candle_nn::Linear output tensor (bf16)
-          if (EPI == GEMV_STORE) {
+          if (EPI == GEMV_PARTIAL_F32) {
+            a.y_f32[row] = acc[0][r];
+          } else if (EPI == GEMV_STORE) {
             ((bf16_t*)a.y)[row] = f2bf(lin);
           } else if (EPI == GEMV_RESIDUAL) {
             ((bf16_t*)a.y)[row] = f2bf(bf2f(((const bf16_t*)a.residual)[row]) + lin);
@@ -277,7 +279,6 @@ GemvPlan plan_gemv(int N, int K, GemvEpi epi) {
   // U must be one of the instantiated values {1,2,4,8}
   int Up = 1;
   while (Up * 2 <= U) Up *= 2;
-  const int ntiles = (N + 4 * R - 1) / (4 * R);
   // persistent blocks: two register buffers of R*U*NW loads => ~2 blocks (8 waves) per CU on 256 CUs
   int gmax = 512;
   // tuning knobs for scripts/bench_gemv.py (not used by the product path unless set)
@@ -296,8 +297,8 @@ GemvPlan plan_gemv(int N, int K, GemvEpi epi) {
     while (q * 2 <= Up) q *= 2;
     Up = q;
   }
-  const int ntiles2 = (N + 4 * R - 1) / (4 * R);
-  int grid = ntiles2 < gmax ? ntiles2 : gmax;
+  const int ntiles = (N + 4 * R - 1) / (4 * R);
+  int grid = ntiles < gmax ? ntiles : gmax;
   return {R, Up, grid};
 }
 
@@ -330,6 +331,7 @@ void launch_gemv(const GemvArgs& a_in, GemvEpi epi, hipStream_t st) {
     case GEMV_RESIDUAL: launch_gemv_epi<GEMV_RESIDUAL>(a, p, st); break;
     case GEMV_SILU_MUL: launch_gemv_epi<GEMV_SILU_MUL>(a, p, st); break;
     case GEMV_LOGITS: launch_gemv_epi<GEMV_LOGITS>(a, p, st); break;
+    case GEMV_PARTIAL_F32: launch_gemv_epi<GEMV_PARTIAL_F32>(a, p, st); break;
   }
 }
 

@@ -97,6 +97,14 @@ struct aha_model {
   float* d_part_o = nullptr;
   float* d_part_ml = nullptr;
   int max_nsplit = 64;
+  // tensor parallelism (desc.tp_rank / tp_size); desc.num_attention_heads etc. hold the LOCAL (per-rank) sizes
+  int tp_rank = 0, tp_size = 1;
+  aha_allreduce_fn allreduce_cb = nullptr;
+  void* allreduce_user = nullptr;
+  void* rccl_comm = nullptr;
+  int async_rc = 0;             // first error of an all-reduce issued from inside an enqueue helper
+  float* d_partial = nullptr;   // decode: (hidden) f32 partial projection
+  float* p_partial = nullptr;   // prefill: (S, hidden) f32
   bool decode_fused = true;  // attention block of a decode step in one launch (kernels_attn.hip attn_decode_fused_kernel)
   float* h_logits = nullptr;  // pinned
   // prefill scratch (grown on demand)
@@ -131,6 +139,11 @@ int model_clear_cache(aha_model* m);
 int model_ensure_pages(aha_model* m, size_t tokens);
 KvLayer model_kv_layer(aha_model* m, int layer);
 int prof_collect(aha_model* m);
+int model_allreduce(aha_model* m, float* buf, size_t count);
+int rccl_allreduce(aha_model* m, float* buf, size_t count);  // tp_rccl.hip
+int tp_unique_id(void* out128);
+int tp_init_rccl(aha_model* m, const void* id128);
+void tp_destroy(aha_model* m);
 
 // helpers shared with vision.hip
 const aha_tensor_view* find_tensor(const aha_tensor_view* w, size_t nw, const std::string& name);

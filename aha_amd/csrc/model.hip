@@ -201,8 +201,48 @@ static int upload_rows_into(aha_model* m, const aha_tensor_view* t, int64_t rows
   return AHA_OK;
 }
 
+// bf16 view of a checkpoint tensor (host tensors are converted into tmp when they are f32 / f16)
+static int bf16_source(const aha_tensor_view* t, int64_t expect, std::vector<uint16_t>& tmp, const void** src) {
+  int64_t tn = 1;
+  for (int i = 0; i < t->ndim; ++i) tn *= t->shape[i];
+  if (tn != expect) {
+    set_error(std::string("tensor ") + t->name + " has " + std::to_string(tn) + " elements, expected " + std::to_string(expect));
+    return AHA_ERR_SHAPE;
+  }
+  *src = t->data;
+  if (t->on_device && t->dtype != AHA_BF16) {
+    set_error(std::string("tensor ") + t->name + ": device-resident weights must be bf16");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  if (t->dtype == AHA_F32) {
+    tmp.resize(tn);
+    for (int64_t i = 0; i < tn; ++i) tmp[i] = f32_to_bf16_host(((const float*)t->data)[i]);
+    *src = tmp.data();
+  } else if (t->dtype == AHA_F16) {
+    tmp.resize(tn);
+    for (int64_t i = 0; i < tn; ++i) tmp[i] = f32_to_bf16_host(f16_to_f32_host(((const uint16_t*)t->data)[i]));
+    *src = tmp.data();
+  } else if (t->dtype != AHA_BF16) {
+    set_error(std::string("tensor ") + t->name + ": unsupported dtype");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  return AHA_OK;
+}
+// copy the (nr x nc) block at (r0, c0) of a (rows x cols) checkpoint matrix into dst rows [dr0, dr0+nr) of a (.. x nc) matrix
+static int upload_block(aha_model* m, const aha_tensor_view* t, int64_t rows, int64_t cols, int64_t r0, int64_t nr, int64_t c0,
+                        int64_t nc, void* dst, int64_t dr0) {
+  std::vector<uint16_t> tmp;
+  const void* src;
+  int rc = bf16_source(t, rows * cols, tmp, &src);
+  if (rc) return rc;
+  AHA_HIP_CHECK(hipMemcpy2D((char*)dst + (size_t)dr0 * nc * 2, (size_t)nc * 2, (const char*)src + ((size_t)r0 * cols + c0) * 2,
+                            (size_t)cols * 2, (size_t)nc * 2, (size_t)nr, hipMemcpyDefault));
+  return AHA_OK;
+}
+
 // gate/up -> one (2I, H) matrix of alternating 16-row blocks: [gate 0..15 | up 0..15 | gate 16..31 | up 16..31 | ...]
-static int upload_gate_up(aha_model* m, const aha_tensor_view* g, const aha_tensor_view* u, int64_t I, int64_t H, void** out) {
+static int upload_gate_up(aha_model* m, const aha_tensor_view* g, const aha_tensor_view* u, int64_t I_full, int64_t row0, int64_t I,
+                          int64_t H, void** out) {
   if (I % 16) {
     set_error("intermediate_size must be a multiple of 16");
     return AHA_ERR_UNSUPPORTED;
@@ -214,7 +254,7 @@ static int upload_gate_up(aha_model* m, const aha_tensor_view* g, const aha_tens
     const aha_tensor_view* t = which ? u : g;
     int64_t tn = 1;
     for (int i = 0; i < t->ndim; ++i) tn *= t->shape[i];
-    if (tn != I * H) {
+    if (tn != I_full * H) {
       set_error(std::string("tensor ") + t->name + " has wrong size");
       return AHA_ERR_SHAPE;
     }
@@ -237,7 +277,8 @@ static int upload_gate_up(aha_model* m, const aha_tensor_view* g, const aha_tens
       return AHA_ERR_UNSUPPORTED;
     }
     const size_t blk = (size_t)16 * H * 2;
-    AHA_HIP_CHECK(hipMemcpy2D((char*)d + which * blk, 2 * blk, src, blk, blk, (size_t)(I / 16), hipMemcpyDefault));
+    AHA_HIP_CHECK(hipMemcpy2D((char*)d + which * blk, 2 * blk, (const char*)src + (size_t)row0 * H * 2, blk, blk, (size_t)(I / 16),
+                              hipMemcpyDefault));
   }
   *out = d;
   return AHA_OK;
@@ -327,23 +368,23 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
     set_error("model_create: null argument");
     return AHA_ERR_INVALID;
   }
-  const aha_model_desc& c = *desc;
-  if (c.head_dim != 128) {
+  const aha_model_desc& cd = *desc;
+  if (cd.head_dim != 128) {
     set_error("only head_dim == 128 is supported by the decoder kernels (Qwen3 family)");
     return AHA_ERR_UNSUPPORTED;
   }
-  if (c.num_attention_heads % c.num_key_value_heads || c.num_attention_heads / c.num_key_value_heads > 16) {
+  if (cd.num_attention_heads % cd.num_key_value_heads || cd.num_attention_heads / cd.num_key_value_heads > 16) {
     set_error("unsupported GQA group size");
     return AHA_ERR_UNSUPPORTED;
   }
-  if (c.hidden_size % 8 || c.intermediate_size % 16) {
+  if (cd.hidden_size % 8 || cd.intermediate_size % 16) {
     set_error("hidden_size must be a multiple of 8 and intermediate_size of 16");
     return AHA_ERR_UNSUPPORTED;
   }
   AHA_HIP_CHECK(hipSetDevice(ctx->device));
   aha_model* m = new aha_model();
   m->ctx = ctx;
-  m->desc = c;
+  m->desc = cd;
   m->stream = ctx->stream;
   if (const char* e = getenv("AHA_DECODE_FUSED")) m->decode_fused = atoi(e) != 0;
   int rc = AHA_OK;
@@ -351,8 +392,21 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
     model_destroy(m);
     return code;
   };
-  const int H = c.hidden_size, I = c.intermediate_size, d = c.head_dim;
-  const int nq = c.num_attention_heads * d, nkv = c.num_key_value_heads * d;
+  // tensor parallelism: from here on m->desc / the locals below hold THIS RANK's share
+  const int T = cd.tp_size > 1 ? cd.tp_size : 1, R = T > 1 ? cd.tp_rank : 0;
+  if (T > 1 && (R < 0 || R >= T || cd.num_key_value_heads % T || cd.num_attention_heads % T || cd.intermediate_size % (16 * T))) {
+    set_error("tp_size must divide num_key_value_heads, num_attention_heads and intermediate_size/16; 0 <= tp_rank < tp_size");
+    return fail(AHA_ERR_INVALID);
+  }
+  m->tp_rank = R;
+  m->tp_size = T;
+  const int nq_full = cd.num_attention_heads * cd.head_dim, nkv_full = cd.num_key_value_heads * cd.head_dim, I_full = cd.intermediate_size;
+  m->desc.num_attention_heads /= T;
+  m->desc.num_key_value_heads /= T;
+  m->desc.intermediate_size /= T;
+  const aha_model_desc& c = m->desc;  // local sizes from here on
+  const int H = c.hidden_size, I = I_full / T, d = c.head_dim;
+  const int nq = nq_full / T, nkv = nkv_full / T;
 
   // name prefixes: Qwen3 "model." optional (qwen3/model.rs:105-109); Qwen3-VL "model.language_model." (qwen3vl/model.rs:847-870)
   std::string pre;
@@ -387,16 +441,20 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
     if ((rc = need(w, nw, p + "self_attn.k_proj.weight", &tk))) return fail(rc);
     if ((rc = need(w, nw, p + "self_attn.v_proj.weight", &tv))) return fail(rc);
     if ((rc = dev_alloc(m, (size_t)(nq + 2 * nkv) * H * 2, &L.wqkv))) return fail(rc);
-    if ((rc = upload_rows_into(m, tq, nq, H, L.wqkv, 0))) return fail(rc);
-    if ((rc = upload_rows_into(m, tk, nkv, H, L.wqkv, nq))) return fail(rc);
-    if ((rc = upload_rows_into(m, tv, nkv, H, L.wqkv, nq + nkv))) return fail(rc);
+    // column-parallel q/k/v (this rank's heads), row-parallel o_proj (the matching input columns)
+    if ((rc = upload_block(m, tq, nq_full, H, (int64_t)R * nq, nq, 0, H, L.wqkv, 0))) return fail(rc);
+    if ((rc = upload_block(m, tk, nkv_full, H, (int64_t)R * nkv, nkv, 0, H, L.wqkv, nq))) return fail(rc);
+    if ((rc = upload_block(m, tv, nkv_full, H, (int64_t)R * nkv, nkv, 0, H, L.wqkv, nq + nkv))) return fail(rc);
     if ((rc = need(w, nw, p + "self_attn.o_proj.weight", &t))) return fail(rc);
-    if ((rc = upload_tensor(m, t, {H, nq}, &L.wo))) return fail(rc);
+    if ((rc = dev_alloc(m, (size_t)H * nq * 2, &L.wo))) return fail(rc);
+    if ((rc = upload_block(m, t, H, nq_full, 0, H, (int64_t)R * nq, nq, L.wo, 0))) return fail(rc);
+    // column-parallel gate/up (this rank's intermediate columns), row-parallel down_proj
     if ((rc = need(w, nw, p + "mlp.gate_proj.weight", &tg))) return fail(rc);
     if ((rc = need(w, nw, p + "mlp.up_proj.weight", &tu))) return fail(rc);
-    if ((rc = upload_gate_up(m, tg, tu, I, H, &L.wgu))) return fail(rc);
+    if ((rc = upload_gate_up(m, tg, tu, I_full, (int64_t)R * I, I, H, &L.wgu))) return fail(rc);
     if ((rc = need(w, nw, p + "mlp.down_proj.weight", &t))) return fail(rc);
-    if ((rc = upload_tensor(m, t, {H, I}, &L.wdown))) return fail(rc);
+    if ((rc = dev_alloc(m, (size_t)H * I * 2, &L.wdown))) return fail(rc);
+    if ((rc = upload_block(m, t, H, I_full, 0, H, (int64_t)R * I, I, L.wdown, 0))) return fail(rc);
     if ((rc = need(w, nw, p + "input_layernorm.weight", &t))) return fail(rc);
     if ((rc = upload_tensor(m, t, {H}, &L.in_norm))) return fail(rc);
     if ((rc = need(w, nw, p + "post_attention_layernorm.weight", &t))) return fail(rc);
@@ -460,6 +518,8 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
   if ((rc = dev_alloc(m, (size_t)nq * 2, &m->d_attn))) return fail(rc);
   if ((rc = dev_alloc(m, (size_t)I * 2, &m->d_act))) return fail(rc);
   if ((rc = dev_alloc(m, (size_t)H * 2, &m->d_hlast, true))) return fail(rc);
+  if ((rc = dev_alloc(m, (size_t)H * 4, &p))) return fail(rc);
+  m->d_partial = (float*)p;
   if ((rc = dev_alloc(m, (size_t)c.vocab_size * 4, &p))) return fail(rc);
   m->d_logits = (float*)p;
   const int nt = std::max(gemv_num_tiles(c.vocab_size, H), 256);
@@ -489,6 +549,7 @@ void model_destroy(aha_model* m) {
   for (auto& r : m->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   vision_destroy(m);
   audio_destroy(m);
+  tp_destroy(m);
   for (void* p : m->owned) hipFree(p);
   for (void* p : m->pf_owned) hipFree(p);
   for (void* p : m->slabs) hipFree(p);
@@ -529,6 +590,7 @@ static int ensure_prefill_scratch(aha_model* m, size_t S) {
   if ((rc = al(cap * nq * 2, &m->p_q))) return rc;
   if ((rc = al(cap * nq * 2, &m->p_attn))) return rc;
   if ((rc = al(cap * I * 2, &m->p_act))) return rc;
+  if (m->tp_size > 1 && (rc = al(cap * H * 4, (void**)&m->p_partial))) return rc;
   m->pf_cap = cap;
   return AHA_OK;
 }
@@ -577,6 +639,54 @@ static int fetch_outputs(aha_model* m, float* logits_out, uint32_t* argmax_out) 
   AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
   if (logits_out) memcpy(logits_out, m->h_logits, (size_t)c.vocab_size * 4);
   if (argmax_out) *argmax_out = m->h_state->next_token;
+  return AHA_OK;
+}
+
+
+// ---- tensor-parallel seam ---------------------------------------------------------------------------------------------
+// Row-parallel projections (o_proj, down_proj): with tp_size > 1 each rank holds a K slice, produces un-rounded f32
+// partial sums, the partials are all-reduced, and only then does the reference's rounding chain run
+// (Linear output -> bf16, + residual -> bf16).  Summing in f32 keeps the result equal to the single-GPU one up to f32
+// summation order.
+int model_allreduce(aha_model* m, float* buf, size_t count) {
+  if (m->tp_size <= 1) return AHA_OK;
+  ProfScope ps(m, "allreduce", (double)count * 4, 0);
+  if (m->rccl_comm) return rccl_allreduce(m, buf, count);
+  if (!m->allreduce_cb) {
+    set_error("tp_size > 1 but no all-reduce was installed (aha_hip_set_allreduce / aha_hip_tp_init_rccl)");
+    return AHA_ERR_STATE;
+  }
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  if (m->allreduce_cb(buf, count, m->allreduce_user) != 0) {
+    set_error("all-reduce callback failed");
+    return AHA_ERR_STATE;
+  }
+  return AHA_OK;
+}
+static void gemv_row_parallel(aha_model* m, GemvArgs g) {
+  if (m->tp_size <= 1) {
+    launch_gemv(g, GEMV_RESIDUAL, m->stream);
+    return;
+  }
+  g.y_f32 = m->d_partial;
+  launch_gemv(g, GEMV_PARTIAL_F32, m->stream);
+  const int rc = model_allreduce(m, m->d_partial, (size_t)g.N);
+  if (rc && !m->async_rc) m->async_rc = rc;
+  launch_residual_add_f32(g.y, m->d_partial, g.N, m->stream);
+}
+static int gemm_row_parallel(aha_model* m, GemmArgs g) {
+  if (m->tp_size <= 1) {
+    launch_gemm(g, m->stream);
+    return AHA_OK;
+  }
+  void* xres = g.C;
+  g.C = m->p_partial;
+  g.residual = nullptr;
+  g.act = ACT_PARTIAL_F32;
+  launch_gemm(g, m->stream);
+  int rc = model_allreduce(m, m->p_partial, (size_t)g.M * g.N);
+  if (rc) return rc;
+  launch_residual_add_f32(xres, m->p_partial, (int64_t)g.M * g.N, m->stream);
   return AHA_OK;
 }
 
@@ -633,7 +743,7 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
         g.W = L.wo; g.x = m->d_attn; g.residual = m->d_x; g.y = m->d_x; g.N = H; g.K = nq;
         g.comb_o = m->d_part_o; g.comb_ml = m->d_part_ml; g.comb_n = nsplit; g.comb_nh = nh;
         ProfScope ps(m, "gemv", (double)g.N * g.K * 2 + g.K * 2.0 + g.N * 4.0, 2.0 * g.N * g.K);
-        launch_gemv(g, GEMV_RESIDUAL, st);
+        gemv_row_parallel(m, g);
       }
     } else {  // three-launch variant (A/B knob AHA_DECODE_FUSED=0)
       {  // q/k norm + rope + append                            (modules.rs:544-566)
@@ -656,7 +766,7 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
         GemvArgs g{};
         g.W = L.wo; g.x = m->d_attn; g.residual = m->d_x; g.y = m->d_x; g.N = H; g.K = nq;
         ProfScope ps(m, "gemv", (double)g.N * g.K * 2 + g.K * 2.0 + g.N * 4.0, 2.0 * g.N * g.K);
-        launch_gemv(g, GEMV_RESIDUAL, st);
+        gemv_row_parallel(m, g);
       }
     }
     {  // act = silu(h Wg^T) * (h Wu^T), h = RMSNorm(x)        (qwen3/model.rs:83, modules.rs:81-84)
@@ -669,7 +779,7 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
       GemvArgs g{};
       g.W = L.wdown; g.x = m->d_act; g.residual = m->d_x; g.y = m->d_x; g.N = H; g.K = I;
       ProfScope ps(m, "gemv", (double)g.N * g.K * 2 + g.K * 2.0 + g.N * 4.0, 2.0 * g.N * g.K);
-      launch_gemv(g, GEMV_RESIDUAL, st);
+      gemv_row_parallel(m, g);
     }
   }
   enqueue_lm_head(m, m->d_x);
@@ -697,6 +807,7 @@ int model_forward_step(aha_model* m, uint32_t token, size_t offset, float* logit
   enqueue_decode_step(m, m->cache_len + 1);
   m->cache_len += 1;
   AHA_HIP_CHECK(hipGetLastError());
+  if (m->async_rc) { const int e = m->async_rc; m->async_rc = 0; return e; }
   return fetch_outputs(m, logits_out, argmax_out);
 }
 
@@ -726,6 +837,7 @@ int model_decode_greedy(aha_model* m, uint32_t first_token, size_t offset, size_
       hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(1), 0, m->stream, m->d_state, m->d_token_log);
     }
     AHA_HIP_CHECK(hipGetLastError());
+    if (m->async_rc) { const int e = m->async_rc; m->async_rc = 0; return e; }
     AHA_HIP_CHECK(hipMemcpyAsync(out + produced, m->d_token_log, n * 4, hipMemcpyDeviceToHost, m->stream));
     AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
     size_t used = n;
@@ -835,7 +947,7 @@ int model_forward_initial(aha_model* m, const uint32_t* ids, size_t n, size_t of
       GemmArgs g{};
       g.A = m->p_attn; g.W = L.wo; g.C = m->p_x; g.residual = m->p_x; g.M = S; g.N = H; g.K = nq; g.lda = nq; g.ldw = nq; g.ldc = H; g.act = ACT_NONE;
       ProfScope ps(m, "gemm", ((double)g.M * g.K + (double)g.N * g.K + 2.0 * g.M * g.N) * 2, 2.0 * g.M * g.N * g.K);
-      launch_gemm(g, st);
+      if ((rc = gemm_row_parallel(m, g))) return rc;
     }
     {
       ProfScope ps(m, "elem", (double)S * H * 4, 0);
@@ -851,7 +963,7 @@ int model_forward_initial(aha_model* m, const uint32_t* ids, size_t n, size_t of
       GemmArgs g{};
       g.A = m->p_act; g.W = L.wdown; g.C = m->p_x; g.residual = m->p_x; g.M = S; g.N = H; g.K = I; g.lda = I; g.ldw = I; g.ldc = H; g.act = ACT_NONE;
       ProfScope ps(m, "gemm", ((double)g.M * g.K + (double)g.N * g.K + 2.0 * g.M * g.N) * 2, 2.0 * g.M * g.N * g.K);
-      launch_gemm(g, st);
+      if ((rc = gemm_row_parallel(m, g))) return rc;
     }
     if (has_image) {
       // DeepStack: add visual feature k to the visual rows after decoder layer k (qwen3vl/model.rs:806-822)

@@ -1,0 +1,53 @@
+// RCCL binding of the tensor-parallel seam: one communicator per model, the all-reduce is enqueued
+// on the model's stream.  "nccl" on ROCm is RCCL; rings run over xGMI (7 links x ~153 GB/s per GPU), so the f32 partial
+// of a long prefill (S x 4096 x 4 B) is bandwidth-bound per link -- sized in DESIGN.md.
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include "model.h"
+
+namespace aha {
+
+int rccl_allreduce(aha_model* m, float* buf, size_t count) {
+  ncclResult_t r = ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, (ncclComm_t)m->rccl_comm, m->stream);
+  if (r != ncclSuccess) {
+    set_error(std::string("ncclAllReduce failed: ") + ncclGetErrorString(r));
+    return AHA_ERR_HIP;
+  }
+  return AHA_OK;
+}
+
+int tp_unique_id(void* out128) {
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) {
+    set_error(std::string("ncclGetUniqueId failed: ") + ncclGetErrorString(r));
+    return AHA_ERR_HIP;
+  }
+  static_assert(sizeof(ncclUniqueId) <= 128, "unique id larger than the ABI slot");
+  memset(out128, 0, 128);
+  memcpy(out128, &id, sizeof(id));
+  return AHA_OK;
+}
+
+int tp_init_rccl(aha_model* m, const void* id128) {
+  if (m->rccl_comm) return AHA_OK;
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  ncclComm_t comm;
+  AHA_HIP_CHECK(hipSetDevice(m->ctx->device));
+  ncclResult_t r = ncclCommInitRank(&comm, m->tp_size, id, m->tp_rank);
+  if (r != ncclSuccess) {
+    set_error(std::string("ncclCommInitRank failed: ") + ncclGetErrorString(r));
+    return AHA_ERR_HIP;
+  }
+  m->rccl_comm = comm;
+  return AHA_OK;
+}
+
+void tp_destroy(aha_model* m) {
+  if (m->rccl_comm) ncclCommDestroy((ncclComm_t)m->rccl_comm);
+  m->rccl_comm = nullptr;
+}
+
+}  // namespace aha

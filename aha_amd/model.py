@@ -91,17 +91,30 @@ def make_desc(cfg, kv_reserve_tokens: int = 0) -> ModelDesc:
     return d
 
 
+def tp_unique_id() -> bytes:
+    """RCCL unique id for aha_hip_tp_init_rccl: rank 0 makes it, every rank of the TP group receives the same bytes."""
+    buf = C.create_string_buffer(128)
+    check(lib().aha_hip_tp_unique_id(buf))
+    return buf.raw
+
+
 class HipInferenceModel:
     """One model instance on one GPU (== XxxGenerateModel::init's model object, qwen3/generate.rs:22-50)."""
 
     def __init__(self, cfg, weights: Dict[str, torch.Tensor], ctx: Optional[HipContext] = None, device: int = 0,
-                 kv_reserve_tokens: int = 0):
+                 kv_reserve_tokens: int = 0, tp_rank: int = 0, tp_size: int = 1, allreduce=None,
+                 rccl_unique_id: Optional[bytes] = None):
+        """tp_size > 1 shards the decoder stack (heads / MLP columns) over ranks; every rank passes the FULL weights and
+        the library slices them.  The all-reduce is either RCCL (rccl_unique_id: 128 bytes from tp_unique_id(), shared
+        by all ranks) or a host callback allreduce(ptr: int, count: int) -> None that sums `count` f32 at device
+        pointer `ptr` over ranks in place (the seam a gloo test or another transport plugs into)."""
         self.cfg = cfg
         self.text_cfg: Qwen3Config = cfg.text if isinstance(cfg, (Qwen3VLConfig, Qwen3ASRConfig)) else cfg
         self._own_ctx = ctx is None
         self.ctx = ctx or HipContext(device)
         self.handle = C.c_void_p()
         desc = make_desc(cfg, kv_reserve_tokens)
+        desc.tp_rank, desc.tp_size = tp_rank, tp_size
         views = (TensorView * len(weights))()
         keep = []
         for i, (name, t) in enumerate(weights.items()):
@@ -120,6 +133,21 @@ class HipInferenceModel:
             torch.cuda.synchronize()
         check(lib().aha_hip_model_create(self.ctx.handle, C.byref(desc), views, len(weights), C.byref(self.handle)))
         del keep
+        self._allreduce_c = None
+        if rccl_unique_id is not None:
+            buf = C.create_string_buffer(bytes(rccl_unique_id), 128)
+            check(lib().aha_hip_tp_init_rccl(self.handle, buf))
+        elif tp_size > 1 and allreduce is not None:
+            def _cb(ptr, count, _user):
+                try:
+                    allreduce(int(ptr), int(count))
+                    return 0
+                except Exception:  # noqa: BLE001 -- must not unwind through C frames
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._allreduce_c = _lib.ALLREDUCE_FN(_cb)
+            check(lib().aha_hip_set_allreduce(self.handle, self._allreduce_c, None))
         self.vocab = self.text_cfg.vocab_size
         self._logits = np.empty(self.vocab, dtype=np.float32)
 
@@ -183,6 +211,11 @@ class HipInferenceModel:
         buf = (C.c_uint32 * max(max_new, 1))()
         n = check(lib().aha_hip_decode_greedy(self.handle, int(first_token), seqlen_offset, max_new, buf))
         return [int(buf[i]) for i in range(n)]
+
+    def debug_allreduce(self, t: torch.Tensor) -> None:
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        torch.cuda.current_stream(t.device).synchronize()
+        check(lib().aha_hip_debug_allreduce(self.handle, t.data_ptr(), t.numel()))
 
     def cache_len(self) -> int:
         return int(lib().aha_hip_cache_len(self.handle))

@@ -64,6 +64,11 @@ typedef struct aha_model_desc {
   int32_t aud_d_model, aud_encoder_layers, aud_attention_heads, aud_ffn_dim, aud_num_mel_bins,
       aud_downsample_hidden_size, aud_output_dim, aud_n_window;
   int32_t audio_token_id;
+  /* Tensor parallelism of the decoder stack (the reference has none): rank tp_rank of tp_size holds
+   * num_attention_heads/tp_size q heads, num_key_value_heads/tp_size kv heads (+ their KV cache) and
+   * intermediate_size/tp_size MLP columns; o_proj / down_proj produce f32 partial sums that are all-reduced (RCCL or the
+   * host callback below) before the residual add.  tp_size 0 or 1 = off.  Every rank passes the FULL checkpoint tensors. */
+  int32_t tp_rank, tp_size;
 } aha_model_desc;
 
 /* One checkpoint tensor: HF name, pointer (host memory, e.g. an mmapped safetensors file; or, when on_device != 0,
@@ -135,6 +140,18 @@ int aha_hip_decode_greedy(aha_model* m, uint32_t first_token, size_t seqlen_offs
  * runs only the vision tower on `mm` and writes (1 + n_deepstack, n_tokens, hidden) bf16 to out_dev (device memory, may be
  * NULL to query n_tokens). */
 int aha_hip_vision_encode(aha_model* m, const aha_mm_input* mm, void* out_dev, int64_t* n_tokens);
+
+/* Tensor-parallel seam.  Either (a) a host callback that must leave buf = sum over ranks of buf (count f32, device memory)
+ * before it returns -- e.g. torch.distributed.all_reduce over RCCL on a tensor view of buf -- or (b) an RCCL communicator
+ * owned by the library: every rank calls aha_hip_tp_unique_id on rank 0's bytes (128) and aha_hip_tp_init_rccl.  With (b)
+ * the all-reduce is enqueued on the model's stream (no host synchronisation). */
+typedef int (*aha_allreduce_fn)(void* buf_f32_dev, size_t count, void* user);
+int aha_hip_set_allreduce(aha_model* m, aha_allreduce_fn fn, void* user);
+int aha_hip_tp_unique_id(void* out128);
+int aha_hip_tp_init_rccl(aha_model* m, const void* unique_id128);
+/* Test hook: run the installed all-reduce (RCCL communicator or callback) once on a caller-owned f32 device buffer and
+ * wait for it.  Lets a 1-GPU box exercise the RCCL wiring with a communicator of size 1. */
+int aha_hip_debug_allreduce(aha_model* m, void* buf_f32_dev, size_t count);
 
 /* ---- introspection used by bench.py / tests ------------------------------------------------------------------ */
 size_t aha_hip_cache_len(const aha_model* m);
