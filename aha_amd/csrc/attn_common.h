@@ -1,0 +1,70 @@
+// MFMA fragment helpers and the online-softmax tile update shared by the attention kernels (kernels_attn.hip) and the
+// persistent decode-step kernel (decode_mega.hip).  Fragment scheme: see the header comment of kernels_attn.hip.
+#pragma once
+#include "common.h"
+#include "kernels.h"
+
+namespace aha {
+
+
+__device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8_t as_frag(u32x4_t v) {
+  union { u32x4_t u; bf16x8_t b; } x;
+  x.u = v;
+  return x.b;
+}
+__device__ __forceinline__ float group_max(float v) {  // across the 4 lane groups (same column c)
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// Online-softmax update for one 64-token tile.  st[sub][reg] holds raw S for token sub*16+G*4+reg, column c.
+// valid(tok_in_tile) masks both causality and the tail of the last page.  Returns the two P^T fragments.
+template <typename ValidFn>
+__device__ __forceinline__ void softmax_tile(f32x4_t (&st)[4], float scale, ValidFn valid, int G, float& m, float& l,
+                                             float& alpha, bf16x8_t (&pf)[2]) {
+  float tmax = -INFINITY;
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s = rbf(rbf(st[sub][r]) * scale);  // matmul output -> bf16, then `* scaling` -> bf16 (modules.rs:782-783)
+      if (!valid(sub * 16 + G * 4 + r)) s = -INFINITY;
+      st[sub][r] = s;
+      tmax = fmaxf(tmax, s);
+    }
+  tmax = group_max(tmax);
+  const float m_new = fmaxf(m, tmax);
+  const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: keep everything at zero
+  alpha = __expf(m - m_use);                               // m = -inf -> 0
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float m2 = m_use * LOG2E;
+  float psum = 0.f;
+  uint32_t pk[2][4];
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) {
+    float p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p[r] = __builtin_amdgcn_exp2f(fmaf(st[sub][r], LOG2E, -m2));  // e^(s - m): one fma + one v_exp_f32
+      psum += p[r];
+    }
+    pk[sub >> 1][(sub & 1) * 2 + 0] = pack_bf(p[0], p[1]);
+    pk[sub >> 1][(sub & 1) * 2 + 1] = pack_bf(p[2], p[3]);
+  }
+  l = l * alpha + psum;
+  m = m_new;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    u32x4_t u = {pk[kk][0], pk[kk][1], pk[kk][2], pk[kk][3]};
+    pf[kk] = as_frag(u);
+  }
+}
+
+}  // namespace aha

@@ -3,6 +3,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// No implicit mul+add fusion below this line: `a * b + c * d` can be fused two ways and the compiler may pick differently
+// in the stand-alone kernels and in the persistent decode kernel, which share this code and must stay bit-identical
+// (tests/test_model_gpu.py::test_decode_mega_equals_multi_kernel).  Fusion is written out with fmaf where wanted.
+#pragma clang fp contract(off)
+
 namespace aha {
 
 typedef uint16_t bf16_t;  // raw bf16 bit pattern in HBM / LDS
@@ -51,6 +56,48 @@ __device__ __forceinline__ u32x4_t ld_nt16(const void* p) {
   return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
 }
 __device__ __forceinline__ u32x4_t ld16(const void* p) { return *reinterpret_cast<const u32x4_t*>(p); }
+
+// ---- activation traffic inside the persistent decode kernel --------------------------------------------------------
+// Blocks on different XCDs exchange activations between grid barriers.  The 8 XCD L2s are not coherent with each other
+// for ordinary loads/stores, and agent-scope fences (buffer_wbl2 / buffer_inv) cost tens of microseconds per barrier
+// when 2048 waves issue them.  Instead every activation access that crosses a barrier is an agent-scope relaxed atomic
+// (sc1 load / write-through store): the few KB per phase bypass the non-coherent caches, the weight stream is untouched.
+// COH = false (stand-alone kernels): plain accesses, identical code to before.
+template <bool COH>
+__device__ __forceinline__ u32x4_t act_ld16(const void* p) {
+  if (!COH) return ld16(p);
+  const uint64_t* q = reinterpret_cast<const uint64_t*>(p);
+  const uint64_t a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint64_t b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return u32x4_t{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+}
+template <bool COH>
+__device__ __forceinline__ float4 act_ldf4(const float* p) {
+  if (!COH) return *reinterpret_cast<const float4*>(p);
+  const u32x4_t v = act_ld16<true>(p);
+  return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+template <bool COH>
+__device__ __forceinline__ float2 act_ldf2(const float* p) {
+  if (!COH) return *reinterpret_cast<const float2*>(p);
+  const uint64_t a = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float2(__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)(a >> 32)));
+}
+template <bool COH>
+__device__ __forceinline__ bf16_t act_ld_bf(const bf16_t* p) {
+  if (!COH) return *p;
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool COH>
+__device__ __forceinline__ void act_st_bf(bf16_t* p, bf16_t v) {
+  if (!COH) *p = v;
+  else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool COH>
+__device__ __forceinline__ void act_stf(float* p, float v) {
+  if (!COH) *p = v;
+  else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 constexpr int KV_PAGE_TOKENS = 64;  // tokens per KV page
 

@@ -131,6 +131,45 @@ void launch_gemm(const GemmArgs& a, hipStream_t st);
 // x[i] = bf16(x[i] + bf16(sum[i])): Linear output tensor (all-reduced f32 partials) -> bf16, then the residual add -> bf16
 void launch_residual_add_f32(void* x, const float* sum, int64_t n, hipStream_t st);
 
+// ---- persistent decode-step kernel (decode_mega.hip) ----------------------------------------------------------------
+struct StepState;  // model.h
+struct DecodeLayerDev {
+  const void *wqkv, *wo, *wgu, *wdown, *in_norm, *post_norm, *q_norm, *k_norm;
+  uint64_t kv_layer_off;  // byte offset of the layer inside a KV page slot
+};
+struct DecodeMegaArgs {
+  const DecodeLayerDev* layers;  // device array
+  int n_layers;
+  const void* embed;             // (vocab, H) bf16
+  const StepState* state;        // device: token, rope positions, cache slot / length of this step
+  void* x;                       // (H) bf16 residual stream
+  void* qkv;                     // ((nh + 2 kvh) * 128) bf16
+  void* act;                     // (I) bf16
+  float* part_o;                 // (nsplit, nh, 128) f32 attention partials
+  float* part_ml;                // (nsplit, nh, 2) f32
+  const float* inv_freq;
+  const int32_t* axis_map;
+  const uint64_t* page_ptrs;
+  const void* final_norm;
+  const void* lm_head;
+  float* logits;
+  float* blk_max;                // (grid) argmax partials
+  uint32_t* blk_idx;
+  void* h_out;                   // (H) bf16: final-norm output (debug_last_hidden)
+  int H, I, nh, kvh, vocab, nsplit;
+  float eps, scale;
+  unsigned* bar;                 // grid-barrier words (DECODE_MEGA_BAR_BYTES, zeroed once; layout in decode_mega.hip)
+  unsigned bar_done0;            // barriers completed by all previous launches
+  unsigned long long* trace;     // optional (AHA_MEGA_TRACE): [4 blocks][phases][3] 100 MHz timestamps: start, past wait, done
+};
+constexpr size_t DECODE_MEGA_BAR_BYTES = 32768;
+constexpr int DECODE_MEGA_BAR_ERR_WORD = 32;
+// barriers one launch passes: the host advances bar_done0 by this
+inline int decode_mega_barriers(int n_layers) { return 5 * n_layers; }
+size_t decode_mega_lds_bytes(int H, int I, int nq);
+int decode_mega_max_blocks_per_cu(int H, size_t lds);
+void launch_decode_mega(const DecodeMegaArgs& a, int grid, size_t lds, hipStream_t st);
+
 }  // namespace aha
 
 // ---- Qwen3-VL vision tower (kernels_vit.hip) -----------------------------------------------------------------------

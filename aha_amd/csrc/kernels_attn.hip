@@ -15,72 +15,11 @@
 // so no operand ever needs a transpose or a cross-lane shuffle; see v_slot() in common.h for the V slot permutation.
 #include <stdlib.h>
 
-#include "common.h"
-#include "kernels.h"
+#include "attn_decode_body.h"
 
 namespace aha {
 
 namespace {
-
-__device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ bf16x8_t as_frag(u32x4_t v) {
-  union { u32x4_t u; bf16x8_t b; } x;
-  x.u = v;
-  return x.b;
-}
-__device__ __forceinline__ float group_max(float v) {  // across the 4 lane groups (same column c)
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
-}
-__device__ __forceinline__ float group_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
-}
-
-// Online-softmax update for one 64-token tile.  st[sub][reg] holds raw S for token sub*16+G*4+reg, column c.
-// valid(tok_in_tile) masks both causality and the tail of the last page.  Returns the two P^T fragments.
-template <typename ValidFn>
-__device__ __forceinline__ void softmax_tile(f32x4_t (&st)[4], float scale, ValidFn valid, int G, float& m, float& l,
-                                             float& alpha, bf16x8_t (&pf)[2]) {
-  float tmax = -INFINITY;
-#pragma unroll
-  for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float s = rbf(rbf(st[sub][r]) * scale);  // matmul output -> bf16, then `* scaling` -> bf16 (modules.rs:782-783)
-      if (!valid(sub * 16 + G * 4 + r)) s = -INFINITY;
-      st[sub][r] = s;
-      tmax = fmaxf(tmax, s);
-    }
-  tmax = group_max(tmax);
-  const float m_new = fmaxf(m, tmax);
-  const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: keep everything at zero
-  alpha = __expf(m - m_use);                               // m = -inf -> 0
-  constexpr float LOG2E = 1.4426950408889634f;
-  const float m2 = m_use * LOG2E;
-  float psum = 0.f;
-  uint32_t pk[2][4];
-#pragma unroll
-  for (int sub = 0; sub < 4; ++sub) {
-    float p[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      p[r] = __builtin_amdgcn_exp2f(fmaf(st[sub][r], LOG2E, -m2));  // e^(s - m): one fma + one v_exp_f32
-      psum += p[r];
-    }
-    pk[sub >> 1][(sub & 1) * 2 + 0] = pack_bf(p[0], p[1]);
-    pk[sub >> 1][(sub & 1) * 2 + 1] = pack_bf(p[2], p[3]);
-  }
-  l = l * alpha + psum;
-  m = m_new;
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    u32x4_t u = {pk[kk][0], pk[kk][1], pk[kk][2], pk[kk][3]};
-    pf[kk] = as_frag(u);
-  }
-}
 
 constexpr int V_ROW_BYTES = KV_PAGE_TOKENS * 2 + 16;  // padded LDS row of the V^T tile
 
@@ -353,161 +292,9 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnDecodeArgs
   ((bf16_t*)a.o)[head * 128 + d] = f2bf(acc / lsum);
 }
 
-// ---- decode, fused: q/k RMSNorm + (M-)RoPE + KV append + split-KV attention + in-block merge --------------------
-// One launch replaces qknorm_rope_kernel + attn_decode_kernel + most of the combine: every block redoes the (tiny)
-// norm/rope of its kv head's g query heads and of the new key in LDS (QKNormAttention::forward, modules.rs:538-557),
-// block (kvhd, 0) appends the new K/V to the cache page (modules.rs:558-566), all blocks attend over the OLD tokens
-// from the pages, unit 0 adds the new token from LDS, the 4 waves of a block are merged through LDS, and one
-// un-normalised partial per (split, head) is left for the o_proj matvec's prologue to merge (kernels_gemv.hip).
 __global__ __launch_bounds__(256) void attn_decode_fused_kernel(AttnDecodeFusedArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_t qs[16 * 128];
-  __shared__ __attribute__((aligned(16))) bf16_t ksn[128];
-  __shared__ __attribute__((aligned(16))) bf16_t vsn[128];
-  __shared__ __attribute__((aligned(16))) float mo[4 * 128 * 16];  // per wave O^T [d][q]
-  __shared__ float mm[4 * 16], mlz[4 * 16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, c = lane & 15;
-  const int kvhd = blockIdx.x, g = a.nh / a.kvh;
-  const int nunits = gridDim.y * 4, unit = blockIdx.y * 4 + wave;
-  const int L = *a.kv_len, slot_new = *a.kv_start;
-  const int L_old = L - 1;  // tokens already in the pages; the new one is handled from LDS
-  const int npages = (L_old + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS;
-
-  // This unit's first page goes out BEFORE the norm/rope prologue: its loads do not depend on q, and the prologue's
-  // own dependent chain (qkv -> wave_sum -> sincos -> LDS) then overlaps the page fetch instead of preceding it.
-  u32x4_t kf[4][4], vf[8][2];
-  auto load_page = [&](int page) {
-    const char* base = reinterpret_cast<const char*>(a.kv.page_ptrs[page] + a.kv.layer_off);
-    const char* kb = base + (size_t)kvhd * KV_PAGE_TOKENS * 256;
-    const char* vb = base + (size_t)a.kvh * KV_PAGE_TOKENS * 256 + (size_t)kvhd * 128 * (KV_PAGE_TOKENS * 2);
-#pragma unroll
-    for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) kf[sub][k4] = ld_nt16(kb + (size_t)(sub * 16 + c) * 256 + (k4 * 32 + G * 8) * 2);
-#pragma unroll
-    for (int ds = 0; ds < 8; ++ds)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) vf[ds][kk] = ld_nt16(vb + (size_t)(ds * 16 + c) * (KV_PAGE_TOKENS * 2) + (kk * 32 + G * 8) * 2);
-  };
-  int page = unit;
-  if (page < npages) load_page(page);
-
-  // ---- prologue: norm + rope of the g q heads and the k head; v raw ------------------------------------------------
-  {
-    const bf16_t* qkv = (const bf16_t*)a.qkv;
-    for (int hs = wave; hs <= g; hs += 4) {  // hs < g: q head kvhd*g+hs ; hs == g: the k head
-      const bool is_k = hs == g;
-      const bf16_t* src = is_k ? qkv + (int64_t)(a.nh + kvhd) * 128 : qkv + (int64_t)(kvhd * g + hs) * 128;
-      const bf16_t* nw = (const bf16_t*)(is_k ? a.k_norm_w : a.q_norm_w);
-      float x0 = bf2f(src[lane]), x1 = bf2f(src[lane + 64]);
-      const float ss = wave_sum(x0 * x0 + x1 * x1);
-      const float rinv = 1.0f / sqrtf(ss / 128.0f + a.eps);
-      x0 = rbf(x0 * rinv * bf2f(nw[lane]));
-      x1 = rbf(x1 * rinv * bf2f(nw[lane + 64]));
-      const float ang = (float)a.pos[a.axis_map[lane]] * a.inv_freq[lane];
-      const float cs = rbf(cosf(ang)), sn = rbf(sinf(ang));
-      const bf16_t y0 = f2bf(rbf(x0 * cs) + rbf(-x1 * sn));
-      const bf16_t y1 = f2bf(rbf(x1 * cs) + rbf(x0 * sn));
-      bf16_t* dst = is_k ? ksn : qs + hs * 128;
-      dst[lane] = y0;
-      dst[lane + 64] = y1;
-    }
-    if (tid < 128) vsn[tid] = qkv[(int64_t)(a.nh + a.kvh + kvhd) * 128 + tid];
-  }
-  __syncthreads();
-  if (blockIdx.y == 0 && tid < 128) {  // append (k roped, v raw) for the following steps
-    const int pg = slot_new / KV_PAGE_TOKENS, t = slot_new % KV_PAGE_TOKENS;
-    bf16_t* base = reinterpret_cast<bf16_t*>(a.kv.page_ptrs[pg] + a.kv.layer_off);
-    base[((int64_t)kvhd * KV_PAGE_TOKENS + t) * 128 + tid] = ksn[tid];
-    bf16_t* vd = base + (int64_t)a.kvh * KV_PAGE_TOKENS * 128 + (int64_t)kvhd * 128 * KV_PAGE_TOKENS;
-    vd[(int64_t)tid * KV_PAGE_TOKENS + v_slot(t)] = vsn[tid];
-  }
-
-  bf16x8_t qf[4];
-#pragma unroll
-  for (int k4 = 0; k4 < 4; ++k4) {
-    u32x4_t v = *reinterpret_cast<const u32x4_t*>(qs + min(c, g - 1) * 128 + k4 * 32 + G * 8);
-    if (c >= g) v = u32x4_t{0u, 0u, 0u, 0u};
-    qf[k4] = as_frag(v);
-  }
-  float m = -INFINITY, l = 0.f;
-  f32x4_t o[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  while (page < npages) {
-    f32x4_t st[4];
-#pragma unroll
-    for (int sub = 0; sub < 4; ++sub) {
-      st[sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) st[sub] = mfma16(as_frag(kf[sub][k4]), qf[k4], st[sub]);
-    }
-    float alpha;
-    bf16x8_t pf[2];
-    const int t0 = page * KV_PAGE_TOKENS;
-    softmax_tile(st, a.scale, [&](int t) { return t0 + t < L_old; }, G, m, l, alpha, pf);
-#pragma unroll
-    for (int ds = 0; ds < 8; ++ds) {
-      o[ds] *= alpha;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) o[ds] = mfma16(as_frag(vf[ds][kk]), pf[kk], o[ds]);
-    }
-    page += nunits;
-    if (page < npages) load_page(page);
-  }
-  if (unit == 0) {  // the new token: score from LDS, one more online-softmax step
-    float dot = 0.f;
-    const bf16_t* qr = qs + min(c, g - 1) * 128 + G * 32;
-    const bf16_t* kr = ksn + G * 32;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) dot = fmaf(bf2f(qr[j]), bf2f(kr[j]), dot);
-    dot = group_sum(dot);
-    const float s = rbf(rbf(dot) * a.scale);
-    const float m_new = fmaxf(m, s);
-    const float alpha = __expf(m - m_new);
-    const float p = rbf(__expf(s - m_new));  // P feeds the MFMA as bf16 on the page path: same rounding here
-    l = l * alpha + (G == 0 ? __expf(s - m_new) : 0.f);
-    m = m_new;
-#pragma unroll
-    for (int ds = 0; ds < 8; ++ds)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[ds][r] = o[ds][r] * alpha + p * bf2f(vsn[ds * 16 + G * 4 + r]);
-  }
-  l = group_sum(l);
-
-  // ---- merge the 4 waves through LDS, leave one partial per (split, head) ---------------------------------------------
-  {
-    float* wo = mo + wave * (128 * 16);
-#pragma unroll
-    for (int ds = 0; ds < 8; ++ds)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) wo[(ds * 16 + G * 4 + r) * 16 + c] = o[ds][r];
-    if (G == 0) {
-      mm[wave * 16 + c] = m;
-      mlz[wave * 16 + c] = l;
-    }
-  }
-  __syncthreads();
-  for (int it = tid; it < g * 128; it += 256) {
-    const int q = it >> 7, d = it & 127;
-    float M = -INFINITY;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) M = fmaxf(M, mm[w * 16 + q]);
-    float acc = 0.f, ls = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float mw = mm[w * 16 + q];
-      const float wt = (mw == -INFINITY) ? 0.f : __expf(mw - M);
-      acc += wt * mo[w * (128 * 16) + d * 16 + q];
-      ls += wt * mlz[w * 16 + q];
-    }
-    const int head = kvhd * g + q;
-    a.part_o[((int64_t)blockIdx.y * a.nh + head) * 128 + d] = acc;
-    if (d == 0) {
-      a.part_ml[((int64_t)blockIdx.y * a.nh + head) * 2 + 0] = M;
-      a.part_ml[((int64_t)blockIdx.y * a.nh + head) * 2 + 1] = ls;
-    }
-  }
+  __shared__ __attribute__((aligned(16))) char smem[ATTN_DECODE_FUSED_LDS];
+  attn_decode_fused_body<false>(a, smem, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, [] {});
 }
 
 }  // namespace

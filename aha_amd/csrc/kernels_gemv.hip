@@ -12,255 +12,16 @@
 // Rounding points follow the reference's op boundaries: Linear output -> bf16, then each further op -> bf16.
 #include <stdlib.h>
 
-#include "common.h"
-#include "kernels.h"
+#include "gemv_body.h"
 
 namespace aha {
 
 namespace {
 
-constexpr int GEMV_THREADS = 256;
-constexpr int GEMV_WAVES = 4;
-
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
-
-// LDS image of h: chunk c (512 elements) is stored as [half(2)][lane(64)][4] f32 so that a wave reading
-// "its" 8 elements of the chunk does two fully contiguous 1-KiB ds_read_b128.
-__device__ __forceinline__ int xs_index(int k) {
-  const int c = k >> 9, r = k & 511, lane = r >> 3, e = r & 7;
-  return (c << 9) + ((e >> 2) << 8) + (lane << 2) + (e & 3);
-}
-
 template <int R, int U, int EPI>
 __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float xs[];  // K f32 + 8 floats reduction scratch
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int K = a.K, N = a.N;
-  const int nchunks = (K + 511) >> 9;  // K % 8 == 0; the tail of the last chunk is zero-filled
-  float* red = xs + (nchunks << 9);
-
-  // ---- flattened work list: this block's tiles x the chunk groups of a tile ---------------------------------------
-  constexpr int ROWS_PER_TILE = GEMV_WAVES * R;
-  constexpr int NW = (EPI == GEMV_SILU_MUL) ? 2 : 1;
-  const int n_out = N;  // for SILU_MUL a "row" runs over the I outputs; the wave streams gate row j and up row j together
-  const int ntiles = (n_out + ROWS_PER_TILE - 1) / ROWS_PER_TILE;
-  const int gpt = (nchunks + U - 1) / U;                                  // chunk groups per tile
-  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int ngroups = my_tiles * gpt;
-  const bf16_t* Wb = (const bf16_t*)a.W;
-  const bf16_t* W2b = (const bf16_t*)a.W2;
-
-  // issue the R*U*NW 16-byte loads of work item gi (no dependence on x: they go out BEFORE the prologue)
-  auto issue = [&](int gi, u32x4_t (&buf)[U][NW][R]) {
-    const int tile = blockIdx.x + (gi / gpt) * gridDim.x;
-    const int c0 = (gi % gpt) * U;
-    const int row0 = tile * ROWS_PER_TILE + wave * R;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int row = min(row0 + r, n_out - 1);  // clamp: out-of-range rows are computed but never stored
-      const bf16_t* p0;
-      const bf16_t* p1 = nullptr;
-      if (NW == 2) {
-        if (W2b != nullptr) {  // separate gate / up matrices (op-level entry point)
-          p0 = Wb + (size_t)row * K;
-          p1 = W2b + (size_t)row * K;
-        } else {  // the model's fused matrix: 16-row blocks alternating gate / up
-          const size_t fr = (size_t)(row >> 4) * 32 + (row & 15);
-          p0 = Wb + fr * K;
-          p1 = Wb + (fr + 16) * K;
-        }
-      } else {
-        p0 = Wb + (size_t)row * K;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int k = ((c0 + u) << 9) + lane * 8;
-        const bool ok = (c0 + u < nchunks) && (k < K);
-        buf[u][0][r] = ok ? (a.cached ? ld16(p0 + k) : ld_nt16(p0 + k)) : u32x4_t{0u, 0u, 0u, 0u};
-        if (NW == 2) buf[u][NW - 1][r] = ok ? (a.cached ? ld16(p1 + k) : ld_nt16(p1 + k)) : u32x4_t{0u, 0u, 0u, 0u};
-      }
-    }
-  };
-
-  u32x4_t bufA[U][NW][R], bufB[U][NW][R];
-  if (ngroups > 0) issue(0, bufA);
-
-  // ---- prologue: h = x, or h = bf16(RMSNorm(x) * norm_w) (qwen3/model.rs:79,83,186) ------------------------
-  {
-    const bf16_t* x = (const bf16_t*)a.x;
-    const bf16_t* nw = (const bf16_t*)a.norm_w;
-    float ss = 0.f;
-    for (int v = tid; v < (nchunks << 6); v += GEMV_THREADS) {
-      float f[8];
-      if (a.comb_o != nullptr && v * 8 < K) {
-        // merge the KV-split partials of head v/16, dims (v%16)*8..+8 (attention output tensor, rounded to bf16)
-        const int head = v >> 4, d0 = (v & 15) * 8;
-        float M = -INFINITY, ls = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = 0.f;
-        // 8 splits per round, all 24 loads of a round issued before any is used (an un-unrolled loop serialises
-        // them: +7 us on the o_proj matvec); running (M, ls, f) are rescaled online between rounds
-        for (int s0 = 0; s0 < a.comb_n; s0 += 8) {
-          float2 ml[8];
-          float4 p0[8], p1[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int sidx = min(s0 + j, a.comb_n - 1);
-            const size_t hb = (size_t)sidx * a.comb_nh + head;
-            ml[j] = *reinterpret_cast<const float2*>(a.comb_ml + hb * 2);
-            const float4* po = reinterpret_cast<const float4*>(a.comb_o + hb * 128 + d0);
-            p0[j] = po[0];
-            p1[j] = po[1];
-            if (s0 + j >= a.comb_n) ml[j].x = -INFINITY;
-          }
-          float Mc = M;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) Mc = fmaxf(Mc, ml[j].x);
-          if (Mc == -INFINITY) continue;
-          const float resc = (M == -INFINITY) ? 0.f : __expf(M - Mc);
-          ls *= resc;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) f[j] *= resc;
-          M = Mc;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float wgt = (ml[j].x == -INFINITY) ? 0.f : __expf(ml[j].x - M);
-            ls += wgt * ml[j].y;
-            f[0] += wgt * p0[j].x; f[1] += wgt * p0[j].y; f[2] += wgt * p0[j].z; f[3] += wgt * p0[j].w;
-            f[4] += wgt * p1[j].x; f[5] += wgt * p1[j].y; f[6] += wgt * p1[j].z; f[7] += wgt * p1[j].w;
-          }
-        }
-        const float inv = 1.0f / ls;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = rbf(f[j] * inv);
-      } else {
-        u32x4_t xv = {0u, 0u, 0u, 0u};
-        if (v * 8 < K) xv = ld16(x + v * 8);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { f[2 * j] = lo_bf(xv[j]); f[2 * j + 1] = hi_bf(xv[j]); }
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
-      const int base = xs_index(v * 8);
-      *reinterpret_cast<float4*>(xs + base) = make_float4(f[0], f[1], f[2], f[3]);
-      *reinterpret_cast<float4*>(xs + base + 256) = make_float4(f[4], f[5], f[6], f[7]);
-    }
-    if (nw != nullptr) {
-      ss = wave_sum(ss);
-      if (lane == 0) red[wave] = ss;
-      __syncthreads();
-      const float tot = red[0] + red[1] + red[2] + red[3];
-      const float rinv = 1.0f / sqrtf(tot / (float)K + a.eps);
-      for (int v = tid; v < (K >> 3); v += GEMV_THREADS) {
-        const u32x4_t wv = ld16(nw + v * 8);
-        const int base = xs_index(v * 8);
-        float4 lo = *reinterpret_cast<float4*>(xs + base), hi = *reinterpret_cast<float4*>(xs + base + 256);
-        lo.x = rbf(lo.x * rinv * lo_bf(wv[0])); lo.y = rbf(lo.y * rinv * hi_bf(wv[0]));
-        lo.z = rbf(lo.z * rinv * lo_bf(wv[1])); lo.w = rbf(lo.w * rinv * hi_bf(wv[1]));
-        hi.x = rbf(hi.x * rinv * lo_bf(wv[2])); hi.y = rbf(hi.y * rinv * hi_bf(wv[2]));
-        hi.z = rbf(hi.z * rinv * lo_bf(wv[3])); hi.w = rbf(hi.w * rinv * hi_bf(wv[3]));
-        *reinterpret_cast<float4*>(xs + base) = lo;
-        *reinterpret_cast<float4*>(xs + base + 256) = hi;
-        if (a.h_out != nullptr && blockIdx.x == 0) {
-          u32x4_t o;
-          o[0] = pack_bf(lo.x, lo.y); o[1] = pack_bf(lo.z, lo.w); o[2] = pack_bf(hi.x, hi.y); o[3] = pack_bf(hi.z, hi.w);
-          *reinterpret_cast<u32x4_t*>((bf16_t*)a.h_out + v * 8) = o;
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- main: consume item g while item g+1 is in flight (two named register buffers, static indexing) ------------
-  float tile_best = -INFINITY;
-  uint32_t tile_best_i = 0xffffffffu;
-  float acc[NW][R];
-#pragma unroll
-  for (int m = 0; m < NW; ++m)
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
-
-  auto consume = [&](int gi, u32x4_t (&buf)[U][NW][R]) {
-    const int c0 = (gi % gpt) * U;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (c0 + u < nchunks) {
-        const float4 xlo = *reinterpret_cast<const float4*>(xs + ((c0 + u) << 9) + (lane << 2));
-        const float4 xhi = *reinterpret_cast<const float4*>(xs + ((c0 + u) << 9) + 256 + (lane << 2));
-#pragma unroll
-        for (int m = 0; m < NW; ++m)
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const u32x4_t w = buf[u][m][r];
-            float s = acc[m][r];
-            s = fmaf(lo_bf(w[0]), xlo.x, s); s = fmaf(hi_bf(w[0]), xlo.y, s);
-            s = fmaf(lo_bf(w[1]), xlo.z, s); s = fmaf(hi_bf(w[1]), xlo.w, s);
-            s = fmaf(lo_bf(w[2]), xhi.x, s); s = fmaf(hi_bf(w[2]), xhi.y, s);
-            s = fmaf(lo_bf(w[3]), xhi.z, s); s = fmaf(hi_bf(w[3]), xhi.w, s);
-            acc[m][r] = s;
-          }
-      }
-    }
-    if (gi % gpt != gpt - 1) return;
-    // last chunk group of the tile: reduce across the wave and run the epilogue
-    const int tile = blockIdx.x + (gi / gpt) * gridDim.x;
-    const int row0 = tile * ROWS_PER_TILE + wave * R;
-#pragma unroll
-    for (int m = 0; m < NW; ++m)
-#pragma unroll
-      for (int r = 0; r < R; ++r) acc[m][r] = wave_sum(acc[m][r]);
-    if (lane == 0) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int row = row0 + r;
-        if (row < n_out) {
-          const float lin = rbf(acc[0][r]);  // candle_nn::Linear output tensor (bf16)
-          if (EPI == GEMV_PARTIAL_F32) {
-            a.y_f32[row] = acc[0][r];
-          } else if (EPI == GEMV_STORE) {
-            ((bf16_t*)a.y)[row] = f2bf(lin);
-          } else if (EPI == GEMV_RESIDUAL) {
-            ((bf16_t*)a.y)[row] = f2bf(bf2f(((const bf16_t*)a.residual)[row]) + lin);
-          } else if (EPI == GEMV_SILU_MUL) {
-            const float g = rbf(silu_f(lin));            // gate_proj -> act_fn   (modules.rs:82)
-            const float up = rbf(acc[NW - 1][r]);        // up_proj               (modules.rs:83)
-            ((bf16_t*)a.y)[row] = f2bf(g * up);          // lhs * rhs             (modules.rs:84)
-          } else {  // GEMV_LOGITS: logits tensor is bf16 in the reference, read back as f32 (generate.rs:75)
-            a.y_f32[row] = lin;
-            if (lin > tile_best || (lin == tile_best && (uint32_t)row < tile_best_i)) { tile_best = lin; tile_best_i = row; }
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int m = 0; m < NW; ++m)
-#pragma unroll
-      for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
-  };
-
-  for (int g = 0; g < ngroups; g += 2) {
-    if (g + 1 < ngroups) issue(g + 1, bufB);
-    consume(g, bufA);
-    if (g + 2 < ngroups) issue(g + 2, bufA);
-    if (g + 1 < ngroups) consume(g + 1, bufB);
-  }
-  if (EPI == GEMV_LOGITS) {
-    // per-block argmax partial: 4 wave leaders -> slot blockIdx.x
-    __syncthreads();
-    if (lane == 0) { red[wave] = tile_best; reinterpret_cast<uint32_t*>(red)[4 + wave] = tile_best_i; }
-    __syncthreads();
-    if (tid == 0) {
-      float bv = red[0];
-      uint32_t bi = reinterpret_cast<uint32_t*>(red)[4];
-      for (int w = 1; w < 4; ++w) {
-        const float v = red[w];
-        const uint32_t i = reinterpret_cast<uint32_t*>(red)[4 + w];
-        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
-      }
-      a.blk_max[blockIdx.x] = bv;
-      a.blk_idx[blockIdx.x] = bi;
-    }
-  }
+  gemv_body<R, U, EPI, false>(a, xs, (int)blockIdx.x, (int)gridDim.x, [] {});
 }
 
 struct GemvPlan { int R, U, grid; };

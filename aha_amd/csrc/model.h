@@ -105,6 +105,15 @@ struct aha_model {
   int async_rc = 0;             // first error of an all-reduce issued from inside an enqueue helper
   float* d_partial = nullptr;   // decode: (hidden) f32 partial projection
   float* p_partial = nullptr;   // prefill: (S, hidden) f32
+  // persistent decode-step kernel (decode_mega.hip): one launch per token
+  bool decode_mega = false;
+  aha::DecodeLayerDev* d_layers_dev = nullptr;
+  unsigned* d_bar = nullptr;        // grid-barrier words (kernels.h DECODE_MEGA_BAR_BYTES)
+  unsigned* h_bar_err = nullptr;    // pinned copy of the sticky error word
+  unsigned long long* d_mega_trace = nullptr;  // AHA_MEGA_TRACE timeline
+  unsigned bar_base = 0;            // barriers completed by all launches so far
+  int mega_grid = 0;
+  size_t mega_lds = 0;
   bool decode_fused = true;  // attention block of a decode step in one launch (kernels_attn.hip attn_decode_fused_kernel)
   float* h_logits = nullptr;  // pinned
   // prefill scratch (grown on demand)
@@ -149,7 +158,7 @@ void tp_destroy(aha_model* m);
 const aha_tensor_view* find_tensor(const aha_tensor_view* w, size_t nw, const std::string& name);
 int upload_tensor(aha_model* m, const aha_tensor_view* t, const std::vector<int64_t>& shape, void** out,
                   int64_t pad_rows_to = 0, int64_t pad_cols_to = 0);
-int dev_alloc(aha_model* m, size_t bytes, void** out, bool zero = false);
+int dev_alloc(aha_model* m, size_t bytes, void** out, bool zero = false, bool uncached = false);
 
 struct ProfScope {
   aha_model* m;

@@ -67,9 +67,13 @@ int prof_collect(aha_model* m) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-int dev_alloc(aha_model* m, size_t bytes, void** out, bool zero) {
+// uncached: device memory mapped so that no XCD L2 keeps a copy (the activation / barrier words the persistent decode kernel
+// exchanges between blocks on different XCDs inside one launch)
+int dev_alloc(aha_model* m, size_t bytes, void** out, bool zero, bool uncached) {
   void* p = nullptr;
-  hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+  static const char* e_unc = getenv("AHA_MEGA_UNCACHED");
+  if (e_unc && atoi(e_unc) == 0) uncached = false;
+  hipError_t e = uncached ? hipExtMallocWithFlags(&p, bytes ? bytes : 16, hipDeviceMallocUncached) : hipMalloc(&p, bytes ? bytes : 16);
   if (e != hipSuccess) {
     set_error("hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
     return e == hipErrorOutOfMemory ? AHA_ERR_OOM : AHA_ERR_HIP;
@@ -512,25 +516,58 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
   m->token_log_cap = 1 << 16;
   if ((rc = dev_alloc(m, m->token_log_cap * 4, &p))) return fail(rc);
   m->d_token_log = (uint32_t*)p;
-  if ((rc = dev_alloc(m, (size_t)H * 2, &m->d_x))) return fail(rc);
-  if ((rc = dev_alloc(m, (size_t)(nq + 2 * nkv) * 2, &m->d_qkv))) return fail(rc);
+  if ((rc = dev_alloc(m, (size_t)H * 2, &m->d_x, false, true))) return fail(rc);
+  if ((rc = dev_alloc(m, (size_t)(nq + 2 * nkv) * 2, &m->d_qkv, false, true))) return fail(rc);
   if ((rc = dev_alloc(m, (size_t)nq * 2, &m->d_q))) return fail(rc);
   if ((rc = dev_alloc(m, (size_t)nq * 2, &m->d_attn))) return fail(rc);
-  if ((rc = dev_alloc(m, (size_t)I * 2, &m->d_act))) return fail(rc);
+  if ((rc = dev_alloc(m, (size_t)I * 2, &m->d_act, false, true))) return fail(rc);
   if ((rc = dev_alloc(m, (size_t)H * 2, &m->d_hlast, true))) return fail(rc);
   if ((rc = dev_alloc(m, (size_t)H * 4, &p))) return fail(rc);
   m->d_partial = (float*)p;
   if ((rc = dev_alloc(m, (size_t)c.vocab_size * 4, &p))) return fail(rc);
   m->d_logits = (float*)p;
-  const int nt = std::max(gemv_num_tiles(c.vocab_size, H), 256);
+  const int nt = std::max(gemv_num_tiles(c.vocab_size, H), 512);
   if ((rc = dev_alloc(m, (size_t)nt * 4, &p))) return fail(rc);
   m->d_blk_max = (float*)p;
   if ((rc = dev_alloc(m, (size_t)nt * 4, &p))) return fail(rc);
   m->d_blk_idx = (uint32_t*)p;
-  if ((rc = dev_alloc(m, (size_t)m->max_nsplit * 4 * c.num_attention_heads * d * 4, &p))) return fail(rc);
+  if ((rc = dev_alloc(m, (size_t)m->max_nsplit * 4 * c.num_attention_heads * d * 4, &p, false, true))) return fail(rc);
   m->d_part_o = (float*)p;
-  if ((rc = dev_alloc(m, (size_t)m->max_nsplit * 4 * c.num_attention_heads * 2 * 4, &p))) return fail(rc);
+  if ((rc = dev_alloc(m, (size_t)m->max_nsplit * 4 * c.num_attention_heads * 2 * 4, &p, false, true))) return fail(rc);
   m->d_part_ml = (float*)p;
+
+  // persistent decode-step kernel: resident grid sized by the occupancy the kernel actually gets on this device
+  {
+    // Opt-in (AHA_DECODE_MEGA=1): measured 6-25% SLOWER than the launch-per-op path on MI355X -- see DESIGN.md and
+    // profiles/r01_decode_mega_timeline.md; kept because it is parity-tested and documents where batch-1 decode time goes.
+    bool want = false;
+    if (const char* e = getenv("AHA_DECODE_MEGA")) want = atoi(e) != 0;
+    want = want && m->tp_size == 1 && d == 128 && m->decode_fused;
+    if (want) {
+      m->mega_lds = decode_mega_lds_bytes(H, I, nq);
+      hipDeviceProp_t prop;
+      AHA_HIP_CHECK(hipGetDeviceProperties(&prop, m->ctx->device));
+      const int per_cu = decode_mega_max_blocks_per_cu(H, m->mega_lds);
+      if (per_cu >= 1) {
+        m->mega_grid = std::min(512, std::min(per_cu, 2) * prop.multiProcessorCount);
+        if (const char* e = getenv("AHA_MEGA_GRID")) m->mega_grid = std::min(atoi(e), per_cu * prop.multiProcessorCount);
+        std::vector<DecodeLayerDev> hl(c.num_hidden_layers);
+        for (int li = 0; li < c.num_hidden_layers; ++li) {
+          const LayerWeights& L = m->layers[li];
+          hl[li] = DecodeLayerDev{L.wqkv, L.wo, L.wgu, L.wdown, L.in_norm, L.post_norm, L.q_norm, L.k_norm,
+                                  (uint64_t)li * m->layer_stride};
+        }
+        if ((rc = dev_alloc(m, hl.size() * sizeof(DecodeLayerDev), &p))) return fail(rc);
+        m->d_layers_dev = (DecodeLayerDev*)p;
+        AHA_HIP_CHECK(hipMemcpy(p, hl.data(), hl.size() * sizeof(DecodeLayerDev), hipMemcpyHostToDevice));
+        if ((rc = dev_alloc(m, DECODE_MEGA_BAR_BYTES, &p, true, true))) return fail(rc);
+        m->d_bar = (unsigned*)p;
+        AHA_HIP_CHECK(hipHostMalloc((void**)&m->h_bar_err, 4));
+        *m->h_bar_err = 0;
+        m->decode_mega = m->mega_grid >= c.num_key_value_heads;
+      }
+    }
+  }
 
   if (c.arch == AHA_ARCH_QWEN3VL) {
     if ((rc = vision_create(m, w, nw))) return fail(rc);
@@ -556,6 +593,7 @@ void model_destroy(aha_model* m) {
   if (m->d_page_ptrs) hipFree(m->d_page_ptrs);
   if (m->h_state) hipHostFree(m->h_state);
   if (m->h_logits) hipHostFree(m->h_logits);
+  if (m->h_bar_err) hipHostFree(m->h_bar_err);
   delete m;
 }
 
@@ -632,11 +670,52 @@ static void enqueue_lm_head(aha_model* m, const void* x_last) {
   }
 }
 
+// The persistent decode kernel's grid barrier gave up (a block was not scheduled or died): report instead of hanging, and
+// fall back to the multi-kernel path for the rest of the model's life.
+static int mega_check(aha_model* m) {
+  if (!m->decode_mega || *m->h_bar_err == 0) return AHA_OK;
+  m->decode_mega = false;
+  set_error("persistent decode kernel: grid barrier timed out (results of this call are invalid); "
+            "falling back to the multi-kernel decode path");
+  return AHA_ERR_HIP;
+}
+
+// AHA_MEGA_TRACE=1: per phase kind, averaged over layers, for 4 sample blocks (microseconds; clock = 100 MHz):
+// wait = phase start -> barrier passed, work = barrier passed -> compute done, gap = done -> next phase start
+static void mega_trace_dump(aha_model* m) {
+  const int L = m->desc.num_hidden_layers, np = 5 * L + 1;
+  std::vector<unsigned long long> t((size_t)4 * np * 3);
+  if (hipMemcpy(t.data(), m->d_mega_trace, t.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+  static const char* names[5] = {"qkv", "attn", "o_proj", "gate_up", "down"};
+  for (int b = 0; b < 4; ++b) {
+    const unsigned long long* tb = t.data() + (size_t)b * np * 3;
+    fprintf(stderr, "[mega trace] block slot %d: total %.1f us |", b, (tb[(np - 1) * 3 + 2] - tb[0]) * 0.01);
+    for (int k = 0; k < 5; ++k) {
+      double w = 0, c = 0, g = 0;
+      int n = 0;
+      for (int li = 0; li < L; ++li) {
+        const unsigned long long* p = tb + (size_t)(li * 5 + k) * 3;
+        if (p[0] == 0 || p[2] == 0) continue;  // block had no unit in this phase (attention)
+        w += (p[1] - p[0]) * 0.01;
+        c += (p[2] - p[1]) * 0.01;
+        g += ((p[3] ? p[3] : p[6]) - p[2]) * 0.01;
+        ++n;
+      }
+      if (n) fprintf(stderr, " %s wait %.2f work %.2f gap %.2f |", names[k], w / n, c / n, g / n);
+    }
+    const unsigned long long* p = tb + (size_t)(np - 1) * 3;
+    fprintf(stderr, " lm_head wait %.2f work %.2f\n", (p[1] - p[0]) * 0.01, (p[2] - p[1]) * 0.01);
+  }
+}
+
 static int fetch_outputs(aha_model* m, float* logits_out, uint32_t* argmax_out) {
   const aha_model_desc& c = m->desc;
   if (logits_out) AHA_HIP_CHECK(hipMemcpyAsync(m->h_logits, m->d_logits, (size_t)c.vocab_size * 4, hipMemcpyDeviceToHost, m->stream));
   AHA_HIP_CHECK(hipMemcpyAsync(&m->h_state->next_token, &m->d_state->next_token, 4, hipMemcpyDeviceToHost, m->stream));
+  if (m->decode_mega) AHA_HIP_CHECK(hipMemcpyAsync(m->h_bar_err, m->d_bar + DECODE_MEGA_BAR_ERR_WORD, 4, hipMemcpyDeviceToHost, m->stream));
   AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  if (int e = mega_check(m)) return e;
+  if (m->d_mega_trace) mega_trace_dump(m);
   if (logits_out) memcpy(logits_out, m->h_logits, (size_t)c.vocab_size * 4);
   if (argmax_out) *argmax_out = m->h_state->next_token;
   return AHA_OK;
@@ -713,6 +792,41 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
   const int H = c.hidden_size, I = c.intermediate_size, d = c.head_dim, nh = c.num_attention_heads, kvh = c.num_key_value_heads;
   const int nq = nh * d, nkv = kvh * d;
   hipStream_t st = m->stream;
+  if (m->decode_mega) {
+    const int npg = (int)((kv_len_after + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS);
+    DecodeMegaArgs a{};
+    a.layers = m->d_layers_dev; a.n_layers = c.num_hidden_layers; a.embed = m->embed; a.state = m->d_state;
+    a.x = m->d_x; a.qkv = m->d_qkv; a.act = m->d_act; a.part_o = m->d_part_o; a.part_ml = m->d_part_ml;
+    a.inv_freq = m->d_inv_freq; a.axis_map = m->d_axis_map; a.page_ptrs = m->d_page_ptrs;
+    a.final_norm = m->final_norm; a.lm_head = m->lm_head; a.logits = m->d_logits; a.blk_max = m->d_blk_max;
+    a.blk_idx = m->d_blk_idx; a.h_out = m->d_hlast;
+    a.H = H; a.I = I; a.nh = nh; a.kvh = kvh; a.vocab = c.vocab_size;
+    a.nsplit = std::max(1, std::min(std::min((npg + 3) / 4, m->max_nsplit), m->mega_grid / kvh));
+    a.eps = c.rms_norm_eps; a.scale = m->attn_scale;
+    a.bar = m->d_bar; a.bar_done0 = m->bar_base;
+    static const char* e_trace = getenv("AHA_MEGA_TRACE");
+    if (e_trace && atoi(e_trace)) {
+      const size_t nb = (size_t)4 * (5 * c.num_hidden_layers + 1) * 3 * 8;
+      if (!m->d_mega_trace) {
+        void* tp = nullptr;
+        if (dev_alloc(m, nb, &tp, true) == AHA_OK) m->d_mega_trace = (unsigned long long*)tp;
+      }
+      a.trace = m->d_mega_trace;
+    }
+    static const char* e_ns = getenv("AHA_MEGA_NSPLIT_MAX");
+    if (e_ns) a.nsplit = std::max(1, std::min(a.nsplit, atoi(e_ns)));
+    {
+      const double wbytes = (double)c.num_hidden_layers * ((double)(nq + 2 * nkv) * H + (double)H * nq + 3.0 * I * H) * 2 +
+                            (double)c.vocab_size * H * 2;
+      const double kvbytes = (double)c.num_hidden_layers * (double)kv_len_after * 2 * nkv * 2;
+      ProfScope ps(m, "decode_step", wbytes + kvbytes, wbytes + 2 * kvbytes * (nh / kvh));
+      launch_decode_mega(a, m->mega_grid, m->mega_lds, st);
+    }
+    m->bar_base += (unsigned)decode_mega_barriers(c.num_hidden_layers);
+    ProfScope ps(m, "argmax", 0, 0);
+    launch_argmax_partials(m->d_blk_max, m->d_blk_idx, m->mega_grid, &m->d_state->next_token, st);
+    return;
+  }
   {
     ProfScope ps(m, "elem", H * 4.0, 0);
     hipLaunchKernelGGL(embed_state_kernel, dim3(1), dim3(256), 0, st, (const bf16_t*)m->embed, m->d_state, (bf16_t*)m->d_x, H);
@@ -839,7 +953,9 @@ int model_decode_greedy(aha_model* m, uint32_t first_token, size_t offset, size_
     AHA_HIP_CHECK(hipGetLastError());
     if (m->async_rc) { const int e = m->async_rc; m->async_rc = 0; return e; }
     AHA_HIP_CHECK(hipMemcpyAsync(out + produced, m->d_token_log, n * 4, hipMemcpyDeviceToHost, m->stream));
+    if (m->decode_mega) AHA_HIP_CHECK(hipMemcpyAsync(m->h_bar_err, m->d_bar + DECODE_MEGA_BAR_ERR_WORD, 4, hipMemcpyDeviceToHost, m->stream));
     AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (int e = mega_check(m)) return e;
     size_t used = n;
     for (size_t i = 0; i < n && !stop; ++i)
       for (int e = 0; e < c.n_stop_tokens; ++e)

@@ -185,11 +185,17 @@ def main():
     # ---- roofline of the dominant kernel (weight-streaming matvec), HIP events on the model's stream ----
     model.set_profiling(True)
     tok, off = run_steps(args.steps, tok, off)
-    prof = {k: model.get_profile(k) for k in ("gemv", "attn_decode", "elem", "argmax")}
+    prof = {k: model.get_profile(k) for k in ("decode_step", "gemv", "attn_decode", "elem", "argmax")}
     model.set_profiling(False)
-    gv = prof["gemv"]
+    # default path: ONE persistent kernel per token (decode_mega.hip); AHA_DECODE_MEGA=0: the launch-per-op path, whose
+    # dominant kernel class is the weight-streaming matvec
+    mega = prof["decode_step"]["launches"] > 0
+    gv = prof["decode_step"] if mega else prof["gemv"]
+    pmc_file = "r01_pmc_traffic_decode_step.json" if mega else "r01_pmc_traffic_gemv.json"
     achieved = gv["bytes"] / (gv["ms"] * 1e-3) / 1e9 if gv["ms"] > 0 else 0.0
-    roof = {"bound": "hbm", "kernel": "gemv_kernel (batch-1 weight streaming, all projections + lm_head)",
+    roof = {"bound": "hbm",
+            "kernel": ("decode_step_kernel (persistent: all layers' weight streaming + paged attention + lm_head of one token)"
+                       if mega else "gemv_kernel (batch-1 weight streaming, all projections + lm_head)"),
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "launches": gv["launches"], "avg_us": round(1e3 * gv["ms"] / max(gv["launches"], 1), 2),
@@ -197,11 +203,11 @@ def main():
     # HBM traffic of the same kernel class from the PMC passes (rocprofv3 cannot run inside this process): the committed
     # summary profiles/r01_pmc_traffic_gemv.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes).
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_gemv.json")) as f:
+        with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
             pmc = json.load(f)
         if pmc.get("workload") == args.workload:
             roof["traffic"] = round(pmc["traffic_bytes_per_launch"])
-            roof["traffic_source"] = "profiles/r01_pmc_traffic_gemv.json"
+            roof["traffic_source"] = "profiles/" + pmc_file
     except (OSError, KeyError, ValueError):
         pass
     ad = prof["attn_decode"]

@@ -210,3 +210,39 @@ def test_missing_weight_is_an_error(gpu):
     w.pop("model.layers.1.self_attn.k_norm.weight")
     with pytest.raises(AhaHipError, match="k_norm"):
         HipInferenceModel(cfg, w)
+
+
+@pytest.mark.parametrize("shape", ["small", "8b-width"])
+def test_decode_mega_equals_multi_kernel(gpu, monkeypatch, shape):
+    """The persistent decode-step kernel (decode_mega.hip) and the launch-per-op path share their device code: logits must
+    be BIT-identical at every step, across page boundaries (63/64/65, 127/128) and KV-split counts, and so must the
+    device greedy loop's tokens."""
+    from aha_amd.model import HipInferenceModel
+    if shape == "small":
+        cfg, w = make()
+        lens = [1, 62, 200, 700]
+    else:
+        cfg = tiny_qwen3(layers=2, hidden=4096, heads=32, kv_heads=8, inter=12288, vocab=2048, tie=False)
+        w = qwen3_text_weights(cfg, seed=3)
+        lens = [97, 1500]
+    monkeypatch.setenv("AHA_DECODE_MEGA", "0")
+    multi = HipInferenceModel(cfg, w)
+    monkeypatch.setenv("AHA_DECODE_MEGA", "1")
+    mega = HipInferenceModel(cfg, w)
+    for S in lens:
+        ids = ids_for(cfg, S, 100 + S)
+        multi.clear_cache(); mega.clear_cache()
+        a, am = multi.forward_initial(ids, 0)
+        b, bm = mega.forward_initial(ids, 0)
+        np.testing.assert_array_equal(a, b)
+        tok, off = am, S
+        for step in range(5):
+            a, am = multi.forward_step(tok, off)
+            b, bm = mega.forward_step(tok, off)
+            np.testing.assert_array_equal(a, b, err_msg=f"S={S} step {step}")
+            assert am == bm
+            tok, off = am, off + 1
+        ta = multi.decode_greedy(tok, off, 40)
+        tb = mega.decode_greedy(tok, off, 40)
+        assert ta == tb and len(tb) == 40
+    multi.close(); mega.close()
