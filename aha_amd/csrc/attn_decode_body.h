@@ -15,8 +15,9 @@ constexpr int ATTN_DECODE_FUSED_LDS = 16 * 128 * 2 + 128 * 2 + 128 * 2 + 4 * 128
 // un-normalised partial per (split, head) is left for the o_proj matvec's prologue to merge (kernels_gemv.hip).
 // smem: ATTN_DECODE_FUSED_LDS bytes, 16-byte aligned.  (kvhd, split) of nsplit: this block's KV head and KV split.
 // after_prefetch() runs after the unit's first page has been requested and before qkv is read.
+// Returns true in the one block per kv head that wrote the final attention output of the head's g query heads.
 template <bool COH, class AfterPrefetch>
-__device__ __forceinline__ void attn_decode_fused_body(const AttnDecodeFusedArgs& a, char* smem, const int kvhd, const int split,
+__device__ __forceinline__ bool attn_decode_fused_body(const AttnDecodeFusedArgs& a, char* smem, const int kvhd, const int split,
                                                        const int nsplit, AfterPrefetch&& after_prefetch) {
   bf16_t* qs = reinterpret_cast<bf16_t*>(smem);                 // [16][128]
   bf16_t* ksn = qs + 16 * 128;                                  // [128]
@@ -148,6 +149,7 @@ __device__ __forceinline__ void attn_decode_fused_body(const AttnDecodeFusedArgs
     }
   }
   __syncthreads();
+  const bool single = nsplit == 1;
   for (int it = tid; it < g * 128; it += 256) {
     const int q = it >> 7, d = it & 127;
     float M = -INFINITY;
@@ -158,16 +160,68 @@ __device__ __forceinline__ void attn_decode_fused_body(const AttnDecodeFusedArgs
     for (int w = 0; w < 4; ++w) {
       const float mw = mm[w * 16 + q];
       const float wt = (mw == -INFINITY) ? 0.f : __expf(mw - M);
-      acc += wt * mo[w * (128 * 16) + d * 16 + q];
-      ls += wt * mlz[w * 16 + q];
+      acc = fmaf(wt, mo[w * (128 * 16) + d * 16 + q], acc);
+      ls = fmaf(wt, mlz[w * 16 + q], ls);
     }
     const int head = kvhd * g + q;
-    act_stf<COH>(a.part_o + ((int64_t)split * a.nh + head) * 128 + d, acc);
-    if (d == 0) {
-      act_stf<COH>(a.part_ml + ((int64_t)split * a.nh + head) * 2 + 0, M);
-      act_stf<COH>(a.part_ml + ((int64_t)split * a.nh + head) * 2 + 1, ls);
+    if (single) {  // the whole cache went through this block: normalise and emit the attention output tensor (bf16)
+      act_st_bf<COH>((bf16_t*)a.o + head * 128 + d, f2bf(acc * (1.0f / ls)));
+    } else {
+      act_stf<true>(a.part_o + ((int64_t)split * a.nh + head) * 128 + d, acc);
+      if (d == 0) {
+        act_stf<true>(a.part_ml + ((int64_t)split * a.nh + head) * 2 + 0, M);
+        act_stf<true>(a.part_ml + ((int64_t)split * a.nh + head) * 2 + 1, ls);
+      }
     }
   }
+  if (single) return true;
+
+  // ---- the LAST split block of this kv head to finish merges all splits of its g heads --------------------------------
+  // Partials cross blocks (possibly XCDs) inside one launch: agent-scope stores above, every wave waits for their
+  // acknowledgement, then one relaxed atomic per block on the head's counter decides who arrived last.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  __syncthreads();
+  int* s_last = reinterpret_cast<int*>(qs);  // q fragments are in registers since the page loop; LDS region is free
+  if (tid == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(a.head_ctr + 32 * kvhd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_last = (prev + 1u == a.ctr_target) ? 1 : 0;
+  }
+  __syncthreads();
+  if (*s_last == 0) return false;
+  for (int it = tid; it < g * 128; it += 256) {
+    const int q = it >> 7, d = it & 127;
+    const int head = kvhd * g + q;
+    float M = -INFINITY, ls = 0.f, f = 0.f;
+    // 8 splits per round, all 16 loads of a round issued before any is used; running (M, ls, f) rescaled between rounds
+    for (int s0 = 0; s0 < nsplit; s0 += 8) {
+      float2 ml[8];
+      float po[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int sidx = min(s0 + j, nsplit - 1);
+        const size_t hb = (size_t)sidx * a.nh + head;
+        ml[j] = act_ldf2<true>(a.part_ml + hb * 2);
+        po[j] = act_ldf<true>(a.part_o + hb * 128 + d);
+        if (s0 + j >= nsplit) ml[j].x = -INFINITY;
+      }
+      float Mc = M;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Mc = fmaxf(Mc, ml[j].x);
+      if (Mc == -INFINITY) continue;
+      const float resc = (M == -INFINITY) ? 0.f : __expf(M - Mc);
+      ls *= resc;
+      f *= resc;
+      M = Mc;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float wgt = (ml[j].x == -INFINITY) ? 0.f : __expf(ml[j].x - M);
+        ls = fmaf(wgt, ml[j].y, ls);
+        f = fmaf(wgt, po[j], f);
+      }
+    }
+    act_st_bf<COH>((bf16_t*)a.o + head * 128 + d, f2bf(f * (1.0f / ls)));  // attention output tensor (bf16)
+  }
+  return true;
 }
 
 }  // namespace aha

@@ -5,7 +5,7 @@
 
 // No implicit mul+add fusion below this line: `a * b + c * d` can be fused two ways and the compiler may pick differently
 // in the stand-alone kernels and in the persistent decode kernel, which share this code and must stay bit-identical
-// (tests/test_model_gpu.py::test_decode_mega_equals_multi_kernel).  Fusion is written out with fmaf where wanted.
+// (tests/test_model_gpu.py::test_decode_fused_launches_equal_launch_per_op).  Fusion is written out with fmaf where wanted.
 #pragma clang fp contract(off)
 
 namespace aha {
@@ -82,6 +82,11 @@ __device__ __forceinline__ float2 act_ldf2(const float* p) {
   if (!COH) return *reinterpret_cast<const float2*>(p);
   const uint64_t a = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return make_float2(__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)(a >> 32)));
+}
+template <bool COH>
+__device__ __forceinline__ float act_ldf(const float* p) {
+  if (!COH) return *p;
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <bool COH>
 __device__ __forceinline__ bf16_t act_ld_bf(const bf16_t* p) {

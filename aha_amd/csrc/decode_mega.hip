@@ -8,7 +8,7 @@
 // (2 blocks per CU) and phases are separated by a grid barrier instead; because weights do not depend on activations,
 // every block requests the first weight tile of phase p+1 BEFORE it waits for phase p to complete, so HBM keeps
 // streaming across the dependency.  The arithmetic is the stand-alone kernels' (gemv_body.h, attn_decode_body.h):
-// the two decode paths are bit-identical (tests/test_model_gpu.py::test_decode_mega_equals_multi_kernel).
+// the two decode paths are bit-identical (tests/test_model_gpu.py::test_decode_fused_launches_equal_launch_per_op).
 //
 // Grid barrier: see GridBarrier below.  A bounded spin turns a would-be hang into a reported error.
 #include <stdlib.h>
@@ -129,15 +129,15 @@ __global__ __launch_bounds__(256, 2) void decode_step_kernel(DecodeMegaArgs a) {
       f.axis_map = a.axis_map; f.kv.page_ptrs = a.page_ptrs; f.kv.layer_off = L.kv_layer_off; f.kv.kvh = a.kvh; f.kv.d = 128;
       f.kv_start = &a.state->kv_start; f.kv_len = &a.state->kv_len; f.part_o = a.part_o; f.part_ml = a.part_ml;
       f.nh = a.nh; f.kvh = a.kvh; f.nsplit = a.nsplit; f.eps = a.eps; f.scale = a.scale;
+      f.o = a.attn; f.head_ctr = a.bar + DECODE_HEAD_CTR_WORD; f.ctr_target = a.head_ctr_target + (unsigned)li * (unsigned)a.nsplit;
       stamp(0);
       attn_decode_fused_body<true>(f, smem, bid % a.kvh, bid / a.kvh, a.nsplit, wait);
       stamp(2);
       bar.arrive();
     }
-    {  // x = x + attn Wo^T, attn = merge of the KV-split partials     (modules.rs:577, qwen3/model.rs:81)
+    {  // x = x + attn Wo^T                                           (modules.rs:577, qwen3/model.rs:81)
       GemvArgs g{};
-      g.W = L.wo; g.residual = x_in; g.y = a.x; g.N = a.H; g.K = nq;
-      g.comb_o = a.part_o; g.comb_ml = a.part_ml; g.comb_n = a.nsplit; g.comb_nh = a.nh;
+      g.W = L.wo; g.x = a.attn; g.residual = x_in; g.y = a.x; g.N = a.H; g.K = nq;
       // Blocks without an attention unit come straight here: their o_proj tile is requested first, then they pass the
       // qkv barrier and announce themselves at the attention barrier in order (group counters assume that no block
       // arrives at barrier k+1 before every block of its group has arrived at barrier k).
@@ -181,6 +181,45 @@ __global__ __launch_bounds__(256, 2) void decode_step_kernel(DecodeMegaArgs a) {
   }
 }
 
+// ---- attention + o_proj in one launch (default decode path) ---------------------------------------------------------------
+// A full grid barrier costs as much as a kernel boundary (profiles/r01_decode_mega_timeline.md), but the attention ->
+// o_proj dependency is few-to-many: the kvh blocks that merged a kv head's splits produce, all blocks consume.  One launch
+// of the o_proj grid: the first kvh*nsplit blocks run the fused attention body, the merging block of each kv head bumps
+// a counter (kvh same-address atomics), every block requests its first o_proj weight tile immediately and waits for the
+// counter only before the prologue that reads the attention output.  Removes one kernel boundary per layer and
+// hides the attention latency behind the o_proj weight stream.  Blocks are dispatched in index order, so the producers
+// are always resident before any consumer spins.
+template <int R, int U>
+__global__ __launch_bounds__(256, 2) void attn_oproj_kernel(AttnDecodeFusedArgs f, GemvArgs g, unsigned* sync, unsigned target) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = blockIdx.x, nblk = gridDim.x;
+  unsigned* ctr = sync + DECODE_AO_CTR_WORD;
+  unsigned* err = sync + DECODE_MEGA_BAR_ERR_WORD;
+  if (bid < f.kvh * f.nsplit) {
+    if (attn_decode_fused_body<true>(f, smem, bid % f.kvh, bid / f.kvh, f.nsplit, [] {})) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's slice of the attention output has been acknowledged
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  gemv_body<R, U, GEMV_RESIDUAL, true>(g, reinterpret_cast<float*>(smem), bid, nblk, [&] {
+    if (threadIdx.x == 0) {
+      unsigned polls = 0;
+      while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if ((++polls & 63u) == 0) {
+          if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+          if (polls > SPIN_LIMIT) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  });
+}
+
 template <class P>
 int occupancy_of(size_t lds) {
   int nb = 0;
@@ -198,6 +237,27 @@ size_t decode_mega_lds_bytes(int H, int I, int nq) {
 
 int decode_mega_max_blocks_per_cu(int H, size_t lds) {
   return H >= 2048 ? occupancy_of<ProfileLarge>(lds) : occupancy_of<ProfileSmall>(lds);
+}
+
+size_t attn_oproj_lds_bytes(int nq) {
+  const size_t xs = (size_t)((nq + 511) / 512) * 512 * 4 + 64;
+  return xs > (size_t)ATTN_DECODE_FUSED_LDS ? xs : (size_t)ATTN_DECODE_FUSED_LDS;
+}
+
+// g: the o_proj matvec (GEMV_RESIDUAL, x = f.o).  target: value the counter reaches when this launch's kvh merging
+// blocks have all arrived.  Grid: the matvec's own persistent grid (>= kvh*nsplit).
+void launch_attn_oproj(const AttnDecodeFusedArgs& f, const GemvArgs& g, unsigned* sync, unsigned target, hipStream_t st) {
+  const int nchunks = (g.K + 511) / 512;
+  const int ntiles = (g.N + 3) / 4;
+  int grid = ntiles < 512 ? ntiles : 512;
+  if (grid < f.kvh * f.nsplit) grid = f.kvh * f.nsplit;
+  const size_t lds = attn_oproj_lds_bytes(g.K);
+  if (nchunks >= 8)
+    hipLaunchKernelGGL((attn_oproj_kernel<1, 8>), dim3(grid), dim3(256), lds, st, f, g, sync, target);
+  else if (nchunks >= 4)
+    hipLaunchKernelGGL((attn_oproj_kernel<1, 4>), dim3(grid), dim3(256), lds, st, f, g, sync, target);
+  else
+    hipLaunchKernelGGL((attn_oproj_kernel<1, 2>), dim3(grid), dim3(256), lds, st, f, g, sync, target);
 }
 
 void launch_decode_mega(const DecodeMegaArgs& a, int grid, size_t lds, hipStream_t st) {

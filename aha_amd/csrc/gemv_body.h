@@ -83,53 +83,10 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, float* xs, const in
     float ss = 0.f;
     for (int v = tid; v < (nchunks << 6); v += GEMV_THREADS) {
       float f[8];
-      if (a.comb_o != nullptr && v * 8 < K) {
-        // merge the KV-split partials of head v/16, dims (v%16)*8..+8 (attention output tensor, rounded to bf16)
-        const int head = v >> 4, d0 = (v & 15) * 8;
-        float M = -INFINITY, ls = 0.f;
+      u32x4_t xv = {0u, 0u, 0u, 0u};
+      if (v * 8 < K) xv = act_ld16<COH>(x + v * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = 0.f;
-        // 8 splits per round, all 24 loads of a round issued before any is used (an un-unrolled loop serialises
-        // them: +7 us on the o_proj matvec); running (M, ls, f) are rescaled online between rounds
-        for (int s0 = 0; s0 < a.comb_n; s0 += 8) {
-          float2 ml[8];
-          float4 p0[8], p1[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int sidx = min(s0 + j, a.comb_n - 1);
-            const size_t hb = (size_t)sidx * a.comb_nh + head;
-            ml[j] = act_ldf2<COH>(a.comb_ml + hb * 2);
-            const float* po = a.comb_o + hb * 128 + d0;
-            p0[j] = act_ldf4<COH>(po);
-            p1[j] = act_ldf4<COH>(po + 4);
-            if (s0 + j >= a.comb_n) ml[j].x = -INFINITY;
-          }
-          float Mc = M;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) Mc = fmaxf(Mc, ml[j].x);
-          if (Mc == -INFINITY) continue;
-          const float resc = (M == -INFINITY) ? 0.f : __expf(M - Mc);
-          ls *= resc;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) f[j] *= resc;
-          M = Mc;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float wgt = (ml[j].x == -INFINITY) ? 0.f : __expf(ml[j].x - M);
-            ls += wgt * ml[j].y;
-            f[0] += wgt * p0[j].x; f[1] += wgt * p0[j].y; f[2] += wgt * p0[j].z; f[3] += wgt * p0[j].w;
-            f[4] += wgt * p1[j].x; f[5] += wgt * p1[j].y; f[6] += wgt * p1[j].z; f[7] += wgt * p1[j].w;
-          }
-        }
-        const float inv = 1.0f / ls;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = rbf(f[j] * inv);
-      } else {
-        u32x4_t xv = {0u, 0u, 0u, 0u};
-        if (v * 8 < K) xv = act_ld16<COH>(x + v * 8);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { f[2 * j] = lo_bf(xv[j]); f[2 * j + 1] = hi_bf(xv[j]); }
-      }
+      for (int j = 0; j < 4; ++j) { f[2 * j] = lo_bf(xv[j]); f[2 * j + 1] = hi_bf(xv[j]); }
 #pragma unroll
       for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
       const int base = xs_index(v * 8);

@@ -32,11 +32,6 @@ struct GemvArgs {
   int N, K;
   float eps;
   int cached;            // 0 (default): non-temporal weight loads (streamed once); 1: default cache policy
-  // optional: x is the attention output still split over comb_n KV splits (attn_decode_fused_kernel); the prologue
-  // merges them: x[h*128+d] = bf16( sum_s e^{m_s-M} o_s[h][d] / sum_s e^{m_s-M} l_s )   (K == comb_nh*128)
-  const float* comb_o;   // (comb_n, comb_nh, 128) f32
-  const float* comb_ml;  // (comb_n, comb_nh, 2) f32
-  int comb_n, comb_nh;
 };
 void launch_gemv(const GemvArgs& a, GemvEpi epi, hipStream_t st);
 int gemv_num_tiles(int N, int K);  // number of (max,idx) partials GEMV_LOGITS writes
@@ -84,7 +79,8 @@ struct AttnDecodeArgs {
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t st);
 
 // Fused decode step of the attention block: q/k norm + rope + KV append + split-KV attention (kernels_attn.hip).
-// Leaves nsplit un-normalised partials per head; the o_proj matvec merges them in its prologue (GemvArgs::comb_*).
+// The last split block of a kv head to finish merges the nsplit partials of the head's query heads and writes the bf16
+// attention output (o); head_ctr / ctr_target decide who is last (monotonic counters, one 128-byte line per kv head).
 struct AttnDecodeFusedArgs {
   const void* qkv;          // ((nh+2kvh)*128) bf16: output of the fused QKV matvec
   const void* q_norm_w;     // (128) bf16
@@ -97,6 +93,9 @@ struct AttnDecodeFusedArgs {
   const int32_t* kv_len;    // device scalar: cache length after the append (= kv_start + 1)
   float* part_o;            // (nsplit, nh, 128) f32
   float* part_ml;           // (nsplit, nh, 2) f32
+  void* o;                  // (nh*128) bf16 attention output
+  unsigned* head_ctr;       // [32 * kvhd]: split blocks of the head that have published their partial (all launches)
+  unsigned ctr_target;      // value head_ctr reaches when this launch's nsplit blocks have all arrived
   int nh, kvh, nsplit;
   float eps, scale;
 };
@@ -147,6 +146,8 @@ struct DecodeMegaArgs {
   void* act;                     // (I) bf16
   float* part_o;                 // (nsplit, nh, 128) f32 attention partials
   float* part_ml;                // (nsplit, nh, 2) f32
+  void* attn;                    // (nh*128) bf16 attention output
+  unsigned head_ctr_target;      // see AttnDecodeFusedArgs::ctr_target
   const float* inv_freq;
   const int32_t* axis_map;
   const uint64_t* page_ptrs;
@@ -164,11 +165,14 @@ struct DecodeMegaArgs {
 };
 constexpr size_t DECODE_MEGA_BAR_BYTES = 32768;
 constexpr int DECODE_MEGA_BAR_ERR_WORD = 32;
+constexpr int DECODE_HEAD_CTR_WORD = 6144;  // + 32 * kv head: split-arrival counters of the fused decode attention
+constexpr int DECODE_AO_CTR_WORD = 2048;  // arrival counter of the attention + o_proj launch (monotonic)
 // barriers one launch passes: the host advances bar_done0 by this
 inline int decode_mega_barriers(int n_layers) { return 5 * n_layers; }
 size_t decode_mega_lds_bytes(int H, int I, int nq);
 int decode_mega_max_blocks_per_cu(int H, size_t lds);
 void launch_decode_mega(const DecodeMegaArgs& a, int grid, size_t lds, hipStream_t st);
+void launch_attn_oproj(const AttnDecodeFusedArgs& f, const GemvArgs& g, unsigned* sync, unsigned target, hipStream_t st);
 
 }  // namespace aha
 

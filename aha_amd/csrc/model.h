@@ -107,6 +107,9 @@ struct aha_model {
   float* p_partial = nullptr;   // prefill: (S, hidden) f32
   // persistent decode-step kernel (decode_mega.hip): one launch per token
   bool decode_mega = false;
+  bool decode_ao = false;           // attention + o_proj in one launch (default decode path)
+  unsigned head_ctr_base = 0;       // value every kv head's split-arrival counter has reached after all launches so far
+  unsigned ao_base = 0;             // value the attn_oproj arrival counter has reached after all launches so far
   aha::DecodeLayerDev* d_layers_dev = nullptr;
   unsigned* d_bar = nullptr;        // grid-barrier words (kernels.h DECODE_MEGA_BAR_BYTES)
   unsigned* h_bar_err = nullptr;    // pinned copy of the sticky error word

@@ -519,7 +519,7 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
   if ((rc = dev_alloc(m, (size_t)H * 2, &m->d_x, false, true))) return fail(rc);
   if ((rc = dev_alloc(m, (size_t)(nq + 2 * nkv) * 2, &m->d_qkv, false, true))) return fail(rc);
   if ((rc = dev_alloc(m, (size_t)nq * 2, &m->d_q))) return fail(rc);
-  if ((rc = dev_alloc(m, (size_t)nq * 2, &m->d_attn))) return fail(rc);
+  if ((rc = dev_alloc(m, (size_t)nq * 2, &m->d_attn, false, true))) return fail(rc);
   if ((rc = dev_alloc(m, (size_t)I * 2, &m->d_act, false, true))) return fail(rc);
   if ((rc = dev_alloc(m, (size_t)H * 2, &m->d_hlast, true))) return fail(rc);
   if ((rc = dev_alloc(m, (size_t)H * 4, &p))) return fail(rc);
@@ -536,6 +536,14 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
   if ((rc = dev_alloc(m, (size_t)m->max_nsplit * 4 * c.num_attention_heads * 2 * 4, &p, false, true))) return fail(rc);
   m->d_part_ml = (float*)p;
 
+  // words the in-kernel synchronisation uses (kernels.h DECODE_MEGA_BAR_BYTES): uncached, zeroed once, only ever grow
+  if ((rc = dev_alloc(m, DECODE_MEGA_BAR_BYTES, &p, true, true))) return fail(rc);
+  m->d_bar = (unsigned*)p;
+  AHA_HIP_CHECK(hipHostMalloc((void**)&m->h_bar_err, 4));
+  *m->h_bar_err = 0;
+  // attention + o_proj in one launch (decode_mega.hip attn_oproj_kernel): default; AHA_DECODE_AO=0 -> two launches
+  m->decode_ao = m->tp_size == 1 && d == 128 && m->decode_fused;
+  if (const char* e = getenv("AHA_DECODE_AO")) m->decode_ao = m->decode_ao && atoi(e) != 0;
   // persistent decode-step kernel: resident grid sized by the occupancy the kernel actually gets on this device
   {
     // Opt-in (AHA_DECODE_MEGA=1): measured 6-25% SLOWER than the launch-per-op path on MI355X -- see DESIGN.md and
@@ -560,10 +568,6 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
         if ((rc = dev_alloc(m, hl.size() * sizeof(DecodeLayerDev), &p))) return fail(rc);
         m->d_layers_dev = (DecodeLayerDev*)p;
         AHA_HIP_CHECK(hipMemcpy(p, hl.data(), hl.size() * sizeof(DecodeLayerDev), hipMemcpyHostToDevice));
-        if ((rc = dev_alloc(m, DECODE_MEGA_BAR_BYTES, &p, true, true))) return fail(rc);
-        m->d_bar = (unsigned*)p;
-        AHA_HIP_CHECK(hipHostMalloc((void**)&m->h_bar_err, 4));
-        *m->h_bar_err = 0;
         m->decode_mega = m->mega_grid >= c.num_key_value_heads;
       }
     }
@@ -673,10 +677,16 @@ static void enqueue_lm_head(aha_model* m, const void* x_last) {
 // The persistent decode kernel's grid barrier gave up (a block was not scheduled or died): report instead of hanging, and
 // fall back to the multi-kernel path for the rest of the model's life.
 static int mega_check(aha_model* m) {
-  if (!m->decode_mega || *m->h_bar_err == 0) return AHA_OK;
+  if (*m->h_bar_err == 0) return AHA_OK;
   m->decode_mega = false;
-  set_error("persistent decode kernel: grid barrier timed out (results of this call are invalid); "
-            "falling back to the multi-kernel decode path");
+  m->decode_ao = false;
+  *m->h_bar_err = 0;
+  hipMemsetAsync(m->d_bar, 0, DECODE_MEGA_BAR_BYTES, m->stream);
+  m->bar_base = 0;
+  m->ao_base = 0;
+  m->head_ctr_base = 0;
+  set_error("decode: an in-kernel wait timed out (results of this call are invalid); "
+            "falling back to one launch per op");
   return AHA_ERR_HIP;
 }
 
@@ -712,7 +722,7 @@ static int fetch_outputs(aha_model* m, float* logits_out, uint32_t* argmax_out) 
   const aha_model_desc& c = m->desc;
   if (logits_out) AHA_HIP_CHECK(hipMemcpyAsync(m->h_logits, m->d_logits, (size_t)c.vocab_size * 4, hipMemcpyDeviceToHost, m->stream));
   AHA_HIP_CHECK(hipMemcpyAsync(&m->h_state->next_token, &m->d_state->next_token, 4, hipMemcpyDeviceToHost, m->stream));
-  if (m->decode_mega) AHA_HIP_CHECK(hipMemcpyAsync(m->h_bar_err, m->d_bar + DECODE_MEGA_BAR_ERR_WORD, 4, hipMemcpyDeviceToHost, m->stream));
+  if (m->decode_mega || m->decode_ao) AHA_HIP_CHECK(hipMemcpyAsync(m->h_bar_err, m->d_bar + DECODE_MEGA_BAR_ERR_WORD, 4, hipMemcpyDeviceToHost, m->stream));
   AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
   if (int e = mega_check(m)) return e;
   if (m->d_mega_trace) mega_trace_dump(m);
@@ -796,7 +806,7 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
     const int npg = (int)((kv_len_after + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS);
     DecodeMegaArgs a{};
     a.layers = m->d_layers_dev; a.n_layers = c.num_hidden_layers; a.embed = m->embed; a.state = m->d_state;
-    a.x = m->d_x; a.qkv = m->d_qkv; a.act = m->d_act; a.part_o = m->d_part_o; a.part_ml = m->d_part_ml;
+    a.x = m->d_x; a.qkv = m->d_qkv; a.act = m->d_act; a.part_o = m->d_part_o; a.part_ml = m->d_part_ml; a.attn = m->d_attn;
     a.inv_freq = m->d_inv_freq; a.axis_map = m->d_axis_map; a.page_ptrs = m->d_page_ptrs;
     a.final_norm = m->final_norm; a.lm_head = m->lm_head; a.logits = m->d_logits; a.blk_max = m->d_blk_max;
     a.blk_idx = m->d_blk_idx; a.h_out = m->d_hlast;
@@ -815,6 +825,8 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
     }
     static const char* e_ns = getenv("AHA_MEGA_NSPLIT_MAX");
     if (e_ns) a.nsplit = std::max(1, std::min(a.nsplit, atoi(e_ns)));
+    a.head_ctr_target = m->head_ctr_base + (unsigned)a.nsplit;  // layer 0's target; layer li adds li * nsplit
+    if (a.nsplit > 1) m->head_ctr_base += (unsigned)(c.num_hidden_layers * a.nsplit);  // a single split never touches it
     {
       const double wbytes = (double)c.num_hidden_layers * ((double)(nq + 2 * nkv) * H + (double)H * nq + 3.0 * I * H) * 2 +
                             (double)c.vocab_size * H * 2;
@@ -843,20 +855,29 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
       launch_gemv(g, GEMV_STORE, st);
     }
     if (m->decode_fused) {
-      {  // q/k norm + rope + KV append + attention over the paged cache, one launch   (modules.rs:544-574, 757-813)
-        AttnDecodeFusedArgs a{};
-        a.qkv = m->d_qkv; a.q_norm_w = L.q_norm; a.k_norm_w = L.k_norm; a.pos = m->d_state->pos; a.inv_freq = m->d_inv_freq;
-        a.axis_map = m->d_axis_map; a.kv = model_kv_layer(m, li); a.kv_start = &m->d_state->kv_start; a.kv_len = &m->d_state->kv_len;
-        a.part_o = m->d_part_o; a.part_ml = m->d_part_ml; a.nh = nh; a.kvh = kvh; a.nsplit = nsplit; a.eps = c.rms_norm_eps;
-        a.scale = m->attn_scale;
-        ProfScope ps(m, "attn_decode", (double)kv_len_after * 2 * nkv * 2 + (nq + 2 * nkv) * 2.0 + nsplit * nq * 4.0, 4.0 * kv_len_after * nq);
-        launch_attn_decode_fused(a, st);
-      }
-      {  // x = x + attn Wo^T, attn = merge of the KV-split partials in the prologue  (modules.rs:577, qwen3/model.rs:81)
-        GemvArgs g{};
-        g.W = L.wo; g.x = m->d_attn; g.residual = m->d_x; g.y = m->d_x; g.N = H; g.K = nq;
-        g.comb_o = m->d_part_o; g.comb_ml = m->d_part_ml; g.comb_n = nsplit; g.comb_nh = nh;
-        ProfScope ps(m, "gemv", (double)g.N * g.K * 2 + g.K * 2.0 + g.N * 4.0, 2.0 * g.N * g.K);
+      // q/k norm + rope + KV append + attention over the paged cache (modules.rs:544-574, 757-813), then
+      // x = x + attn Wo^T with the KV-split partials merged in the matvec prologue (modules.rs:577, qwen3/model.rs:81)
+      AttnDecodeFusedArgs a{};
+      a.qkv = m->d_qkv; a.q_norm_w = L.q_norm; a.k_norm_w = L.k_norm; a.pos = m->d_state->pos; a.inv_freq = m->d_inv_freq;
+      a.axis_map = m->d_axis_map; a.kv = model_kv_layer(m, li); a.kv_start = &m->d_state->kv_start; a.kv_len = &m->d_state->kv_len;
+      a.part_o = m->d_part_o; a.part_ml = m->d_part_ml; a.nh = nh; a.kvh = kvh; a.nsplit = nsplit; a.eps = c.rms_norm_eps;
+      a.scale = m->attn_scale; a.o = m->d_attn; a.head_ctr = m->d_bar + DECODE_HEAD_CTR_WORD;
+      if (nsplit > 1) m->head_ctr_base += (unsigned)nsplit;  // a single split never touches the counter
+      a.ctr_target = m->head_ctr_base;
+      GemvArgs g{};
+      g.W = L.wo; g.x = m->d_attn; g.residual = m->d_x; g.y = m->d_x; g.N = H; g.K = nq;
+      const double attn_bytes = (double)kv_len_after * 2 * nkv * 2 + (nq + 2 * nkv) * 2.0 + nsplit * nq * 4.0;
+      const double gemv_bytes = (double)g.N * g.K * 2 + g.K * 2.0 + g.N * 4.0;
+      if (m->decode_ao) {  // one launch: attention blocks signal the o_proj grid through a counter
+        m->ao_base += (unsigned)kvh;
+        ProfScope ps(m, "attn_oproj", attn_bytes + gemv_bytes, 4.0 * kv_len_after * nq + 2.0 * g.N * g.K);
+        launch_attn_oproj(a, g, m->d_bar, m->ao_base, st);
+      } else {
+        {
+          ProfScope ps(m, "attn_decode", attn_bytes, 4.0 * kv_len_after * nq);
+          launch_attn_decode_fused(a, st);
+        }
+        ProfScope ps(m, "gemv", gemv_bytes, 2.0 * g.N * g.K);
         gemv_row_parallel(m, g);
       }
     } else {  // three-launch variant (A/B knob AHA_DECODE_FUSED=0)
@@ -953,7 +974,7 @@ int model_decode_greedy(aha_model* m, uint32_t first_token, size_t offset, size_
     AHA_HIP_CHECK(hipGetLastError());
     if (m->async_rc) { const int e = m->async_rc; m->async_rc = 0; return e; }
     AHA_HIP_CHECK(hipMemcpyAsync(out + produced, m->d_token_log, n * 4, hipMemcpyDeviceToHost, m->stream));
-    if (m->decode_mega) AHA_HIP_CHECK(hipMemcpyAsync(m->h_bar_err, m->d_bar + DECODE_MEGA_BAR_ERR_WORD, 4, hipMemcpyDeviceToHost, m->stream));
+    if (m->decode_mega || m->decode_ao) AHA_HIP_CHECK(hipMemcpyAsync(m->h_bar_err, m->d_bar + DECODE_MEGA_BAR_ERR_WORD, 4, hipMemcpyDeviceToHost, m->stream));
     AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
     if (int e = mega_check(m)) return e;
     size_t used = n;

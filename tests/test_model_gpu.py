@@ -213,10 +213,11 @@ def test_missing_weight_is_an_error(gpu):
 
 
 @pytest.mark.parametrize("shape", ["small", "8b-width"])
-def test_decode_mega_equals_multi_kernel(gpu, monkeypatch, shape):
-    """The persistent decode-step kernel (decode_mega.hip) and the launch-per-op path share their device code: logits must
-    be BIT-identical at every step, across page boundaries (63/64/65, 127/128) and KV-split counts, and so must the
-    device greedy loop's tokens."""
+@pytest.mark.parametrize("path", ["attn_oproj", "mega"])
+def test_decode_fused_launches_equal_launch_per_op(gpu, monkeypatch, shape, path):
+    """The decode paths that synchronise inside a launch -- attention + o_proj in one launch (default) and the persistent
+    decode-step kernel (AHA_DECODE_MEGA=1) -- share their device code with the launch-per-op path (AHA_DECODE_AO=0): logits
+    must be BIT-identical at every step, across page boundaries and KV-split counts, and so must the device greedy loop."""
     from aha_amd.model import HipInferenceModel
     if shape == "small":
         cfg, w = make()
@@ -226,8 +227,10 @@ def test_decode_mega_equals_multi_kernel(gpu, monkeypatch, shape):
         w = qwen3_text_weights(cfg, seed=3)
         lens = [97, 1500]
     monkeypatch.setenv("AHA_DECODE_MEGA", "0")
+    monkeypatch.setenv("AHA_DECODE_AO", "0")
     multi = HipInferenceModel(cfg, w)
-    monkeypatch.setenv("AHA_DECODE_MEGA", "1")
+    monkeypatch.setenv("AHA_DECODE_MEGA", "1" if path == "mega" else "0")
+    monkeypatch.setenv("AHA_DECODE_AO", "1")
     mega = HipInferenceModel(cfg, w)
     for S in lens:
         ids = ids_for(cfg, S, 100 + S)
