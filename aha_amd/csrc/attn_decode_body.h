@@ -60,7 +60,7 @@ __device__ __forceinline__ bool attn_decode_fused_body(const AttnDecodeFusedArgs
       const bf16_t* src = is_k ? qkv + (int64_t)(a.nh + kvhd) * 128 : qkv + (int64_t)(kvhd * g + hs) * 128;
       const bf16_t* nw = (const bf16_t*)(is_k ? a.k_norm_w : a.q_norm_w);
       float x0 = bf2f(act_ld_bf<COH>(src + lane)), x1 = bf2f(act_ld_bf<COH>(src + lane + 64));
-      const float ss = wave_sum(x0 * x0 + x1 * x1);
+      const float ss = wave_sum(fmaf(x0, x0, x1 * x1));  // explicit: `a*a + b*b` can be fused two ways
       const float rinv = 1.0f / sqrtf(ss / 128.0f + a.eps);
       x0 = rbf(x0 * rinv * bf2f(nw[lane]));
       x1 = rbf(x1 * rinv * bf2f(nw[lane + 64]));
@@ -132,7 +132,7 @@ __device__ __forceinline__ bool attn_decode_fused_body(const AttnDecodeFusedArgs
 #pragma unroll
     for (int ds = 0; ds < 8; ++ds)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[ds][r] = o[ds][r] * alpha + p * bf2f(vsn[ds * 16 + G * 4 + r]);
+      for (int r = 0; r < 4; ++r) o[ds][r] = fmaf(p, bf2f(vsn[ds * 16 + G * 4 + r]), o[ds][r] * alpha);
   }
   l = group_sum(l);
 

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void decode_step_kernel(DecodeMegaArgs a) {
   }
 }
 
-// ---- attention + o_proj in one launch (default decode path) ---------------------------------------------------------------
+// ---- attention + o_proj in one launch (opt-in: AHA_DECODE_AO=1) ---------------------------------------------------------------
 // A full grid barrier costs as much as a kernel boundary (profiles/r01_decode_mega_timeline.md), but the attention ->
 // o_proj dependency is few-to-many: the kvh blocks that merged a kv head's splits produce, all blocks consume.  One launch
 // of the o_proj grid: the first kvh*nsplit blocks run the fused attention body, the merging block of each kv head bumps

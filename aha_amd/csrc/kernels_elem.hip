@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(RopeArgs a) {
   const bool is_k = !is_q && slot < a.nh + a.kvh;
   if (is_q || is_k) {
     const bf16_t* nw = (const bf16_t*)(is_q ? a.q_norm_w : a.k_norm_w);
-    const float ss = wave_sum(x0 * x0 + x1 * x1);
+    const float ss = wave_sum(fmaf(x0, x0, x1 * x1));
     const float rinv = 1.0f / sqrtf(ss / 128.0f + a.eps);
     x0 = rbf(x0 * rinv * bf2f(nw[lane]));
     x1 = rbf(x1 * rinv * bf2f(nw[lane + 64]));

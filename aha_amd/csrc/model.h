@@ -107,7 +107,7 @@ struct aha_model {
   float* p_partial = nullptr;   // prefill: (S, hidden) f32
   // persistent decode-step kernel (decode_mega.hip): one launch per token
   bool decode_mega = false;
-  bool decode_ao = false;           // attention + o_proj in one launch (default decode path)
+  bool decode_ao = false;           // attention + o_proj in one launch (opt-in)
   unsigned head_ctr_base = 0;       // value every kv head's split-arrival counter has reached after all launches so far
   unsigned ao_base = 0;             // value the attn_oproj arrival counter has reached after all launches so far
   aha::DecodeLayerDev* d_layers_dev = nullptr;
@@ -161,7 +161,7 @@ void tp_destroy(aha_model* m);
 const aha_tensor_view* find_tensor(const aha_tensor_view* w, size_t nw, const std::string& name);
 int upload_tensor(aha_model* m, const aha_tensor_view* t, const std::vector<int64_t>& shape, void** out,
                   int64_t pad_rows_to = 0, int64_t pad_cols_to = 0);
-int dev_alloc(aha_model* m, size_t bytes, void** out, bool zero = false, bool uncached = false);
+int dev_alloc(aha_model* m, size_t bytes, void** out, bool zero = false);
 
 struct ProfScope {
   aha_model* m;

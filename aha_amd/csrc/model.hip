@@ -67,13 +67,9 @@ int prof_collect(aha_model* m) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// uncached: device memory mapped so that no XCD L2 keeps a copy (the activation / barrier words the persistent decode kernel
-// exchanges between blocks on different XCDs inside one launch)
-int dev_alloc(aha_model* m, size_t bytes, void** out, bool zero, bool uncached) {
+int dev_alloc(aha_model* m, size_t bytes, void** out, bool zero) {
   void* p = nullptr;
-  static const char* e_unc = getenv("AHA_MEGA_UNCACHED");
-  if (e_unc && atoi(e_unc) == 0) uncached = false;
-  hipError_t e = uncached ? hipExtMallocWithFlags(&p, bytes ? bytes : 16, hipDeviceMallocUncached) : hipMalloc(&p, bytes ? bytes : 16);
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
   if (e != hipSuccess) {
     set_error("hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
     return e == hipErrorOutOfMemory ? AHA_ERR_OOM : AHA_ERR_HIP;
@@ -516,11 +512,11 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
   m->token_log_cap = 1 << 16;
   if ((rc = dev_alloc(m, m->token_log_cap * 4, &p))) return fail(rc);
   m->d_token_log = (uint32_t*)p;
-  if ((rc = dev_alloc(m, (size_t)H * 2, &m->d_x, false, true))) return fail(rc);
-  if ((rc = dev_alloc(m, (size_t)(nq + 2 * nkv) * 2, &m->d_qkv, false, true))) return fail(rc);
+  if ((rc = dev_alloc(m, (size_t)H * 2, &m->d_x))) return fail(rc);
+  if ((rc = dev_alloc(m, (size_t)(nq + 2 * nkv) * 2, &m->d_qkv))) return fail(rc);
   if ((rc = dev_alloc(m, (size_t)nq * 2, &m->d_q))) return fail(rc);
-  if ((rc = dev_alloc(m, (size_t)nq * 2, &m->d_attn, false, true))) return fail(rc);
-  if ((rc = dev_alloc(m, (size_t)I * 2, &m->d_act, false, true))) return fail(rc);
+  if ((rc = dev_alloc(m, (size_t)nq * 2, &m->d_attn))) return fail(rc);
+  if ((rc = dev_alloc(m, (size_t)I * 2, &m->d_act))) return fail(rc);
   if ((rc = dev_alloc(m, (size_t)H * 2, &m->d_hlast, true))) return fail(rc);
   if ((rc = dev_alloc(m, (size_t)H * 4, &p))) return fail(rc);
   m->d_partial = (float*)p;
@@ -531,19 +527,21 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
   m->d_blk_max = (float*)p;
   if ((rc = dev_alloc(m, (size_t)nt * 4, &p))) return fail(rc);
   m->d_blk_idx = (uint32_t*)p;
-  if ((rc = dev_alloc(m, (size_t)m->max_nsplit * 4 * c.num_attention_heads * d * 4, &p, false, true))) return fail(rc);
+  if ((rc = dev_alloc(m, (size_t)m->max_nsplit * 4 * c.num_attention_heads * d * 4, &p))) return fail(rc);
   m->d_part_o = (float*)p;
-  if ((rc = dev_alloc(m, (size_t)m->max_nsplit * 4 * c.num_attention_heads * 2 * 4, &p, false, true))) return fail(rc);
+  if ((rc = dev_alloc(m, (size_t)m->max_nsplit * 4 * c.num_attention_heads * 2 * 4, &p))) return fail(rc);
   m->d_part_ml = (float*)p;
 
-  // words the in-kernel synchronisation uses (kernels.h DECODE_MEGA_BAR_BYTES): uncached, zeroed once, only ever grow
-  if ((rc = dev_alloc(m, DECODE_MEGA_BAR_BYTES, &p, true, true))) return fail(rc);
+  // words the in-kernel synchronisation uses (kernels.h DECODE_MEGA_BAR_BYTES): zeroed once, only ever grow; all accesses
+  // are agent-scope atomics (ordinary device memory: scripts/bench_barrier.hip saw no stale read in either mapping)
+  if ((rc = dev_alloc(m, DECODE_MEGA_BAR_BYTES, &p, true))) return fail(rc);
   m->d_bar = (unsigned*)p;
   AHA_HIP_CHECK(hipHostMalloc((void**)&m->h_bar_err, 4));
   *m->h_bar_err = 0;
-  // attention + o_proj in one launch (decode_mega.hip attn_oproj_kernel): default; AHA_DECODE_AO=0 -> two launches
-  m->decode_ao = m->tp_size == 1 && d == 128 && m->decode_fused;
-  if (const char* e = getenv("AHA_DECODE_AO")) m->decode_ao = m->decode_ao && atoi(e) != 0;
+  // attention + o_proj in one launch (decode_mega.hip attn_oproj_kernel): opt-in (AHA_DECODE_AO=1) -- measured 1.5-3%
+  // slower than two launches (profiles/r01_decode_mega_timeline.md)
+  m->decode_ao = false;
+  if (const char* e = getenv("AHA_DECODE_AO")) m->decode_ao = atoi(e) != 0 && m->tp_size == 1 && d == 128 && m->decode_fused;
   // persistent decode-step kernel: resident grid sized by the occupancy the kernel actually gets on this device
   {
     // Opt-in (AHA_DECODE_MEGA=1): measured 6-25% SLOWER than the launch-per-op path on MI355X -- see DESIGN.md and

@@ -215,8 +215,8 @@ def test_missing_weight_is_an_error(gpu):
 @pytest.mark.parametrize("shape", ["small", "8b-width"])
 @pytest.mark.parametrize("path", ["attn_oproj", "mega"])
 def test_decode_fused_launches_equal_launch_per_op(gpu, monkeypatch, shape, path):
-    """The decode paths that synchronise inside a launch -- attention + o_proj in one launch (default) and the persistent
-    decode-step kernel (AHA_DECODE_MEGA=1) -- share their device code with the launch-per-op path (AHA_DECODE_AO=0): logits
+    """The decode paths that synchronise inside a launch -- attention + o_proj in one launch (AHA_DECODE_AO=1) and the
+    persistent decode-step kernel (AHA_DECODE_MEGA=1) -- share their device code with the default launch-per-op path: logits
     must be BIT-identical at every step, across page boundaries and KV-split counts, and so must the device greedy loop."""
     from aha_amd.model import HipInferenceModel
     if shape == "small":
