@@ -92,6 +92,12 @@ SIGNATURES = {
                                        C.c_int32, C.c_int32, C.c_float, _P]),
     "aha_hip_argmax": (C.c_int, [_P, C.c_int64, _P, _P]),
     "aha_hip_logmel": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "aha_hip_config_parse": (C.c_int, [C.c_char_p, _P]),
+    "aha_hip_weights_open": (C.c_int, [C.c_char_p, _P]),
+    "aha_hip_weights_count": (C.c_size_t, [_P]),
+    "aha_hip_weights_get": (C.c_int, [_P, C.c_size_t, _P]),
+    "aha_hip_weights_close": (None, [_P]),
+    "aha_hip_model_load": (C.c_int, [_P, C.c_char_p, C.c_size_t, _P]),
     "aha_hip_set_allreduce": (C.c_int, [_P, _P, _P]),
     "aha_hip_tp_unique_id": (C.c_int, [_P]),
     "aha_hip_tp_init_rccl": (C.c_int, [_P, _P]),

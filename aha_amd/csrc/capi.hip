@@ -341,6 +341,44 @@ int aha_hip_image_to_patches(const uint8_t* img_hwc, void* out, int32_t H, int32
   return AHA_OK;
 }
 
+int aha_hip_config_parse(const char* model_dir, aha_model_desc* out) {
+  API_GUARD_BEGIN
+  if (!model_dir || !out) {
+    set_error("aha_hip_config_parse: null argument");
+    return AHA_ERR_INVALID;
+  }
+  return config_parse(model_dir, out);
+  API_GUARD_END
+}
+int aha_hip_weights_open(const char* model_dir, aha_weights** out) {
+  API_GUARD_BEGIN
+  if (!model_dir || !out) {
+    set_error("aha_hip_weights_open: null argument");
+    return AHA_ERR_INVALID;
+  }
+  return weights_open(model_dir, out);
+  API_GUARD_END
+}
+size_t aha_hip_weights_count(const aha_weights* w) { return w ? w->views.size() : 0; }
+int aha_hip_weights_get(const aha_weights* w, size_t index, aha_tensor_view* out) {
+  if (!w || !out || index >= w->views.size()) {
+    set_error("aha_hip_weights_get: bad handle or index");
+    return AHA_ERR_INVALID;
+  }
+  *out = w->views[index];
+  return AHA_OK;
+}
+void aha_hip_weights_close(aha_weights* w) { delete w; }
+int aha_hip_model_load(aha_ctx* ctx, const char* model_dir, size_t kv_reserve_tokens, aha_model** out) {
+  API_GUARD_BEGIN
+  if (!ctx || !model_dir || !out) {
+    set_error("aha_hip_model_load: null argument");
+    return AHA_ERR_INVALID;
+  }
+  return model_load(ctx, model_dir, kv_reserve_tokens, out);
+  API_GUARD_END
+}
+
 int aha_hip_set_allreduce(aha_model* m, aha_allreduce_fn fn, void* user) {
   if (!m) {
     set_error("null model");

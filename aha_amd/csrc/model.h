@@ -56,6 +56,15 @@ struct AudioModel;   // audio.h
 
 }  // namespace aha
 
+// mmapped checkpoint directory (loader.hip)
+struct aha_weights {
+  struct Mapping { void* base; size_t len; };
+  std::vector<Mapping> maps;
+  std::vector<std::string> names;       // stable storage for aha_tensor_view::name
+  std::vector<aha_tensor_view> views;
+  ~aha_weights();
+};
+
 struct aha_model {
   aha_ctx* ctx = nullptr;
   aha_model_desc desc{};
@@ -152,6 +161,10 @@ int model_ensure_pages(aha_model* m, size_t tokens);
 KvLayer model_kv_layer(aha_model* m, int layer);
 int prof_collect(aha_model* m);
 int model_allreduce(aha_model* m, float* buf, size_t count);
+// loader.hip
+int config_parse(const char* dir, aha_model_desc* out);
+int weights_open(const char* dir, aha_weights** out);
+int model_load(aha_ctx* ctx, const char* dir, size_t kv_reserve_tokens, aha_model** out);
 int rccl_allreduce(aha_model* m, float* buf, size_t count);  // tp_rccl.hip
 int tp_unique_id(void* out128);
 int tp_init_rccl(aha_model* m, const void* id128);

@@ -10,6 +10,7 @@ Everything numeric happens inside libaha_hip.so; this file only marshals buffers
 from __future__ import annotations
 
 import ctypes as C
+import os
 import time
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
@@ -150,6 +151,24 @@ class HipInferenceModel:
             check(lib().aha_hip_set_allreduce(self.handle, self._allreduce_c, None))
         self.vocab = self.text_cfg.vocab_size
         self._logits = np.empty(self.vocab, dtype=np.float32)
+
+    @classmethod
+    def from_pretrained(cls, path: str, ctx: Optional[HipContext] = None, device: int = 0, kv_reserve_tokens: int = 0):
+        """== XxxGenerateModel::init(path, device, dtype) minus tokenizer / chat template (qwen3/generate.rs:22-50): the
+        native loader reads config.json + generation_config.json, mmaps every *.safetensors file and builds the model."""
+        from .checkpoint import config_from_desc, parse_config
+        self = cls.__new__(cls)
+        self.desc = parse_config(path)
+        self.cfg = config_from_desc(self.desc)
+        self.text_cfg = self.cfg.text if isinstance(self.cfg, (Qwen3VLConfig, Qwen3ASRConfig)) else self.cfg
+        self._own_ctx = ctx is None
+        self.ctx = ctx or HipContext(device)
+        self.handle = C.c_void_p()
+        self._allreduce_c = None
+        check(lib().aha_hip_model_load(self.ctx.handle, os.fsencode(path), kv_reserve_tokens, C.byref(self.handle)))
+        self.vocab = int(self.desc.vocab_size)
+        self._logits = np.empty(self.vocab, dtype=np.float32)
+        return self
 
     # -- InferenceModel ------------------------------------------------------------------------------------------
     def forward_initial(self, input_ids: Sequence[int], seqlen_offset: int, data: Optional[MultiModalData] = None,

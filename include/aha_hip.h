@@ -117,6 +117,24 @@ int aha_hip_model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_ten
                          aha_model** out);
 void aha_hip_model_destroy(aha_model* m);
 
+/* ---- checkpoint directory -> model (XxxGenerateModel::init minus tokenizer / chat template) --------------------------
+ * aha_hip_config_parse: <dir>/config.json -> aha_model_desc, the same field mapping serde does into Qwen3Config
+ *   (/root/reference/src/models/qwen3/config.rs:4-27), Qwen3VLConfig (qwen3vl/config.rs:51-133, text_config / vision_config,
+ *   top-level tie_word_embeddings qwen3vl/model.rs:853) or Qwen3ASRConfig (qwen3_asr/config.rs:6-22, thinker_config.*);
+ *   stop tokens from <dir>/generation_config.json eos_token_id (qwen3/generate.rs:33-36; a scalar or a list).  The
+ *   architecture is taken from "model_type" / the presence of vision_config / thinker_config.  Host only (no GPU).
+ * aha_hip_weights_open: mmaps every *.safetensors file in <dir> (find_type_files, utils/mod.rs:121-137 +
+ *   VarBuilder::from_mmaped_safetensors, qwen3/generate.rs:30-31) and indexes the tensors; views point into the mappings
+ *   and stay valid until aha_hip_weights_close.  Host only.
+ * aha_hip_model_load = config_parse + weights_open + aha_hip_model_create + weights_close. */
+typedef struct aha_weights aha_weights;
+int aha_hip_config_parse(const char* model_dir, aha_model_desc* out);
+int aha_hip_weights_open(const char* model_dir, aha_weights** out);
+size_t aha_hip_weights_count(const aha_weights* w);
+int aha_hip_weights_get(const aha_weights* w, size_t index, aha_tensor_view* out);
+void aha_hip_weights_close(aha_weights* w);
+int aha_hip_model_load(aha_ctx* ctx, const char* model_dir, size_t kv_reserve_tokens, aha_model** out);
+
 /* ---- InferenceModel (common/mod.rs:25-45) ------------------------------------------------------------------- */
 /* forward_initial(&mut self, input_ids, seqlen_offset, data) -> logits (1,1,V).
  * logits_out (V floats, host, may be NULL) receives the last position's logits as f32 exactly as the generic loop
