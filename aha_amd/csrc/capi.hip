@@ -341,6 +341,15 @@ int aha_hip_image_to_patches(const uint8_t* img_hwc, void* out, int32_t H, int32
   return AHA_OK;
 }
 
+int aha_hip_embed(aha_model* m, const uint32_t* input_ids, size_t n_ids, float* out) {
+  API_GUARD_BEGIN
+  if (!m) {
+    set_error("null model");
+    return AHA_ERR_INVALID;
+  }
+  return model_embed(m, input_ids, n_ids, out);
+  API_GUARD_END
+}
 int aha_hip_config_parse(const char* model_dir, aha_model_desc* out) {
   API_GUARD_BEGIN
   if (!model_dir || !out) {

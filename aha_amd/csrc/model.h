@@ -152,6 +152,7 @@ namespace aha {
 // model.hip
 int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view* w, size_t nw, aha_model** out);
 void model_destroy(aha_model* m);
+int model_embed(aha_model* m, const uint32_t* ids, size_t n, float* out);
 int model_forward_initial(aha_model* m, const uint32_t* ids, size_t n, size_t offset, const aha_mm_input* mm,
                           float* logits_out, uint32_t* argmax_out);
 int model_forward_step(aha_model* m, uint32_t token, size_t offset, float* logits_out, uint32_t* argmax_out);

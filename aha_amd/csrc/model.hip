@@ -990,8 +990,46 @@ int model_decode_greedy(aha_model* m, uint32_t first_token, size_t offset, size_
 }
 
 // ---- prefill ---------------------------------------------------------------------------------------------------
+static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, size_t offset, const aha_mm_input* mm,
+                                float* logits_out, uint32_t* argmax_out, bool hidden_only);
+
 int model_forward_initial(aha_model* m, const uint32_t* ids, size_t n, size_t offset, const aha_mm_input* mm,
                           float* logits_out, uint32_t* argmax_out) {
+  return forward_initial_impl(m, ids, n, offset, mm, logits_out, argmax_out, false);
+}
+
+// Qwen3Embedding::embed_one (qwen3_embedding/mod.rs:50-64): forward_hidden(ids, offset 0) -> last position after the final
+// RMSNorm, bf16 -> f32, l2_normalize over the last dim (modules.rs:1287-1294: x / sqrt(sum(x^2) + 1e-6)), cache cleared.
+// The stack runs on the GPU without the lm_head; the H-element normalisation is f32 host arithmetic like the reference's.
+int model_embed(aha_model* m, const uint32_t* ids, size_t n, float* out) {
+  if (!out) {
+    set_error("embed: out is null");
+    return AHA_ERR_INVALID;
+  }
+  if (m->desc.arch != AHA_ARCH_QWEN3) {
+    set_error("embed: only the Qwen3 text stack has an embedding head in the reference (qwen3_embedding/mod.rs)");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  int rc = model_clear_cache(m);
+  if (rc) return rc;
+  if ((rc = forward_initial_impl(m, ids, n, 0, nullptr, nullptr, nullptr, true))) return rc;
+  const int H = m->desc.hidden_size;
+  std::vector<uint16_t> h((size_t)H);
+  AHA_HIP_CHECK(hipMemcpyAsync(h.data(), m->d_hlast, (size_t)H * 2, hipMemcpyDeviceToHost, m->stream));
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  float ss = 0.f;
+  for (int i = 0; i < H; ++i) {
+    uint32_t u = (uint32_t)h[i] << 16;
+    memcpy(&out[i], &u, 4);
+    ss += out[i] * out[i];
+  }
+  const float nrm = sqrtf(ss + 1e-6f);
+  for (int i = 0; i < H; ++i) out[i] /= nrm;
+  return model_clear_cache(m);
+}
+
+static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, size_t offset, const aha_mm_input* mm,
+                                float* logits_out, uint32_t* argmax_out, bool hidden_only) {
   const aha_model_desc& c = m->desc;
   if (!ids || n == 0) {
     set_error("forward_initial: empty input_ids");
@@ -1104,6 +1142,12 @@ int model_forward_initial(aha_model* m, const uint32_t* ids, size_t n, size_t of
       // DeepStack: add visual feature k to the visual rows after decoder layer k (qwen3vl/model.rs:806-822)
       if ((rc = vision_deepstack_add(m, li, m->p_x))) return rc;
     }
+  }
+  if (hidden_only) {  // forward_hidden: final norm of the last position only (qwen3/model.rs:186-188)
+    launch_rmsnorm_rows((const char*)m->p_x + (size_t)(S - 1) * H * 2, m->final_norm, m->d_hlast, 1, H, H, H, c.rms_norm_eps, st);
+    m->cache_len += n;
+    AHA_HIP_CHECK(hipGetLastError());
+    return AHA_OK;
   }
   enqueue_lm_head(m, (const char*)m->p_x + (size_t)(S - 1) * H * 2);
   m->cache_len += n;

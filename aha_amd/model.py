@@ -236,6 +236,25 @@ class HipInferenceModel:
         torch.cuda.current_stream(t.device).synchronize()
         check(lib().aha_hip_debug_allreduce(self.handle, t.data_ptr(), t.numel()))
 
+    # -- TextEmbedding / TextRerank (common/embedding.rs:7-9, common/reranker.rs:5-7) ------------------------------------
+    def embed_one(self, input_ids: Sequence[int]) -> np.ndarray:
+        """Qwen3Embedding::embed_one after tokenisation (qwen3_embedding/mod.rs:50-64): L2-normalised last hidden state."""
+        ids = np.ascontiguousarray(np.asarray(input_ids, dtype=np.uint32).reshape(-1))
+        out = np.empty(self.text_cfg.hidden_size, dtype=np.float32)
+        check(lib().aha_hip_embed(self.handle, ids.ctypes.data_as(C.POINTER(C.c_uint32)), ids.size,
+                                  out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def embed_multi(self, inputs: Sequence[Sequence[int]]) -> np.ndarray:
+        if len(inputs) == 0:
+            raise ValueError("embedding input cannot be empty")  # qwen3_embedding/mod.rs:39-41
+        return np.stack([self.embed_one(x) for x in inputs], 0)
+
+    def rerank(self, query_ids: Sequence[int], documents_ids: Sequence[Sequence[int]]) -> np.ndarray:
+        """Qwen3Reranker::rerank (qwen3_reranker/mod.rs:23-31): cosine_similarity_no_l2(query, docs) on normalised vectors."""
+        q = self.embed_one(query_ids)[None, :]
+        return (q @ self.embed_multi(documents_ids).T)[0]
+
     def cache_len(self) -> int:
         return int(lib().aha_hip_cache_len(self.handle))
 

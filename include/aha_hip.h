@@ -117,6 +117,14 @@ int aha_hip_model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_ten
                          aha_model** out);
 void aha_hip_model_destroy(aha_model* m);
 
+/* ---- Qwen3-Embedding / Qwen3-Reranker ------------------------------------------------
+ * == Qwen3Embedding::embed_one after tokenisation (/root/reference/src/models/qwen3_embedding/mod.rs:50-64):
+ * forward_hidden(input_ids, offset 0) -> last position after the final RMSNorm -> f32 -> l2_normalize
+ * (common/modules.rs:1287-1294) -> out[hidden_size]; the KV cache is cleared before and after, as the reference does.
+ * Qwen3Reranker::rerank (qwen3_reranker/mod.rs:23-31) is the dot product of two such vectors
+ * (cosine_similarity_no_l2, modules.rs:1381-1389) -- host arithmetic on the caller's side. */
+int aha_hip_embed(aha_model* m, const uint32_t* input_ids, size_t n_ids, float* out);
+
 /* ---- checkpoint directory -> model (XxxGenerateModel::init minus tokenizer / chat template) --------------------------
  * aha_hip_config_parse: <dir>/config.json -> aha_model_desc, the same field mapping serde does into Qwen3Config
  *   (/root/reference/src/models/qwen3/config.rs:4-27), Qwen3VLConfig (qwen3vl/config.rs:51-133, text_config / vision_config,

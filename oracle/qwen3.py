@@ -201,6 +201,27 @@ class OracleQwen3:
         return self.nm.linear(h, self.lm_head)
 
 
+def l2_normalize(t: torch.Tensor) -> torch.Tensor:
+    """common/modules.rs:1287-1294: t / sqrt(sum(t^2, last dim) + 1e-6), in the tensor's dtype (f32 at the call site)."""
+    return t / torch.sqrt((t * t).sum(-1, keepdim=True) + 1e-6)
+
+
+def embed_one(model: "OracleQwen3", input_ids) -> torch.Tensor:
+    """Qwen3Embedding::embed_one (qwen3_embedding/mod.rs:50-64): forward_hidden(ids, None, 0).squeeze(0) -> f32 ->
+    clear_kv_cache -> NormalizeType::L2 over the last dim -> squeeze(0) => (hidden,) f32."""
+    model.clear_cache()
+    hidden = model.forward_hidden(input_ids, None, 0).squeeze(0).float()
+    model.clear_cache()
+    return l2_normalize(hidden).squeeze(0)
+
+
+def rerank(model: "OracleQwen3", query_ids, documents_ids) -> torch.Tensor:
+    """Qwen3Reranker::rerank (qwen3_reranker/mod.rs:23-31) with cosine_similarity_no_l2 (modules.rs:1381-1389)."""
+    q = embed_one(model, query_ids).unsqueeze(0)
+    d = torch.stack([embed_one(model, x) for x in documents_ids], 0)
+    return (q @ d.transpose(-1, -2)).squeeze(0)
+
+
 def greedy_generate(model, input_ids, max_tokens: int, mm=None, return_logits: bool = False):
     """generate_generic with temperature 0 (common/generate.rs:115-159; sample.rs:13-37 -> Sampling::ArgMax):
     prefill, argmax (first maximal index), then up to max_tokens-1 single-token steps; stop after pushing an eos id."""

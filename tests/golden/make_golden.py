@@ -50,6 +50,35 @@ def qwen3_case():
                         logits=np.stack(logits).astype(np.float32), tokens=np.asarray(toks, dtype=np.int64), seed=0)
 
 
+def qwen3_embedding_case():
+    """Qwen3-Embedding = the Qwen3 stack without lm_head, last-token pooling, L2 normalisation (HF model card recipe:
+    last_hidden_state[:, -1] -> F.normalize).  Stores the pooled hidden state un-normalised and normalised."""
+    from transformers import Qwen3Config as HFC, Qwen3Model
+    cfg = tiny_qwen3()
+    w = qwen3_text_weights(cfg, seed=0, dtype=torch.float32)
+    hf = HFC(hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size, num_hidden_layers=cfg.num_hidden_layers,
+             num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+             vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta, tie_word_embeddings=True,
+             attention_bias=False, max_position_embeddings=4096)
+    hf._attn_implementation = "eager"
+    m = Qwen3Model(hf).eval()
+    sd = {k[len("model."):]: v for k, v in w.items() if k.startswith("model.")}
+    r = m.load_state_dict(sd, strict=False)
+    assert not r.missing_keys and not r.unexpected_keys
+    g = torch.Generator().manual_seed(7)
+    lens = [5, 23, 64, 1]
+    ids = [torch.randint(0, cfg.vocab_size, (n,), generator=g) for n in lens]
+    hid, emb = [], []
+    with torch.no_grad():
+        for x in ids:
+            h = m(x[None]).last_hidden_state[0, -1]
+            hid.append(h.numpy())
+            emb.append(torch.nn.functional.normalize(h, dim=-1).numpy())
+    np.savez_compressed(os.path.join(OUT, "qwen3_embedding_tiny_f32.npz"), seed=0, lens=np.asarray(lens),
+                        ids=np.concatenate([x.numpy() for x in ids]).astype(np.int64),
+                        hidden=np.stack(hid).astype(np.float32), embedding=np.stack(emb).astype(np.float32))
+
+
 def qwen3vl_case():
     from transformers.models.qwen3_vl import Qwen3VLConfig as HFC, Qwen3VLForConditionalGeneration
     from oracle.numerics import Numerics
@@ -102,6 +131,7 @@ def qwen3vl_case():
 
 if __name__ == "__main__":
     qwen3_case()
+    qwen3_embedding_case()
     qwen3vl_case()
     print("wrote", [f for f in os.listdir(OUT) if f.endswith(".npz")])
 

@@ -162,3 +162,27 @@ def test_asr_encoder_matches_golden_f32():
     # and the reference's own behaviour differs measurably (so the switches are live)
     ref = oa.OracleAudioEncoder(cfg.audio, w, Numerics("f32")).forward(torch.from_numpy(g["feats"]), upto="ln_post").numpy()
     assert np.abs(ref - g["ln_post"]).max() > 1e-3
+
+
+def test_qwen3_embedding_oracle_matches_golden_f32():
+    """Qwen3Embedding::embed_one / Qwen3Reranker::rerank restatement vs HF Qwen3Model last-token pooling + F.normalize
+    (tests/golden/make_golden.py qwen3_embedding_case).  The reference's l2_normalize adds 1e-6 under the square root
+    (modules.rs:1292) where HF clamps the norm at 1e-12: a 1e-8-relative difference at these norms."""
+    g = np.load(os.path.join(GOLD, "qwen3_embedding_tiny_f32.npz"))
+    cfg = tiny_qwen3()
+    w = qwen3_text_weights(cfg, seed=int(g["seed"]), dtype=torch.float32)
+    o = oq.OracleQwen3(cfg, w, Numerics("f32"))
+    off, seqs = 0, []
+    for n in g["lens"]:
+        seqs.append(g["ids"][off:off + n].tolist())
+        off += n
+    for i, ids in enumerate(seqs):
+        hid = o.forward_hidden(ids, None, 0).reshape(-1).numpy()
+        o.clear_cache()
+        assert np.abs(hid - g["hidden"][i]).max() < 3e-5
+        e = oq.embed_one(o, ids).numpy()
+        assert np.abs(e - g["embedding"][i]).max() < 2e-6
+        assert abs(float(np.linalg.norm(e)) - 1.0) < 1e-5
+    scores = oq.rerank(o, seqs[0], seqs[1:]).numpy()
+    want = g["embedding"][0] @ g["embedding"][1:].T
+    assert np.abs(scores - want).max() < 5e-6
