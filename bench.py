@@ -28,6 +28,14 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 T
 MFMA_PEAK_TFLOPS = 2500.0  # bf16 dense
 
 
+METRICS = {
+    "qwen3vl8b": "decode tokens/s (greedy, batch 1) -- Qwen3-VL-8B, 1x1024^2 image + 512-token prompt; prefill tok/s alongside",
+    "qwen3vl8b-text": "decode tokens/s (greedy, batch 1) -- Qwen3-VL-8B text stack, 1542-token prompt; prefill tok/s alongside",
+    "qwen3-0.6b": "decode tokens/s (greedy, batch 1) -- Qwen3-0.6B, 2048-token prompt (BASELINE cfg 2); prefill tok/s alongside",
+    "qwen3-asr": "decode tokens/s (greedy, batch 1) -- Qwen3-ASR-0.6B, 30 s of 16 kHz audio (BASELINE cfg 4); prefill (log-mel + audio encoder + text) alongside",
+}
+
+
 def build_workload(name: str):
     from aha_amd import configs
     if name == "qwen3vl8b":
@@ -36,6 +44,8 @@ def build_workload(name: str):
         return configs.qwen3vl_8b(), dict(image=0, prompt=1542)
     if name == "qwen3-0.6b":
         return configs.qwen3_0_6b(), dict(image=0, prompt=2048)
+    if name == "qwen3-asr":   # BASELINE.md section 4 cfg 4: 30 s of 16 kHz audio -> 390 audio tokens + template, decode 64
+        return configs.qwen3_asr_0_6b(), dict(image=0, prompt=0, audio_samples=480000)
     if name == "tiny":
         return configs.tiny_qwen3(layers=2, hidden=512, heads=4, kv_heads=2, inter=1024, vocab=2048), dict(image=0, prompt=96)
     raise SystemExit(f"unknown workload {name}")
@@ -124,11 +134,14 @@ def main():
     from aha_amd.model import HipInferenceModel, MultiModalData
 
     cfg, wl = build_workload(args.workload)
-    is_vl = hasattr(cfg, "text")
-    tcfg = cfg.text if is_vl else cfg
+    is_asr = hasattr(cfg, "audio")
+    is_vl = hasattr(cfg, "text") and not is_asr
+    tcfg = cfg.text if hasattr(cfg, "text") else cfg
     dev = f"cuda:{local_rank}"
     t0 = time.perf_counter()
-    if is_vl:
+    if is_asr:
+        w = W.qwen3_asr_weights(cfg, seed=rank, device=dev)
+    elif is_vl:
         w = W.qwen3vl_weights(cfg, seed=rank, device=dev) if wl["image"] else \
             W.qwen3_text_weights(tcfg, seed=rank, prefix="model.language_model.", device=dev)
     else:
@@ -145,6 +158,16 @@ def main():
     if wl["image"]:
         from aha_amd.vision_host import synthetic_image_request
         ids, data = synthetic_image_request(cfg, wl["image"], wl["prompt"], g)
+    elif is_asr:
+        # seed-4 N(0, 0.1^2) clipped to [-1, 1]; the library computes the log-mel features on the GPU from the raw samples
+        n = wl["audio_samples"]
+        wave = np.clip(np.random.default_rng(4 + rank).normal(0, 0.1, n), -1, 1).astype(np.float32)
+        from aha_amd.audio_host import audio_prompt_ids
+        hi = min(tcfg.vocab_size, 151643)
+        pre = torch.randint(0, hi, (9,), generator=g).tolist()     # <|im_start|>system ... user\n
+        post = torch.randint(0, hi, (5,), generator=g).tolist()    # <|im_end|>\n<|im_start|>assistant\n
+        ids = audio_prompt_ids(cfg, n, pre, post)
+        data = MultiModalData(audio_samples=wave)
     else:
         ids = torch.randint(0, min(tcfg.vocab_size, 151643), (wl["prompt"],), generator=g).tolist()
 
@@ -216,7 +239,7 @@ def main():
     if rank == 0:
         step_bytes = decode_bytes_per_token(cfg, kv_mid)
         line = {
-            "metric": "decode tokens/s (greedy, batch 1) -- Qwen3-VL-8B, 1x1024^2 image + 512-token prompt; prefill tok/s alongside",
+            "metric": METRICS.get(args.workload, "decode tokens/s (greedy, batch 1) -- " + args.workload),
             "value": round(job_value, 3), "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",

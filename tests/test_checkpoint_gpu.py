@@ -73,3 +73,32 @@ def test_missing_tensor_in_directory_is_an_error(gpu, tmp_path):
     save_checkpoint(str(tmp_path), cfg, w)
     with pytest.raises(AhaHipError, match="down_proj"):
         HipInferenceModel.from_pretrained(str(tmp_path))
+
+
+def test_plain_c_host_over_the_abi(gpu, tmp_path):
+    """examples/c_harness.c: a C program (no Python, no torch, no HIP headers) loads the checkpoint directory through
+    the C ABI and runs the reference's greedy loop host-driven and device-resident; both must equal the Python mirror."""
+    import os
+    import subprocess
+    from aha_amd._lib import LIB_PATH
+    from aha_amd.model import HipInferenceModel, generate_generic
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_harness")
+    libdir = os.path.dirname(LIB_PATH)
+    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "c_harness.c"), "-o", exe, "-L" + libdir, "-laha_hip",
+                    "-Wl,-rpath," + libdir, "-lm"], check=True)
+    cfg = tiny_qwen3(layers=2, hidden=256, heads=4, kv_heads=2, inter=512, vocab=1024, tie=True)
+    w = qwen3_text_weights(cfg, seed=4)
+    ckpt = tmp_path / "ckpt"
+    save_checkpoint(str(ckpt), cfg, w, shards=2)
+    ids = ids_for(cfg.vocab_size, 33, 8)
+    out = subprocess.run([exe, str(ckpt), "24"] + [str(i) for i in ids], check=True, capture_output=True, text=True,
+                         timeout=300).stdout.strip().splitlines()
+    host = [int(x) for x in out[0].split()[1:]]
+    dev = [int(x) for x in out[1].split()[1:]]
+    assert out[0].startswith("host:") and out[1].startswith("device:")
+    m = HipInferenceModel(cfg, w)
+    want, _ = generate_generic(m, ids, 24, device_loop=False)
+    m.close()
+    assert host == dev == want
