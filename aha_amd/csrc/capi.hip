@@ -149,6 +149,14 @@ int aha_hip_debug_scramble_pages(aha_model* m, int enable) {
   }
   return AHA_OK;
 }
+int aha_hip_debug_gemm_plan(int32_t tile, int32_t splitk) {
+  if ((tile != 0 && tile != 128 && tile != 256) || splitk < 0 || splitk > 8) {
+    set_error("debug_gemm_plan: tile must be 0, 128 or 256; splitk 0..8");
+    return AHA_ERR_INVALID;
+  }
+  set_gemm_plan_override(tile, splitk);
+  return AHA_OK;
+}
 int aha_hip_debug_last_hidden(aha_model* m, float* out, size_t n) {
   API_GUARD_BEGIN
   if (!m || !out || n != (size_t)m->desc.hidden_size) {
@@ -214,6 +222,18 @@ int aha_hip_gemm(const void* A, const void* W, void* C, int32_t M, int32_t N, in
   }
   GemmArgs g{};
   g.A = A; g.W = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.bias = bias; g.residual = residual; g.act = act;
+  // op-level entry (tests, scripts): one process-wide split-K scratch, grown on demand; not for concurrent callers
+  static void* ws = nullptr;
+  static size_t ws_bytes = 0;
+  const size_t want = (size_t)4 * M * N * 4;
+  if (want > ws_bytes && want <= ((size_t)1 << 30)) {
+    if (ws) hipFree(ws);
+    ws = nullptr;
+    ws_bytes = 0;
+    if (hipMalloc(&ws, want) == hipSuccess) ws_bytes = want;
+  }
+  g.workspace = ws;
+  g.workspace_bytes = ws_bytes;
   launch_gemm(g, (hipStream_t)stream);
   AHA_HIP_CHECK(hipGetLastError());
   return AHA_OK;

@@ -125,8 +125,17 @@ struct GemmArgs {
   int M, N, K;
   int64_t lda, ldw, ldc;
   int act;
+  void* workspace = nullptr;     // optional f32 scratch for split-K slabs (splitk * M * N * 4 bytes)
+  size_t workspace_bytes = 0;
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
+// split-K scratch used by launch_gemm calls of this THREAD whose GemmArgs carry none (the model sets it per forward)
+void set_gemm_workspace(void* ws, size_t bytes);
+void set_gemm_plan_override(int tile, int splitk);  // tests: force the 128 / 256 tile kernel and a split-K factor; 0 = automatic
+struct GemmWorkspaceScope {
+  GemmWorkspaceScope(void* ws, size_t bytes) { set_gemm_workspace(ws, bytes); }
+  ~GemmWorkspaceScope() { set_gemm_workspace(nullptr, 0); }
+};
 // x[i] = bf16(x[i] + bf16(sum[i])): Linear output tensor (all-reduced f32 partials) -> bf16, then the residual add -> bf16
 void launch_residual_add_f32(void* x, const float* sum, int64_t n, hipStream_t st);
 

@@ -133,6 +133,8 @@ struct aha_model {
   uint32_t* p_ids = nullptr;
   int32_t* p_pos = nullptr;
   void *p_x = nullptr, *p_h = nullptr, *p_qkv = nullptr, *p_q = nullptr, *p_attn = nullptr, *p_act = nullptr;
+  void* p_gemm_ws = nullptr;    // f32 split-K slabs (kernels_gemm.hip)
+  size_t gemm_ws_bytes = 0;
   std::vector<void*> pf_owned;
   // vision tower (Qwen3-VL)
   aha::VisionModel* vision = nullptr;

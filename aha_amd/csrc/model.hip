@@ -631,6 +631,8 @@ static int ensure_prefill_scratch(aha_model* m, size_t S) {
   if ((rc = al(cap * nq * 2, &m->p_attn))) return rc;
   if ((rc = al(cap * I * 2, &m->p_act))) return rc;
   if (m->tp_size > 1 && (rc = al(cap * H * 4, (void**)&m->p_partial))) return rc;
+  m->gemm_ws_bytes = std::min((size_t)4 * cap * H * 4, (size_t)512 << 20);  // split-K slabs of the N = hidden GEMMs
+  if ((rc = al(m->gemm_ws_bytes, &m->p_gemm_ws))) return rc;
   m->pf_cap = cap;
   return AHA_OK;
 }
@@ -1053,6 +1055,7 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
   hipStream_t st = m->stream;
   int rc;
   if ((rc = ensure_prefill_scratch(m, n))) return rc;
+  GemmWorkspaceScope ws_scope(m->p_gemm_ws, m->gemm_ws_bytes);  // split-K slabs for this thread's GEMM launches
   if ((rc = model_ensure_pages(m, m->cache_len + n))) return rc;
 
   // positions: 1-D arange(offset, offset+S) on all three rows (rope.rs:599-604), or get_rope_index for Qwen3-VL

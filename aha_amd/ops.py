@@ -68,6 +68,11 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
     return Cm
 
 
+def gemm_plan(tile: int = 0, splitk: int = 0) -> None:
+    """Test hook: force the 128 / 256 tile kernel and a split-K factor for the following GEMMs; (0, 0) = automatic."""
+    check(lib().aha_hip_debug_gemm_plan(tile, splitk))
+
+
 def interleave_gate_up(Wg: torch.Tensor, Wu: torch.Tensor) -> torch.Tensor:
     """The model loader's fused layout: 16-row blocks alternating gate / up (csrc/model.hip upload_gate_up)."""
     I, K = Wg.shape

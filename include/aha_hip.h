@@ -191,6 +191,9 @@ int aha_hip_debug_scramble_pages(aha_model* m, int enable);
 /* Copies the last hidden state before lm_head (hidden_size floats) / the image embeddings of the last
  * forward_initial (rows x out_hidden floats) to the host, for parity tests of intermediate tensors. */
 int aha_hip_debug_last_hidden(aha_model* m, float* out, size_t n);
+/* Test hook: force the GEMM tile (128 or 256) and split-K factor of every following GEMM launch of the process;
+ * (0, 0) restores the automatic choice (csrc/kernels_gemm.hip plan_gemm). */
+int aha_hip_debug_gemm_plan(int32_t tile, int32_t splitk);
 int aha_hip_debug_image_embeds(aha_model* m, int which /*0=merged, 1..=deepstack k*/, float* out, size_t n);
 
 /* ---- op-level entry points (device pointers; stream = hipStream_t as void*, NULL = default stream) ---------- */

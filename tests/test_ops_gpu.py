@@ -91,6 +91,41 @@ def test_gemm_plain(gpu, M, N, K):
     assert_close_ulps(got, ref, 1, 0.98, "gemm")
 
 
+@pytest.mark.parametrize("tile,splitk", [(128, 0), (256, 1), (256, 2), (256, 4)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 520, 1032), (1542, 1024, 4096), (257, 4304, 1152), (513, 72 * 4, 72)])
+def test_gemm_every_tile_kernel(gpu, tile, splitk, M, N, K):
+    """The same op through every GEMM kernel: 128^2 tile, 256^2 tile, 256^2 with K split into 2 / 4 f32 slabs + the reduce
+    pass (odd M / N / K tails, K shorter than a slice).  All must meet the oracle bound; split-K changes only the f32
+    summation order."""
+    from aha_amd import ops, _lib
+    A, W, b, res = rnd((M, K), 31), rnd((N, K), 32, 0.02), rnd((N,), 33, 0.5), rnd((M, N), 34)
+    y = NM.r(torch.nn.functional.gelu(NM.linear(A.float(), W.float(), b.float()), approximate="tanh"))
+    ref = NM.r(res.float() + y)
+    ops.gemm_plan(tile, splitk)
+    try:
+        got = ops.gemm(A.to(gpu), W.to(gpu), b.to(gpu), res.to(gpu), _lib.ACT_GELU_TANH)
+        plain = ops.gemm(A.to(gpu), W.to(gpu))
+    finally:
+        ops.gemm_plan(0, 0)
+    assert_close_ulps(got, ref, 2, 0.97, f"gemm tile {tile} splitk {splitk}")
+    assert_close_ulps(plain, NM.linear(A.float(), W.float()), 1, 0.98, f"plain gemm tile {tile} splitk {splitk}")
+
+
+def test_gemm_gate_up_pairs_256_tile(gpu):
+    from aha_amd import ops, _lib
+    M, I, K = 700, 1024, 512
+    A, Wg, Wu = rnd((M, K), 17), rnd((I, K), 18, 0.05), rnd((I, K), 19, 0.05)
+    lhs = NM.r(oq.silu(NM.linear(A.float(), Wg.float())))
+    ref = NM.r(lhs * NM.linear(A.float(), Wu.float()))
+    Wf = ops.interleave_gate_up(Wg, Wu)
+    ops.gemm_plan(256, 1)
+    try:
+        got = ops.gemm(A.to(gpu), Wf.to(gpu), act=_lib.ACT_SILU_MUL_PAIRS)
+    finally:
+        ops.gemm_plan(0, 0)
+    assert_close_ulps(got, ref, 2, 0.97, "gemm gate/up pairs, 256 tile")
+
+
 def test_gemm_transpose_detect(gpu):
     """A = I against an asymmetric W: catches swapped C rows/cols (cdna guide: always A=I-check with asymmetric B)."""
     from aha_amd import ops
