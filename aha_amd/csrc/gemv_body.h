@@ -72,8 +72,14 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, float* xs, const in
     }
   };
 
+  const int tslot = bid == 0 ? 0 : bid == 255 ? 1 : bid == nblk - 1 ? 2 : -1;
+  auto stamp = [&](int k) {
+    if (a.trace != nullptr && tslot >= 0 && tid == 0) a.trace[tslot * 6 + k] = wall_clock64();
+  };
+  stamp(0);
   u32x4_t bufA[U][NW][R], bufB[U][NW][R];
   if (ngroups > 0) issue(0, bufA);
+  stamp(1);
   after_issue();  // grid barrier of the persistent decode kernel: the first weight tile is already in flight
 
   // ---- prologue: h = x, or h = bf16(RMSNorm(x) * norm_w) (qwen3/model.rs:79,83,186) ------------------------
@@ -186,12 +192,15 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, float* xs, const in
       for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
   };
 
+  stamp(2);
   for (int g = 0; g < ngroups; g += 2) {
     if (g + 1 < ngroups) issue(g + 1, bufB);
     consume(g, bufA);
+    if (g == 0) stamp(3);
     if (g + 2 < ngroups) issue(g + 2, bufA);
     if (g + 1 < ngroups) consume(g + 1, bufB);
   }
+  stamp(4);
   if (EPI == GEMV_LOGITS) {
     // per-block argmax partial: 4 wave leaders -> slot bid
     __syncthreads();

@@ -32,6 +32,8 @@ struct GemvArgs {
   int N, K;
   float eps;
   int cached;            // 0 (default): non-temporal weight loads (streamed once); 1: default cache policy
+  unsigned long long* trace;  // optional (AHA_GEMV_TRACE): 100 MHz stamps of blocks 0 / 255 / last: start, issued, prologue done,
+                              // first group consumed, last group consumed, end
 };
 void launch_gemv(const GemvArgs& a, GemvEpi epi, hipStream_t st);
 int gemv_num_tiles(int N, int K);  // number of (max,idx) partials GEMV_LOGITS writes

@@ -123,6 +123,7 @@ struct aha_model {
   unsigned* d_bar = nullptr;        // grid-barrier words (kernels.h DECODE_MEGA_BAR_BYTES)
   unsigned* h_bar_err = nullptr;    // pinned copy of the sticky error word
   unsigned long long* d_mega_trace = nullptr;  // AHA_MEGA_TRACE timeline
+  unsigned long long* d_gemv_trace = nullptr;  // AHA_GEMV_TRACE timeline
   unsigned bar_base = 0;            // barriers completed by all launches so far
   int mega_grid = 0;
   size_t mega_lds = 0;

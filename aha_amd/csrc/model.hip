@@ -692,6 +692,7 @@ static int mega_check(aha_model* m) {
 
 // AHA_MEGA_TRACE=1: per phase kind, averaged over layers, for 4 sample blocks (microseconds; clock = 100 MHz):
 // wait = phase start -> barrier passed, work = barrier passed -> compute done, gap = done -> next phase start
+static void gemv_trace_dump(aha_model* m);
 static void mega_trace_dump(aha_model* m) {
   const int L = m->desc.num_hidden_layers, np = 5 * L + 1;
   std::vector<unsigned long long> t((size_t)4 * np * 3);
@@ -726,6 +727,7 @@ static int fetch_outputs(aha_model* m, float* logits_out, uint32_t* argmax_out) 
   AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
   if (int e = mega_check(m)) return e;
   if (m->d_mega_trace) mega_trace_dump(m);
+  if (m->d_gemv_trace) gemv_trace_dump(m);
   if (logits_out) memcpy(logits_out, m->h_logits, (size_t)c.vocab_size * 4);
   if (argmax_out) *argmax_out = m->h_state->next_token;
   return AHA_OK;
@@ -797,6 +799,48 @@ __global__ void advance_state_kernel(StepState* st, uint32_t* token_log) {
   st->kv_len += 1;
 }
 
+// AHA_GEMV_TRACE=1: in-kernel timeline of the decode matvecs (launch-per-op path), dumped by fetch_outputs
+static unsigned long long* gemv_trace_slot(aha_model* m, int launch_idx) {
+  static const char* e = getenv("AHA_GEMV_TRACE");
+  if (!e || !atoi(e)) return nullptr;
+  const size_t n = (size_t)(4 * m->desc.num_hidden_layers + 1) * 18;
+  if (!m->d_gemv_trace) {
+    void* p = nullptr;
+    if (dev_alloc(m, n * 8, &p, true) != AHA_OK) return nullptr;
+    m->d_gemv_trace = (unsigned long long*)p;
+  }
+  return m->d_gemv_trace + (size_t)launch_idx * 18;
+}
+
+static void gemv_trace_dump(aha_model* m) {
+  const int L = m->desc.num_hidden_layers, nl = 4 * L + 1;
+  std::vector<unsigned long long> t((size_t)nl * 18);
+  if (hipMemcpy(t.data(), m->d_gemv_trace, t.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+  static const char* names[4] = {"qkv", "o_proj", "gate_up", "down"};
+  for (int k = 0; k < 4; ++k) {
+    double d[3][5] = {}, gap = 0, span = 0;
+    int n = 0;
+    for (int li = 1; li < L; ++li) {
+      const unsigned long long* p = t.data() + (size_t)(li * 4 + k) * 18;
+      const unsigned long long* prev = p - 18;
+      if (p[0] == 0 || prev[4] == 0) continue;
+      for (int b = 0; b < 3; ++b)
+        for (int j = 0; j < 4; ++j) d[b][j] += (double)(p[b * 6 + j + 1] - p[b * 6 + j]) * 0.01;
+      unsigned long long pend = std::max(prev[4], std::max(prev[6 + 4], prev[12 + 4]));
+      unsigned long long start = std::min(p[0], std::min(p[6], p[12]));
+      unsigned long long end = std::max(p[4], std::max(p[6 + 4], p[12 + 4]));
+      gap += (double)(start - pend) * 0.01;   // previous launch's last consume -> this launch's first instruction
+      span += (double)(end - start) * 0.01;
+      ++n;
+    }
+    if (!n) continue;
+    fprintf(stderr, "[gemv trace] %-8s span %.2f us, gap since previous launch's last consume %.2f us |", names[k], span / n, gap / n);
+    for (int b = 0; b < 3; ++b)
+      fprintf(stderr, " blk%d: issue %.2f prologue %.2f first-consume %.2f rest %.2f |", b, d[b][0] / n, d[b][1] / n, d[b][2] / n, d[b][3] / n);
+    fprintf(stderr, "\n");
+  }
+}
+
 static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
   const aha_model_desc& c = m->desc;
   const int H = c.hidden_size, I = c.intermediate_size, d = c.head_dim, nh = c.num_attention_heads, kvh = c.num_key_value_heads;
@@ -851,6 +895,7 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
     {  // h = RMSNorm(x); qkv = h Wqkv^T                      (qwen3/model.rs:79, modules.rs:538-552)
       GemvArgs g{};
       g.W = L.wqkv; g.x = m->d_x; g.norm_w = L.in_norm; g.eps = c.rms_norm_eps; g.y = m->d_qkv; g.N = nq + 2 * nkv; g.K = H;
+      g.trace = gemv_trace_slot(m, li * 4 + 0);
       ProfScope ps(m, "gemv", (double)g.N * g.K * 2 + g.K * 4.0 + g.N * 2.0, 2.0 * g.N * g.K);
       launch_gemv(g, GEMV_STORE, st);
     }
@@ -866,6 +911,7 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
       a.ctr_target = m->head_ctr_base;
       GemvArgs g{};
       g.W = L.wo; g.x = m->d_attn; g.residual = m->d_x; g.y = m->d_x; g.N = H; g.K = nq;
+      g.trace = gemv_trace_slot(m, li * 4 + 1);
       const double attn_bytes = (double)kv_len_after * 2 * nkv * 2 + (nq + 2 * nkv) * 2.0 + nsplit * nq * 4.0;
       const double gemv_bytes = (double)g.N * g.K * 2 + g.K * 2.0 + g.N * 4.0;
       if (m->decode_ao) {  // one launch: attention blocks signal the o_proj grid through a counter
@@ -907,12 +953,14 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
     {  // act = silu(h Wg^T) * (h Wu^T), h = RMSNorm(x)        (qwen3/model.rs:83, modules.rs:81-84)
       GemvArgs g{};
       g.W = L.wgu; g.W2 = nullptr; g.x = m->d_x; g.norm_w = L.post_norm; g.eps = c.rms_norm_eps; g.y = m->d_act; g.N = I; g.K = H;
+      g.trace = gemv_trace_slot(m, li * 4 + 2);
       ProfScope ps(m, "gemv", (double)2 * I * H * 2 + H * 4.0 + I * 2.0, 4.0 * I * H);
       launch_gemv(g, GEMV_SILU_MUL, st);
     }
     {  // x = x + act Wd^T                                     (modules.rs:85, qwen3/model.rs:86)
       GemvArgs g{};
       g.W = L.wdown; g.x = m->d_act; g.residual = m->d_x; g.y = m->d_x; g.N = H; g.K = I;
+      g.trace = gemv_trace_slot(m, li * 4 + 3);
       ProfScope ps(m, "gemv", (double)g.N * g.K * 2 + g.K * 2.0 + g.N * 4.0, 2.0 * g.N * g.K);
       gemv_row_parallel(m, g);
     }
