@@ -77,6 +77,24 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, float* xs, const in
     if (a.trace != nullptr && tslot >= 0 && tid == 0) a.trace[tslot * 6 + k] = wall_clock64();
   };
   stamp(0);
+  // Memory returns are IN ORDER within a wave: a load issued behind the first weight tile only returns after that
+  // tile has arrived (several microseconds under a chip-wide burst).  The activation vector and the norm weights the
+  // prologue needs are therefore requested FIRST (stand-alone kernels, K <= 8 * 2048), the weight tile right behind them.
+  constexpr int XPRE = 8;
+  const bool pre = !COH && (nchunks << 6) <= XPRE * GEMV_THREADS;
+  u32x4_t xpre[XPRE], npre[XPRE];
+  if (pre) {
+#pragma unroll
+    for (int j = 0; j < XPRE; ++j) {
+      const int v = tid + j * GEMV_THREADS;
+      xpre[j] = u32x4_t{0u, 0u, 0u, 0u};
+      npre[j] = u32x4_t{0u, 0u, 0u, 0u};
+      if (v * 8 < K) {
+        xpre[j] = ld16((const bf16_t*)a.x + v * 8);
+        if (a.norm_w != nullptr) npre[j] = ld16((const bf16_t*)a.norm_w + v * 8);
+      }
+    }
+  }
   u32x4_t bufA[U][NW][R], bufB[U][NW][R];
   if (ngroups > 0) issue(0, bufA);
   stamp(1);
@@ -87,10 +105,8 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, float* xs, const in
     const bf16_t* x = (const bf16_t*)a.x;
     const bf16_t* nw = (const bf16_t*)a.norm_w;
     float ss = 0.f;
-    for (int v = tid; v < (nchunks << 6); v += GEMV_THREADS) {
+    auto stage = [&](int v, u32x4_t xv) {  // bf16 x8 -> the f32 LDS image, running sum of squares
       float f[8];
-      u32x4_t xv = {0u, 0u, 0u, 0u};
-      if (v * 8 < K) xv = act_ld16<COH>(x + v * 8);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { f[2 * j] = lo_bf(xv[j]); f[2 * j + 1] = hi_bf(xv[j]); }
 #pragma unroll
@@ -98,6 +114,19 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, float* xs, const in
       const int base = xs_index(v * 8);
       *reinterpret_cast<float4*>(xs + base) = make_float4(f[0], f[1], f[2], f[3]);
       *reinterpret_cast<float4*>(xs + base + 256) = make_float4(f[4], f[5], f[6], f[7]);
+    };
+    if (pre) {
+#pragma unroll
+      for (int it = 0; it < XPRE; ++it) {
+        const int v = tid + it * GEMV_THREADS;
+        if (v < (nchunks << 6)) stage(v, xpre[it]);
+      }
+    } else {
+      for (int v = tid; v < (nchunks << 6); v += GEMV_THREADS) {
+        u32x4_t xv = {0u, 0u, 0u, 0u};
+        if (v * 8 < K) xv = act_ld16<COH>(x + v * 8);
+        stage(v, xv);
+      }
     }
     if (nw != nullptr) {
       ss = wave_sum(ss);
@@ -105,8 +134,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, float* xs, const in
       __syncthreads();
       const float tot = red[0] + red[1] + red[2] + red[3];
       const float rinv = 1.0f / sqrtf(tot / (float)K + a.eps);
-      for (int v = tid; v < (K >> 3); v += GEMV_THREADS) {
-        const u32x4_t wv = ld16(nw + v * 8);
+      auto norm = [&](int v, u32x4_t wv) {
         const int base = xs_index(v * 8);
         float4 lo = *reinterpret_cast<float4*>(xs + base), hi = *reinterpret_cast<float4*>(xs + base + 256);
         lo.x = rbf(lo.x * rinv * lo_bf(wv[0])); lo.y = rbf(lo.y * rinv * hi_bf(wv[0]));
@@ -120,6 +148,15 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, float* xs, const in
           o[0] = pack_bf(lo.x, lo.y); o[1] = pack_bf(lo.z, lo.w); o[2] = pack_bf(hi.x, hi.y); o[3] = pack_bf(hi.z, hi.w);
           *reinterpret_cast<u32x4_t*>((bf16_t*)a.h_out + v * 8) = o;
         }
+      };
+      if (pre) {
+#pragma unroll
+        for (int it = 0; it < XPRE; ++it) {
+          const int v = tid + it * GEMV_THREADS;
+          if (v < (K >> 3)) norm(v, npre[it]);
+        }
+      } else {
+        for (int v = tid; v < (K >> 3); v += GEMV_THREADS) norm(v, ld16(nw + v * 8));
       }
     }
     __syncthreads();
