@@ -183,6 +183,33 @@ inline int decode_mega_barriers(int n_layers) { return 5 * n_layers; }
 size_t decode_mega_lds_bytes(int H, int I, int nq);
 int decode_mega_max_blocks_per_cu(int H, size_t lds);
 void launch_decode_mega(const DecodeMegaArgs& a, int grid, size_t lds, hipStream_t st);
+// ---- decode chain engine (decode_chain.hip): up to 4 dependent matvecs of one token in one persistent launch ---------
+constexpr int CH_MAX_OPS = 4;
+struct ChainOp {
+  const void* W;             // weight matrix (for GEMV_SILU_MUL the fused gate/up matrix, 16-row blocks interleaved)
+  const void* norm_w;        // optional fused RMSNorm of the input vector
+  const void* in_plain;      // input vector (K bf16) written by an EARLIER launch; nullptr = the previous op's granules
+  const void* res_plain;     // GEMV_RESIDUAL: residual vector from an earlier launch, or nullptr -> res_own_op
+  void* out_plain;           // optional plain bf16 copy of the output vector (read by later launches)
+  unsigned long long* gran;  // optional granule buffer (n_out / 2 x 8 bytes) the op publishes for the next op
+  int n_out, K, kind;        // kind: GEMV_STORE / GEMV_RESIDUAL / GEMV_SILU_MUL
+  int res_own_op;            // GEMV_RESIDUAL without res_plain: index of the earlier op whose rows (same CU) are the residual
+  float eps;
+};
+struct ChainArgs {
+  ChainOp op[CH_MAX_OPS];
+  int n_ops;
+  int kmax;                  // longest input vector of the chain (LDS sizing)
+  unsigned tag_base;         // launch-unique: op i publishes granules tagged tag_base + i
+  unsigned* err;             // device word: a bounded wait gave up
+  unsigned long long* trace; // optional timeline (AHA_CHAIN_TRACE)
+  int exact;                 // 1: fmaf consumer (bit-identical to gemv_body.h); 0: v_dot2c_f32_bf16 consumer (faster)
+  int dbg;                   // experiments (AHA_CHAIN_DBG): 1 = consumers skip the dot products, 2 = loader skips the DMA
+};
+size_t decode_chain_lds_bytes(int kmax);
+bool decode_chain_op_ok(int n_out, int K, int kind, int ncu);
+void launch_decode_chain(const ChainArgs& a, int ncu, hipStream_t st);
+
 void launch_attn_oproj(const AttnDecodeFusedArgs& f, const GemvArgs& g, unsigned* sync, unsigned target, hipStream_t st);
 
 }  // namespace aha

@@ -116,6 +116,10 @@ struct aha_model {
   float* p_partial = nullptr;   // prefill: (S, hidden) f32
   // persistent decode-step kernel (decode_mega.hip): one launch per token
   bool decode_mega = false;
+  bool decode_chain = false;        // o_proj -> gate/up -> down -> next qkv in one persistent launch (decode_chain.hip)
+  int chain_ncu = 0;                // workgroups (= CUs) of the chain launch
+  unsigned chain_tag = 0;           // launch-unique granule tag base
+  unsigned long long* d_gran[3] = {nullptr, nullptr, nullptr};  // granule buffers of the chain's three hand-offs
   bool decode_ao = false;           // attention + o_proj in one launch (opt-in)
   unsigned head_ctr_base = 0;       // value every kv head's split-arrival counter has reached after all launches so far
   unsigned ao_base = 0;             // value the attn_oproj arrival counter has reached after all launches so far
@@ -124,6 +128,7 @@ struct aha_model {
   unsigned* h_bar_err = nullptr;    // pinned copy of the sticky error word
   unsigned long long* d_mega_trace = nullptr;  // AHA_MEGA_TRACE timeline
   unsigned long long* d_gemv_trace = nullptr;  // AHA_GEMV_TRACE timeline
+  unsigned long long* d_chain_trace = nullptr; // AHA_CHAIN_TRACE timeline
   unsigned bar_base = 0;            // barriers completed by all launches so far
   int mega_grid = 0;
   size_t mega_lds = 0;

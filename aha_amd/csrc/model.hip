@@ -542,6 +542,32 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
   // slower than two launches (profiles/r01_decode_mega_timeline.md)
   m->decode_ao = false;
   if (const char* e = getenv("AHA_DECODE_AO")) m->decode_ao = atoi(e) != 0 && m->tp_size == 1 && d == 128 && m->decode_fused;
+  // decode chain engine (decode_chain.hip): o_proj -> gate/up -> down -> next qkv in one persistent launch per layer
+  {
+    bool want = false;
+    if (const char* e = getenv("AHA_DECODE_CHAIN")) want = atoi(e) != 0;
+    want = want && m->tp_size == 1 && d == 128 && m->decode_fused;
+    if (want) {
+      hipDeviceProp_t prop;
+      AHA_HIP_CHECK(hipGetDeviceProperties(&prop, m->ctx->device));
+      const int kmax = std::max(std::max(H, I), nq);
+      for (int ncu = prop.multiProcessorCount; ncu >= 8 && !m->decode_chain; ncu >>= 1) {
+        if (decode_chain_op_ok(H, nq, GEMV_RESIDUAL, ncu) && decode_chain_op_ok(I, H, GEMV_SILU_MUL, ncu) &&
+            decode_chain_op_ok(H, I, GEMV_RESIDUAL, ncu) && decode_chain_op_ok(nq + 2 * nkv, H, GEMV_STORE, ncu) &&
+            decode_chain_lds_bytes(kmax) <= (size_t)160 * 1024) {
+          m->decode_chain = true;
+          m->chain_ncu = ncu;
+        }
+      }
+      if (m->decode_chain) {
+        for (int k = 0; k < 3; ++k) {
+          if ((rc = dev_alloc(m, (size_t)kmax * 4, &p, true))) return fail(rc);
+          m->d_gran[k] = (unsigned long long*)p;
+        }
+        m->chain_tag = 16;
+      }
+    }
+  }
   // persistent decode-step kernel: resident grid sized by the occupancy the kernel actually gets on this device
   {
     // Opt-in (AHA_DECODE_MEGA=1): measured 6-25% SLOWER than the launch-per-op path on MI355X -- see DESIGN.md and
@@ -680,6 +706,7 @@ static int mega_check(aha_model* m) {
   if (*m->h_bar_err == 0) return AHA_OK;
   m->decode_mega = false;
   m->decode_ao = false;
+  m->decode_chain = false;
   *m->h_bar_err = 0;
   hipMemsetAsync(m->d_bar, 0, DECODE_MEGA_BAR_BYTES, m->stream);
   m->bar_base = 0;
@@ -693,6 +720,37 @@ static int mega_check(aha_model* m) {
 // AHA_MEGA_TRACE=1: per phase kind, averaged over layers, for 4 sample blocks (microseconds; clock = 100 MHz):
 // wait = phase start -> barrier passed, work = barrier passed -> compute done, gap = done -> next phase start
 static void gemv_trace_dump(aha_model* m);
+static void chain_trace_dump(aha_model* m) {
+  const int L = m->desc.num_hidden_layers;
+  const size_t LS = 2 * CH_MAX_OPS * 5 + 64;
+  std::vector<unsigned long long> t((size_t)L * LS);
+  if (hipMemcpy(t.data(), m->d_chain_trace, t.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+  static const char* names[4] = {"o_proj", "gate_up", "down", "qkv"};
+  for (int b = 0; b < 2; ++b) {
+    fprintf(stderr, "[chain trace] block %d (times relative to the loader's first issue, us; avg over layers):", b);
+    for (int oi = 0; oi < 4; ++oi) {
+      double v[5] = {};
+      int n = 0;
+      for (int li = 1; li + 1 < L; ++li) {
+        const unsigned long long* p = t.data() + (size_t)li * LS + ((size_t)b * CH_MAX_OPS + oi) * 5;
+        const unsigned long long t0 = t[(size_t)li * LS + (size_t)b * CH_MAX_OPS * 5];
+        if (p[0] == 0 || p[4] == 0) continue;
+        for (int k = 0; k < 5; ++k) v[k] += (double)(p[k] - t0) * 0.01;
+        ++n;
+      }
+      if (n) fprintf(stderr, " %s: load %.1f-%.1f gathered %.1f normed %.1f done %.1f |", names[oi], v[0] / n, v[1] / n, v[2] / n, v[3] / n, v[4] / n);
+    }
+    fprintf(stderr, "\n");
+  }
+  {  // consumer wave 1 of block 0, gate_up, layer 3: per slot [wait for landed, compute]
+    const unsigned long long* q = t.data() + (size_t)3 * LS + 2 * CH_MAX_OPS * 5;
+    fprintf(stderr, "[chain trace] gate_up consumer 0 slots (wait us / compute us):");
+    for (int i = 0; i < 16; ++i)
+      fprintf(stderr, " %.2f/%.2f(+%.2f)", (double)(q[i * 3 + 1] - q[i * 3]) * 0.01, (double)(q[i * 3 + 2] - q[i * 3 + 1]) * 0.01,
+              i + 1 < 16 ? (double)(q[(i + 1) * 3] - q[i * 3 + 2]) * 0.01 : 0.0);
+    fprintf(stderr, "\n");
+  }
+}
 static void mega_trace_dump(aha_model* m) {
   const int L = m->desc.num_hidden_layers, np = 5 * L + 1;
   std::vector<unsigned long long> t((size_t)4 * np * 3);
@@ -723,11 +781,12 @@ static int fetch_outputs(aha_model* m, float* logits_out, uint32_t* argmax_out) 
   const aha_model_desc& c = m->desc;
   if (logits_out) AHA_HIP_CHECK(hipMemcpyAsync(m->h_logits, m->d_logits, (size_t)c.vocab_size * 4, hipMemcpyDeviceToHost, m->stream));
   AHA_HIP_CHECK(hipMemcpyAsync(&m->h_state->next_token, &m->d_state->next_token, 4, hipMemcpyDeviceToHost, m->stream));
-  if (m->decode_mega || m->decode_ao) AHA_HIP_CHECK(hipMemcpyAsync(m->h_bar_err, m->d_bar + DECODE_MEGA_BAR_ERR_WORD, 4, hipMemcpyDeviceToHost, m->stream));
+  if (m->decode_mega || m->decode_ao || m->decode_chain) AHA_HIP_CHECK(hipMemcpyAsync(m->h_bar_err, m->d_bar + DECODE_MEGA_BAR_ERR_WORD, 4, hipMemcpyDeviceToHost, m->stream));
   AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
   if (int e = mega_check(m)) return e;
   if (m->d_mega_trace) mega_trace_dump(m);
   if (m->d_gemv_trace) gemv_trace_dump(m);
+  if (m->d_chain_trace) chain_trace_dump(m);
   if (logits_out) memcpy(logits_out, m->h_logits, (size_t)c.vocab_size * 4);
   if (argmax_out) *argmax_out = m->h_state->next_token;
   return AHA_OK;
@@ -892,6 +951,9 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
   nsplit = std::max(1, std::min(nsplit, m->max_nsplit));
   for (int li = 0; li < c.num_hidden_layers; ++li) {
     const LayerWeights& L = m->layers[li];
+    if (m->decode_chain && li > 0) {
+      // qkv of this layer came out of the previous layer's chain launch
+    } else
     {  // h = RMSNorm(x); qkv = h Wqkv^T                      (qwen3/model.rs:79, modules.rs:538-552)
       GemvArgs g{};
       g.W = L.wqkv; g.x = m->d_x; g.norm_w = L.in_norm; g.eps = c.rms_norm_eps; g.y = m->d_qkv; g.N = nq + 2 * nkv; g.K = H;
@@ -914,6 +976,51 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
       g.trace = gemv_trace_slot(m, li * 4 + 1);
       const double attn_bytes = (double)kv_len_after * 2 * nkv * 2 + (nq + 2 * nkv) * 2.0 + nsplit * nq * 4.0;
       const double gemv_bytes = (double)g.N * g.K * 2 + g.K * 2.0 + g.N * 4.0;
+      if (m->decode_chain) {
+        {
+          ProfScope ps(m, "attn_decode", attn_bytes, 4.0 * kv_len_after * nq);
+          launch_attn_decode_fused(a, st);
+        }
+        const bool has_next = li + 1 < c.num_hidden_layers;
+        ChainArgs ch{};
+        ch.n_ops = has_next ? 4 : 3;
+        ch.kmax = std::max(std::max(H, I), nq);
+        m->chain_tag += 4;
+        ch.tag_base = m->chain_tag;
+        ch.err = m->d_bar + DECODE_MEGA_BAR_ERR_WORD;
+        ChainOp& o0 = ch.op[0];  // x1 = x + attn Wo^T                               (modules.rs:577, qwen3/model.rs:81)
+        o0.W = L.wo; o0.in_plain = m->d_attn; o0.res_plain = m->d_x; o0.gran = m->d_gran[0];
+        o0.n_out = H; o0.K = nq; o0.kind = GEMV_RESIDUAL; o0.res_own_op = -1; o0.eps = c.rms_norm_eps;
+        ChainOp& o1 = ch.op[1];  // act = silu(h Wg^T) * (h Wu^T), h = RMSNorm(x1)       (qwen3/model.rs:83, modules.rs:81-84)
+        o1.W = L.wgu; o1.norm_w = L.post_norm; o1.gran = m->d_gran[1];
+        o1.n_out = I; o1.K = H; o1.kind = GEMV_SILU_MUL; o1.res_own_op = -1; o1.eps = c.rms_norm_eps;
+        ChainOp& o2 = ch.op[2];  // x2 = x1 + act Wd^T                                (modules.rs:85, qwen3/model.rs:86)
+        o2.W = L.wdown; o2.out_plain = m->d_x; o2.gran = has_next ? m->d_gran[2] : nullptr;
+        o2.n_out = H; o2.K = I; o2.kind = GEMV_RESIDUAL; o2.res_own_op = 0; o2.eps = c.rms_norm_eps;
+        double bytes = ((double)H * nq + 3.0 * I * H) * 2;
+        if (has_next) {
+          const LayerWeights& Ln = m->layers[li + 1];
+          ChainOp& o3 = ch.op[3];  // next layer: h = RMSNorm(x2); qkv = h Wqkv^T      (qwen3/model.rs:79, modules.rs:538-552)
+          o3.W = Ln.wqkv; o3.norm_w = Ln.in_norm; o3.out_plain = m->d_qkv;
+          o3.n_out = nq + 2 * nkv; o3.K = H; o3.kind = GEMV_STORE; o3.res_own_op = -1; o3.eps = c.rms_norm_eps;
+          bytes += (double)(nq + 2 * nkv) * H * 2;
+        }
+        static const char* e_ct = getenv("AHA_CHAIN_TRACE");
+        if (e_ct && atoi(e_ct)) {
+          if (!m->d_chain_trace) {
+            void* tp = nullptr;
+            if (dev_alloc(m, (size_t)c.num_hidden_layers * (2 * CH_MAX_OPS * 5 + 64) * 8, &tp, true) == AHA_OK) m->d_chain_trace = (unsigned long long*)tp;
+          }
+          if (m->d_chain_trace) ch.trace = m->d_chain_trace + (size_t)li * (2 * CH_MAX_OPS * 5 + 64);
+        }
+        static const char* e_dbg = getenv("AHA_CHAIN_DBG");
+        ch.dbg = e_dbg ? atoi(e_dbg) : 0;
+        static const char* e_exact = getenv("AHA_CHAIN_EXACT");
+        ch.exact = e_exact ? atoi(e_exact) : 0;
+        ProfScope ps(m, "decode_chain", bytes, bytes);
+        launch_decode_chain(ch, m->chain_ncu, st);
+        continue;
+      }
       if (m->decode_ao) {  // one launch: attention blocks signal the o_proj grid through a counter
         m->ao_base += (unsigned)kvh;
         ProfScope ps(m, "attn_oproj", attn_bytes + gemv_bytes, 4.0 * kv_len_after * nq + 2.0 * g.N * g.K);
@@ -1022,7 +1129,7 @@ int model_decode_greedy(aha_model* m, uint32_t first_token, size_t offset, size_
     AHA_HIP_CHECK(hipGetLastError());
     if (m->async_rc) { const int e = m->async_rc; m->async_rc = 0; return e; }
     AHA_HIP_CHECK(hipMemcpyAsync(out + produced, m->d_token_log, n * 4, hipMemcpyDeviceToHost, m->stream));
-    if (m->decode_mega || m->decode_ao) AHA_HIP_CHECK(hipMemcpyAsync(m->h_bar_err, m->d_bar + DECODE_MEGA_BAR_ERR_WORD, 4, hipMemcpyDeviceToHost, m->stream));
+    if (m->decode_mega || m->decode_ao || m->decode_chain) AHA_HIP_CHECK(hipMemcpyAsync(m->h_bar_err, m->d_bar + DECODE_MEGA_BAR_ERR_WORD, 4, hipMemcpyDeviceToHost, m->stream));
     AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
     if (int e = mega_check(m)) return e;
     size_t used = n;

@@ -213,7 +213,7 @@ def test_missing_weight_is_an_error(gpu):
 
 
 @pytest.mark.parametrize("shape", ["small", "8b-width"])
-@pytest.mark.parametrize("path", ["attn_oproj", "mega"])
+@pytest.mark.parametrize("path", ["attn_oproj", "mega", "chain"])
 def test_decode_fused_launches_equal_launch_per_op(gpu, monkeypatch, shape, path):
     """The decode paths that synchronise inside a launch -- attention + o_proj in one launch (AHA_DECODE_AO=1) and the
     persistent decode-step kernel (AHA_DECODE_MEGA=1) -- share their device code with the default launch-per-op path: logits
@@ -228,9 +228,12 @@ def test_decode_fused_launches_equal_launch_per_op(gpu, monkeypatch, shape, path
         lens = [97, 1500]
     monkeypatch.setenv("AHA_DECODE_MEGA", "0")
     monkeypatch.setenv("AHA_DECODE_AO", "0")
+    monkeypatch.setenv("AHA_DECODE_CHAIN", "0")
     multi = HipInferenceModel(cfg, w)
     monkeypatch.setenv("AHA_DECODE_MEGA", "1" if path == "mega" else "0")
-    monkeypatch.setenv("AHA_DECODE_AO", "1")
+    monkeypatch.setenv("AHA_DECODE_AO", "1" if path != "chain" else "0")
+    monkeypatch.setenv("AHA_DECODE_CHAIN", "1" if path == "chain" else "0")
+    monkeypatch.setenv("AHA_CHAIN_EXACT", "1")   # the fmaf consumer: same arithmetic as gemv_body.h
     mega = HipInferenceModel(cfg, w)
     for S in lens:
         ids = ids_for(cfg, S, 100 + S)
