@@ -127,7 +127,14 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 // Its internal rounding differs from two fmaf's, so this path is NOT bit-identical to gemv_body.h (tests compare it
 // within the f32-accumulation tolerance; AHA_CHAIN_EXACT=1 selects the fmaf path).
 __device__ __forceinline__ float dot2c_bf16(unsigned a, unsigned b, float acc) {
-  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+  asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+  return acc;
+}
+// Last dot of a chain.  A DOT result may be read by a DIFFERENT VALU instruction only 3 wait states later
+// (GCNHazardRecognizer DotWriteDifferentVALURead); the compiler inserts those for its own instructions but cannot see
+// inside inline asm, so the wait states are part of the asm (without them the following v_add reads stale sums).
+__device__ __forceinline__ float dot2c_bf16_last(unsigned a, unsigned b, float acc) {
+  asm volatile("v_dot2c_f32_bf16 %0, %1, %2\n\ts_nop 3" : "+v"(acc) : "v"(a), "v"(b));
   return acc;
 }
 
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(256, 1) void decode_chain_kernel(ChainArgs a) {
                 c0 = dot2c_bf16(wreg[p][0], xreg[p][0], c0);
                 c1 = dot2c_bf16(wreg[p][1], xreg[p][1], c1);
                 c2 = dot2c_bf16(wreg[p][2], xreg[p][2], c2);
-                c3 = dot2c_bf16(wreg[p][3], xreg[p][3], c3);
+                c3 = p == h * 8 + 7 ? dot2c_bf16_last(wreg[p][3], xreg[p][3], c3) : dot2c_bf16(wreg[p][3], xreg[p][3], c3);
               }
               cur += (c0 + c1) + (c2 + c3);
               chunk += 8;
