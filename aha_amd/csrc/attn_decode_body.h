@@ -16,18 +16,25 @@ constexpr int ATTN_DECODE_FUSED_LDS = 16 * 128 * 2 + 128 * 2 + 128 * 2 + 4 * 128
 // smem: ATTN_DECODE_FUSED_LDS bytes, 16-byte aligned.  (kvhd, split) of nsplit: this block's KV head and KV split.
 // after_prefetch() runs after the unit's first page has been requested and before qkv is read.
 // Returns true in the one block per kv head that wrote the final attention output of the head's g query heads.
-template <bool COH, class AfterPrefetch>
-__device__ __forceinline__ bool attn_decode_fused_body(const AttnDecodeFusedArgs& a, char* smem, const int kvhd, const int split,
-                                                       const int nsplit, AfterPrefetch&& after_prefetch) {
+// General form: NW waves cooperate as one "block" (wave = 0..NW-1, tid = wave * 64 + lane); sync() is a barrier among exactly
+// those waves (__syncthreads() for a whole workgroup; the chain engine's consumer-wave barrier otherwise); emit(head, d, v)
+// receives the final attention output (called for consecutive d by consecutive tid).  LDS: attn_decode_lds_bytes(NW).
+constexpr int attn_decode_lds_bytes(int nw) { return 16 * 128 * 2 + 128 * 2 + 128 * 2 + nw * 128 * 16 * 4 + 2 * nw * 16 * 4; }
+
+template <bool COH, int NW, class AfterPrefetch, class Sync, class Emit>
+__device__ __forceinline__ bool attn_decode_fused_body_t(const AttnDecodeFusedArgs& a, char* smem, const int kvhd, const int split,
+                                                         const int nsplit, const int wave, const int tid,
+                                                         AfterPrefetch&& after_prefetch, Sync&& sync, Emit&& emit) {
+  constexpr int NT = NW * 64;
   bf16_t* qs = reinterpret_cast<bf16_t*>(smem);                 // [16][128]
   bf16_t* ksn = qs + 16 * 128;                                  // [128]
   bf16_t* vsn = ksn + 128;                                      // [128]
-  float* mo = reinterpret_cast<float*>(vsn + 128);              // per wave O^T [4][d 128][q 16]
-  float* mm = mo + 4 * 128 * 16;                                // [4][16]
-  float* mlz = mm + 4 * 16;                                     // [4][16]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, c = lane & 15;
+  float* mo = reinterpret_cast<float*>(vsn + 128);              // per wave O^T [NW][d 128][q 16]
+  float* mm = mo + NW * 128 * 16;                               // [NW][16]
+  float* mlz = mm + NW * 16;                                    // [NW][16]
+  const int lane = tid & 63, G = lane >> 4, c = lane & 15;
   const int g = a.nh / a.kvh;
-  const int nunits = nsplit * 4, unit = split * 4 + wave;
+  const int nunits = nsplit * NW, unit = split * NW + wave;
   const int L = *a.kv_len, slot_new = *a.kv_start;
   const int L_old = L - 1;  // tokens already in the pages; the new one is handled from LDS
   const int npages = (L_old + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS;
@@ -55,7 +62,7 @@ __device__ __forceinline__ bool attn_decode_fused_body(const AttnDecodeFusedArgs
   // ---- prologue: norm + rope of the g q heads and the k head; v raw ------------------------------------------------
   {
     const bf16_t* qkv = (const bf16_t*)a.qkv;
-    for (int hs = wave; hs <= g; hs += 4) {  // hs < g: q head kvhd*g+hs ; hs == g: the k head
+    for (int hs = wave; hs <= g; hs += NW) {  // hs < g: q head kvhd*g+hs ; hs == g: the k head
       const bool is_k = hs == g;
       const bf16_t* src = is_k ? qkv + (int64_t)(a.nh + kvhd) * 128 : qkv + (int64_t)(kvhd * g + hs) * 128;
       const bf16_t* nw = (const bf16_t*)(is_k ? a.k_norm_w : a.q_norm_w);
@@ -72,15 +79,17 @@ __device__ __forceinline__ bool attn_decode_fused_body(const AttnDecodeFusedArgs
       dst[lane] = y0;
       dst[lane + 64] = y1;
     }
-    if (tid < 128) vsn[tid] = act_ld_bf<COH>(qkv + (int64_t)(a.nh + a.kvh + kvhd) * 128 + tid);
+    for (int i = tid; i < 128; i += NT) vsn[i] = act_ld_bf<COH>(qkv + (int64_t)(a.nh + a.kvh + kvhd) * 128 + i);
   }
-  __syncthreads();
-  if (split == 0 && tid < 128) {  // append (k roped, v raw) for the following steps
+  sync();
+  if (split == 0) {  // append (k roped, v raw) for the following steps
     const int pg = slot_new / KV_PAGE_TOKENS, t = slot_new % KV_PAGE_TOKENS;
     bf16_t* base = reinterpret_cast<bf16_t*>(a.kv.page_ptrs[pg] + a.kv.layer_off);
-    base[((int64_t)kvhd * KV_PAGE_TOKENS + t) * 128 + tid] = ksn[tid];
     bf16_t* vd = base + (int64_t)a.kvh * KV_PAGE_TOKENS * 128 + (int64_t)kvhd * 128 * KV_PAGE_TOKENS;
-    vd[(int64_t)tid * KV_PAGE_TOKENS + v_slot(t)] = vsn[tid];
+    for (int i = tid; i < 128; i += NT) {
+      base[((int64_t)kvhd * KV_PAGE_TOKENS + t) * 128 + i] = ksn[i];
+      vd[(int64_t)i * KV_PAGE_TOKENS + v_slot(t)] = vsn[i];
+    }
   }
 
   bf16x8_t qf[4];
@@ -148,16 +157,16 @@ __device__ __forceinline__ bool attn_decode_fused_body(const AttnDecodeFusedArgs
       mlz[wave * 16 + c] = l;
     }
   }
-  __syncthreads();
+  sync();
   const bool single = nsplit == 1;
-  for (int it = tid; it < g * 128; it += 256) {
+  for (int it = tid; it < g * 128; it += NT) {
     const int q = it >> 7, d = it & 127;
     float M = -INFINITY;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) M = fmaxf(M, mm[w * 16 + q]);
+    for (int w = 0; w < NW; ++w) M = fmaxf(M, mm[w * 16 + q]);
     float acc = 0.f, ls = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
       const float mw = mm[w * 16 + q];
       const float wt = (mw == -INFINITY) ? 0.f : __expf(mw - M);
       acc = fmaf(wt, mo[w * (128 * 16) + d * 16 + q], acc);
@@ -165,7 +174,7 @@ __device__ __forceinline__ bool attn_decode_fused_body(const AttnDecodeFusedArgs
     }
     const int head = kvhd * g + q;
     if (single) {  // the whole cache went through this block: normalise and emit the attention output tensor (bf16)
-      act_st_bf<COH>((bf16_t*)a.o + head * 128 + d, f2bf(acc * (1.0f / ls)));
+      emit(head, d, acc * (1.0f / ls));
     } else {
       act_stf<true>(a.part_o + ((int64_t)split * a.nh + head) * 128 + d, acc);
       if (d == 0) {
@@ -180,15 +189,15 @@ __device__ __forceinline__ bool attn_decode_fused_body(const AttnDecodeFusedArgs
   // Partials cross blocks (possibly XCDs) inside one launch: agent-scope stores above, every wave waits for their
   // acknowledgement, then one relaxed atomic per block on the head's counter decides who arrived last.
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-  __syncthreads();
+  sync();
   int* s_last = reinterpret_cast<int*>(qs);  // q fragments are in registers since the page loop; LDS region is free
   if (tid == 0) {
     const unsigned prev = __hip_atomic_fetch_add(a.head_ctr + 32 * kvhd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *s_last = (prev + 1u == a.ctr_target) ? 1 : 0;
   }
-  __syncthreads();
+  sync();
   if (*s_last == 0) return false;
-  for (int it = tid; it < g * 128; it += 256) {
+  for (int it = tid; it < g * 128; it += NT) {
     const int q = it >> 7, d = it & 127;
     const int head = kvhd * g + q;
     float M = -INFINITY, ls = 0.f, f = 0.f;
@@ -219,9 +228,19 @@ __device__ __forceinline__ bool attn_decode_fused_body(const AttnDecodeFusedArgs
         f = fmaf(wgt, po[j], f);
       }
     }
-    act_st_bf<COH>((bf16_t*)a.o + head * 128 + d, f2bf(f * (1.0f / ls)));  // attention output tensor (bf16)
+    emit(head, d, f * (1.0f / ls));  // attention output tensor (rounded to bf16 by the receiver)
   }
   return true;
+}
+
+// The whole-workgroup form used by attn_decode_fused_kernel and the persistent decode-step kernel: 4 waves, __syncthreads,
+// output written to a.o as bf16.
+template <bool COH, class AfterPrefetch>
+__device__ __forceinline__ bool attn_decode_fused_body(const AttnDecodeFusedArgs& a, char* smem, const int kvhd, const int split,
+                                                       const int nsplit, AfterPrefetch&& after_prefetch) {
+  return attn_decode_fused_body_t<COH, 4>(
+      a, smem, kvhd, split, nsplit, (int)(threadIdx.x >> 6), (int)threadIdx.x, after_prefetch, [] { __syncthreads(); },
+      [&](int head, int d, float v) { act_st_bf<COH>((bf16_t*)a.o + head * 128 + d, f2bf(v)); });
 }
 
 }  // namespace aha

@@ -192,11 +192,19 @@ struct ChainOp {
   const void* res_plain;     // GEMV_RESIDUAL: residual vector from an earlier launch, or nullptr -> res_own_op
   void* out_plain;           // optional plain bf16 copy of the output vector (read by later launches)
   unsigned long long* gran;  // optional granule buffer (n_out / 2 x 8 bytes) the op publishes for the next op
+  const unsigned long long* gran_in;  // in_plain == nullptr: granules to gather the input vector from, tagged tag_base + tag_in
+  int tag_in;
   int n_out, K, kind;        // kind: GEMV_STORE / GEMV_RESIDUAL / GEMV_SILU_MUL
   int res_own_op;            // GEMV_RESIDUAL without res_plain: index of the earlier op whose rows (same CU) are the residual
   float eps;
 };
 struct ChainArgs {
+  // optional attention stage in front of op[0] (has_attn): the first attn.kvh * attn.nsplit workgroups run the fused decode
+  // attention with their three consumer waves and publish the output as granules (attn_gran, tag_base + 7) while every
+  // loader already streams op[0]'s weights
+  AttnDecodeFusedArgs attn;
+  unsigned long long* attn_gran;
+  int has_attn;
   ChainOp op[CH_MAX_OPS];
   int n_ops;
   int kmax;                  // longest input vector of the chain (LDS sizing)

@@ -119,7 +119,7 @@ struct aha_model {
   bool decode_chain = false;        // o_proj -> gate/up -> down -> next qkv in one persistent launch (decode_chain.hip)
   int chain_ncu = 0;                // workgroups (= CUs) of the chain launch
   unsigned chain_tag = 0;           // launch-unique granule tag base
-  unsigned long long* d_gran[3] = {nullptr, nullptr, nullptr};  // granule buffers of the chain's three hand-offs
+  unsigned long long* d_gran[4] = {nullptr, nullptr, nullptr, nullptr};  // granule buffers: x1, act, x2, attention output
   bool decode_ao = false;           // attention + o_proj in one launch (opt-in)
   unsigned head_ctr_base = 0;       // value every kv head's split-arrival counter has reached after all launches so far
   unsigned ao_base = 0;             // value the attn_oproj arrival counter has reached after all launches so far

@@ -560,7 +560,7 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
         }
       }
       if (m->decode_chain) {
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < 4; ++k) {
           if ((rc = dev_alloc(m, (size_t)kmax * 4, &p, true))) return fail(rc);
           m->d_gran[k] = (unsigned long long*)p;
         }
@@ -977,31 +977,44 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
       const double attn_bytes = (double)kv_len_after * 2 * nkv * 2 + (nq + 2 * nkv) * 2.0 + nsplit * nq * 4.0;
       const double gemv_bytes = (double)g.N * g.K * 2 + g.K * 2.0 + g.N * 4.0;
       if (m->decode_chain) {
-        {
+        static const char* e_ca = getenv("AHA_CHAIN_ATTN");
+        const bool chain_attn = e_ca ? atoi(e_ca) != 0 : false;  // measured: attention inside the launch is slower (101 vs 98 us/layer)
+        const bool has_next = li + 1 < c.num_hidden_layers;
+        ChainArgs ch{};
+        if (chain_attn) {  // attention inside the chain launch: 3 KV units (waves) per workgroup
+          if (nsplit > 1) m->head_ctr_base -= (unsigned)nsplit;  // undo the 4-wave split count taken above
+          int ns3 = (npages + 2) / 3;
+          ns3 = std::max(1, std::min(std::min(ns3, m->max_nsplit), m->chain_ncu / kvh));
+          a.nsplit = ns3;
+          if (ns3 > 1) m->head_ctr_base += (unsigned)ns3;
+          a.ctr_target = m->head_ctr_base;
+          ch.attn = a;
+          ch.attn_gran = m->d_gran[3];
+          ch.has_attn = 1;
+        } else {
           ProfScope ps(m, "attn_decode", attn_bytes, 4.0 * kv_len_after * nq);
           launch_attn_decode_fused(a, st);
         }
-        const bool has_next = li + 1 < c.num_hidden_layers;
-        ChainArgs ch{};
         ch.n_ops = has_next ? 4 : 3;
         ch.kmax = std::max(std::max(H, I), nq);
-        m->chain_tag += 4;
+        m->chain_tag += 8;
         ch.tag_base = m->chain_tag;
         ch.err = m->d_bar + DECODE_MEGA_BAR_ERR_WORD;
         ChainOp& o0 = ch.op[0];  // x1 = x + attn Wo^T                               (modules.rs:577, qwen3/model.rs:81)
-        o0.W = L.wo; o0.in_plain = m->d_attn; o0.res_plain = m->d_x; o0.gran = m->d_gran[0];
+        o0.W = L.wo; o0.in_plain = chain_attn ? nullptr : m->d_attn; o0.gran_in = m->d_gran[3]; o0.tag_in = 7;
+        o0.res_plain = m->d_x; o0.gran = m->d_gran[0];
         o0.n_out = H; o0.K = nq; o0.kind = GEMV_RESIDUAL; o0.res_own_op = -1; o0.eps = c.rms_norm_eps;
         ChainOp& o1 = ch.op[1];  // act = silu(h Wg^T) * (h Wu^T), h = RMSNorm(x1)       (qwen3/model.rs:83, modules.rs:81-84)
-        o1.W = L.wgu; o1.norm_w = L.post_norm; o1.gran = m->d_gran[1];
+        o1.W = L.wgu; o1.norm_w = L.post_norm; o1.gran = m->d_gran[1]; o1.gran_in = m->d_gran[0]; o1.tag_in = 0;
         o1.n_out = I; o1.K = H; o1.kind = GEMV_SILU_MUL; o1.res_own_op = -1; o1.eps = c.rms_norm_eps;
         ChainOp& o2 = ch.op[2];  // x2 = x1 + act Wd^T                                (modules.rs:85, qwen3/model.rs:86)
-        o2.W = L.wdown; o2.out_plain = m->d_x; o2.gran = has_next ? m->d_gran[2] : nullptr;
+        o2.W = L.wdown; o2.out_plain = m->d_x; o2.gran = has_next ? m->d_gran[2] : nullptr; o2.gran_in = m->d_gran[1]; o2.tag_in = 1;
         o2.n_out = H; o2.K = I; o2.kind = GEMV_RESIDUAL; o2.res_own_op = 0; o2.eps = c.rms_norm_eps;
         double bytes = ((double)H * nq + 3.0 * I * H) * 2;
         if (has_next) {
           const LayerWeights& Ln = m->layers[li + 1];
           ChainOp& o3 = ch.op[3];  // next layer: h = RMSNorm(x2); qkv = h Wqkv^T      (qwen3/model.rs:79, modules.rs:538-552)
-          o3.W = Ln.wqkv; o3.norm_w = Ln.in_norm; o3.out_plain = m->d_qkv;
+          o3.W = Ln.wqkv; o3.norm_w = Ln.in_norm; o3.out_plain = m->d_qkv; o3.gran_in = m->d_gran[2]; o3.tag_in = 2;
           o3.n_out = nq + 2 * nkv; o3.K = H; o3.kind = GEMV_STORE; o3.res_own_op = -1; o3.eps = c.rms_norm_eps;
           bytes += (double)(nq + 2 * nkv) * H * 2;
         }

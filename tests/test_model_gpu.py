@@ -234,6 +234,7 @@ def test_decode_fused_launches_equal_launch_per_op(gpu, monkeypatch, shape, path
     monkeypatch.setenv("AHA_DECODE_AO", "1" if path != "chain" else "0")
     monkeypatch.setenv("AHA_DECODE_CHAIN", "1" if path == "chain" else "0")
     monkeypatch.setenv("AHA_CHAIN_EXACT", "1")   # the fmaf consumer: same arithmetic as gemv_body.h
+    monkeypatch.setenv("AHA_CHAIN_ATTN", "0")    # attention as its own launch (inside the chain its 3-wave units merge in a different order)
     mega = HipInferenceModel(cfg, w)
     for S in lens:
         ids = ids_for(cfg, S, 100 + S)
@@ -254,10 +255,12 @@ def test_decode_fused_launches_equal_launch_per_op(gpu, monkeypatch, shape, path
     multi.close(); mega.close()
 
 
-def test_decode_chain_dot2c_consumer_close_to_launch_per_op(gpu, monkeypatch):
-    """The chain engine's default consumer uses v_dot2c_f32_bf16 (packed bf16 pairs, hardware-internal rounding of the pair sum)
-    instead of two fmaf's: not bit-identical, but inside the f32-accumulation tolerance every other cross-kernel comparison
-    uses (max |dlogit| <= 0.05 std, rms <= 0.02 std), at the Qwen3-VL-8B layer width."""
+@pytest.mark.parametrize("attn_in_chain", ["0", "1"])
+def test_decode_chain_dot2c_consumer_close_to_launch_per_op(gpu, monkeypatch, attn_in_chain):
+    """The chain engine's default configuration: v_dot2c_f32_bf16 consumer (packed bf16 pairs, hardware-internal rounding of
+    the pair sum) and, with attn_in_chain, the attention stage inside the launch (3-wave KV units: another merge order).
+    Not bit-identical, but inside the f32-accumulation tolerance every other cross-kernel comparison uses
+    (max |dlogit| <= 0.05 std, rms <= 0.02 std), at the Qwen3-VL-8B layer width, across KV-split counts."""
     from aha_amd.model import HipInferenceModel
     cfg = tiny_qwen3(layers=2, hidden=4096, heads=32, kv_heads=8, inter=12288, vocab=2048, tie=False)
     w = qwen3_text_weights(cfg, seed=3)
@@ -265,8 +268,9 @@ def test_decode_chain_dot2c_consumer_close_to_launch_per_op(gpu, monkeypatch):
     ref = HipInferenceModel(cfg, w)
     monkeypatch.setenv("AHA_DECODE_CHAIN", "1")
     monkeypatch.setenv("AHA_CHAIN_EXACT", "0")
+    monkeypatch.setenv("AHA_CHAIN_ATTN", attn_in_chain)
     ch = HipInferenceModel(cfg, w)
-    for S in (70, 1500):
+    for S in (1, 70, 190, 1500):
         ids = ids_for(cfg, S, 200 + S)
         ref.clear_cache(); ch.clear_cache()
         a, tok = ref.forward_initial(ids, 0)
