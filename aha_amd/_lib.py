@@ -126,6 +126,13 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: run `python -m aha_amd.build` (or __graft_entry__.build()) first; "
                               "there is no CPU fallback for the HIP path")
+        # Load order matters: torch bundles its own HIP / HSA / RCCL runtime (same SONAMEs as /opt/rocm's).  If
+        # libaha_hip.so is dlopen'ed first it pulls in /opt/rocm's copies, torch then mixes both and device discovery
+        # fails ("no ROCm-capable device is detected").  Importing torch first makes the process use one runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError here means the .so does not export a declared symbol
