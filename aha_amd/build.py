@@ -27,7 +27,7 @@ def _digest(paths) -> str:
     h = hashlib.sha256()
     for p in sorted(paths):
         with open(p, "rb") as f:
-            h.update(p.encode())
+            h.update(os.path.basename(p).encode())  # not the absolute path: the tree is copied to other roots (gpurun)
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
