@@ -40,8 +40,9 @@ GemvPlan plan_gemv(int N, int K, GemvEpi epi) {
   // U must be one of the instantiated values {1,2,4,8}
   int Up = 1;
   while (Up * 2 <= U) Up *= 2;
-  // persistent blocks: two register buffers of R*U*NW loads => ~2 blocks (8 waves) per CU on 256 CUs
-  int gmax = 512;
+  // persistent blocks: 3 per CU on 256 CUs (<= 160 VGPRs: 12 waves per CU).  A/B on the Qwen3-VL-8B decode step, same box:
+  // 512 -> 267.7 tok/s, 640 -> 270.9, 768 -> 276.2, 1024 -> 269.6.
+  int gmax = 768;
   // tuning knobs for scripts/bench_gemv.py (not used by the product path unless set)
   static const char* e_grid = getenv("AHA_GEMV_GRID");
   static const char* e_r = getenv("AHA_GEMV_R");
