@@ -39,6 +39,9 @@ void launch_gemv(const GemvArgs& a, GemvEpi epi, hipStream_t st);
 int gemv_num_tiles(int N, int K);  // number of (max,idx) partials GEMV_LOGITS writes
 
 void launch_argmax_partials(const float* blk_max, const uint32_t* blk_idx, int n, uint32_t* out, hipStream_t st);
+// vocab-parallel lm_head (tensor parallelism): per-rank (max, global index) pair into a zeroed 2T vector / pick after the all-reduce
+void launch_argmax_pair(const float* blk_max, const uint32_t* blk_idx, int n, int row0, float* pairs, int rank, int T, hipStream_t st);
+void launch_argmax_pick(const float* pairs, int T, uint32_t* out, hipStream_t st);
 void launch_argmax_f32(const float* x, int64_t n, float* ws_max, uint32_t* ws_idx, uint32_t* out, hipStream_t st);
 
 void launch_embed_gather(const void* table, const uint32_t* ids, void* out, int S, int H, hipStream_t st);

@@ -201,6 +201,39 @@ __global__ __launch_bounds__(256) void argmax_partials_kernel(const float* __res
     *out = bi;
   }
 }
+// vocab-parallel lm_head: pairs[2r] = this rank's max logit, pairs[2r+1] = its GLOBAL index (exact in f32: < 2^24), every
+// other slot 0, so that a sum all-reduce over ranks leaves all T pairs everywhere
+__global__ __launch_bounds__(256) void argmax_pair_kernel(const float* __restrict__ pv, const uint32_t* __restrict__ pi, int n,
+                                                          int row0, float* __restrict__ pairs, int rank, int T) {
+  __shared__ float sv[4];
+  __shared__ uint32_t si[4];
+  float bv = -INFINITY;
+  uint32_t bi = 0xffffffffu;
+  for (int i = threadIdx.x; i < n; i += 256) argmax_combine(bv, bi, pv[i], pi[i]);
+  wave_argmax(bv, bi);
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * T) pairs[threadIdx.x] = 0.f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) argmax_combine(bv, bi, sv[w], si[w]);
+    pairs[2 * rank] = bv;
+    pairs[2 * rank + 1] = (float)(bi + (uint32_t)row0);
+  }
+}
+__global__ void argmax_pick_kernel(const float* __restrict__ pairs, int T, uint32_t* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  float bv = -INFINITY;
+  uint32_t bi = 0xffffffffu;
+  for (int r = 0; r < T; ++r) argmax_combine(bv, bi, pairs[2 * r], (uint32_t)pairs[2 * r + 1]);
+  *out = bi;
+}
+void launch_argmax_pair(const float* blk_max, const uint32_t* blk_idx, int n, int row0, float* pairs, int rank, int T, hipStream_t st) {
+  hipLaunchKernelGGL(argmax_pair_kernel, dim3(1), dim3(256), 0, st, blk_max, blk_idx, n, row0, pairs, rank, T);
+}
+void launch_argmax_pick(const float* pairs, int T, uint32_t* out, hipStream_t st) {
+  hipLaunchKernelGGL(argmax_pick_kernel, dim3(1), dim3(64), 0, st, pairs, T, out);
+}
 void launch_argmax_partials(const float* blk_max, const uint32_t* blk_idx, int n, uint32_t* out, hipStream_t st) {
   hipLaunchKernelGGL(argmax_partials_kernel, dim3(1), dim3(256), 0, st, blk_max, blk_idx, n, out);
 }

@@ -48,6 +48,8 @@ GemvPlan plan_gemv(int N, int K, GemvEpi epi) {
   static const char* e_r = getenv("AHA_GEMV_R");
   static const char* e_u = getenv("AHA_GEMV_U");
   if (e_grid) gmax = atoi(e_grid);
+  static const char* e_grid1 = getenv("AHA_GEMV_GRID_R1");  // separate cap for the 1-row-per-wave kernels (118 VGPRs: 4 blocks per CU fit)
+  if (e_grid1 && R == 1) gmax = atoi(e_grid1);
   if (e_r) {
     R = atoi(e_r);
     if (nw == 2 && R > 2) R = 2;

@@ -112,7 +112,8 @@ struct aha_model {
   void* allreduce_user = nullptr;
   void* rccl_comm = nullptr;
   int async_rc = 0;             // first error of an all-reduce issued from inside an enqueue helper
-  float* d_partial = nullptr;   // decode: (hidden) f32 partial projection
+  int lm_rows = 0, lm_row0 = 0; // lm_head rows this rank streams (vocab-parallel under TP) and the first of them
+  float* d_partial = nullptr;   // decode: (hidden) f32 partial projection; also the 2T-float argmax pair exchange
   float* p_partial = nullptr;   // prefill: (S, hidden) f32
   // persistent decode-step kernel (decode_mega.hip): one launch per token
   bool decode_mega = false;

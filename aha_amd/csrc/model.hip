@@ -417,7 +417,15 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
   const aha_tensor_view* t = nullptr;
   if ((rc = need(w, nw, pre + "embed_tokens.weight", &t))) return fail(rc);
   if ((rc = upload_tensor(m, t, {c.vocab_size, H}, &m->embed))) return fail(rc);
-  if (c.tie_word_embeddings) m->lm_head = m->embed;
+  // lm_head under tensor parallelism: rank r streams vocab rows [r V/T, (r+1) V/T); the tied
+  // case needs no copy (a row window of the embedding table, which every rank holds in full for the gather)
+  m->lm_rows = c.vocab_size;
+  m->lm_row0 = 0;
+  if (T > 1 && c.vocab_size % T == 0) {
+    m->lm_rows = c.vocab_size / T;
+    m->lm_row0 = R * m->lm_rows;
+  }
+  if (c.tie_word_embeddings) m->lm_head = (char*)m->embed + (size_t)m->lm_row0 * H * 2;
   else {
     // HF stores lm_head at top level; the reference's Qwen3 (non-VL) branch would look it up under the prefix
     // (qwen3/model.rs:124) -- accept either.
@@ -427,7 +435,12 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
       set_error("missing weight tensor: lm_head.weight");
       return fail(AHA_ERR_MISSING_WEIGHT);
     }
-    if ((rc = upload_tensor(m, t, {c.vocab_size, H}, &m->lm_head))) return fail(rc);
+    if (m->lm_rows == c.vocab_size) {
+      if ((rc = upload_tensor(m, t, {c.vocab_size, H}, &m->lm_head))) return fail(rc);
+    } else {
+      if ((rc = dev_alloc(m, (size_t)m->lm_rows * H * 2, &m->lm_head))) return fail(rc);
+      if ((rc = upload_block(m, t, c.vocab_size, H, m->lm_row0, m->lm_rows, 0, H, m->lm_head, 0))) return fail(rc);
+    }
   }
   if ((rc = need(w, nw, pre + "norm.weight", &t))) return fail(rc);
   if ((rc = upload_tensor(m, t, {H}, &m->final_norm))) return fail(rc);
@@ -684,20 +697,28 @@ static void enqueue_lm_head(aha_model* m, const void* x_last) {
   g.x = x_last;
   g.norm_w = m->final_norm;
   g.eps = c.rms_norm_eps;
-  g.N = c.vocab_size;
+  g.N = m->lm_rows;
   g.K = c.hidden_size;
-  g.y_f32 = m->d_logits;
+  g.y_f32 = m->d_logits + m->lm_row0;
   g.blk_max = m->d_blk_max;
   g.blk_idx = m->d_blk_idx;
   g.h_out = m->d_hlast;
   {
-    ProfScope ps(m, "gemv", (double)c.vocab_size * c.hidden_size * 2 + c.hidden_size * 2 + c.vocab_size * 4.0, 2.0 * c.vocab_size * c.hidden_size);
+    ProfScope ps(m, "gemv", (double)m->lm_rows * c.hidden_size * 2 + c.hidden_size * 2 + m->lm_rows * 4.0, 2.0 * m->lm_rows * c.hidden_size);
     launch_gemv(g, GEMV_LOGITS, m->stream);
   }
-  {
-    ProfScope ps(m, "argmax", 0, 0);
-    launch_argmax_partials(m->d_blk_max, m->d_blk_idx, gemv_num_tiles(c.vocab_size, c.hidden_size), &m->d_state->next_token, m->stream);
+  ProfScope ps(m, "argmax", 0, 0);
+  const int ntiles = gemv_num_tiles(m->lm_rows, c.hidden_size);
+  if (m->lm_rows == c.vocab_size) {
+    launch_argmax_partials(m->d_blk_max, m->d_blk_idx, ntiles, &m->d_state->next_token, m->stream);
+    return;
   }
+  // vocab-parallel: each rank contributes its (max, global index) pair to a zeroed 2T-float vector; the all-reduce (sum)
+  // is then an all-gather; the pick keeps the smallest index among equal maxima (candle argmax = first maximal index)
+  launch_argmax_pair(m->d_blk_max, m->d_blk_idx, ntiles, m->lm_row0, m->d_partial, m->tp_rank, m->tp_size, m->stream);
+  const int rc = model_allreduce(m, m->d_partial, (size_t)2 * m->tp_size);
+  if (rc && !m->async_rc) m->async_rc = rc;
+  launch_argmax_pick(m->d_partial, m->tp_size, &m->d_state->next_token, m->stream);
 }
 
 // The persistent decode kernel's grid barrier gave up (a block was not scheduled or died): report instead of hanging, and
@@ -779,6 +800,14 @@ static void mega_trace_dump(aha_model* m) {
 
 static int fetch_outputs(aha_model* m, float* logits_out, uint32_t* argmax_out) {
   const aha_model_desc& c = m->desc;
+  if (logits_out && m->lm_rows != c.vocab_size) {
+    // vocab-parallel lm_head: every rank zeroes the slices it does not own and the all-reduce assembles the full vector
+    if (m->lm_row0 > 0) AHA_HIP_CHECK(hipMemsetAsync(m->d_logits, 0, (size_t)m->lm_row0 * 4, m->stream));
+    const int tail0 = m->lm_row0 + m->lm_rows;
+    if (tail0 < c.vocab_size) AHA_HIP_CHECK(hipMemsetAsync(m->d_logits + tail0, 0, (size_t)(c.vocab_size - tail0) * 4, m->stream));
+    const int rc = model_allreduce(m, m->d_logits, (size_t)c.vocab_size);
+    if (rc) return rc;
+  }
   if (logits_out) AHA_HIP_CHECK(hipMemcpyAsync(m->h_logits, m->d_logits, (size_t)c.vocab_size * 4, hipMemcpyDeviceToHost, m->stream));
   AHA_HIP_CHECK(hipMemcpyAsync(&m->h_state->next_token, &m->d_state->next_token, 4, hipMemcpyDeviceToHost, m->stream));
   if (m->decode_mega || m->decode_ao || m->decode_chain) AHA_HIP_CHECK(hipMemcpyAsync(m->h_bar_err, m->d_bar + DECODE_MEGA_BAR_ERR_WORD, 4, hipMemcpyDeviceToHost, m->stream));

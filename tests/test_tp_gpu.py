@@ -79,7 +79,8 @@ def test_tp2_matches_single_gpu_text(gpu, S):
     ids = [int(x) for x in np.random.default_rng(S).integers(0, cfg.vocab_size, size=S)]
     ref, _ = single.forward_initial(ids, 0)
     got = run_ranks([lambda m=m: m.forward_initial(ids, 0)[0].copy() for m in ranks])
-    assert red.calls == 2 * cfg.num_hidden_layers
+    # two row-parallel projections per layer + the vocab-parallel lm_head's argmax pair exchange + the full-logits assembly
+    assert red.calls == 2 * cfg.num_hidden_layers + 2
     np.testing.assert_array_equal(got[0], got[1])  # both ranks see the same reduced sums
     close(got[0], ref, f"tp2 prefill S={S}")
     tok, off = int(np.argmax(ref)), S
@@ -114,6 +115,35 @@ def test_tp2_greedy_tokens_and_vl(gpu):
     assert list(toks[0]) == list(toks[1])
     # greedy ties can flip under a different f32 summation order; the tiny random model has well separated logits
     assert list(toks[0]) == list(want)
+    for m in ranks + [single]:
+        m.close()
+
+
+def test_tp2_vocab_parallel_lm_head_is_exact_given_the_hidden_state(gpu):
+    """With ONE decoder layer whose row-parallel partial sums are exact in f32 (weights and activations are small integers /
+    powers of two in bf16), the TP stack's hidden state equals the single-GPU one bit for bit, so the vocab-sharded lm_head
+    (each rank streams half the rows, argmax pairs and logits slices exchanged through the all-reduce seam) must reproduce
+    logits and argmax EXACTLY, including a tie across the shard boundary (first maximal index wins)."""
+    from aha_amd.model import HipContext, HipInferenceModel
+    cfg = tiny_qwen3(layers=1, hidden=256, heads=4, kv_heads=2, inter=512, vocab=1024, tie=False)
+    w = qwen3_text_weights(cfg, seed=0)
+    g = torch.Generator().manual_seed(5)
+    for k in list(w):   # integer-valued weights: every partial sum is exact, so TP == single GPU bit for bit
+        if k.endswith("proj.weight"):
+            w[k] = torch.randint(-2, 3, w[k].shape, generator=g).to(torch.bfloat16) / 64
+    lm = torch.randint(-3, 4, w["lm_head.weight"].shape, generator=g).to(torch.bfloat16) / 8
+    lm[900] = lm[100]            # identical rows on both sides of the shard boundary (512): a guaranteed tie
+    w["lm_head.weight"] = lm
+    single = HipInferenceModel(cfg, w, ctx=HipContext(0))
+    red = TwoRankSum()
+    ranks = [HipInferenceModel(cfg, w, tp_rank=r, tp_size=2, allreduce=lambda p, n, r=r: red.allreduce(r, p, n)) for r in range(2)]
+    ids = [int(x) for x in np.random.default_rng(0).integers(0, cfg.vocab_size, size=9)]
+    ref, am = single.forward_initial(ids, 0)
+    got = run_ranks([lambda m=m: m.forward_initial(ids, 0) for m in ranks])
+    for lg, tok in got:
+        np.testing.assert_array_equal(lg, ref)
+        assert tok == am == int(np.argmax(ref))
+    assert ref[100] == ref[900]
     for m in ranks + [single]:
         m.close()
 
