@@ -41,14 +41,42 @@ __device__ __forceinline__ uint32_t pack_bf(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, p);
 }
 
+// Butterfly reductions over the 64 lanes (partners xor 32, 16, 8, 4, 2, 1 in that order; every lane ends with the total).
+// gfx950 form without the LDS crossbar (ds_bpermute): v_permlane32_swap / v_permlane16_swap for the two cross-row steps,
+// DPP row rotations inside a 16-lane row -- after the xor-8 step lanes i and i^8 hold the same value, so a rotation by 4
+// delivers exactly the xor-4 partner's value, and so on.  Same pairings and order as the __shfl_xor loop => same bits.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x124 /* row_ror:4 */, 0xf, 0xf, false));
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x122 /* row_ror:2 */, 0xf, 0xf, false));
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+  {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+  v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x128, 0xf, 0xf, false)));
+  v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x124, 0xf, 0xf, false)));
+  v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x122, 0xf, 0xf, false)));
+  v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x121, 0xf, 0xf, false)));
   return v;
 }
 

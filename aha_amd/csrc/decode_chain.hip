@@ -101,27 +101,6 @@ __device__ __forceinline__ bool lds_wait_ge(const unsigned* p, unsigned target, 
   return true;
 }
 
-// Same butterfly as common.h wave_sum (xor 32, 16, 8, 4, 2, 1 -- bit-identical sums) without the LDS crossbar: gfx950
-// permlane swaps for the two cross-row steps, DPP row rotations inside a row (after the xor-8 step lanes i and i^8 hold the
-// same value, so a rotation by 4 delivers the xor-4 partner's value, and so on).
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  {
-    const unsigned u = __float_as_uint(v);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-  {
-    const unsigned u = __float_as_uint(v);
-    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-  v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
-  v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x124 /* row_ror:4 */, 0xf, 0xf, false));
-  v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x122 /* row_ror:2 */, 0xf, 0xf, false));
-  v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
-  return v;
-}
-
 // acc += a.lo * b.lo + a.hi * b.hi on packed bf16 pairs (gfx950 VOP2; this compiler has no builtin for it).  One
 // instruction per two MACs and no unpacking: the consumer's instruction count per 16-KiB slot drops from ~400 to ~70.
 // Its internal rounding differs from two fmaf's, so this path is NOT bit-identical to gemv_body.h (tests compare it
@@ -334,7 +313,7 @@ __global__ __launch_bounds__(256, 1) void decode_chain_kernel(ChainArgs a) {
             ss = fmaf(f1, f1, ss);
           }
         }
-        part[w4] = wave_sum_dpp(ss);
+        part[w4] = wave_sum(ss);
       }
       const float tot = part[0] + part[1] + part[2] + part[3];
       const float rinv = 1.0f / sqrtf(tot / (float)K + op.eps);
@@ -379,7 +358,7 @@ __global__ __launch_bounds__(256, 1) void decode_chain_kernel(ChainArgs a) {
         const int np = min(16, pieces_per_group - s * 16);
         // the chunk index of every piece of the slot is known up front: all 32 LDS reads can be in flight together
         auto row_done = [&]() {  // a row('s half) is complete: reduce across the wave, park it with its lane
-          const float tot = wave_sum_dpp(cur);
+          const float tot = wave_sum(cur);
           if (ai < g.G) {
             if (lane == ai) v0 = tot;
           } else if (lane == ai - g.G) {

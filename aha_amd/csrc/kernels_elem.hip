@@ -87,60 +87,77 @@ void launch_rmsnorm_rows(const void* x, const void* w, void* y, int64_t rows, in
 // angle = f32(pos[axis(i)]) * inv_freq[i], cos/sin in f32, cast to bf16 before use; each of q*cos, rot(q)*sin and
 // their sum is a materialised bf16 tensor in the reference, so each is rounded here too.
 // One wave per (token, head): lane l owns elements l and l+64 of the 128-wide head == one rotate_half pair.
+constexpr int ROPE_SLOTS_PER_WAVE = 8;  // cos/sin depend on (token, lane) only: one wave computes them once for 8 head slots
 __global__ __launch_bounds__(256) void qknorm_rope_kernel(RopeArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nslot = a.nh + 2 * a.kvh;
-  if (wid >= (int64_t)a.S * nslot) return;
-  const int s = (int)(wid / nslot);
-  const int slot = (int)(wid % nslot);
-  const bf16_t* src = (const bf16_t*)a.qkv + (int64_t)s * a.ld + (int64_t)slot * 128;
-  float x0 = bf2f(src[lane]), x1 = bf2f(src[lane + 64]);
-  const bool is_q = slot < a.nh;
-  const bool is_k = !is_q && slot < a.nh + a.kvh;
-  if (is_q || is_k) {
-    const bf16_t* nw = (const bf16_t*)(is_q ? a.q_norm_w : a.k_norm_w);
-    const float ss = wave_sum(fmaf(x0, x0, x1 * x1));
-    const float rinv = 1.0f / sqrtf(ss / 128.0f + a.eps);
-    x0 = rbf(x0 * rinv * bf2f(nw[lane]));
-    x1 = rbf(x1 * rinv * bf2f(nw[lane + 64]));
-    const int ax = a.axis_map[lane];
-    const float ang = (float)a.pos[(int64_t)ax * a.pos_ld + s] * a.inv_freq[lane];
-    const float c = rbf(cosf(ang)), sn = rbf(sinf(ang));
-    const float y0 = rbf(rbf(x0 * c) + rbf(-x1 * sn));
-    const float y1 = rbf(rbf(x1 * c) + rbf(x0 * sn));
-    x0 = y0;
-    x1 = y1;
+  const int ngrp = (nslot + ROPE_SLOTS_PER_WAVE - 1) / ROPE_SLOTS_PER_WAVE;
+  if (wid >= (int64_t)a.S * ngrp) return;
+  const int s = (int)(wid / ngrp);
+  const int slot0 = (int)(wid % ngrp) * ROPE_SLOTS_PER_WAVE;
+  const int ax = a.axis_map[lane];
+  const float ang = (float)a.pos[(int64_t)ax * a.pos_ld + s] * a.inv_freq[lane];
+  const float c = rbf(cosf(ang)), sn = rbf(sinf(ang));
+  const float qw0 = bf2f(((const bf16_t*)a.q_norm_w)[lane]), qw1 = bf2f(((const bf16_t*)a.q_norm_w)[lane + 64]);
+  const float kw0 = bf2f(((const bf16_t*)a.k_norm_w)[lane]), kw1 = bf2f(((const bf16_t*)a.k_norm_w)[lane + 64]);
+  const bf16_t* row = (const bf16_t*)a.qkv + (int64_t)s * a.ld;
+  const int nloc = min(ROPE_SLOTS_PER_WAVE, nslot - slot0);
+  float xa[ROPE_SLOTS_PER_WAVE], xb[ROPE_SLOTS_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < ROPE_SLOTS_PER_WAVE; ++j) {  // all loads of the group in flight together
+    if (j < nloc) {
+      xa[j] = bf2f(row[(int64_t)(slot0 + j) * 128 + lane]);
+      xb[j] = bf2f(row[(int64_t)(slot0 + j) * 128 + lane + 64]);
+    }
   }
-  const bf16_t b0 = f2bf(x0), b1 = f2bf(x1);
-  if (is_q) {
-    bf16_t* dst = (bf16_t*)a.q_out + (int64_t)s * a.nh * 128 + (int64_t)slot * 128;
-    dst[lane] = b0;
-    dst[lane + 64] = b1;
-    return;
-  }
-  const int h = is_k ? slot - a.nh : slot - a.nh - a.kvh;
-  if (a.kv.page_ptrs == nullptr) {
-    bf16_t* dst = (bf16_t*)(is_k ? a.k_out : a.v_out) + (int64_t)s * a.kvh * 128 + (int64_t)h * 128;
-    dst[lane] = b0;
-    dst[lane + 64] = b1;
-    return;
-  }
-  const int tok = *a.kv_start + s;
-  const int page = tok / KV_PAGE_TOKENS, t = tok % KV_PAGE_TOKENS;
-  char* base = reinterpret_cast<char*>(a.kv.page_ptrs[page] + a.kv.layer_off);
-  if (is_k) {
-    bf16_t* dst = reinterpret_cast<bf16_t*>(base) + ((int64_t)h * KV_PAGE_TOKENS + t) * 128;
-    dst[lane] = b0;
-    dst[lane + 64] = b1;
-  } else {
-    bf16_t* dst = reinterpret_cast<bf16_t*>(base) + (int64_t)a.kvh * KV_PAGE_TOKENS * 128 + (int64_t)h * 128 * KV_PAGE_TOKENS;
-    dst[(int64_t)lane * KV_PAGE_TOKENS + v_slot(t)] = b0;
-    dst[(int64_t)(lane + 64) * KV_PAGE_TOKENS + v_slot(t)] = b1;
+#pragma unroll
+  for (int j = 0; j < ROPE_SLOTS_PER_WAVE; ++j) {
+    if (j >= nloc) break;
+    const int slot = slot0 + j;
+    float x0 = xa[j], x1 = xb[j];
+    const bool is_q = slot < a.nh;
+    const bool is_k = !is_q && slot < a.nh + a.kvh;
+    if (is_q || is_k) {
+      const float ss = wave_sum(fmaf(x0, x0, x1 * x1));
+      const float rinv = 1.0f / sqrtf(ss / 128.0f + a.eps);
+      x0 = rbf(x0 * rinv * (is_q ? qw0 : kw0));
+      x1 = rbf(x1 * rinv * (is_q ? qw1 : kw1));
+      const float y0 = rbf(rbf(x0 * c) + rbf(-x1 * sn));
+      const float y1 = rbf(rbf(x1 * c) + rbf(x0 * sn));
+      x0 = y0;
+      x1 = y1;
+    }
+    const bf16_t b0 = f2bf(x0), b1 = f2bf(x1);
+    if (is_q) {
+      bf16_t* dst = (bf16_t*)a.q_out + (int64_t)s * a.nh * 128 + (int64_t)slot * 128;
+      dst[lane] = b0;
+      dst[lane + 64] = b1;
+      continue;
+    }
+    const int h = is_k ? slot - a.nh : slot - a.nh - a.kvh;
+    if (a.kv.page_ptrs == nullptr) {
+      bf16_t* dst = (bf16_t*)(is_k ? a.k_out : a.v_out) + (int64_t)s * a.kvh * 128 + (int64_t)h * 128;
+      dst[lane] = b0;
+      dst[lane + 64] = b1;
+      continue;
+    }
+    const int tok = *a.kv_start + s;
+    const int page = tok / KV_PAGE_TOKENS, t = tok % KV_PAGE_TOKENS;
+    char* base = reinterpret_cast<char*>(a.kv.page_ptrs[page] + a.kv.layer_off);
+    if (is_k) {
+      bf16_t* dst = reinterpret_cast<bf16_t*>(base) + ((int64_t)h * KV_PAGE_TOKENS + t) * 128;
+      dst[lane] = b0;
+      dst[lane + 64] = b1;
+    } else {
+      bf16_t* dst = reinterpret_cast<bf16_t*>(base) + (int64_t)a.kvh * KV_PAGE_TOKENS * 128 + (int64_t)h * 128 * KV_PAGE_TOKENS;
+      dst[(int64_t)lane * KV_PAGE_TOKENS + v_slot(t)] = b0;
+      dst[(int64_t)(lane + 64) * KV_PAGE_TOKENS + v_slot(t)] = b1;
+    }
   }
 }
 void launch_qknorm_rope(const RopeArgs& a, hipStream_t st) {
-  const int64_t waves = (int64_t)a.S * (a.nh + 2 * a.kvh);
+  const int64_t waves = (int64_t)a.S * ((a.nh + 2 * a.kvh + ROPE_SLOTS_PER_WAVE - 1) / ROPE_SLOTS_PER_WAVE);
   if (waves <= 0) return;
   hipLaunchKernelGGL(qknorm_rope_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
 }

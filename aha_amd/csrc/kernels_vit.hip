@@ -113,47 +113,55 @@ void launch_pos_embed_add(void* x, const void* table, const int32_t* idx, const 
 // and repack into the attention kernel's operand layouts.  One wave per (token, head).  head_dim hd = 72:
 // rotate_half pairs element e with e + hd/2; angle(e) = (e < hd/4 ? row : col) * inv_freq[e % (hd/4)] for e < hd/2,
 // and the same again for e >= hd/2 (emb = cat(rotary, rotary), model.rs:704).
+constexpr int VIT_HEADS_PER_WAVE = 4;  // cos/sin depend on (patch, lane) only
 __global__ __launch_bounds__(256) void vit_rope_pack_kernel(VitRopeArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wid >= (int64_t)a.N * a.nh) return;
-  const int n = (int)(wid / a.nh), h = (int)(wid % a.nh);
+  const int ngrp = (a.nh + VIT_HEADS_PER_WAVE - 1) / VIT_HEADS_PER_WAVE;
+  if (wid >= (int64_t)a.N * ngrp) return;
+  const int n = (int)(wid / ngrp), h0 = (int)(wid % ngrp) * VIT_HEADS_PER_WAVE;
   const int hd = a.hd, half = hd / 2, quarter = hd / 4;
   const int D = a.nh * hd;
-  const bf16_t* src = (const bf16_t*)a.qkv + (int64_t)n * 3 * D + (int64_t)h * hd;
   const int page = a.page_of[n], slot = a.slot_of[n];
   bf16_t* pbase = reinterpret_cast<bf16_t*>(a.kv.page_ptrs[page] + a.kv.layer_off);
-  bf16_t* qd = (bf16_t*)a.q_out + ((int64_t)n * a.nh + h) * VIT_DQK;
-  bf16_t* kd = pbase + ((int64_t)h * KV_PAGE_TOKENS + slot) * VIT_DQK;
-  bf16_t* vd = pbase + (int64_t)a.nh * KV_PAGE_TOKENS * VIT_DQK + (int64_t)h * VIT_DV * KV_PAGE_TOKENS;
-  if (lane < half) {
-    const int e = lane;
-    const int pos = (e < quarter) ? a.rowcol[2 * n] : a.rowcol[2 * n + 1];
-    const float ang = (float)pos * a.inv_freq[e % quarter];
-    const float c = rbf(cosf(ang)), s = rbf(sinf(ang));
-#pragma unroll
-    for (int which = 0; which < 2; ++which) {
-      const bf16_t* p = src + (int64_t)which * D;
-      const float x0 = bf2f(p[e]), x1 = bf2f(p[e + half]);
-      const bf16_t y0 = f2bf(rbf(x0 * c) + rbf(-x1 * s));
-      const bf16_t y1 = f2bf(rbf(x1 * c) + rbf(x0 * s));
-      bf16_t* d = which ? kd : qd;
-      d[e] = y0;
-      d[e + half] = y1;
-    }
-  }
-  // zero the pad lanes of q and k rows [hd, VIT_DQK)
-  if (lane < VIT_DQK - hd) {
-    qd[hd + lane] = 0;
-    kd[hd + lane] = 0;
-  }
-  // V: dim-major, slot-permuted (common.h v_slot); pad rows [hd, VIT_DV) zero
-  const bf16_t* vp = src + 2 * (int64_t)D;
   const int vs = v_slot(slot);
-  for (int e = lane; e < VIT_DV; e += 64) vd[(int64_t)e * KV_PAGE_TOKENS + vs] = (e < hd) ? vp[e] : (bf16_t)0;
+  float c = 0.f, s = 0.f;
+  if (lane < half) {
+    const int pos = (lane < quarter) ? a.rowcol[2 * n] : a.rowcol[2 * n + 1];
+    const float ang = (float)pos * a.inv_freq[lane % quarter];
+    c = rbf(cosf(ang));
+    s = rbf(sinf(ang));
+  }
+  for (int h = h0; h < min(h0 + VIT_HEADS_PER_WAVE, a.nh); ++h) {
+    const bf16_t* src = (const bf16_t*)a.qkv + (int64_t)n * 3 * D + (int64_t)h * hd;
+    bf16_t* qd = (bf16_t*)a.q_out + ((int64_t)n * a.nh + h) * VIT_DQK;
+    bf16_t* kd = pbase + ((int64_t)h * KV_PAGE_TOKENS + slot) * VIT_DQK;
+    bf16_t* vd = pbase + (int64_t)a.nh * KV_PAGE_TOKENS * VIT_DQK + (int64_t)h * VIT_DV * KV_PAGE_TOKENS;
+    if (lane < half) {
+      const int e = lane;
+#pragma unroll
+      for (int which = 0; which < 2; ++which) {
+        const bf16_t* p = src + (int64_t)which * D;
+        const float x0 = bf2f(p[e]), x1 = bf2f(p[e + half]);
+        const bf16_t y0 = f2bf(rbf(x0 * c) + rbf(-x1 * s));
+        const bf16_t y1 = f2bf(rbf(x1 * c) + rbf(x0 * s));
+        bf16_t* d = which ? kd : qd;
+        d[e] = y0;
+        d[e + half] = y1;
+      }
+    }
+    // zero the pad lanes of q and k rows [hd, VIT_DQK)
+    if (lane < VIT_DQK - hd) {
+      qd[hd + lane] = 0;
+      kd[hd + lane] = 0;
+    }
+    // V: dim-major, slot-permuted (common.h v_slot); pad rows [hd, VIT_DV) zero
+    const bf16_t* vp = src + 2 * (int64_t)D;
+    for (int e = lane; e < VIT_DV; e += 64) vd[(int64_t)e * KV_PAGE_TOKENS + vs] = (e < hd) ? vp[e] : (bf16_t)0;
+  }
 }
 void launch_vit_rope_pack(const VitRopeArgs& a, hipStream_t st) {
-  const int64_t waves = (int64_t)a.N * a.nh;
+  const int64_t waves = (int64_t)a.N * ((a.nh + VIT_HEADS_PER_WAVE - 1) / VIT_HEADS_PER_WAVE);
   if (waves <= 0) return;
   hipLaunchKernelGGL(vit_rope_pack_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
 }
