@@ -93,6 +93,7 @@ SIGNATURES = {
     "aha_hip_argmax": (C.c_int, [_P, C.c_int64, _P, _P]),
     "aha_hip_logmel": (C.c_int, [_P, C.c_int64, _P, _P]),
     "aha_hip_debug_gemm_plan": (C.c_int, [C.c_int32, C.c_int32]),
+    "aha_hip_get_rope_index": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int32, _P, _P]),
     "aha_hip_embed": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "aha_hip_config_parse": (C.c_int, [C.c_char_p, _P]),
     "aha_hip_weights_open": (C.c_int, [C.c_char_p, _P]),

@@ -361,6 +361,22 @@ int aha_hip_image_to_patches(const uint8_t* img_hwc, void* out, int32_t H, int32
   return AHA_OK;
 }
 
+int aha_hip_get_rope_index(const aha_model_desc* desc, const uint32_t* input_ids, size_t n_ids, const uint32_t* image_grid_thw,
+                           int32_t n_images, int32_t* pos_out, int64_t* rope_delta_out) {
+  API_GUARD_BEGIN
+  if (!desc || !input_ids || !pos_out || !rope_delta_out || (n_images > 0 && !image_grid_thw)) {
+    set_error("aha_hip_get_rope_index: null argument");
+    return AHA_ERR_INVALID;
+  }
+  if (n_images <= 0) {
+    for (int a = 0; a < 3; ++a)
+      for (size_t i = 0; i < n_ids; ++i) pos_out[a * n_ids + i] = (int32_t)i;
+    *rope_delta_out = 0;
+    return AHA_OK;
+  }
+  return rope_index_core(*desc, input_ids, n_ids, image_grid_thw, n_images, pos_out, rope_delta_out);
+  API_GUARD_END
+}
 int aha_hip_embed(aha_model* m, const uint32_t* input_ids, size_t n_ids, float* out) {
   API_GUARD_BEGIN
   if (!m) {

@@ -976,7 +976,10 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
     hipLaunchKernelGGL(embed_state_kernel, dim3(1), dim3(256), 0, st, (const bf16_t*)m->embed, m->d_state, (bf16_t*)m->d_x, H);
   }
   const int npages = (int)((kv_len_after + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS);
-  int nsplit = (npages + 3) / 4;
+  // KV splits of the fused decode attention: one block (4 waves = 4 KV units) per `div` pages
+  static const char* e_div = getenv("AHA_ATTN_PAGES_PER_BLOCK");
+  const int div = e_div ? std::max(1, atoi(e_div)) : 4;
+  int nsplit = (npages + div - 1) / div;
   nsplit = std::max(1, std::min(nsplit, m->max_nsplit));
   for (int li = 0; li < c.num_hidden_layers; ++li) {
     const LayerWeights& L = m->layers[li];

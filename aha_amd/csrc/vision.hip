@@ -26,6 +26,17 @@ int vl_rope_index(aha_model* m, const uint32_t* ids, size_t n, size_t offset, co
     m->rope_delta_valid = true;
     return AHA_OK;
   }
+  int64_t delta = 0;
+  const int rc = rope_index_core(c, ids, n, mm->image_grid_thw, mm->n_images, pos, &delta);
+  if (rc) return rc;
+  m->rope_delta = delta;
+  m->rope_delta_valid = true;
+  return AHA_OK;
+}
+
+// The index arithmetic of get_rope_index alone (host only, no model state): positions (3, S) and rope_delta.
+int rope_index_core(const aha_model_desc& c, const uint32_t* ids, size_t S, const uint32_t* grid_thw, int n_images, int32_t* pos,
+                    int64_t* rope_delta) {
   const int merge = c.vis_spatial_merge_size;
   size_t text_start = 0, out = 0;
   int64_t max_pos = -1;  // max over the previous block (llm_pos_ids_list.last().max_all())
@@ -35,11 +46,11 @@ int vl_rope_index(aha_model* m, const uint32_t* ids, size_t n, size_t offset, co
     if (ids[j] != (uint32_t)c.vision_start_token_id) continue;
     const size_t e = j + 1;  // index of the first token after <|vision_start|>
     if (ids[e] != (uint32_t)c.image_token_id) continue;  // video tokens are out of scope
-    if (image_index >= mm->n_images) {
+    if (image_index >= n_images) {
       set_error("get_rope_index: more <|vision_start|><|image_pad|> runs than images");
       return AHA_ERR_SHAPE;
     }
-    const uint32_t* thw = mm->image_grid_thw + 3 * (size_t)image_index++;
+    const uint32_t* thw = grid_thw + 3 * (size_t)image_index++;
     const int64_t t = thw[0], gh = thw[1] / merge, gw = thw[2] / merge;
     if (e < text_start) {
       set_error("get_rope_index: overlapping vision runs");
@@ -82,8 +93,7 @@ int vl_rope_index(aha_model* m, const uint32_t* ids, size_t n, size_t offset, co
   }
   int64_t mx = 0;
   for (size_t i = 0; i < 3 * S; ++i) mx = std::max<int64_t>(mx, pos[i]);
-  m->rope_delta = mx + 1 - (int64_t)S;
-  m->rope_delta_valid = true;
+  *rope_delta = mx + 1 - (int64_t)S;
   return AHA_OK;
 }
 

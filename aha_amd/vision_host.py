@@ -61,3 +61,19 @@ def synthetic_image_request(cfg: Qwen3VLConfig, image_px: int, prompt_tokens: in
     prefix = torch.randint(0, hi, (4,), generator=gen).tolist()
     suffix = torch.randint(0, hi, (prompt_tokens,), generator=gen).tolist()
     return image_prompt_ids(cfg, data.image_grid_thw, prefix, suffix), data
+
+
+def get_rope_index(cfg: Qwen3VLConfig, input_ids, image_grid_thw):
+    """Qwen3VLModel::get_rope_index through the library's host code (csrc/vision.hip rope_index_core): (3, S) int32
+    positions and rope_delta.  No GPU involved."""
+    import ctypes as C
+    from ._lib import check, lib
+    from .model import make_desc
+    ids = np.ascontiguousarray(np.asarray(input_ids, dtype=np.uint32).reshape(-1))
+    grid = np.ascontiguousarray(np.asarray(image_grid_thw, dtype=np.uint32).reshape(-1, 3))
+    pos = np.empty((3, ids.size), dtype=np.int32)
+    delta = C.c_int64()
+    desc = make_desc(cfg)
+    check(lib().aha_hip_get_rope_index(C.byref(desc), ids.ctypes.data_as(C.c_void_p), ids.size, grid.ctypes.data_as(C.c_void_p),
+                                       grid.shape[0], pos.ctypes.data_as(C.c_void_p), C.byref(delta)))
+    return pos, int(delta.value)

@@ -117,6 +117,13 @@ int aha_hip_model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_ten
                          aha_model** out);
 void aha_hip_model_destroy(aha_model* m);
 
+/* Host-only: Qwen3VLModel::get_rope_index (/root/reference/src/models/qwen3vl/model.rs:901-1133) for images: the (3, n_ids)
+ * M-RoPE position rows T, H, W and rope_delta = max(position) + 1 - n_ids.  Only the token ids and vis_spatial_merge_size
+ * of `desc` are read.  forward_initial runs the same code on its own input; this entry point exists so the index
+ * arithmetic can be tested (and reused by a host) without a GPU. */
+int aha_hip_get_rope_index(const aha_model_desc* desc, const uint32_t* input_ids, size_t n_ids, const uint32_t* image_grid_thw,
+                           int32_t n_images, int32_t* pos_out, int64_t* rope_delta_out);
+
 /* ---- Qwen3-Embedding / Qwen3-Reranker ------------------------------------------------
  * == Qwen3Embedding::embed_one after tokenisation (/root/reference/src/models/qwen3_embedding/mod.rs:50-64):
  * forward_hidden(input_ids, offset 0) -> last position after the final RMSNorm -> f32 -> l2_normalize

@@ -102,3 +102,22 @@ def test_safetensors_rejects_corrupt_files(tmp_path):
     (d / "y.safetensors").write_bytes(struct.pack("<Q", len(good)) + good + b"\0" * 4)    # same name in two shards
     with pytest.raises(AhaHipError, match="more than one file"):
         open_weights(str(d))
+
+
+def test_safetensors_reader_survives_odd_names_and_metadata(tmp_path):
+    """Tensor names are JSON object keys: escapes, non-ASCII, very long names, a large __metadata__ block, many tensors."""
+    from safetensors.torch import save_file
+    names = ["plain", "with space", "quote\"inside", "back\\slash", "tab\tname", "unicode-é中\U0001F600", "a" * 300,
+             "model.layers.0.self_attn.q_proj.weight", "/slashes/and.dots", "new\nline"]
+    names += [f"bulk.{i}" for i in range(400)]
+    g = torch.Generator().manual_seed(0)
+    tensors = {n: torch.randn((i % 5 + 1, 3), generator=g).to(torch.bfloat16) for i, n in enumerate(names)}
+    d = tmp_path / "w"
+    d.mkdir()
+    save_file(tensors, str(d / "model.safetensors"), metadata={"format": "pt", "note": "x" * 5000, "k\"ey": "v\\al"})
+    got = open_weights(str(d))
+    assert set(got) == set(tensors)
+    for n, t in tensors.items():
+        dt, shape, raw = got[n]
+        assert dt == _lib.AHA_BF16 and shape == tuple(t.shape)
+        assert raw == t.contiguous().reshape(-1).view(torch.uint8).numpy().tobytes()

@@ -126,3 +126,50 @@ def test_v_slot_permutation_is_a_bijection():
         return (t & 32) | (((t >> 2) & 3) << 3) | (((t >> 4) & 1) << 2) | (t & 3)
     assert sorted(v_slot(t) for t in range(64)) == list(range(64))
     assert v_slot(16) == 4 and v_slot(4) == 8 and v_slot(47) == 32 + 3 * 8 + 0 * 4 + 3
+
+
+# ---- get_rope_index: the library's host code vs the oracle restatement (pure integer work: bit-exact) -------------------
+def _rope_case(rng, cfg, n_images):
+    """A random prompt: text, then per image <|vision_start|> + t*gh*gw <|image_pad|> + <|vision_end|>, text in between
+    (possibly empty), optional trailing text."""
+    ids, grids = [], []
+    ids += [int(x) for x in rng.integers(0, 1000, size=rng.integers(0, 5))]
+    for _ in range(n_images):
+        gh, gw = int(rng.integers(1, 5)), int(rng.integers(1, 6))
+        grids.append([1, 2 * gh, 2 * gw])   # grid in patches; merge size 2
+        ids += [cfg.vision_start_token_id] + [cfg.image_token_id] * (gh * gw) + [cfg.vision_end_token_id]
+        ids += [int(x) for x in rng.integers(0, 1000, size=rng.integers(0, 4))]
+    return ids, np.asarray(grids, dtype=np.uint32).reshape(-1, 3)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_get_rope_index_matches_oracle(seed):
+    from aha_amd.configs import tiny_qwen3vl
+    from aha_amd.vision_host import get_rope_index
+    from oracle import qwen3vl as ov
+    cfg = tiny_qwen3vl()
+    rng = np.random.default_rng(seed)
+    ids, grid = _rope_case(rng, cfg, n_images=int(rng.integers(1, 4)))
+    pos, delta = get_rope_index(cfg, ids, grid)
+    ref_pos, ref_delta = ov.get_rope_index(ids, grid, cfg)
+    assert pos.shape == (3, len(ids))
+    np.testing.assert_array_equal(pos, np.asarray(ref_pos))
+    assert delta == int(ref_delta) and delta <= 0
+
+
+def test_get_rope_index_hand_checked_and_errors():
+    from aha_amd._lib import AhaHipError
+    from aha_amd.configs import tiny_qwen3vl
+    from aha_amd.vision_host import get_rope_index
+    cfg = tiny_qwen3vl()
+    ids = [1, 2, cfg.vision_start_token_id] + [cfg.image_token_id] * 6 + [cfg.vision_end_token_id, 3, 4]
+    pos, delta = get_rope_index(cfg, ids, [[1, 4, 6]])
+    assert pos[:, :3].tolist() == [[0, 1, 2]] * 3
+    assert pos[0, 3:9].tolist() == [3] * 6 and pos[1, 3:9].tolist() == [3, 3, 3, 4, 4, 4] and pos[2, 3:9].tolist() == [3, 4, 5] * 2
+    assert pos[:, 9:].tolist() == [[6, 7, 8]] * 3 and delta == 9 - len(ids)
+    p0, d0 = get_rope_index(cfg, [5, 6, 7], np.zeros((0, 3), dtype=np.uint32))   # text only: arange on all three rows
+    assert p0.tolist() == [[0, 1, 2]] * 3 and d0 == 0
+    with pytest.raises(AhaHipError, match="more <\\|vision_start\\|>"):   # two image runs, one grid
+        get_rope_index(cfg, ids + ids, [[1, 4, 6]])
+    with pytest.raises(AhaHipError, match="longer than the remaining"):   # grid says 12 tokens, prompt has 6
+        get_rope_index(cfg, ids, [[1, 4, 12]])

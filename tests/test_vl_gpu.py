@@ -127,17 +127,6 @@ def test_vl_token_count_mismatch_is_an_error(vl):
     m.clear_cache()
 
 
-def test_rope_index_matches_oracle():
-    """Host get_rope_index restatement vs the hand-checked example shapes (pure integer, no GPU kernels involved)."""
-    cfg = tiny_qwen3vl()
-    ids = [1, 2, cfg.vision_start_token_id] + [cfg.image_token_id] * 6 + [cfg.vision_end_token_id, 3, 4]
-    pos, delta = ov.get_rope_index(ids, np.array([[1, 4, 6]], dtype=np.uint32), cfg)
-    assert pos.shape == (3, len(ids))
-    assert pos[:, :3].tolist() == [[0, 1, 2]] * 3
-    assert pos[0, 3:9].tolist() == [3] * 6 and pos[1, 3:9].tolist() == [3, 3, 3, 4, 4, 4] and pos[2, 3:9].tolist() == [3, 4, 5] * 2
-    assert pos[:, 9:].tolist() == [[6, 7, 8]] * 3 and delta == 9 - len(ids)
-
-
 def test_vision_encode_then_precomputed_embeds(vl, gpu):
     """aha_hip_vision_encode + forward_initial(image_embeds=...) (the image-parallel path on one GPU) must reproduce the
     fused forward bit for bit."""
