@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default=os.environ.get("AHA_BENCH_WORKLOAD", "qwen3vl8b"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prompt", type=int, default=0, help="override the workload's text prompt length (diagnostics; the JSON names it)")
     ap.add_argument("--host-loop", action="store_true", help="drive decode with forward_step (one host sync per token)")
     args = ap.parse_args()
 
@@ -134,6 +135,8 @@ def main():
     from aha_amd.model import HipInferenceModel, MultiModalData
 
     cfg, wl = build_workload(args.workload)
+    if args.prompt > 0:
+        wl = dict(wl, prompt=args.prompt)
     is_asr = hasattr(cfg, "audio")
     is_vl = hasattr(cfg, "text") and not is_asr
     tcfg = cfg.text if hasattr(cfg, "text") else cfg
