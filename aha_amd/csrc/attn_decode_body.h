@@ -55,6 +55,13 @@ __device__ __forceinline__ bool attn_decode_fused_body_t(const AttnDecodeFusedAr
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) vf[ds][kk] = ld_nt16(vb + (size_t)(ds * 16 + c) * (KV_PAGE_TOKENS * 2) + (kk * 32 + G * 8) * 2);
   };
+  // optional timeline (AHA_ATTN_TRACE): block (kv head 0, split 0) and (kv head 0, last split), thread 0, 100 MHz stamps:
+  // start, prologue done, pages done, partial published, arrival known, end
+  const int tslot = (kvhd == 0 && split == 0) ? 0 : (kvhd == 0 && split == nsplit - 1 ? 1 : -1);
+  auto stamp = [&](int k) {
+    if (a.trace != nullptr && tslot >= 0 && tid == 0) a.trace[tslot * 6 + k] = wall_clock64();
+  };
+  stamp(0);
   int page = unit;
   if (page < npages) load_page(page);
   after_prefetch();  // grid barrier of the persistent decode kernel: qkv of this step is complete past this point
@@ -82,6 +89,7 @@ __device__ __forceinline__ bool attn_decode_fused_body_t(const AttnDecodeFusedAr
     for (int i = tid; i < 128; i += NT) vsn[i] = act_ld_bf<COH>(qkv + (int64_t)(a.nh + a.kvh + kvhd) * 128 + i);
   }
   sync();
+  stamp(1);
   if (split == 0) {  // append (k roped, v raw) for the following steps
     const int pg = slot_new / KV_PAGE_TOKENS, t = slot_new % KV_PAGE_TOKENS;
     bf16_t* base = reinterpret_cast<bf16_t*>(a.kv.page_ptrs[pg] + a.kv.layer_off);
@@ -125,6 +133,7 @@ __device__ __forceinline__ bool attn_decode_fused_body_t(const AttnDecodeFusedAr
     page += nunits;
     if (page < npages) load_page(page);
   }
+  stamp(2);
   if (unit == 0) {  // the new token: score from LDS, one more online-softmax step
     float dot = 0.f;
     const bf16_t* qr = qs + min(c, g - 1) * 128 + G * 32;
@@ -183,7 +192,11 @@ __device__ __forceinline__ bool attn_decode_fused_body_t(const AttnDecodeFusedAr
       }
     }
   }
-  if (single) return true;
+  if (single) {
+    stamp(5);
+    return true;
+  }
+  stamp(3);
 
   // ---- the LAST split block of this kv head to finish merges all splits of its g heads --------------------------------
   // Partials cross blocks (possibly XCDs) inside one launch: agent-scope stores above, every wave waits for their
@@ -196,6 +209,7 @@ __device__ __forceinline__ bool attn_decode_fused_body_t(const AttnDecodeFusedAr
     *s_last = (prev + 1u == a.ctr_target) ? 1 : 0;
   }
   sync();
+  stamp(4);
   if (*s_last == 0) return false;
   for (int it = tid; it < g * 128; it += NT) {
     const int q = it >> 7, d = it & 127;
@@ -230,6 +244,7 @@ __device__ __forceinline__ bool attn_decode_fused_body_t(const AttnDecodeFusedAr
     }
     emit(head, d, f * (1.0f / ls));  // attention output tensor (rounded to bf16 by the receiver)
   }
+  stamp(5);
   return true;
 }
 

@@ -101,6 +101,7 @@ struct AttnDecodeFusedArgs {
   void* o;                  // (nh*128) bf16 attention output
   unsigned* head_ctr;       // [32 * kvhd]: split blocks of the head that have published their partial (all launches)
   unsigned ctr_target;      // value head_ctr reaches when this launch's nsplit blocks have all arrived
+  unsigned long long* trace;  // optional timeline (AHA_ATTN_TRACE)
   int nh, kvh, nsplit;
   float eps, scale;
 };

@@ -130,6 +130,7 @@ struct aha_model {
   unsigned long long* d_mega_trace = nullptr;  // AHA_MEGA_TRACE timeline
   unsigned long long* d_gemv_trace = nullptr;  // AHA_GEMV_TRACE timeline
   unsigned long long* d_chain_trace = nullptr; // AHA_CHAIN_TRACE timeline
+  unsigned long long* d_attn_trace = nullptr;  // AHA_ATTN_TRACE timeline
   unsigned bar_base = 0;            // barriers completed by all launches so far
   int mega_grid = 0;
   size_t mega_lds = 0;

@@ -816,6 +816,23 @@ static int fetch_outputs(aha_model* m, float* logits_out, uint32_t* argmax_out) 
   if (m->d_mega_trace) mega_trace_dump(m);
   if (m->d_gemv_trace) gemv_trace_dump(m);
   if (m->d_chain_trace) chain_trace_dump(m);
+  if (m->d_attn_trace) {
+    const int L = m->desc.num_hidden_layers;
+    std::vector<unsigned long long> t((size_t)L * 12);
+    if (hipMemcpy(t.data(), m->d_attn_trace, t.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+      for (int b = 0; b < 2; ++b) {
+        double v[5] = {};
+        int n = 0;
+        for (int li = 1; li < L; ++li) {
+          const unsigned long long* p = t.data() + (size_t)li * 12 + b * 6;
+          if (p[0] == 0 || p[4] == 0) continue;
+          for (int k = 0; k < 5; ++k) v[k] += (p[k + 1] > p[k] ? (double)(p[k + 1] - p[k]) : 0.0) * 0.01;
+          ++n;
+        }
+        if (n) fprintf(stderr, "[attn trace] block %d: prologue %.2f | pages %.2f | merge+publish %.2f | arrive %.2f | final merge %.2f us\n", b, v[0] / n, v[1] / n, v[2] / n, v[3] / n, v[4] / n);
+      }
+    }
+  }
   if (logits_out) memcpy(logits_out, m->h_logits, (size_t)c.vocab_size * 4);
   if (argmax_out) *argmax_out = m->h_state->next_token;
   return AHA_OK;
@@ -1003,6 +1020,14 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
       a.scale = m->attn_scale; a.o = m->d_attn; a.head_ctr = m->d_bar + DECODE_HEAD_CTR_WORD;
       if (nsplit > 1) m->head_ctr_base += (unsigned)nsplit;  // a single split never touches the counter
       a.ctr_target = m->head_ctr_base;
+      static const char* e_at = getenv("AHA_ATTN_TRACE");
+      if (e_at && atoi(e_at)) {
+        if (!m->d_attn_trace) {
+          void* tp = nullptr;
+          if (dev_alloc(m, (size_t)c.num_hidden_layers * 12 * 8, &tp, true) == AHA_OK) m->d_attn_trace = (unsigned long long*)tp;
+        }
+        if (m->d_attn_trace) a.trace = m->d_attn_trace + (size_t)li * 12;
+      }
       GemvArgs g{};
       g.W = L.wo; g.x = m->d_attn; g.residual = m->d_x; g.y = m->d_x; g.N = H; g.K = nq;
       g.trace = gemv_trace_slot(m, li * 4 + 1);
