@@ -53,10 +53,12 @@ def image_prompt_ids(cfg: Qwen3VLConfig, grids: np.ndarray, prefix: List[int], s
     return ids + list(suffix)
 
 
-def synthetic_image_request(cfg: Qwen3VLConfig, image_px: int, prompt_tokens: int, gen: torch.Generator, device="cuda"):
-    """BASELINE.md section 4 cfg 3: one uniform-random uint8 image + 4 template tokens + prompt_tokens random text ids."""
-    img = torch.randint(0, 256, (image_px, image_px, 3), generator=gen, dtype=torch.uint8).to(device)
-    data = process_images([img], cfg)
+def synthetic_image_request(cfg: Qwen3VLConfig, image_px: int, prompt_tokens: int, gen: torch.Generator, device="cuda",
+                            n_images: int = 1):
+    """BASELINE.md section 4 cfg 3 (one image) / cfg 5 (n_images = 8 at 2048^2): uniform-random uint8 images + 4 template
+    tokens + prompt_tokens random text ids."""
+    imgs = [torch.randint(0, 256, (image_px, image_px, 3), generator=gen, dtype=torch.uint8).to(device) for _ in range(n_images)]
+    data = process_images(imgs, cfg)
     hi = min(cfg.text.vocab_size, 151643)
     prefix = torch.randint(0, hi, (4,), generator=gen).tolist()
     suffix = torch.randint(0, hi, (prompt_tokens,), generator=gen).tolist()

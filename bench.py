@@ -30,6 +30,7 @@ MFMA_PEAK_TFLOPS = 2500.0  # bf16 dense
 
 METRICS = {
     "qwen3vl8b": "decode tokens/s (greedy, batch 1) -- Qwen3-VL-8B, 1x1024^2 image + 512-token prompt; prefill tok/s alongside",
+    "qwen3vl8b-cfg5": "decode tokens/s (greedy, batch 1) -- Qwen3-VL-8B, 8 x 2048^2 images + 8192-token prompt (BASELINE cfg 5 on one GPU, S ~ 41k); prefill tok/s alongside",
     "qwen3vl8b-text": "decode tokens/s (greedy, batch 1) -- Qwen3-VL-8B text stack, 1542-token prompt; prefill tok/s alongside",
     "qwen3-0.6b": "decode tokens/s (greedy, batch 1) -- Qwen3-0.6B, 2048-token prompt (BASELINE cfg 2); prefill tok/s alongside",
     "qwen3-asr": "decode tokens/s (greedy, batch 1) -- Qwen3-ASR-0.6B, 30 s of 16 kHz audio (BASELINE cfg 4); prefill (log-mel + audio encoder + text) alongside",
@@ -40,6 +41,8 @@ def build_workload(name: str):
     from aha_amd import configs
     if name == "qwen3vl8b":
         return configs.qwen3vl_8b(), dict(image=1024, prompt=512)
+    if name == "qwen3vl8b-cfg5":   # BASELINE.md section 4 cfg 5 on ONE GPU: 8 images of 2048^2 + 8192 text ids (S ~ 41k); prefill-dominated
+        return configs.qwen3vl_8b(), dict(image=2048, prompt=8192, n_images=8)
     if name == "qwen3vl8b-text":
         return configs.qwen3vl_8b(), dict(image=0, prompt=1542)
     if name == "qwen3-0.6b":
@@ -150,7 +153,7 @@ def main():
     else:
         w = W.qwen3_text_weights(tcfg, seed=rank, device=dev)
     torch.cuda.synchronize()
-    model = HipInferenceModel(cfg, w, device=local_rank, kv_reserve_tokens=4096)
+    model = HipInferenceModel(cfg, w, device=local_rank, kv_reserve_tokens=4096 if wl.get("n_images", 1) == 1 else 45056)
     del w
     torch.cuda.empty_cache()
     t_load = time.perf_counter() - t0
@@ -160,7 +163,7 @@ def main():
     data = None
     if wl["image"]:
         from aha_amd.vision_host import synthetic_image_request
-        ids, data = synthetic_image_request(cfg, wl["image"], wl["prompt"], g)
+        ids, data = synthetic_image_request(cfg, wl["image"], wl["prompt"], g, n_images=wl.get("n_images", 1))
     elif is_asr:
         # seed-4 N(0, 0.1^2) clipped to [-1, 1]; the library computes the log-mel features on the GPU from the raw samples
         n = wl["audio_samples"]
