@@ -1,7 +1,7 @@
 """GPU diagnostic: error statistics of each HIP op vs the oracle (not a test; prints a table)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import torch
 from test_ops_gpu import *  # noqa
 from test_ops_gpu import _attn_ref, _rope_ref
