@@ -132,7 +132,13 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
       if (!act[t]) continue;
       const int qpos = a.kv_offset + q0 + t * 16 + c;  // cache position of this lane's q row
       const int lim = a.causal ? min(qpos, a.kv_total - 1) : a.kv_total - 1;
-      softmax_tile(st[t], a.scale, [&](int tk) { return t0 + tk <= lim; }, G, m[t], l[t], alpha[t], pf[t]);
+      // Interior tiles (every token visible to every q row of the sub-tile: all but the diagonal / last tile) skip the
+      // per-element predicate -- two compares and a select per score in a VALU-bound softmax.
+      const int lim_min = a.causal ? min(a.kv_offset + q0 + t * 16, a.kv_total - 1) : a.kv_total - 1;
+      if (t0 + KV_PAGE_TOKENS - 1 <= lim_min)
+        softmax_tile(st[t], a.scale, [](int) { return true; }, G, m[t], l[t], alpha[t], pf[t]);
+      else
+        softmax_tile(st[t], a.scale, [&](int tk) { return t0 + tk <= lim; }, G, m[t], l[t], alpha[t], pf[t]);
 #pragma unroll
       for (int ds = 0; ds < DS; ++ds) o[t][ds] *= alpha[t];
     }
