@@ -284,3 +284,30 @@ def test_decode_chain_dot2c_consumer_close_to_launch_per_op(gpu, monkeypatch, at
             assert float(np.sqrt(((a - b) ** 2).mean())) <= LOGIT_RMS_STD * std
             tok = am
     ref.close(); ch.close()
+
+
+def test_many_requests_reuse_pages_deterministically(tiny):
+    """A serving loop: 150 requests of random lengths through one handle (clear_cache between them, as the reference's
+    generate() does): page pool reuse, chunked growth and the device loop must stay deterministic -- the first request,
+    replayed at the end, gives the same logits bit for bit, and the cache length bookkeeping never drifts."""
+    cfg, w, m, o = tiny
+    rng = np.random.default_rng(7)
+    first_ids = ids_for(cfg, 90, 31)
+    m.clear_cache()
+    ref, tok = m.forward_initial(first_ids, 0)
+    ref_toks = m.decode_greedy(tok, 90, 12)
+    for r in range(150):
+        n = int(rng.integers(1, 400))
+        ids = ids_for(cfg, n, 1000 + r)
+        m.clear_cache()
+        assert m.cache_len() == 0
+        lg, t = m.forward_initial(ids, 0)
+        k = int(rng.integers(1, 20))
+        out = m.decode_greedy(t, n, k)
+        assert len(out) == k and m.cache_len() == n + k
+        assert np.isfinite(lg).all()
+    m.clear_cache()
+    again, tok2 = m.forward_initial(first_ids, 0)
+    np.testing.assert_array_equal(again, ref)
+    assert tok2 == tok and m.decode_greedy(tok2, 90, 12) == ref_toks
+    m.clear_cache()
