@@ -28,15 +28,19 @@ constexpr int V_ROW_BYTES = KV_PAGE_TOKENS * 2 + 16;  // padded LDS row of the V
 // Text decoder: 128/128.  ViT (head_dim 72): 96/80, pad lanes are zero in Q, K and V (csrc/kernels_vit.hip).
 // QT q sub-tiles per wave share every K / V^T fragment read from LDS (LDS reads per MFMA 1 -> 1/QT) and every
 // global->LDS staging pass is amortised over 64*QT query rows.
-template <int DQK, int DV, int QT>
-__global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
+// NWV waves per block (4 or 8) share every staged K / V^T tile: at long S the kernel is bound by re-reading K / V tiles from
+// L2 / Infinity Cache (cfg 5: 210 GB per layer at 64 q rows per tile = 65 FLOP per byte = 250 TFLOP/s), so 8 waves = 128 q rows
+// per tile halve that traffic at the same occupancy (181 VGPRs: 8 waves per CU either way).
+template <int DQK, int DV, int QT, int NWV>
+__global__ __launch_bounds__(NWV * 64) void attn_prefill_kernel(AttnPrefillArgs a) {
+  constexpr int NT = NWV * 64;
   constexpr int KS = DQK / 32, DS = DV / 16;
   constexpr int K_ROW_BYTES = DQK * 2 + 16;  // padded LDS row of the K tile (bank-conflict-free b128 reads)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x [K tile | V^T tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, c = lane & 15;
   const int head = blockIdx.y;
   const int kvhd = head / (a.nh / a.kvh);
-  const int qb = blockIdx.x * (64 * QT);       // first q row of the block
+  const int qb = blockIdx.x * (16 * QT * NWV);  // first q row of the block
   const int q0 = qb + wave * (16 * QT);        // first q row of the wave
   bf16x8_t qf[QT][KS];
 #pragma unroll
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
 #pragma unroll
     for (int k4 = 0; k4 < KS; ++k4) qf[t][k4] = as_frag(ld16(qp + k4 * 32 + G * 8));
   }
-  const int blk_last_q = min(qb + 64 * QT - 1, a.S - 1);
+  const int blk_last_q = min(qb + 16 * QT * NWV - 1, a.S - 1);
   const int last_tok = a.causal ? min(a.kv_offset + blk_last_q, a.kv_total - 1) : a.kv_total - 1;
   const int ntiles = last_tok / KV_PAGE_TOKENS + 1;
 
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
   // Software pipeline over KV pages: the next page travels global -> registers while the MFMAs of the current one run
   // from LDS, and is written to the other LDS buffer afterwards (one barrier per page).
   constexpr int KP = KV_PAGE_TOKENS * DQK / 8, VP = DV * KV_PAGE_TOKENS / 8, SPR = DQK / 8;  // 16-byte pieces
-  constexpr int KI = (KP + 255) / 256, VI = (VP + 255) / 256;
+  constexpr int KI = (KP + NT - 1) / NT, VI = (VP + NT - 1) / NT;
   constexpr int STAGE_BYTES = KV_PAGE_TOKENS * K_ROW_BYTES + DV * V_ROW_BYTES;
   u32x4_t rk[KI], rv[VI];
   auto gload = [&](int tile) {
@@ -72,13 +76,13 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
     const char* vb = base + (size_t)a.kvh * KV_PAGE_TOKENS * (DQK * 2) + (size_t)kvhd * DV * (KV_PAGE_TOKENS * 2);
 #pragma unroll
     for (int i = 0; i < KI; ++i) {
-      const int p = tid + i * 256;
-      if (KP % 256 == 0 || p < KP) rk[i] = ld16(kb + (size_t)p * 16);
+      const int p = tid + i * NT;
+      if (KP % NT == 0 || p < KP) rk[i] = ld16(kb + (size_t)p * 16);
     }
 #pragma unroll
     for (int i = 0; i < VI; ++i) {
-      const int p = tid + i * 256;
-      if (VP % 256 == 0 || p < VP) rv[i] = ld16(vb + (size_t)p * 16);
+      const int p = tid + i * NT;
+      if (VP % NT == 0 || p < VP) rv[i] = ld16(vb + (size_t)p * 16);
     }
   };
   auto lstore = [&](int stage) {
@@ -86,13 +90,13 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
     char* vsw = ksw + KV_PAGE_TOKENS * K_ROW_BYTES;
 #pragma unroll
     for (int i = 0; i < KI; ++i) {
-      const int p = tid + i * 256;
-      if (KP % 256 == 0 || p < KP) *reinterpret_cast<u32x4_t*>(ksw + (p / SPR) * K_ROW_BYTES + (p % SPR) * 16) = rk[i];
+      const int p = tid + i * NT;
+      if (KP % NT == 0 || p < KP) *reinterpret_cast<u32x4_t*>(ksw + (p / SPR) * K_ROW_BYTES + (p % SPR) * 16) = rk[i];
     }
 #pragma unroll
     for (int i = 0; i < VI; ++i) {
-      const int p = tid + i * 256;
-      if (VP % 256 == 0 || p < VP) *reinterpret_cast<u32x4_t*>(vsw + (p >> 3) * V_ROW_BYTES + (p & 7) * 16) = rv[i];
+      const int p = tid + i * NT;
+      if (VP % NT == 0 || p < VP) *reinterpret_cast<u32x4_t*>(vsw + (p >> 3) * V_ROW_BYTES + (p & 7) * 16) = rv[i];
     }
   };
   gload(0);
@@ -315,20 +319,30 @@ void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st) {
     const char* e = getenv("AHA_ATTN_QT");
     return e ? atoi(e) : 0;
   }();
-  // 2 q sub-tiles per wave (128 rows per block) once there are enough rows to fill the chip that way
-  const int qt = (qt_env && a.d != 64) ? qt_env : 1;  // measured: QT=2 loses to QT=1 (fewer resident blocks per CU)
-  dim3 grid((a.S + 64 * qt - 1) / (64 * qt), a.nh), block(256);
+  static const int nw_env = [] {
+    const char* e = getenv("AHA_ATTN_WAVES");
+    return e ? atoi(e) : 0;
+  }();
+  // 2 q sub-tiles per wave: measured slower (300 registers: one wave per SIMD) -- kept behind AHA_ATTN_QT for A/B
+  const int qt = (qt_env && a.d != 64) ? qt_env : 1;
+  // 8 waves (128 q rows) per staged tile once there are enough q rows for every CU to get a block that way
+  int nwv = (a.d != 64 && (int64_t)((a.S + 127) / 128) * a.nh >= 256) ? 8 : 4;
+  if (nw_env == 4 || (nw_env == 8 && a.d != 64)) nwv = nw_env;
+  if (qt == 2) nwv = 4;
+  dim3 grid((a.S + 16 * qt * nwv - 1) / (16 * qt * nwv), a.nh), block(nwv * 64);
   if (a.d == 128) {
     const size_t lds = 2 * (KV_PAGE_TOKENS * (128 * 2 + 16) + 128 * V_ROW_BYTES);
-    if (qt == 2) hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 2>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 1>), grid, block, lds, st, a);
+    if (qt == 2) hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 2, 4>), grid, block, lds, st, a);
+    else if (nwv == 8) hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 1, 8>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 1, 4>), grid, block, lds, st, a);
   } else if (a.d == 64) {  // Qwen3-ASR audio encoder
     const size_t lds = 2 * (KV_PAGE_TOKENS * (64 * 2 + 16) + 64 * V_ROW_BYTES);
-    hipLaunchKernelGGL((attn_prefill_kernel<64, 64, 1>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((attn_prefill_kernel<64, 64, 1, 4>), grid, block, lds, st, a);
   } else {  // head_dim 72 (Qwen3-VL ViT): Q/K rows padded to 96, V block to 80
     const size_t lds = 2 * (KV_PAGE_TOKENS * (96 * 2 + 16) + 80 * V_ROW_BYTES);
-    if (qt == 2) hipLaunchKernelGGL((attn_prefill_kernel<96, 80, 2>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((attn_prefill_kernel<96, 80, 1>), grid, block, lds, st, a);
+    if (qt == 2) hipLaunchKernelGGL((attn_prefill_kernel<96, 80, 2, 4>), grid, block, lds, st, a);
+    else if (nwv == 8) hipLaunchKernelGGL((attn_prefill_kernel<96, 80, 1, 8>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((attn_prefill_kernel<96, 80, 1, 4>), grid, block, lds, st, a);
   }
 }
 
