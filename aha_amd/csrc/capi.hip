@@ -343,6 +343,19 @@ int aha_hip_attn_prefill(const void* q, const void* k, const void* v, void* o, i
   a.q = q; a.kv = t.kv; a.o = o; a.S = S; a.nh = nh; a.kvh = kvh; a.d = d; a.kv_offset = kv_offset; a.kv_total = L;
   a.causal = causal; a.scale = scale;
   launch_attn_prefill(a, st);
+  if (const char* reps_env = getenv("AHA_ATTN_TIME")) {  // microbenchmark hook (scripts/bench_attn.py): kernel-only time
+    const int reps = atoi(reps_env) > 0 ? atoi(reps_env) : 5;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, st);
+    for (int i = 0; i < reps; ++i) launch_attn_prefill(a, st);
+    hipEventRecord(e1, st);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    fprintf(stderr, "[attn_prefill] S=%d L=%d nh=%d causal=%d: %.3f ms/launch\n", S, L, nh, causal, ms / reps);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+  }
   hipError_t e = hipGetLastError();
   hipStreamSynchronize(st);
   AHA_HIP_CHECK(e);

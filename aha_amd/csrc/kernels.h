@@ -117,6 +117,7 @@ struct AttnPrefillArgs {
   int causal;
   float scale;
   int64_t q_ld;            // elements between consecutive q rows; 0 => nh * padded head dim
+  int nqb;                 // set by the launcher: > 0 selects the XCD-aware 1-D block order over nqb q blocks x nh heads
 };
 void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st);
 

@@ -21,26 +21,40 @@ namespace aha {
 
 namespace {
 
-constexpr int V_ROW_BYTES = KV_PAGE_TOKENS * 2 + 16;  // padded LDS row of the V^T tile
 
 // ---- prefill: 4 waves x QT*16 q rows per block, K / V^T page staged in LDS and shared by the 4 waves ---------------
 // DQK = padded head dim of Q/K rows (multiple of 32), DV = padded head dim of the V block (multiple of 16).
 // Text decoder: 128/128.  ViT (head_dim 72): 96/80, pad lanes are zero in Q, K and V (csrc/kernels_vit.hip).
 // QT q sub-tiles per wave share every K / V^T fragment read from LDS (LDS reads per MFMA 1 -> 1/QT) and every
 // global->LDS staging pass is amortised over 64*QT query rows.
-// NWV waves per block (4 or 8) share every staged K / V^T tile: at long S the kernel is bound by re-reading K / V tiles from
-// L2 / Infinity Cache (cfg 5: 210 GB per layer at 64 q rows per tile = 65 FLOP per byte = 250 TFLOP/s), so 8 waves = 128 q rows
-// per tile halve that traffic at the same occupancy (181 VGPRs: 8 waves per CU either way).
+// NWV waves per block (4 or 8) share every staged K / V^T tile (8 waves = 128 q rows per tile halve the staging traffic).
+// The waves of a block move in lockstep (one barrier per tile), so MFMA, softmax VALU and LDS phases only overlap ACROSS
+// blocks: the kernel is held to 128 VGPRs (amdgpu_waves_per_eu 4) so that two 8-wave blocks are resident per CU.
 template <int DQK, int DV, int QT, int NWV>
-__global__ __launch_bounds__(NWV * 64) void attn_prefill_kernel(AttnPrefillArgs a) {
+__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV == 8 || DQK < 128) ? 4 : 3, 4))) void attn_prefill_kernel(AttnPrefillArgs a) {
   constexpr int NT = NWV * 64;
   constexpr int KS = DQK / 32, DS = DV / 16;
-  constexpr int K_ROW_BYTES = DQK * 2 + 16;  // padded LDS row of the K tile (bank-conflict-free b128 reads)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x [K tile | V^T tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, c = lane & 15;
-  const int head = blockIdx.y;
+  // Block order.  Workgroups go round-robin over the 8 XCDs by linear id, and each XCD has its own 4 MB L2: in the XCD-aware
+  // order (a.nqb > 0; kv heads a multiple of 8) XCD x only ever works on kv heads x, x+8, ..., all q heads of a kv head ride
+  // together, and consecutive slots of one XCD take consecutive q blocks -- so the ~64 blocks resident on an XCD stream the same
+  // K / V^T pages of one kv head in near lockstep and each page crosses the fabric once per XCD instead of once per block
+  // (at 41 k tokens the per-kv-head K/V is 21 MB: in grid order the blocks drift apart and every tile comes from Infinity Cache).
+  // Causal launches hand out the long (late) q blocks first.
+  int head, qblk;
+  if (a.nqb > 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int g = a.nh / a.kvh, hpx = a.nh >> 3;  // q heads per kv head / q heads per XCD
+    const int hq = slot % hpx, qi = slot / hpx;
+    head = (xcd + 8 * (hq / g)) * g + hq % g;
+    qblk = a.causal ? a.nqb - 1 - qi : qi;
+  } else {
+    head = blockIdx.y;
+    qblk = blockIdx.x;
+  }
   const int kvhd = head / (a.nh / a.kvh);
-  const int qb = blockIdx.x * (16 * QT * NWV);  // first q row of the block
+  const int qb = qblk * (16 * QT * NWV);  // first q row of the block
   const int q0 = qb + wave * (16 * QT);        // first q row of the wave
   bf16x8_t qf[QT][KS];
 #pragma unroll
@@ -66,46 +80,61 @@ __global__ __launch_bounds__(NWV * 64) void attn_prefill_kernel(AttnPrefillArgs 
 
   // Software pipeline over KV pages: the next page travels global -> registers while the MFMAs of the current one run
   // from LDS, and is written to the other LDS buffer afterwards (one barrier per page).
-  constexpr int KP = KV_PAGE_TOKENS * DQK / 8, VP = DV * KV_PAGE_TOKENS / 8, SPR = DQK / 8;  // 16-byte pieces
+  // LDS layout: fragment-major.  Every K (16 tokens x 32 dims) and V^T (16 dims x 32 token slots) MFMA operand is one
+  // contiguous 1 KB block whose 16-byte piece l belongs to lane l (row c = l & 15, 8-element chunk G = l >> 4), so a fragment
+  // read is ds_read_b128 at base + lane * 16 and a staging store is ds_write_b128 at base + tid * 16: both conflict-free.
+  // (A padded row-major tile cannot be: the b128 lane groups {0-3, 12-15, 20-27}, ... put rows 0-3,12-15 of chunk G and rows
+  // 4-11 of chunk G+1 in one LDS cycle, which collide for every row pitch -- 8 instead of 4 cycles per read, and the ViT
+  // kernel sat at 76 % LDS-busy.)  The global side of the staging copy reads 16 rows x 64 B per wave instruction.
+  constexpr int KP = KV_PAGE_TOKENS * DQK / 8, VP = DV * KV_PAGE_TOKENS / 8;  // 16-byte pieces
   constexpr int KI = (KP + NT - 1) / NT, VI = (VP + NT - 1) / NT;
-  constexpr int STAGE_BYTES = KV_PAGE_TOKENS * K_ROW_BYTES + DV * V_ROW_BYTES;
+  constexpr int STAGE_BYTES = (KP + VP) * 16;
   u32x4_t rk[KI], rv[VI];
-  auto gload = [&](int tile) {
+  auto gload_k = [&](int tile) {
     const char* base = reinterpret_cast<const char*>(a.kv.page_ptrs[tile] + a.kv.layer_off);
     const char* kb = base + (size_t)kvhd * KV_PAGE_TOKENS * (DQK * 2);
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const int blk = wave + i * NWV;  // fragment block (sub, k4) = (blk / KS, blk % KS)
+      if (KP % NT == 0 || blk < KP / 64)
+        rk[i] = ld16(kb + ((blk / KS) * 16 + c) * (DQK * 2) + ((blk % KS) * 4 + G) * 16);
+    }
+  };
+  auto gload_v = [&](int tile) {
+    const char* base = reinterpret_cast<const char*>(a.kv.page_ptrs[tile] + a.kv.layer_off);
     const char* vb = base + (size_t)a.kvh * KV_PAGE_TOKENS * (DQK * 2) + (size_t)kvhd * DV * (KV_PAGE_TOKENS * 2);
 #pragma unroll
-    for (int i = 0; i < KI; ++i) {
-      const int p = tid + i * NT;
-      if (KP % NT == 0 || p < KP) rk[i] = ld16(kb + (size_t)p * 16);
-    }
-#pragma unroll
     for (int i = 0; i < VI; ++i) {
-      const int p = tid + i * NT;
-      if (VP % NT == 0 || p < VP) rv[i] = ld16(vb + (size_t)p * 16);
+      const int blk = wave + i * NWV;  // fragment block (ds, kk) = (blk >> 1, blk & 1)
+      if (VP % NT == 0 || blk < VP / 64)
+        rv[i] = ld16(vb + ((blk >> 1) * 16 + c) * (KV_PAGE_TOKENS * 2) + ((blk & 1) * 4 + G) * 16);
     }
   };
-  auto lstore = [&](int stage) {
+  auto lstore_k = [&](int stage) {
     char* ksw = smem + stage * STAGE_BYTES;
-    char* vsw = ksw + KV_PAGE_TOKENS * K_ROW_BYTES;
 #pragma unroll
     for (int i = 0; i < KI; ++i) {
       const int p = tid + i * NT;
-      if (KP % NT == 0 || p < KP) *reinterpret_cast<u32x4_t*>(ksw + (p / SPR) * K_ROW_BYTES + (p % SPR) * 16) = rk[i];
+      if (KP % NT == 0 || p < KP) *reinterpret_cast<u32x4_t*>(ksw + p * 16) = rk[i];
     }
+  };
+  auto lstore_v = [&](int stage) {
+    char* vsw = smem + stage * STAGE_BYTES + KP * 16;
 #pragma unroll
     for (int i = 0; i < VI; ++i) {
       const int p = tid + i * NT;
-      if (VP % NT == 0 || p < VP) *reinterpret_cast<u32x4_t*>(vsw + (p >> 3) * V_ROW_BYTES + (p & 7) * 16) = rv[i];
+      if (VP % NT == 0 || p < VP) *reinterpret_cast<u32x4_t*>(vsw + p * 16) = rv[i];
     }
   };
+  auto gload = [&](int tile) { gload_k(tile); gload_v(tile); };
+  auto lstore = [&](int stage) { lstore_k(stage); lstore_v(stage); };
   gload(0);
   lstore(0);
   __syncthreads();
   for (int tile = 0; tile < ntiles; ++tile) {
     if (tile + 1 < ntiles) gload(tile + 1);
     const char* ks = smem + (tile & 1) * STAGE_BYTES;
-    const char* vs = ks + KV_PAGE_TOKENS * K_ROW_BYTES;
+    const char* vs = ks + KP * 16;
     const int t0 = tile * KV_PAGE_TOKENS;
     // wave-uniform activity of each q sub-tile (causal: its 16 rows may see nothing of this tile)
     bool act[QT];
@@ -123,7 +152,7 @@ __global__ __launch_bounds__(NWV * 64) void attn_prefill_kernel(AttnPrefillArgs 
       for (int t = 0; t < QT; ++t) st[t][sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k4 = 0; k4 < KS; ++k4) {
-        const bf16x8_t kf = as_frag(*reinterpret_cast<const u32x4_t*>(ks + (sub * 16 + c) * K_ROW_BYTES + (k4 * 32 + G * 8) * 2));
+        const bf16x8_t kf = as_frag(*reinterpret_cast<const u32x4_t*>(ks + ((sub * KS + k4) * 64 + lane) * 16));
 #pragma unroll
         for (int t = 0; t < QT; ++t)
           if (act[t]) st[t][sub] = mfma16(kf, qf[t][k4], st[t][sub]);
@@ -150,7 +179,7 @@ __global__ __launch_bounds__(NWV * 64) void attn_prefill_kernel(AttnPrefillArgs 
     for (int ds = 0; ds < DS; ++ds) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        const bf16x8_t vf = as_frag(*reinterpret_cast<const u32x4_t*>(vs + (ds * 16 + c) * V_ROW_BYTES + (kk * 32 + G * 8) * 2));
+        const bf16x8_t vf = as_frag(*reinterpret_cast<const u32x4_t*>(vs + ((ds * 2 + kk) * 64 + lane) * 16));
 #pragma unroll
         for (int t = 0; t < QT; ++t)
           if (act[t]) o[t][ds] = mfma16(vf, pf[t][kk], o[t][ds]);
@@ -313,35 +342,34 @@ void launch_attn_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(a.kvh, a.nsplit), dim3(256), 0, st, a);
 }
 
-void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st) {
-  if (a.S <= 0) return;
-  static const int qt_env = [] {
-    const char* e = getenv("AHA_ATTN_QT");
-    return e ? atoi(e) : 0;
-  }();
+void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
+  if (a_in.S <= 0) return;
+  AttnPrefillArgs a = a_in;
   static const int nw_env = [] {
     const char* e = getenv("AHA_ATTN_WAVES");
     return e ? atoi(e) : 0;
   }();
-  // 2 q sub-tiles per wave: measured slower (300 registers: one wave per SIMD) -- kept behind AHA_ATTN_QT for A/B
-  const int qt = (qt_env && a.d != 64) ? qt_env : 1;
+  constexpr int qt = 1;  // 2 q sub-tiles per wave were measured slower (300 registers: one wave per SIMD)
   // 8 waves (128 q rows) per staged tile once there are enough q rows for every CU to get a block that way
   int nwv = (a.d != 64 && (int64_t)((a.S + 127) / 128) * a.nh >= 256) ? 8 : 4;
   if (nw_env == 4 || (nw_env == 8 && a.d != 64)) nwv = nw_env;
-  if (qt == 2) nwv = 4;
-  dim3 grid((a.S + 16 * qt * nwv - 1) / (16 * qt * nwv), a.nh), block(nwv * 64);
+  static const int sched_env = [] {
+    const char* e = getenv("AHA_ATTN_SCHED");
+    return e ? atoi(e) : 1;
+  }();
+  const int nqb = (a.S + 16 * qt * nwv - 1) / (16 * qt * nwv);
+  a.nqb = (sched_env && a.kvh % 8 == 0 && a.nh % a.kvh == 0) ? nqb : 0;
+  dim3 grid = a.nqb ? dim3(nqb * a.nh) : dim3(nqb, a.nh), block(nwv * 64);
   if (a.d == 128) {
-    const size_t lds = 2 * (KV_PAGE_TOKENS * (128 * 2 + 16) + 128 * V_ROW_BYTES);
-    if (qt == 2) hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 2, 4>), grid, block, lds, st, a);
-    else if (nwv == 8) hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 1, 8>), grid, block, lds, st, a);
+    const size_t lds = 2 * KV_PAGE_TOKENS * 2 * (128 + 128);
+    if (nwv == 8) hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 1, 8>), grid, block, lds, st, a);
     else hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 1, 4>), grid, block, lds, st, a);
   } else if (a.d == 64) {  // Qwen3-ASR audio encoder
-    const size_t lds = 2 * (KV_PAGE_TOKENS * (64 * 2 + 16) + 64 * V_ROW_BYTES);
+    const size_t lds = 2 * KV_PAGE_TOKENS * 2 * (64 + 64);
     hipLaunchKernelGGL((attn_prefill_kernel<64, 64, 1, 4>), grid, block, lds, st, a);
   } else {  // head_dim 72 (Qwen3-VL ViT): Q/K rows padded to 96, V block to 80
-    const size_t lds = 2 * (KV_PAGE_TOKENS * (96 * 2 + 16) + 80 * V_ROW_BYTES);
-    if (qt == 2) hipLaunchKernelGGL((attn_prefill_kernel<96, 80, 2, 4>), grid, block, lds, st, a);
-    else if (nwv == 8) hipLaunchKernelGGL((attn_prefill_kernel<96, 80, 1, 8>), grid, block, lds, st, a);
+    const size_t lds = 2 * KV_PAGE_TOKENS * 2 * (96 + 80);
+    if (nwv == 8) hipLaunchKernelGGL((attn_prefill_kernel<96, 80, 1, 8>), grid, block, lds, st, a);
     else hipLaunchKernelGGL((attn_prefill_kernel<96, 80, 1, 4>), grid, block, lds, st, a);
   }
 }
