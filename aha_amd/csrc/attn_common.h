@@ -16,8 +16,16 @@ __device__ __forceinline__ bf16x8_t as_frag(u32x4_t v) {
   return x.b;
 }
 __device__ __forceinline__ float group_max(float v) {  // across the 4 lane groups (same column c)
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
+  // v_permlane32_swap / v_permlane16_swap instead of __shfl_xor (ds_bpermute: an LDS round trip in the middle of the softmax's
+  // dependency chain, once per tile); max is exact in any order
+  {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ float group_sum(float v) {
   v += __shfl_xor(v, 16, 64);

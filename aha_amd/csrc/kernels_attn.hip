@@ -172,8 +172,11 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
         softmax_tile(st[t], a.scale, [](int) { return true; }, G, m[t], l[t], alpha[t], pf[t]);
       else
         softmax_tile(st[t], a.scale, [&](int tk) { return t0 + tk <= lim; }, G, m[t], l[t], alpha[t], pf[t]);
+      // once the running max has settled alpha is exactly 1 in every lane of the wave: skip the DS*4 multiplies (x * 1 == x)
+      if (__builtin_amdgcn_ballot_w64(alpha[t] != 1.f) != 0) {
 #pragma unroll
-      for (int ds = 0; ds < DS; ++ds) o[t][ds] *= alpha[t];
+        for (int ds = 0; ds < DS; ++ds) o[t][ds] *= alpha[t];
+      }
     }
 #pragma unroll
     for (int ds = 0; ds < DS; ++ds) {
