@@ -73,6 +73,10 @@ SIGNATURES = {
     "aha_hip_clear_cache": (C.c_int, [_P]),
     "aha_hip_stop_token_ids": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_size_t]),
     "aha_hip_decode_greedy": (C.c_int, [_P, C.c_uint32, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "aha_hip_sample_candidates": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_size_t, C.c_float, C.c_float, C.c_int32,
+                                            C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_float),
+                                            C.POINTER(C.c_float)]),
+    "aha_hip_last_logits": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "aha_hip_cache_len": (C.c_size_t, [_P]),
     "aha_hip_set_profiling": (C.c_int, [_P, C.c_int]),
     "aha_hip_get_profile": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),

@@ -112,6 +112,27 @@ int aha_hip_decode_greedy(aha_model* m, uint32_t first_token, size_t seqlen_offs
   API_GUARD_END
 }
 
+int aha_hip_sample_candidates(aha_model* m, const uint32_t* context, size_t n_context, float repeat_penalty, float temperature,
+                              int32_t k, float* vals_out, uint32_t* idx_out, float* max_out, float* sumexp_out) {
+  API_GUARD_BEGIN
+  if (!m) {
+    set_error("null handle");
+    return AHA_ERR_INVALID;
+  }
+  return model_sample_candidates(m, context, n_context, repeat_penalty, temperature, k, vals_out, idx_out, max_out, sumexp_out);
+  API_GUARD_END
+}
+
+int aha_hip_last_logits(aha_model* m, float* logits_out) {
+  API_GUARD_BEGIN
+  if (!m || !logits_out) {
+    set_error("null argument");
+    return AHA_ERR_INVALID;
+  }
+  return model_last_logits(m, logits_out);
+  API_GUARD_END
+}
+
 size_t aha_hip_cache_len(const aha_model* m) { return m ? m->cache_len : 0; }
 
 int aha_hip_set_profiling(aha_model* m, int enable) {

@@ -44,6 +44,14 @@ void launch_argmax_pair(const float* blk_max, const uint32_t* blk_idx, int n, in
 void launch_argmax_pick(const float* pairs, int T, uint32_t* out, hipStream_t st);
 void launch_argmax_f32(const float* x, int64_t n, float* ws_max, uint32_t* ws_idx, uint32_t* out, hipStream_t st);
 
+// D11 candidates (kernels_sample.hip): repeat penalty into a working copy of the logits; k largest + full-vocabulary softmax
+// normaliser.  cand_* hold sample_stage1_waves(V) * k entries, part_* one entry per stage-1 wave, out_ms = {max, sumexp}.
+int sample_stage1_waves(int V);
+bool sample_shape_ok(int V, int k);
+void launch_repeat_penalty(const float* logits, float* work, const uint32_t* ctx, int n, float penalty, int V, hipStream_t st);
+void launch_topk_candidates(const float* x, int V, int k, float inv_temp, float* cand_val, unsigned* cand_idx, float* part_m,
+                            float* part_s, float* out_val, unsigned* out_idx, float* out_ms, hipStream_t st);
+
 void launch_embed_gather(const void* table, const uint32_t* ids, void* out, int S, int H, hipStream_t st);
 void launch_rmsnorm_rows(const void* x, const void* w, void* y, int64_t rows, int dim, int64_t ldx, int64_t ldy,
                          float eps, hipStream_t st);

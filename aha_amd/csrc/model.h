@@ -136,6 +136,14 @@ struct aha_model {
   size_t mega_lds = 0;
   bool decode_fused = true;  // attention block of a decode step in one launch (kernels_attn.hip attn_decode_fused_kernel)
   float* h_logits = nullptr;  // pinned
+  bool have_logits = false;   // d_logits holds the logits of a completed forward call
+  bool logits_assembled = false;  // vocab-parallel TP: d_logits already all-reduced into the full vector
+  // D11 candidate extraction (kernels_sample.hip), allocated on first use
+  float* d_samp_work = nullptr;   // (V) penalised copy of the logits
+  float* d_samp_f = nullptr;      // cand_val | part_m | part_s | out_val | out_ms
+  unsigned* d_samp_u = nullptr;   // cand_idx | out_idx
+  uint32_t* d_samp_ctx = nullptr;
+  size_t samp_ctx_cap = 0;
   // prefill scratch (grown on demand)
   size_t pf_cap = 0;
   uint32_t* p_ids = nullptr;
@@ -168,6 +176,9 @@ int model_forward_initial(aha_model* m, const uint32_t* ids, size_t n, size_t of
 int model_forward_step(aha_model* m, uint32_t token, size_t offset, float* logits_out, uint32_t* argmax_out);
 int model_decode_greedy(aha_model* m, uint32_t first_token, size_t offset, size_t max_new, uint32_t* out);
 int model_clear_cache(aha_model* m);
+int model_last_logits(aha_model* m, float* logits_out);
+int model_sample_candidates(aha_model* m, const uint32_t* ctx, size_t n_ctx, float repeat_penalty, float temperature, int k,
+                            float* vals_out, uint32_t* idx_out, float* max_out, float* sumexp_out);
 int model_ensure_pages(aha_model* m, size_t tokens);
 KvLayer model_kv_layer(aha_model* m, int layer);
 int prof_collect(aha_model* m);

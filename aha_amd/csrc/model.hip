@@ -352,6 +352,84 @@ KvLayer model_kv_layer(aha_model* m, int layer) {
   return kv;
 }
 
+static int assemble_logits(aha_model* m);
+
+// D11 candidates: see kernels_sample.hip.  Works on the logits the last forward_initial / forward_step / decode_greedy left
+// on the device; the caller slices `ctx` the way use_repeat_penalty does (sample.rs:47-53: the last repeat_last_n generated ids).
+int model_sample_candidates(aha_model* m, const uint32_t* ctx, size_t n_ctx, float repeat_penalty, float temperature, int k,
+                            float* vals_out, uint32_t* idx_out, float* max_out, float* sumexp_out) {
+  const int V = m->desc.vocab_size;
+  if (!m->have_logits) {
+    set_error("sample_candidates: no forward call has produced logits yet");
+    return AHA_ERR_STATE;
+  }
+  if (!sample_shape_ok(V, k)) {
+    set_error("sample_candidates: k must be in [1, 64] (and vocab * k within the stage-2 capacity)");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  if (!(repeat_penalty > 0.f) || (n_ctx && !ctx) || !vals_out || !idx_out) {
+    set_error("sample_candidates: bad argument");
+    return AHA_ERR_INVALID;
+  }
+  const int nw = sample_stage1_waves(V);
+  if (!m->d_samp_f) {
+    const size_t nf = (size_t)nw * 64 + 2 * (size_t)nw + 64 + 2, nu = (size_t)nw * 64 + 64;
+    void *pw = nullptr, *pf = nullptr, *pu = nullptr;
+    if (int rc = dev_alloc(m, (size_t)V * 4, &pw, false)) return rc;
+    if (int rc = dev_alloc(m, nf * 4, &pf, false)) return rc;
+    if (int rc = dev_alloc(m, nu * 4, &pu, false)) return rc;
+    m->d_samp_work = (float*)pw;
+    m->d_samp_f = (float*)pf;
+    m->d_samp_u = (unsigned*)pu;
+  }
+  if (int rc = assemble_logits(m)) return rc;
+  const float* src = m->d_logits;
+  if (repeat_penalty != 1.0f && n_ctx > 0) {  // sample.rs:47 `repeat_penalty == 1.0` => logits unchanged
+    if (n_ctx > m->samp_ctx_cap) {
+      void* p = nullptr;
+      const size_t cap = std::max<size_t>(1024, n_ctx * 2);
+      if (int rc = dev_alloc(m, cap * 4, &p, false)) return rc;
+      m->d_samp_ctx = (uint32_t*)p;  // the smaller buffer stays in m->owned until destroy
+      m->samp_ctx_cap = cap;
+    }
+    AHA_HIP_CHECK(hipMemcpyAsync(m->d_samp_ctx, ctx, n_ctx * 4, hipMemcpyHostToDevice, m->stream));
+    AHA_HIP_CHECK(hipMemcpyAsync(m->d_samp_work, m->d_logits, (size_t)V * 4, hipMemcpyDeviceToDevice, m->stream));
+    launch_repeat_penalty(m->d_logits, m->d_samp_work, m->d_samp_ctx, (int)n_ctx, repeat_penalty, V, m->stream);
+    src = m->d_samp_work;
+  }
+  // `&logits / temperature` in LogitsProcessor::sample is an affine by 1/T computed in f64 and applied in f32
+  const float inv_temp = temperature > 0.f ? (float)(1.0 / (double)temperature) : 1.0f;
+  float* cand_val = m->d_samp_f;
+  float* part_m = cand_val + (size_t)nw * 64;
+  float* part_s = part_m + nw;
+  float* out_val = part_s + nw;
+  float* out_ms = out_val + 64;
+  unsigned* cand_idx = m->d_samp_u;
+  unsigned* out_idx = cand_idx + (size_t)nw * 64;
+  launch_topk_candidates(src, V, k, inv_temp, cand_val, cand_idx, part_m, part_s, out_val, out_idx, out_ms, m->stream);
+  AHA_HIP_CHECK(hipGetLastError());
+  float ms[2];
+  AHA_HIP_CHECK(hipMemcpyAsync(vals_out, out_val, (size_t)k * 4, hipMemcpyDeviceToHost, m->stream));
+  AHA_HIP_CHECK(hipMemcpyAsync(idx_out, out_idx, (size_t)k * 4, hipMemcpyDeviceToHost, m->stream));
+  AHA_HIP_CHECK(hipMemcpyAsync(ms, out_ms, 8, hipMemcpyDeviceToHost, m->stream));
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  if (max_out) *max_out = ms[0];
+  if (sumexp_out) *sumexp_out = ms[1];
+  return AHA_OK;
+}
+
+int model_last_logits(aha_model* m, float* logits_out) {
+  if (!m->have_logits) {
+    set_error("last_logits: no forward call has produced logits yet");
+    return AHA_ERR_STATE;
+  }
+  if (int rc = assemble_logits(m)) return rc;
+  AHA_HIP_CHECK(hipMemcpyAsync(m->h_logits, m->d_logits, (size_t)m->desc.vocab_size * 4, hipMemcpyDeviceToHost, m->stream));
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  memcpy(logits_out, m->h_logits, (size_t)m->desc.vocab_size * 4);
+  return AHA_OK;
+}
+
 int model_clear_cache(aha_model* m) {
   // QKNormAttention::clear_kv_cache (modules.rs:581-583): the cache becomes empty; pages go back to the pool
   for (size_t i = m->n_pages; i > 0; --i) m->free_pages.push_back(m->h_page_ptrs[i - 1]);
@@ -798,14 +876,25 @@ static void mega_trace_dump(aha_model* m) {
   }
 }
 
+// vocab-parallel lm_head: every rank zeroes the slices it does not own and the all-reduce assembles the full vector
+static int assemble_logits(aha_model* m) {
+  const aha_model_desc& c = m->desc;
+  if (m->lm_rows == c.vocab_size || m->logits_assembled) return AHA_OK;
+  if (m->lm_row0 > 0) AHA_HIP_CHECK(hipMemsetAsync(m->d_logits, 0, (size_t)m->lm_row0 * 4, m->stream));
+  const int tail0 = m->lm_row0 + m->lm_rows;
+  if (tail0 < c.vocab_size) AHA_HIP_CHECK(hipMemsetAsync(m->d_logits + tail0, 0, (size_t)(c.vocab_size - tail0) * 4, m->stream));
+  const int rc = model_allreduce(m, m->d_logits, (size_t)c.vocab_size);
+  if (rc) return rc;
+  m->logits_assembled = true;
+  return AHA_OK;
+}
+
 static int fetch_outputs(aha_model* m, float* logits_out, uint32_t* argmax_out) {
   const aha_model_desc& c = m->desc;
-  if (logits_out && m->lm_rows != c.vocab_size) {
-    // vocab-parallel lm_head: every rank zeroes the slices it does not own and the all-reduce assembles the full vector
-    if (m->lm_row0 > 0) AHA_HIP_CHECK(hipMemsetAsync(m->d_logits, 0, (size_t)m->lm_row0 * 4, m->stream));
-    const int tail0 = m->lm_row0 + m->lm_rows;
-    if (tail0 < c.vocab_size) AHA_HIP_CHECK(hipMemsetAsync(m->d_logits + tail0, 0, (size_t)(c.vocab_size - tail0) * 4, m->stream));
-    const int rc = model_allreduce(m, m->d_logits, (size_t)c.vocab_size);
+  m->have_logits = true;
+  m->logits_assembled = false;
+  if (logits_out) {
+    const int rc = assemble_logits(m);
     if (rc) return rc;
   }
   if (logits_out) AHA_HIP_CHECK(hipMemcpyAsync(m->h_logits, m->d_logits, (size_t)c.vocab_size * 4, hipMemcpyDeviceToHost, m->stream));
@@ -1213,6 +1302,8 @@ int model_decode_greedy(aha_model* m, uint32_t first_token, size_t offset, size_
     m->cache_len += used;  // inputs consumed: first_token and the first used-1 generated tokens of this chunk
     produced += used;
   }
+  m->have_logits = produced > 0 || m->have_logits;
+  if (produced > 0) m->logits_assembled = false;
   return (int)produced;
 }
 

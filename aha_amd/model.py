@@ -231,6 +231,25 @@ class HipInferenceModel:
         n = check(lib().aha_hip_decode_greedy(self.handle, int(first_token), seqlen_offset, max_new, buf))
         return [int(buf[i]) for i in range(n)]
 
+    def sample_candidates(self, context: Sequence[int], repeat_penalty: float, temperature: float, k: int):
+        """Device half of sample_and_push (common/generate.rs:70-86): repeat penalty over `context`, then the k largest
+        logits of the last forward call -> (values f32[k], indices u32[k], max, sumexp over the whole vocabulary)."""
+        ctx = np.ascontiguousarray(np.asarray(context, dtype=np.uint32).reshape(-1))
+        n = max(int(k), 1)  # a bad k is reported by the library, not by numpy
+        vals = np.empty(n, dtype=np.float32)
+        idx = np.empty(n, dtype=np.uint32)
+        mx, se = C.c_float(), C.c_float()
+        check(lib().aha_hip_sample_candidates(self.handle, ctx.ctypes.data_as(C.POINTER(C.c_uint32)), ctx.size,
+                                              float(repeat_penalty), float(temperature), int(k),
+                                              vals.ctypes.data_as(C.POINTER(C.c_float)),
+                                              idx.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(mx), C.byref(se)))
+        return vals, idx, float(mx.value), float(se.value)
+
+    def last_logits(self) -> np.ndarray:
+        out = np.empty(self.text_cfg.vocab_size, dtype=np.float32)
+        check(lib().aha_hip_last_logits(self.handle, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
     def debug_allreduce(self, t: torch.Tensor) -> None:
         assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
         torch.cuda.current_stream(t.device).synchronize()

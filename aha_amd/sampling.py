@@ -1,0 +1,191 @@
+"""Host mirror of the reference's sampling step (D11) on top of the device candidate extraction.
+
+Reference: `GenerationContext` / `sample_and_push` (src/models/common/generate.rs:21-86), `get_logit_processor` and
+`use_repeat_penalty` (src/models/common/sample.rs:7-60), candle_transformers::generation::LogitsProcessor (0.9.2).
+
+Split of the work: the device (aha_hip_sample_candidates) applies the repeat penalty and returns the k largest logits plus
+the full-vocabulary softmax normaliser; this module turns them into the weight vector candle would draw from (top-k,
+top-k-then-top-p, top-p) and draws.  The draw uses numpy's PCG64 -- candle's `StdRng` stream is third-party and not
+reproduced, so sampled token SEQUENCES differ from the reference's for the same seed while the DISTRIBUTION of every draw is
+the same.  Greedy requests never come here (forward_* already returns the arg-max token).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+MAX_CANDIDATES = 64  # aha_hip_sample_candidates limit
+
+
+@dataclass
+class Sampling:
+    kind: str                   # "ArgMax" | "All" | "TopK" | "TopP" | "TopKThenTopP"  (candle Sampling)
+    temperature: float = 1.0
+    k: int = 0
+    p: float = 1.0
+
+
+def get_logit_processor(temperature: Optional[float], top_p: Optional[float], top_k: Optional[int], seed: int) -> "LogitsProcessor":
+    """sample.rs:7-38 (temperature < 1e-7 => greedy; top_k None => LogitsProcessor::new's ArgMax / All / TopP)."""
+    if temperature is not None and np.float32(temperature) < np.float32(1e-7):
+        temperature = None
+    t = None if temperature is None else float(np.float32(temperature))
+    p = None if top_p is None else float(np.float32(top_p))
+    if t is None:
+        s = Sampling("ArgMax")
+    elif top_k is None:
+        s = Sampling("All", t) if p is None else Sampling("TopP", t, p=p)
+    else:
+        s = Sampling("TopK", t, k=int(top_k)) if p is None else Sampling("TopKThenTopP", t, k=int(top_k), p=p)
+    return LogitsProcessor(seed, s)
+
+
+def _topp_mask(prs: np.ndarray, top_p: float) -> np.ndarray:
+    """LogitsProcessor::sample_topp: descending walk, zero everything after the running sum has reached top_p."""
+    prs = prs.astype(np.float32).copy()
+    cumsum = np.float32(0.0)
+    for i in np.argsort(-prs, kind="stable"):
+        if cumsum >= np.float32(top_p):
+            prs[i] = 0.0
+        else:
+            cumsum = np.float32(cumsum + prs[i])
+    return prs
+
+
+class LogitsProcessor:
+    def __init__(self, seed: int, sampling: Sampling):
+        self.sampling = sampling
+        self.rng = np.random.Generator(np.random.PCG64(seed))
+
+    # -- deterministic part ------------------------------------------------------------------------------------------
+    def candidates_needed(self, vocab_size: int) -> int:
+        """How many candidates to ask the device for; 0 = this sampler needs the full logits vector (or none at all)."""
+        s = self.sampling
+        if s.kind in ("TopK", "TopKThenTopP"):
+            return s.k if 1 <= s.k <= MAX_CANDIDATES and s.k < vocab_size else 0
+        if s.kind == "TopP":
+            return min(MAX_CANDIDATES, vocab_size)
+        return 0
+
+    def weights_from_candidates(self, vals: np.ndarray, mx: float, sumexp: float) -> Optional[np.ndarray]:
+        """Weights over the candidates (same order) that candle's sampler would hand to the weighted draw, or None when the
+        candidates do not cover the sampler's support (TopP nucleus wider than the candidate list)."""
+        s = self.sampling
+        inv_t = np.float32(1.0 / s.temperature)
+        prs = (np.exp((vals.astype(np.float32) - np.float32(mx)) * inv_t, dtype=np.float32) / np.float32(sumexp)).astype(np.float32)
+        if s.kind == "TopK":
+            return prs
+        if s.kind == "TopKThenTopP":
+            sum_p = prs.sum(dtype=np.float32)
+            return prs if (s.p <= 0.0 or s.p >= sum_p) else _topp_mask(prs, s.p)
+        if s.kind == "TopP":
+            if prs.sum(dtype=np.float32) < np.float32(s.p):
+                return None  # the nucleus reaches past the candidates
+            return _topp_mask(prs, s.p)
+        raise ValueError(f"{s.kind} does not sample from candidates")
+
+    def weights_from_logits(self, logits: np.ndarray) -> np.ndarray:
+        """Full-vector path (Sampling::All, oversized k, TopP fallback): LogitsProcessor::sample on host logits."""
+        s = self.sampling
+        logits = np.asarray(logits, dtype=np.float32)
+        if s.kind == "ArgMax":
+            w = np.zeros_like(logits)
+            w[int(np.argmax(logits))] = 1.0
+            return w
+        x = logits * np.float32(1.0 / s.temperature)
+        e = np.exp(x - x.max(), dtype=np.float32)
+        prs = (e / e.sum(dtype=np.float32)).astype(np.float32)
+        if s.kind == "All":
+            return prs
+        if s.kind == "TopP" or (s.kind == "TopKThenTopP" and s.k >= logits.shape[0]):
+            return _topp_mask(prs, s.p)
+        if s.k >= logits.shape[0]:
+            return prs
+        keep = np.argsort(-prs, kind="stable")[: s.k]
+        sub = prs[keep]
+        if s.kind == "TopKThenTopP" and not (s.p <= 0.0 or s.p >= sub.sum(dtype=np.float32)):
+            sub = _topp_mask(sub, s.p)
+        w = np.zeros_like(prs)
+        w[keep] = sub
+        return w
+
+    # -- the draw ----------------------------------------------------------------------------------------------------
+    def draw(self, weights: np.ndarray) -> int:
+        """WeightedIndex semantics: index of the first cumulative weight that exceeds u * total."""
+        c = np.cumsum(weights.astype(np.float64))
+        if not c[-1] > 0:
+            raise ValueError("all sampling weights are zero")
+        return int(min(np.searchsorted(c, self.rng.random() * c[-1], side="right"), len(c) - 1))
+
+
+class GenerationContext:
+    """common/generate.rs:21-53 (defaults: repeat_penalty 1.0, repeat_last_n 64)."""
+
+    def __init__(self, temperature: Optional[float], top_p: Optional[float], top_k: Optional[int], repeat_penalty: Optional[float],
+                 repeat_last_n: Optional[int], seed: int, initial_seq_len: int, max_tokens: int):
+        self.logit_processor = get_logit_processor(temperature, top_p, top_k, seed)
+        self.repeat_penalty = 1.0 if repeat_penalty is None else float(repeat_penalty)
+        self.repeat_last_n = 64 if repeat_last_n is None else int(repeat_last_n)
+        self.seqlen_offset = 0
+        self.seq_len = initial_seq_len
+        self.sample_len = max_tokens
+
+
+def penalty_context(repeat_penalty: float, repeat_last_n: Optional[int], generated: Sequence[int]) -> Tuple[float, Sequence[int]]:
+    """use_repeat_penalty's slicing (sample.rs:47-53): (effective penalty, ids it applies to)."""
+    if np.float32(repeat_penalty) == np.float32(1.0) or repeat_last_n == 0:
+        return 1.0, []
+    start_at = 0 if repeat_last_n is None else max(len(generated) - repeat_last_n, 0)
+    ids = generated[start_at:]
+    return (float(repeat_penalty), ids) if len(ids) else (1.0, [])
+
+
+def sample_and_push(ctx: GenerationContext, model, argmax_token: int, generated: List[int]) -> int:
+    """common/generate.rs:70-86 on the logits of the model's last forward call."""
+    lp = ctx.logit_processor
+    pen, pctx = penalty_context(ctx.repeat_penalty, ctx.repeat_last_n, generated)
+    V = model.text_cfg.vocab_size
+    if lp.sampling.kind == "ArgMax" and pen == 1.0:
+        token = int(argmax_token)
+    else:
+        k = 1 if lp.sampling.kind == "ArgMax" else lp.candidates_needed(V)
+        token = None
+        if k:
+            vals, idx, mx, se = model.sample_candidates(pctx, pen, lp.sampling.temperature if lp.sampling.kind != "ArgMax" else 0.0, k)
+            if lp.sampling.kind == "ArgMax":
+                token = int(idx[0])  # arg-max of the penalised logits (first maximal index)
+            else:
+                w = lp.weights_from_candidates(vals, mx, se)
+                if w is not None:
+                    token = int(idx[lp.draw(w)])
+        if token is None:  # full-vector fallback
+            logits = model.last_logits()
+            if pen != 1.0:
+                seen = set()
+                for t in pctx:
+                    if t not in seen and 0 <= t < V:
+                        logits[t] = logits[t] / np.float32(pen) if logits[t] >= 0 else logits[t] * np.float32(pen)
+                    seen.add(t)
+            token = lp.draw(lp.weights_from_logits(logits))
+    generated.append(token)
+    return token
+
+
+def generate_generic_sampled(model, input_ids: Sequence[int], ctx: GenerationContext, data=None) -> List[int]:
+    """generate_generic_text's token loop (common/generate.rs:87-112) with the sampler of `ctx`."""
+    eos = set(model.stop_token_ids())
+    generated: List[int] = []
+    _, am = model.forward_initial(input_ids, ctx.seqlen_offset, data, want_logits=False)
+    tok = sample_and_push(ctx, model, am, generated)
+    ctx.seqlen_offset += ctx.seq_len  # prepare_for_next_token
+    ctx.seq_len = 1
+    for _ in range(1, ctx.sample_len):
+        _, am = model.forward_step(tok, ctx.seqlen_offset, want_logits=False)
+        tok = sample_and_push(ctx, model, am, generated)
+        if tok in eos:
+            break
+        ctx.seqlen_offset += ctx.seq_len
+    model.clear_cache()
+    return generated

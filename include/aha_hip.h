@@ -169,6 +169,26 @@ int aha_hip_stop_token_ids(const aha_model* m, uint32_t* out, size_t cap);
  * Returns the number of tokens written or a negative status. */
 int aha_hip_decode_greedy(aha_model* m, uint32_t first_token, size_t seqlen_offset, size_t max_new, uint32_t* tokens_out);
 
+/* D11, device half of sample_and_push (common/generate.rs:70-86) for the non-greedy samplers of get_logit_processor
+ * (common/sample.rs:7-38: candle LogitsProcessor TopK / TopKThenTopP / TopP).  Works on the logits the last
+ * forward_initial / forward_step / decode_greedy call left on the device:
+ *   1. use_repeat_penalty (sample.rs:41-60 -> candle_transformers::utils::apply_repeat_penalty): every DISTINCT id of
+ *      `context` (the caller passes the last repeat_last_n generated ids, sample.rs:49-53) has its logit divided by
+ *      repeat_penalty if >= 0, multiplied otherwise; repeat_penalty == 1 or n_context == 0 leaves the logits unchanged;
+ *   2. the k (1..64) largest penalised logits, ordered by (value descending, index ascending), into vals_out / idx_out;
+ *   3. max_out / sumexp_out = max_i x_i and sum_i exp((x_i - max) / temperature) over the WHOLE vocabulary, so that
+ *      exp((vals_out[j] - max) / temperature) / sumexp equals the probability candle's softmax(logits / temperature)
+ *      assigns to candidate j (temperature <= 0 is treated as 1).
+ * The host finishes with its own RNG (top-p cut over the candidates + weighted draw): 8k + 8 bytes leave the device per
+ * token instead of the V-float logits vector.  Not in the reference as a function: it replaces the body of
+ * LogitsProcessor::sample up to the random draw. */
+int aha_hip_sample_candidates(aha_model* m, const uint32_t* context, size_t n_context, float repeat_penalty, float temperature,
+                              int32_t k, float* vals_out, uint32_t* idx_out, float* max_out, float* sumexp_out);
+
+/* The V f32 logits of the last forward call, exactly what logits_out of that call would have received (fallback of the
+ * candidate path: Sampling::All, or a TopP whose nucleus is wider than 64 tokens). */
+int aha_hip_last_logits(aha_model* m, float* logits_out);
+
 /* Extension for the image-parallel ViT (each GPU encodes its share of the images, embeddings are all-gathered over RCCL):
  * runs only the vision tower on `mm` and writes (1 + n_deepstack, n_tokens, hidden) bf16 to out_dev (device memory, may be
  * NULL to query n_tokens). */

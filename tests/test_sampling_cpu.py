@@ -1,0 +1,175 @@
+"""D11 on the CPU: the oracle's restatement of candle's sampler on hand-computed cases, and the host mirror
+(aha_amd/sampling.py: candidates -> draw weights, generation loop bookkeeping) against the oracle."""
+import numpy as np
+import pytest
+
+from aha_amd import sampling as hs
+from oracle import sampling as osamp
+
+
+def test_apply_repeat_penalty_hand_case():
+    logits = np.array([2.0, -1.0, 0.0, 3.0, -4.0], dtype=np.float32)
+    out = osamp.apply_repeat_penalty(logits, 2.0, [0, 1, 0, 7, 4, 4])  # duplicates once; id 7 outside the vocabulary: ignored
+    np.testing.assert_array_equal(out, np.array([1.0, -2.0, 0.0, 3.0, -8.0], dtype=np.float32))
+    assert osamp.apply_repeat_penalty(np.array([0.0], np.float32), 2.0, [0])[0] == 0.0  # >= 0 branch: 0 / p
+    # use_repeat_penalty: identity for penalty 1 or repeat_last_n == Some(0); otherwise the LAST n ids only (sample.rs:47-53)
+    np.testing.assert_array_equal(osamp.use_repeat_penalty(1.0, 64, logits, [0, 1]), logits)
+    np.testing.assert_array_equal(osamp.use_repeat_penalty(2.0, 0, logits, [0, 1]), logits)
+    np.testing.assert_array_equal(osamp.use_repeat_penalty(2.0, 1, logits, [0, 1]), np.array([2.0, -2.0, 0.0, 3.0, -4.0], np.float32))
+    np.testing.assert_array_equal(osamp.use_repeat_penalty(2.0, None, logits, [0, 1]), np.array([1.0, -2.0, 0.0, 3.0, -4.0], np.float32))
+
+
+@pytest.mark.parametrize("t,p,k,kind", [(None, None, None, "ArgMax"), (0.0, 0.9, 20, "ArgMax"), (1e-8, None, None, "ArgMax"),
+                                        (0.6, None, None, "All"), (0.6, 0.95, None, "TopP"), (0.6, None, 20, "TopK"),
+                                        (0.6, 0.95, 20, "TopKThenTopP"), (None, 0.95, 20, "ArgMax")])
+def test_get_logit_processor_mapping(t, p, k, kind):
+    o = osamp.get_logit_processor(t, p, k)
+    h = hs.get_logit_processor(t, p, k, seed=1).sampling
+    assert o.kind == kind and h.kind == kind
+    if kind != "ArgMax":
+        assert h.temperature == o.temperature == float(np.float32(t))  # `temp as f64` of the request's f32
+    if p is not None and kind in ("TopP", "TopKThenTopP"):
+        assert h.p == o.p == float(np.float32(p))
+
+
+def test_topp_mask_keeps_the_crossing_token():
+    # sample_topp: 0.5, 0.3 reach 0.8 >= 0.7 only AFTER adding 0.3, so 0.3 is kept and the rest zeroed
+    w = osamp.final_weights(np.log(np.array([0.5, 0.3, 0.15, 0.05], np.float32)), osamp.Sampling("TopP", 1.0, p=0.7))
+    np.testing.assert_allclose(w, [0.5, 0.3, 0.0, 0.0], atol=1e-6)
+    w = osamp.final_weights(np.log(np.array([0.5, 0.3, 0.15, 0.05], np.float32)), osamp.Sampling("TopKThenTopP", 1.0, k=3, p=0.4))
+    np.testing.assert_allclose(w, [0.5, 0.0, 0.0, 0.0], atol=1e-6)
+    # top_p >= sum of the k kept probabilities: plain top-k (generation/mod.rs sample_topk_topp)
+    w = osamp.final_weights(np.log(np.array([0.5, 0.3, 0.15, 0.05], np.float32)), osamp.Sampling("TopKThenTopP", 1.0, k=2, p=0.9))
+    np.testing.assert_allclose(w, [0.5, 0.3, 0.0, 0.0], atol=1e-6)
+
+
+def _peaked_logits(V, seed, scale):
+    g = np.random.default_rng(seed)
+    return (g.standard_normal(V) * scale).astype(np.float32)
+
+
+@pytest.mark.parametrize("sampling", [osamp.Sampling("TopK", 0.6, k=20), osamp.Sampling("TopKThenTopP", 0.6, k=20, p=0.95),
+                                      osamp.Sampling("TopKThenTopP", 1.0, k=64, p=0.5), osamp.Sampling("TopP", 0.6, p=0.8)])
+@pytest.mark.parametrize("penalty", [1.0, 1.3])
+def test_host_weights_from_candidates_match_oracle(sampling, penalty):
+    V = 4096
+    logits = _peaked_logits(V, 3, 4.0)
+    ctxt = [5, 9, 5, 4095, 17, 9999]
+    pen = osamp.use_repeat_penalty(penalty, None, logits, ctxt)
+    want = osamp.final_weights(pen, sampling)
+    lp = hs.LogitsProcessor(0, hs.Sampling(sampling.kind, sampling.temperature, sampling.k, sampling.p))
+    k = lp.candidates_needed(V)
+    assert k == (sampling.k if sampling.kind != "TopP" else 64)
+    vals, idx, mx, se = osamp.topk_candidates(pen, k, sampling.temperature)
+    w = lp.weights_from_candidates(vals, mx, se)
+    assert w is not None
+    got = np.zeros(V, np.float32)
+    got[idx] = w
+    assert set(np.nonzero(got)[0]) == set(np.nonzero(want)[0])
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-9)
+    # and the full-vector fallback is the same function of the logits
+    np.testing.assert_allclose(lp.weights_from_logits(pen), want, rtol=1e-6, atol=1e-12)
+
+
+def test_topp_nucleus_wider_than_candidates_falls_back():
+    V = 4096
+    flat = _peaked_logits(V, 4, 0.1)  # nearly uniform: 64 candidates hold ~2 % of the mass
+    lp = hs.LogitsProcessor(0, hs.Sampling("TopP", 1.0, p=0.9))
+    vals, idx, mx, se = osamp.topk_candidates(flat, 64, 1.0)
+    assert lp.weights_from_candidates(vals, mx, se) is None
+    np.testing.assert_allclose(lp.weights_from_logits(flat), osamp.final_weights(flat, osamp.Sampling("TopP", 1.0, p=0.9)), rtol=1e-6)
+    assert hs.LogitsProcessor(0, hs.Sampling("All", 0.7)).candidates_needed(V) == 0
+    assert hs.LogitsProcessor(0, hs.Sampling("TopK", 0.7, k=100)).candidates_needed(V) == 0  # above the device limit
+
+
+def test_draw_is_weighted_index():
+    lp = hs.LogitsProcessor(0, hs.Sampling("TopK", 1.0, k=4))
+
+    class _R:
+        def __init__(self, u): self.u = u
+        def random(self): return self.u
+    w = np.array([0.0, 2.0, 0.0, 6.0], np.float32)
+    for u, want in [(0.0, 1), (0.2499, 1), (0.25, 3), (0.999999, 3)]:
+        lp.rng = _R(u)
+        assert lp.draw(w) == want
+    with pytest.raises(ValueError):
+        lp.draw(np.zeros(3, np.float32))
+    # frequencies follow the weights
+    lp = hs.LogitsProcessor(7, hs.Sampling("TopK", 1.0, k=4))
+    n = 20000
+    counts = np.bincount([lp.draw(w) for _ in range(n)], minlength=4)
+    assert counts[0] == counts[2] == 0 and abs(counts[3] / n - 0.75) < 0.02
+
+
+class _FakeModel:
+    """Scripted stand-in for HipInferenceModel: checks the calls sample_and_push / the generation loop make."""
+
+    def __init__(self, V, eos):
+        class _C: pass
+        self.text_cfg = _C(); self.text_cfg.vocab_size = V
+        self.eos = eos
+        self.calls = []
+        self.logits = None
+        self.step = 0
+
+    def stop_token_ids(self): return [self.eos]
+
+    def _new_logits(self):
+        self.logits = _peaked_logits(self.text_cfg.vocab_size, 100 + self.step, 3.0)
+        self.step += 1
+
+    def forward_initial(self, ids, off, data, want_logits=False):
+        self.calls.append(("init", len(ids), off)); self._new_logits()
+        return None, int(np.argmax(self.logits))
+
+    def forward_step(self, tok, off, want_logits=False):
+        self.calls.append(("step", tok, off)); self._new_logits()
+        return None, int(np.argmax(self.logits))
+
+    def sample_candidates(self, ctx, pen, temp, k):
+        self.calls.append(("cand", list(ctx), pen, k))
+        return osamp.topk_candidates(osamp.apply_repeat_penalty(self.logits, pen, ctx) if pen != 1.0 else self.logits, k, temp)
+
+    def last_logits(self):
+        self.calls.append(("logits",)); return self.logits.copy()
+
+    def clear_cache(self): self.calls.append(("clear",))
+
+
+def test_generation_loop_bookkeeping():
+    m = _FakeModel(512, eos=511)
+    ctx = hs.GenerationContext(0.6, 0.95, 20, 1.1, 2, seed=5, initial_seq_len=7, max_tokens=5)
+    toks = hs.generate_generic_sampled(m, list(range(7)), ctx)
+    assert len(toks) == 5 and m.calls[-1] == ("clear",)
+    steps = [c for c in m.calls if c[0] == "step"]
+    assert [c[2] for c in steps] == [7, 8, 9, 10]            # seqlen_offset += seq_len; seq_len = 1 (generate.rs:55-63)
+    assert [c[1] for c in steps] == toks[:4]                 # each step is fed the previous sample
+    cands = [c for c in m.calls if c[0] == "cand"]
+    assert cands[0][1] == [] and cands[0][2] == 1.0          # nothing generated yet: no penalty
+    assert cands[3][1] == toks[1:3] and cands[3][3] == 20    # last repeat_last_n = 2 generated ids
+    assert abs(cands[3][2] - 1.1) < 1e-6
+    # greedy with penalty: arg-max of the PENALISED logits through a 1-candidate query; greedy without: the forward's token
+    m = _FakeModel(512, eos=511)
+    ctx = hs.GenerationContext(None, None, None, None, None, seed=5, initial_seq_len=3, max_tokens=3)
+    toks = hs.generate_generic_sampled(m, [1, 2, 3], ctx)
+    assert not [c for c in m.calls if c[0] in ("cand", "logits")] and len(toks) == 3
+    m = _FakeModel(512, eos=511)
+    ctx = hs.GenerationContext(0.0, None, None, 5.0, None, seed=5, initial_seq_len=3, max_tokens=3)
+    toks = hs.generate_generic_sampled(m, [1, 2, 3], ctx)
+    assert [c[3] for c in m.calls if c[0] == "cand"] == [1, 1]   # first token: nothing to penalise yet -> forward's arg-max
+    # Sampling::All needs the whole vector
+    m = _FakeModel(512, eos=511)
+    ctx = hs.GenerationContext(0.8, None, None, None, None, seed=5, initial_seq_len=3, max_tokens=2)
+    hs.generate_generic_sampled(m, [1, 2, 3], ctx)
+    assert len([c for c in m.calls if c[0] == "logits"]) == 2
+
+
+def test_generation_stops_on_eos():
+    m = _FakeModel(64, eos=0)
+    m._new_logits_orig = m._new_logits
+    def peaked():
+        m._new_logits_orig(); m.logits[:] = -50.0; m.logits[0 if m.step >= 3 else 5] = 50.0
+    m._new_logits = peaked
+    ctx = hs.GenerationContext(0.6, 0.95, 20, None, None, seed=1, initial_seq_len=4, max_tokens=10)
+    toks = hs.generate_generic_sampled(m, [1, 2, 3, 4], ctx)
+    assert toks == [5, 5, 0]

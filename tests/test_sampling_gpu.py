@@ -1,0 +1,120 @@
+"""-m gpu: D11 candidate extraction (aha_hip_sample_candidates / aha_hip_last_logits) against the oracle restatement of
+candle's repeat penalty + top-k (oracle/sampling.py).  Selection is integer/compare work: indices and values bit-exact,
+ordered by (value desc, index asc); the softmax normaliser is an f32 sum in a different order: relative 2e-5."""
+import numpy as np
+import pytest
+
+from aha_amd import _lib
+from aha_amd import sampling as hs
+from aha_amd.configs import tiny_qwen3
+from aha_amd.weights import qwen3_text_weights
+from oracle import sampling as osamp
+
+pytestmark = pytest.mark.gpu
+
+
+def make(vocab):
+    from aha_amd.model import HipInferenceModel
+    cfg = tiny_qwen3(layers=1, hidden=256, heads=4, kv_heads=2, inter=512, vocab=vocab)
+    return cfg, HipInferenceModel(cfg, qwen3_text_weights(cfg, seed=0))
+
+
+@pytest.fixture(scope="module", params=[2048, 151936, 3000])
+def model(gpu, request):
+    cfg, m = make(request.param)
+    yield cfg, m
+    m.close()
+
+
+def check_candidates(m, logits, ctx, pen, temp, k):
+    vals, idx, mx, se = m.sample_candidates(ctx, pen, temp, k)
+    ref_logits = osamp.apply_repeat_penalty(logits, pen, ctx) if pen != 1.0 else logits
+    rv, ri, rmx, rse = osamp.topk_candidates(ref_logits, k, temp)
+    np.testing.assert_array_equal(idx, ri)
+    np.testing.assert_array_equal(vals.view(np.uint32), rv.view(np.uint32))
+    assert np.float32(mx) == np.float32(rmx)
+    assert abs(se - rse) <= 2e-5 * rse
+    return vals, idx, mx, se
+
+
+def test_state_and_argument_errors(gpu):
+    cfg, m = make(1024)
+    try:
+        with pytest.raises(_lib.AhaHipError):  # no forward yet
+            m.sample_candidates([], 1.0, 1.0, 4)
+        with pytest.raises(_lib.AhaHipError):
+            m.last_logits()
+        m.forward_initial([1, 2, 3], 0, want_logits=False)
+        for bad_k in (0, 65, -1):
+            with pytest.raises(_lib.AhaHipError):
+                m.sample_candidates([], 1.0, 1.0, bad_k)
+        with pytest.raises(_lib.AhaHipError):
+            m.sample_candidates([1], 0.0, 1.0, 4)  # non-positive penalty
+    finally:
+        m.close()
+
+
+def test_candidates_match_oracle(model):
+    cfg, m = model
+    V = cfg.vocab_size
+    g = np.random.default_rng(V)
+    ids = [int(x) for x in g.integers(0, V, size=9)]
+    logits, am = m.forward_initial(ids, 0)
+    np.testing.assert_array_equal(m.last_logits().view(np.uint32), logits.view(np.uint32))
+    top = [int(i) for i in np.argsort(-logits)[:6]]
+    contexts = [[], top[:3] + top[:2] + [V + 5, 0xFFFFFFFF], [int(x) for x in g.integers(0, V, size=200)] + top]
+    for ctx in contexts:
+        for pen in (1.0, 1.1, 3.0):
+            for temp, k in ((0.6, 20), (1.0, 64), (0.0, 1), (0.25, 7)):
+                vals, idx, mx, se = check_candidates(m, logits, ctx, pen, temp, k)
+    # arg-max of the unpenalised logits is the forward's token (first maximal index)
+    assert check_candidates(m, logits, [], 1.0, 0.0, 1)[1][0] == am
+    # a decode step replaces the logits the candidates come from
+    logits2, _ = m.forward_step(am, len(ids))
+    check_candidates(m, logits2, top, 1.3, 0.6, 20)
+    m.clear_cache()
+
+
+def test_ties_and_ordering(gpu):
+    """Exact ties must come out in ascending index order."""
+    cfg, m = make(2048)
+    try:
+        logits, _ = m.forward_initial([3, 4], 0)
+        # an infinite penalty sends every non-negative logit to exactly 0: ~V/2 exact ties at the top
+        ctx = [int(i) for i in np.nonzero(logits >= 0)[0]]
+        assert len(ctx) > 200
+        vals, idx, mx, se = m.sample_candidates(ctx, float("inf"), 1.0, 64)
+        ref = osamp.apply_repeat_penalty(logits, float("inf"), ctx)
+        rv, ri, _, rse = osamp.topk_candidates(ref, 64, 1.0)
+        np.testing.assert_array_equal(idx, ri)
+        np.testing.assert_array_equal(idx, np.sort(np.asarray(ctx, dtype=np.uint32))[:64])
+        assert mx == 0.0 and abs(se - rse) <= 2e-5 * rse  # the untouched negative logits still carry mass
+        assert all(vals[i] == 0.0 for i in range(64))
+    finally:
+        m.close()
+
+
+def test_sampled_generation_distribution(gpu):
+    """End to end through the host mirror: with top-k 20 / top-p 0.95 / T 0.6 every sampled token lies in the oracle's support
+    for that step, and the loop's bookkeeping (offsets, cache) matches a replay with plain forward calls."""
+    cfg, m = make(2048)
+    try:
+        prompt = [5, 6, 7, 8, 9]
+        ctx = hs.GenerationContext(0.6, 0.95, 20, 1.2, 8, seed=11, initial_seq_len=len(prompt), max_tokens=12)
+        toks = hs.generate_generic_sampled(m, prompt, ctx)
+        assert len(toks) == 12
+        s = osamp.Sampling("TopKThenTopP", float(np.float32(0.6)), k=20, p=float(np.float32(0.95)))
+        logits, _ = m.forward_initial(prompt, 0)
+        off = len(prompt)
+        for i, t in enumerate(toks):
+            w = osamp.final_weights(osamp.use_repeat_penalty(1.2, 8, logits, toks[:i]), s)
+            assert w[t] > 0, f"step {i}: token {t} outside the sampler's support"
+            if i + 1 < len(toks):
+                logits, _ = m.forward_step(t, off)
+                off += 1
+        m.clear_cache()
+        # same seed, same draws
+        ctx = hs.GenerationContext(0.6, 0.95, 20, 1.2, 8, seed=11, initial_seq_len=len(prompt), max_tokens=12)
+        assert hs.generate_generic_sampled(m, prompt, ctx) == toks
+    finally:
+        m.close()
