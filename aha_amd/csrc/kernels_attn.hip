@@ -21,8 +21,7 @@ namespace aha {
 
 namespace {
 
-
-// ---- prefill: 4 waves x QT*16 q rows per block, K / V^T page staged in LDS and shared by the 4 waves ---------------
+// ---- prefill: NWV waves x QT*16 q rows per block, K / V^T page staged in LDS and shared by the waves ----------------
 // DQK = padded head dim of Q/K rows (multiple of 32), DV = padded head dim of the V block (multiple of 16).
 // Text decoder: 128/128.  ViT (head_dim 72): 96/80, pad lanes are zero in Q, K and V (csrc/kernels_vit.hip).
 // QT q sub-tiles per wave share every K / V^T fragment read from LDS (LDS reads per MFMA 1 -> 1/QT) and every
