@@ -45,7 +45,8 @@ void launch_argmax_pick(const float* pairs, int T, uint32_t* out, hipStream_t st
 void launch_argmax_f32(const float* x, int64_t n, float* ws_max, uint32_t* ws_idx, uint32_t* out, hipStream_t st);
 
 // D11 candidates (kernels_sample.hip): repeat penalty into a working copy of the logits; k largest + full-vocabulary softmax
-// normaliser.  cand_* hold sample_stage1_waves(V) * k entries, part_* one entry per stage-1 wave, out_ms = {max, sumexp}.
+// normaliser.  cand_* hold (sample_stage1_waves(V) + 16) * 64 entries (stage-1 candidates, then the 16 x k intermediates),
+// part_* one entry per stage-1 wave, out_ms = {max, sumexp}.
 int sample_stage1_waves(int V);
 bool sample_shape_ok(int V, int k);
 void launch_repeat_penalty(const float* logits, float* work, const uint32_t* ctx, int n, float penalty, int V, hipStream_t st);

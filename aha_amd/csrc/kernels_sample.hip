@@ -111,82 +111,70 @@ __global__ __launch_bounds__(64 * S1_WAVES_PER_BLOCK) void topk_stage1_kernel(co
 constexpr int S2_WAVES = 16;
 constexpr int S2_C = 20;  // 16 waves x 64 lanes x 20 >= 297 stage-1 waves x 64 candidates
 
-// stage 2 (one block): stage-1 candidates -> 16 x k (LDS) -> k, and the softmax partials -> (max, sumexp)
-__global__ __launch_bounds__(64 * S2_WAVES) void topk_stage2_kernel(const float* cand_val, const unsigned* cand_idx, int n_cand,
-                                                                    const float* part_m, const float* part_s, int n_part,
-                                                                    int k, float inv_temp, float* out_val, unsigned* out_idx,
-                                                                    float* out_ms) {
-  __shared__ float s_val[S2_WAVES * 64];
-  __shared__ unsigned s_idx[S2_WAVES * 64];
-  __shared__ float s_red[2 * S2_WAVES];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  {  // softmax partials
+// stage 2a (16 one-wave blocks, one per CU -- the rounds are VALU-bound, so the waves must not share a SIMD): each wave
+// reduces a contiguous sixteenth of the stage-1 candidates to its k best
+__global__ __launch_bounds__(64) void topk_stage2a_kernel(const float* cand_val, const unsigned* cand_idx, int n_cand, int k,
+                                                          float* mid_val, unsigned* mid_idx) {
+  const int lane = threadIdx.x, wave = blockIdx.x;
+  const int chunk = (n_cand + S2_WAVES - 1) / S2_WAVES;
+  const int c0 = wave * chunk, c1 = min(c0 + chunk, n_cand);
+  float v[S2_C];
+  unsigned id[S2_C];
+#pragma unroll
+  for (int j = 0; j < S2_C; ++j) {
+    const int i = c0 + j * 64 + lane;
+    const bool ok = i < c1;
+    v[j] = ok ? cand_val[ok ? i : 0] : -INFINITY;
+    id[j] = ok ? cand_idx[ok ? i : 0] : NO_IDX;
+    if (id[j] == NO_IDX) v[j] = -INFINITY;
+  }
+  wave_topk_rounds<S2_C>(v, id, k, [&](int r, float val, unsigned idx) {
+    if (lane == 0) {
+      mid_val[wave * k + r] = val;
+      mid_idx[wave * k + r] = idx;
+    }
+  });
+}
+
+// stage 2b (one wave): 16 x k -> k in (value desc, index asc) order, and the softmax partials -> (max, sumexp)
+__global__ __launch_bounds__(64) void topk_stage2b_kernel(const float* mid_val, const unsigned* mid_idx, const float* part_m,
+                                                          const float* part_s, int n_part, int k, float inv_temp,
+                                                          float* out_val, unsigned* out_idx, float* out_ms) {
+  const int lane = threadIdx.x;
+  {
     float m = -INFINITY;
-    for (int i = threadIdx.x; i < n_part; i += 64 * S2_WAVES) m = fmaxf(m, part_m[i]);
-    m = wave_max(m);
-    if (lane == 0) s_red[wave] = m;
-    __syncthreads();
-    float M = s_red[0];
-#pragma unroll
-    for (int i = 1; i < S2_WAVES; ++i) M = fmaxf(M, s_red[i]);
+    for (int i = lane; i < n_part; i += 64) m = fmaxf(m, part_m[i]);
+    const float M = wave_max(m);
     float s = 0.f;
-    for (int i = threadIdx.x; i < n_part; i += 64 * S2_WAVES) s += part_s[i] * __expf((part_m[i] - M) * inv_temp);
+    for (int i = lane; i < n_part; i += 64) s += part_s[i] * __expf((part_m[i] - M) * inv_temp);
     s = wave_sum(s);
-    if (lane == 0) s_red[S2_WAVES + wave] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float S = 0.f;
-#pragma unroll
-      for (int i = 0; i < S2_WAVES; ++i) S += s_red[S2_WAVES + i];
+    if (lane == 0) {
       out_ms[0] = M;
-      out_ms[1] = S;
+      out_ms[1] = s;
     }
   }
-  {  // level A: each wave takes a contiguous chunk of the stage-1 candidates
-    const int chunk = (n_cand + S2_WAVES - 1) / S2_WAVES;
-    const int c0 = wave * chunk, c1 = min(c0 + chunk, n_cand);
-    float v[S2_C];
-    unsigned id[S2_C];
+  float v[S2_WAVES];
+  unsigned id[S2_WAVES];
 #pragma unroll
-    for (int j = 0; j < S2_C; ++j) {
-      const int i = c0 + j * 64 + lane;
-      const bool ok = i < c1;
-      v[j] = ok ? cand_val[ok ? i : 0] : -INFINITY;
-      id[j] = ok ? cand_idx[ok ? i : 0] : NO_IDX;
-      if (id[j] == NO_IDX) v[j] = -INFINITY;
-    }
-    wave_topk_rounds<S2_C>(v, id, k, [&](int r, float val, unsigned idx) {
-      if (lane == 0) {
-        s_val[wave * k + r] = val;
-        s_idx[wave * k + r] = idx;
-      }
-    });
+  for (int j = 0; j < S2_WAVES; ++j) {
+    const int i = j * 64 + lane;
+    const bool ok = i < S2_WAVES * k;
+    v[j] = ok ? mid_val[ok ? i : 0] : -INFINITY;
+    id[j] = ok ? mid_idx[ok ? i : 0] : NO_IDX;
+    if (id[j] == NO_IDX) v[j] = -INFINITY;
   }
-  __syncthreads();
-  if (wave == 0) {  // level B: 16 x k -> k
-    float v[S2_WAVES];
-    unsigned id[S2_WAVES];
-#pragma unroll
-    for (int j = 0; j < S2_WAVES; ++j) {
-      const int i = j * 64 + lane;
-      const bool ok = i < S2_WAVES * k;
-      v[j] = ok ? s_val[ok ? i : 0] : -INFINITY;
-      id[j] = ok ? s_idx[ok ? i : 0] : NO_IDX;
-      if (id[j] == NO_IDX) v[j] = -INFINITY;
+  wave_topk_rounds<S2_WAVES>(v, id, k, [&](int r, float val, unsigned idx) {
+    if (lane == 0) {
+      out_val[r] = val;
+      out_idx[r] = idx;
     }
-    wave_topk_rounds<S2_WAVES>(v, id, k, [&](int r, float val, unsigned idx) {
-      if (lane == 0) {
-        out_val[r] = val;
-        out_idx[r] = idx;
-      }
-    });
-  }
+  });
 }
 
 }  // namespace
 
 int sample_stage1_waves(int V) { return (V + S1_WAVE_ELEMS - 1) / S1_WAVE_ELEMS; }
-// k <= 64 (one LDS slot per wave and round) and stage-1 candidates within what stage 2 holds in registers (16 x 64 x 20)
+// k <= 64 and the stage-1 candidates within what stage 2a holds in registers (16 waves x 64 lanes x 20)
 bool sample_shape_ok(int V, int k) { return V > 0 && k >= 1 && k <= 64 && (int64_t)sample_stage1_waves(V) * k <= S2_WAVES * 64 * S2_C; }
 
 void launch_repeat_penalty(const float* logits, float* work, const uint32_t* ctx, int n, float penalty, int V, hipStream_t st) {
@@ -199,8 +187,12 @@ void launch_topk_candidates(const float* x, int V, int k, float inv_temp, float*
   const int nw = sample_stage1_waves(V);
   hipLaunchKernelGGL(topk_stage1_kernel, dim3((nw + S1_WAVES_PER_BLOCK - 1) / S1_WAVES_PER_BLOCK), dim3(64 * S1_WAVES_PER_BLOCK), 0,
                      st, x, V, k, inv_temp, cand_val, cand_idx, part_m, part_s);
-  hipLaunchKernelGGL(topk_stage2_kernel, dim3(1), dim3(64 * S2_WAVES), 0, st, cand_val, cand_idx, nw * k, part_m, part_s, nw, k,
-                     inv_temp, out_val, out_idx, out_ms);
+  // the 16 x k intermediates live right behind the stage-1 candidates (model.hip sizes cand_* as (nw + 16) * 64)
+  float* mid_val = cand_val + (size_t)nw * 64;
+  unsigned* mid_idx = cand_idx + (size_t)nw * 64;
+  hipLaunchKernelGGL(topk_stage2a_kernel, dim3(S2_WAVES), dim3(64), 0, st, cand_val, cand_idx, nw * k, k, mid_val, mid_idx);
+  hipLaunchKernelGGL(topk_stage2b_kernel, dim3(1), dim3(64), 0, st, mid_val, mid_idx, part_m, part_s, nw, k, inv_temp, out_val,
+                     out_idx, out_ms);
 }
 
 }  // namespace aha

@@ -140,9 +140,10 @@ struct aha_model {
   bool logits_assembled = false;  // vocab-parallel TP: d_logits already all-reduced into the full vector
   // D11 candidate extraction (kernels_sample.hip), allocated on first use
   float* d_samp_work = nullptr;   // (V) penalised copy of the logits
-  float* d_samp_f = nullptr;      // cand_val | part_m | part_s | out_val | out_ms
-  unsigned* d_samp_u = nullptr;   // cand_idx | out_idx
+  float* d_samp_f = nullptr;      // cand_val | part_m | part_s | out block {vals[64], max, sumexp, idx[64]}
+  unsigned* d_samp_u = nullptr;   // cand_idx
   uint32_t* d_samp_ctx = nullptr;
+  uint32_t* h_samp = nullptr;     // pinned: context ids (samp_ctx_cap) followed by the 130-word out block
   size_t samp_ctx_cap = 0;
   // prefill scratch (grown on demand)
   size_t pf_cap = 0;

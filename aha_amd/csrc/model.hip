@@ -372,8 +372,12 @@ int model_sample_candidates(aha_model* m, const uint32_t* ctx, size_t n_ctx, flo
     return AHA_ERR_INVALID;
   }
   const int nw = sample_stage1_waves(V);
+  // device scratch: cand_val (+ intermediates) | part_m | part_s | out block {vals[64] f32, ms[2] f32, idx[64] u32}; cand_idx separately.
+  // One pinned host block carries the context up and the 520-byte out block down (pageable copies cost ~30 us each).
+  constexpr size_t OUT_WORDS = 64 + 2 + 64;
   if (!m->d_samp_f) {
-    const size_t nf = (size_t)nw * 64 + 2 * (size_t)nw + 64 + 2, nu = (size_t)nw * 64 + 64;
+    const size_t nc = ((size_t)nw + 16) * 64;  // stage-1 candidates + the 16 x 64 intermediates behind them
+    const size_t nf = nc + 2 * (size_t)nw + OUT_WORDS, nu = nc;
     void *pw = nullptr, *pf = nullptr, *pu = nullptr;
     if (int rc = dev_alloc(m, (size_t)V * 4, &pw, false)) return rc;
     if (int rc = dev_alloc(m, nf * 4, &pf, false)) return rc;
@@ -382,17 +386,22 @@ int model_sample_candidates(aha_model* m, const uint32_t* ctx, size_t n_ctx, flo
     m->d_samp_f = (float*)pf;
     m->d_samp_u = (unsigned*)pu;
   }
+  if (!m->h_samp || n_ctx > m->samp_ctx_cap) {
+    const size_t cap = std::max<size_t>(1024, n_ctx * 2);
+    void* pd = nullptr;
+    if (int rc = dev_alloc(m, cap * 4, &pd, false)) return rc;  // a smaller predecessor stays in m->owned until destroy
+    uint32_t* ph = nullptr;
+    AHA_HIP_CHECK(hipHostMalloc((void**)&ph, (cap + OUT_WORDS) * 4));
+    if (m->h_samp) hipHostFree(m->h_samp);
+    m->h_samp = ph;
+    m->d_samp_ctx = (uint32_t*)pd;
+    m->samp_ctx_cap = cap;
+  }
   if (int rc = assemble_logits(m)) return rc;
   const float* src = m->d_logits;
   if (repeat_penalty != 1.0f && n_ctx > 0) {  // sample.rs:47 `repeat_penalty == 1.0` => logits unchanged
-    if (n_ctx > m->samp_ctx_cap) {
-      void* p = nullptr;
-      const size_t cap = std::max<size_t>(1024, n_ctx * 2);
-      if (int rc = dev_alloc(m, cap * 4, &p, false)) return rc;
-      m->d_samp_ctx = (uint32_t*)p;  // the smaller buffer stays in m->owned until destroy
-      m->samp_ctx_cap = cap;
-    }
-    AHA_HIP_CHECK(hipMemcpyAsync(m->d_samp_ctx, ctx, n_ctx * 4, hipMemcpyHostToDevice, m->stream));
+    memcpy(m->h_samp, ctx, n_ctx * 4);
+    AHA_HIP_CHECK(hipMemcpyAsync(m->d_samp_ctx, m->h_samp, n_ctx * 4, hipMemcpyHostToDevice, m->stream));
     AHA_HIP_CHECK(hipMemcpyAsync(m->d_samp_work, m->d_logits, (size_t)V * 4, hipMemcpyDeviceToDevice, m->stream));
     launch_repeat_penalty(m->d_logits, m->d_samp_work, m->d_samp_ctx, (int)n_ctx, repeat_penalty, V, m->stream);
     src = m->d_samp_work;
@@ -400,21 +409,21 @@ int model_sample_candidates(aha_model* m, const uint32_t* ctx, size_t n_ctx, flo
   // `&logits / temperature` in LogitsProcessor::sample is an affine by 1/T computed in f64 and applied in f32
   const float inv_temp = temperature > 0.f ? (float)(1.0 / (double)temperature) : 1.0f;
   float* cand_val = m->d_samp_f;
-  float* part_m = cand_val + (size_t)nw * 64;
+  float* part_m = cand_val + ((size_t)nw + 16) * 64;
   float* part_s = part_m + nw;
   float* out_val = part_s + nw;
   float* out_ms = out_val + 64;
+  unsigned* out_idx = reinterpret_cast<unsigned*>(out_ms + 2);
   unsigned* cand_idx = m->d_samp_u;
-  unsigned* out_idx = cand_idx + (size_t)nw * 64;
   launch_topk_candidates(src, V, k, inv_temp, cand_val, cand_idx, part_m, part_s, out_val, out_idx, out_ms, m->stream);
   AHA_HIP_CHECK(hipGetLastError());
-  float ms[2];
-  AHA_HIP_CHECK(hipMemcpyAsync(vals_out, out_val, (size_t)k * 4, hipMemcpyDeviceToHost, m->stream));
-  AHA_HIP_CHECK(hipMemcpyAsync(idx_out, out_idx, (size_t)k * 4, hipMemcpyDeviceToHost, m->stream));
-  AHA_HIP_CHECK(hipMemcpyAsync(ms, out_ms, 8, hipMemcpyDeviceToHost, m->stream));
+  uint32_t* h_out = m->h_samp + m->samp_ctx_cap;
+  AHA_HIP_CHECK(hipMemcpyAsync(h_out, out_val, OUT_WORDS * 4, hipMemcpyDeviceToHost, m->stream));
   AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
-  if (max_out) *max_out = ms[0];
-  if (sumexp_out) *sumexp_out = ms[1];
+  memcpy(vals_out, h_out, (size_t)k * 4);
+  memcpy(idx_out, h_out + 66, (size_t)k * 4);
+  if (max_out) memcpy(max_out, h_out + 64, 4);
+  if (sumexp_out) memcpy(sumexp_out, h_out + 65, 4);
   return AHA_OK;
 }
 
@@ -712,6 +721,7 @@ void model_destroy(aha_model* m) {
   if (m->d_page_ptrs) hipFree(m->d_page_ptrs);
   if (m->h_state) hipHostFree(m->h_state);
   if (m->h_logits) hipHostFree(m->h_logits);
+  if (m->h_samp) hipHostFree(m->h_samp);
   if (m->h_bar_err) hipHostFree(m->h_bar_err);
   delete m;
 }
