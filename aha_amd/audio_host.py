@@ -22,3 +22,22 @@ def audio_prompt_ids(cfg, n_samples: int, prefix: Sequence[int], suffix: Sequenc
     (hop 160 -> n_samples // 160 frames; the default template is qwen3_asr/generate.rs:85)."""
     n_tok = get_feat_extract_output_lengths(n_samples // 160)
     return list(prefix) + [cfg.audio_start_token_id] + [cfg.audio_token_id] * n_tok + [cfg.audio_end_token_id] + list(suffix)
+
+
+def resample_audio_from_vec_f32(ctx_handle, audio_vec, channels: int, orig_sr: int, target_sample_rate: int):
+    """resample_audio_from_vec_f32 (reference src/utils/audio_utils.rs:590-616) through aha_hip_audio_resample: interleaved PCM
+    f32 -> mono f32 at target_sample_rate (channel mean + sinc/Hann resampling on the GPU).  ``ctx_handle`` is the aha_ctx the
+    model was created on (HipInferenceModel.ctx)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from ._lib import check, lib
+    a = np.ascontiguousarray(np.asarray(audio_vec, dtype=np.float32).reshape(-1))
+    frames = a.size // channels
+    pf = C.POINTER(C.c_float)
+    n = check(lib().aha_hip_audio_resample(ctx_handle, a.ctypes.data_as(pf), frames, channels, orig_sr, target_sample_rate, None, 0))
+    out = np.empty(max(n, 1), dtype=np.float32)
+    n = check(lib().aha_hip_audio_resample(ctx_handle, a.ctypes.data_as(pf), frames, channels, orig_sr, target_sample_rate,
+                                           out.ctypes.data_as(pf), out.size))
+    return out[:n]

@@ -10,5 +10,9 @@ void audio_destroy(aha_model* m);
 int audio_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, const aha_mm_input* mm, void* x);
 int audio_debug_embeds(aha_model* m, float* out, size_t n);
 int logmel_standalone(const float* d_samples, int64_t n_samples, float* d_out, hipStream_t st);
+// audio_pre.hip: resample_audio_from_vec_f32 (audio_utils.rs:590-616)
+int64_t resample_output_len(int64_t length, int64_t orig_sr, int64_t target_sr);
+int64_t audio_resample(aha_ctx* ctx, const float* pcm, int64_t n_frames, int channels, int orig_sr, int target_sr, float* out,
+                       int64_t out_cap);
 
 }  // namespace aha

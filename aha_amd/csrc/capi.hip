@@ -518,6 +518,17 @@ int aha_hip_logmel(const float* samples, int64_t n_samples, float* out, void* st
   API_GUARD_END
 }
 
+int64_t aha_hip_audio_resample(aha_ctx* ctx, const float* pcm, int64_t n_frames, int32_t channels, int32_t orig_sr,
+                               int32_t target_sr, float* out, int64_t out_cap) {
+  API_GUARD_BEGIN
+  if (!ctx || n_frames < 0 || channels < 1 || orig_sr <= 0 || target_sr <= 0 || (n_frames > 0 && !pcm)) {
+    set_error("audio_resample: frequencies must be positive, channels >= 1");  // audio_utils.rs:225-227
+    return AHA_ERR_INVALID;
+  }
+  return audio_resample(ctx, pcm, n_frames, channels, orig_sr, target_sr, out, out_cap);
+  API_GUARD_END
+}
+
 int aha_hip_debug_audio_embeds(aha_model* m, float* out, size_t n) {
   API_GUARD_BEGIN
   if (!m || !out) {

@@ -259,6 +259,14 @@ int aha_hip_image_to_patches(const uint8_t* img_hwc, void* out, int32_t H, int32
  * device samples -> out (128, n_samples/160) f32 device (n_fft 400, hop 160, symmetric Hann, Slaney mel, log10, max-8 clamp,
  * (x+4)/4).  n_samples must be >= 401. */
 int aha_hip_logmel(const float* samples, int64_t n_samples, float* out, void* stream);
+/* A0-pre: resample_audio_from_vec_f32 (src/utils/audio_utils.rs:590-616), the step between the audio decoder and the
+ * feature extractor on the Qwen3-ASR request path (qwen3_asr/processor.rs:76,85: 16 kHz, 1 channel): interleaved PCM f32
+ * (n_frames x channels, host) -> mean over channels -> resample_simple (audio_utils.rs:247-255: sinc interpolation, Hann
+ * window, lowpass_filter_width 6, rolloff 0.99; kernel :66-151, strided convolution :154-214) -> mono f32 at target_sr
+ * (host).  Returns the number of output samples, min(ceil(new * n / orig), (n / orig + 1) * new) with orig / new the rates
+ * divided by their gcd (n_frames itself when the rates are equal), or a negative status; out == NULL only queries it. */
+int64_t aha_hip_audio_resample(aha_ctx* ctx, const float* pcm, int64_t n_frames, int32_t channels, int32_t orig_sr,
+                               int32_t target_sr, float* out, int64_t out_cap);
 /* Debug: audio embeddings of the last forward_initial (rows x output_dim floats). */
 int aha_hip_debug_audio_embeds(aha_model* m, float* out, size_t n);
 /* D11 greedy: first maximal index of an f32 vector. */
