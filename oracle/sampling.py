@@ -6,7 +6,8 @@ Path: `sample_and_push` (reference src/models/common/generate.rs:70-86) = logits
 
 PARITY UNPINNED: the arithmetic lives in the third-party crate candle-transformers 0.9.2 (Cargo.lock:590-593;
 `utils::apply_repeat_penalty`, `generation::{LogitsProcessor, Sampling}`), which is not under /root/reference and cannot be
-built here (no cargo).  The functions below restate its published algorithm; the reference holds no golden vectors for it.
+built here (no cargo).  The functions below restate its published algorithm; the reference holds no golden vectors for it (the penalty rule alone is
+cross-checked against transformers' RepetitionPenaltyLogitsProcessor in tests/test_sampling_cpu.py).
 The random draw (`rand::distr::weighted::WeightedIndex` over a seeded `StdRng`) is NOT restated: everything here stops at
 the probability vector the draw is made from, which is the deterministic part the device path has to reproduce.
 """

@@ -173,3 +173,16 @@ def test_generation_stops_on_eos():
     ctx = hs.GenerationContext(0.6, 0.95, 20, None, None, seed=1, initial_seq_len=4, max_tokens=10)
     toks = hs.generate_generic_sampled(m, [1, 2, 3, 4], ctx)
     assert toks == [5, 5, 0]
+
+
+def test_repeat_penalty_agrees_with_transformers():
+    """Independent check of the penalty rule (divide if >= 0 ... wait: HF divides when > 0 and multiplies when < 0; at exactly 0
+    both give 0): transformers' RepetitionPenaltyLogitsProcessor on the same ids."""
+    torch = pytest.importorskip("torch")
+    tr = pytest.importorskip("transformers")
+    g = np.random.default_rng(9)
+    logits = g.standard_normal(5000).astype(np.float32) * 3
+    ctxt = [int(x) for x in g.integers(0, 5000, size=300)] + [7, 7, 7]
+    proc = tr.RepetitionPenaltyLogitsProcessor(penalty=1.3)
+    want = proc(torch.tensor([ctxt]), torch.tensor(logits)[None].clone())[0].numpy()
+    np.testing.assert_array_equal(osamp.apply_repeat_penalty(logits, 1.3, ctxt), want)
