@@ -4,7 +4,9 @@
  *
  *   gcc -O2 -Iinclude examples/c_harness.c -o examples/c_harness -Laha_amd/csrc -laha_hip -Wl,-rpath,$PWD/aha_amd/csrc -lm
  *   examples/c_harness <checkpoint_dir> <max_tokens> <id0> <id1> ...
- * Output: one line "host: t0 t1 ..." and one line "device: t0 t1 ..." (they must be equal), exit code 0.
+ * Output: one line "host: t0 t1 ..." and one line "device: t0 t1 ..." (they must be equal), then "candidates: i0 i1 i2 i3"
+ * (the 4 largest penalised logits of the prompt's last position: aha_hip_sample_candidates) and "resampled: n" (length of a
+ * 44.1 kHz stereo second brought to 16 kHz mono by aha_hip_audio_resample); exit code 0.
  * No torch, no HIP headers: only the C ABI. */
 #include <stdint.h>
 #include <stdio.h>
@@ -89,6 +91,34 @@ int main(int argc, char** argv) {
   printf("\ndevice:");
   for (int i = 0; i < n_dev; ++i) printf(" %u", dev_toks[i]);
   printf("\n");
+
+  /* (3) the sampled path: repeat penalty over the generated tokens + top-4 candidates of the prompt's logits, all on the device */
+  CHECK(aha_hip_clear_cache(model));
+  CHECK(aha_hip_forward_initial(model, ids, n_ids, 0, NULL, NULL, NULL));
+  float cand_val[4], cmax = 0.f, csum = 0.f;
+  uint32_t cand_idx[4];
+  CHECK(aha_hip_sample_candidates(model, host_toks, (size_t)n_host, 1.1f, 0.6f, 4, cand_val, cand_idx, &cmax, &csum));
+  printf("candidates: %u %u %u %u\n", cand_idx[0], cand_idx[1], cand_idx[2], cand_idx[3]);
+  if (!(cand_val[0] >= cand_val[1] && cand_val[1] >= cand_val[2] && cand_val[2] >= cand_val[3] && cmax == cand_val[0] && csum >= 1.0f)) {
+    fprintf(stderr, "candidate ordering / normaliser inconsistent\n");
+    return 1;
+  }
+
+  /* (4) audio pre-processing: one second of 44.1 kHz stereo -> 16 kHz mono */
+  {
+    const int frames = 44100;
+    float* pcm = (float*)calloc((size_t)frames * 2, sizeof(float));
+    for (int i = 0; i < frames; ++i) pcm[2 * i] = pcm[2 * i + 1] = (float)((i % 100) - 50) / 100.0f;
+    const int64_t n_out = aha_hip_audio_resample(ctx, pcm, frames, 2, 44100, 16000, NULL, 0);
+    float* res = (float*)malloc((size_t)(n_out > 0 ? n_out : 1) * sizeof(float));
+    const int64_t n_got = aha_hip_audio_resample(ctx, pcm, frames, 2, 44100, 16000, res, n_out);
+    if (n_out != 16000 || n_got != n_out) {
+      fprintf(stderr, "audio_resample: %lld / %lld samples: %s\n", (long long)n_out, (long long)n_got, aha_hip_last_error());
+      return 1;
+    }
+    printf("resampled: %lld\n", (long long)n_got);
+    free(pcm); free(res);
+  }
 
   aha_hip_model_destroy(model);
   aha_hip_shutdown(ctx);

@@ -100,5 +100,10 @@ def test_plain_c_host_over_the_abi(gpu, tmp_path):
     assert out[0].startswith("host:") and out[1].startswith("device:")
     m = HipInferenceModel(cfg, w)
     want, _ = generate_generic(m, ids, 24, device_loop=False)
-    m.close()
     assert host == dev == want
+    # the sampled path and the resampler from C agree with the Python mirror over the same ABI
+    m.forward_initial(ids, 0, want_logits=False)
+    _, idx, _, _ = m.sample_candidates(want, 1.1, 0.6, 4)
+    m.close()
+    assert out[2].split() == ["candidates:"] + [str(int(i)) for i in idx]
+    assert out[3].split() == ["resampled:", "16000"]
