@@ -8,7 +8,10 @@ dev = torch.device("cuda:0")
 shapes = [("qkv", 1542, 6144, 4096, 0), ("o", 1542, 4096, 4096, 0), ("gateup", 1542, 24576, 4096, 4), ("down", 1542, 4096, 12288, 0),
           ("vit_qkv", 4096, 3456, 1152, 0), ("vit_proj", 4096, 1152, 1152, 0), ("vit_fc1", 4096, 4304, 1152, 1), ("vit_fc2", 4096, 1152, 4304, 0),
           ("big", 8192, 8192, 8192, 0)]
+only = os.environ.get("AHA_GEMM_ONLY")
 for name, M, N, K, act in shapes:
+    if only and name not in only.split(","):
+        continue
     A = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
     W = torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02
     for _ in range(3): ops.gemm(A, W, act=act)
