@@ -181,7 +181,9 @@ int aha_hip_decode_greedy(aha_model* m, uint32_t first_token, size_t seqlen_offs
  *      assigns to candidate j (temperature <= 0 is treated as 1).
  * The host finishes with its own RNG (top-p cut over the candidates + weighted draw): 8k + 8 bytes leave the device per
  * token instead of the V-float logits vector.  Not in the reference as a function: it replaces the body of
- * LogitsProcessor::sample up to the random draw. */
+ * LogitsProcessor::sample up to the random draw.  If k exceeds the vocabulary the surplus entries come back as value -inf /
+ * index 0xFFFFFFFF.  Under tensor parallelism (vocab-parallel lm_head) the call is collective: every rank makes it, the
+ * shards of the logits are all-reduced first. */
 int aha_hip_sample_candidates(aha_model* m, const uint32_t* context, size_t n_context, float repeat_penalty, float temperature,
                               int32_t k, float* vals_out, uint32_t* idx_out, float* max_out, float* sumexp_out);
 
