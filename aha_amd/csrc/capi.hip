@@ -395,6 +395,27 @@ int aha_hip_image_to_patches(const uint8_t* img_hwc, void* out, int32_t H, int32
   return AHA_OK;
 }
 
+int aha_hip_img_smart_resize(uint32_t h, uint32_t w, uint32_t factor, uint32_t min_pixels, uint32_t max_pixels, uint32_t* h_out,
+                             uint32_t* w_out) {
+  API_GUARD_BEGIN
+  if (!h_out || !w_out) {
+    set_error("null argument");
+    return AHA_ERR_INVALID;
+  }
+  return img_smart_resize(h, w, factor, min_pixels, max_pixels, h_out, w_out);
+  API_GUARD_END
+}
+
+int aha_hip_image_resize(const uint8_t* src_hwc, int32_t H, int32_t W, uint8_t* dst_hwc, int32_t new_h, int32_t new_w, void* stream) {
+  API_GUARD_BEGIN
+  if (!src_hwc || !dst_hwc || H <= 0 || W <= 0 || new_h <= 0 || new_w <= 0) {
+    set_error("image_resize: bad arguments");
+    return AHA_ERR_INVALID;
+  }
+  return image_resize(src_hwc, H, W, dst_hwc, new_h, new_w, (hipStream_t)stream);
+  API_GUARD_END
+}
+
 int aha_hip_get_rope_index(const aha_model_desc* desc, const uint32_t* input_ids, size_t n_ids, const uint32_t* image_grid_thw,
                            int32_t n_images, int32_t* pos_out, int64_t* rope_delta_out) {
   API_GUARD_BEGIN

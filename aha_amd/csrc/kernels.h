@@ -257,6 +257,9 @@ struct VitRopeArgs {
 };
 void launch_vit_rope_pack(const VitRopeArgs& a, hipStream_t st);
 void launch_scatter_rows(void* dst, const void* src, const int32_t* rows, int64_t n, int D, int add, hipStream_t st);
+// image_pre.hip (V0-pre): img_smart_resize (img_utils.rs:294-331) and resize_exact(.., CatmullRom) of an RGB8 image on the device
+int img_smart_resize(uint32_t h, uint32_t w, uint32_t factor, uint32_t min_pixels, uint32_t max_pixels, uint32_t* h_out, uint32_t* w_out);
+int image_resize(const uint8_t* src, int H, int W, uint8_t* dst, int new_h, int new_w, hipStream_t st);
 void launch_image_to_patches(const uint8_t* img, void* out, int H, int W, int patch, int merge, const float* mean,
                              const float* stdv, hipStream_t st);
 }  // namespace aha

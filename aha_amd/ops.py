@@ -142,6 +142,16 @@ def image_to_patches(img_u8_hwc: torch.Tensor, patch: int = 16, merge: int = 2, 
     return out
 
 
+def image_resize(img_u8_hwc: torch.Tensor, new_h: int, new_w: int) -> torch.Tensor:
+    """V0-pre: DynamicImage::resize_exact(new_w, new_h, CatmullRom) of an RGB8 (H, W, 3) image on the GPU."""
+    _chk(img_u8_hwc)
+    assert img_u8_hwc.dtype == torch.uint8 and img_u8_hwc.dim() == 3 and img_u8_hwc.shape[2] == 3
+    H, W = int(img_u8_hwc.shape[0]), int(img_u8_hwc.shape[1])
+    out = torch.empty(new_h, new_w, 3, dtype=torch.uint8, device=img_u8_hwc.device)
+    check(lib().aha_hip_image_resize(_ptr(img_u8_hwc), H, W, _ptr(out), new_h, new_w, _stream()))
+    return out
+
+
 def logmel(samples: torch.Tensor) -> torch.Tensor:
     """A0: 16 kHz mono f32 samples on the GPU -> Whisper log-mel features (128, n_samples // 160) f32."""
     _chk(samples)

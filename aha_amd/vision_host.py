@@ -32,13 +32,16 @@ def img_smart_resize(h: int, w: int, factor: int = 32, min_pixels: int = 65536, 
 
 
 def process_images(imgs_u8: List[torch.Tensor], cfg: Qwen3VLConfig) -> MultiModalData:
-    """process_images (processor.rs:229-251) for images already at their smart-resize size, on the GPU (V0 kernel)."""
+    """process_images (processor.rs:229-251) on the GPU: process_img's smart-resize + CatmullRom resize_exact (processor.rs:159-166,
+    `ops.image_resize`) when the image is not already at its target size, then the V0 patchify kernel."""
     v = cfg.vision
     pv, grids = [], []
     for im in imgs_u8:
         H, W = int(im.shape[0]), int(im.shape[1])
-        if (H, W) != img_smart_resize(H, W, v.patch_size * v.spatial_merge_size):
-            raise ValueError("image is not at its smart-resize size; CatmullRom resize is a 'next' row (SURVEY.md 8f)")
+        th, tw = img_smart_resize(H, W, v.patch_size * v.spatial_merge_size)
+        if (H, W) != (th, tw):
+            im = ops.image_resize(im, th, tw)
+            H, W = th, tw
         pv.append(ops.image_to_patches(im, v.patch_size, v.spatial_merge_size))
         grids.append([1, H // v.patch_size, W // v.patch_size])
     return MultiModalData(torch.cat(pv, 0), np.asarray(grids, dtype=np.uint32))

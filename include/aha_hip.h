@@ -252,6 +252,17 @@ int aha_hip_attn_decode(const void* q, const void* k, const void* v, void* o, in
  * k/v (L, kvh*d) token-major, L = kv_offset + S.  causal = 0 gives full (ViT) attention. */
 int aha_hip_attn_prefill(const void* q, const void* k, const void* v, void* o, int32_t S, int32_t L, int32_t nh,
                          int32_t kvh, int32_t d, int32_t kv_offset, int32_t causal, float scale, void* stream);
+/* V0-pre, host arithmetic: img_smart_resize (src/utils/img_utils.rs:294-331) -- the size Qwen3VLProcessor::process_img
+ * (qwen3vl/processor.rs:159-165) resizes an image to: multiples of `factor` (patch * merge = 32), area within
+ * [min_pixels, max_pixels] (shortest_edge / longest_edge of the preprocessor config).  AHA_ERR_INVALID when the aspect ratio
+ * exceeds 200, as the reference. */
+int aha_hip_img_smart_resize(uint32_t h, uint32_t w, uint32_t factor, uint32_t min_pixels, uint32_t max_pixels, uint32_t* h_out,
+                             uint32_t* w_out);
+/* V0-pre: DynamicImage::resize_exact(new_w, new_h, FilterType::CatmullRom) (qwen3vl/processor.rs:166) of an RGB8 image
+ * (H, W, 3) in device memory into dst (new_h, new_w, 3), device.  Algorithm of crate image 0.25.10 imageops::resize as
+ * restated in oracle/image_pre.py ([unverified] against the crate itself): vertical pass into f32, horizontal pass,
+ * CatmullRom taps scaled by max(ratio, 1) and normalised, clamp, round half away from zero.  Synchronises the stream. */
+int aha_hip_image_resize(const uint8_t* src_hwc, int32_t H, int32_t W, uint8_t* dst_hwc, int32_t new_h, int32_t new_w, void* stream);
 /* V0: one RGB8 image (H, W, 3) in device memory, H and W multiples of patch*merge -> the processor's pixel_values rows
  * ((H/patch)*(W/patch), 3*2*patch*patch) bf16 in merge-window order with the frame duplicated to T = 2
  * (/root/reference/src/models/qwen3vl/processor.rs:174-251; img_transform, /root/reference/src/utils/img_utils.rs:272-293). */
