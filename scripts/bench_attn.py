@@ -1,6 +1,7 @@
 """GPU microbenchmark of the prefill attention kernel alone (text decoder geometry: 32 q heads, 8 kv heads, head_dim 128).
-AHA_ATTN_TIME=<reps> makes the C ABI debug op time the kernel with HIP events and print ms/launch; AHA_ATTN_DBG selects an
-elimination variant (wrong results, timing only): 1 no global->LDS staging, 2 no softmax, 4 no LDS fragment reads, 8 no barrier."""
+AHA_ATTN_TIME=<reps> makes the C ABI debug op time the kernel with HIP events and print ms/launch.  A/B knobs of the kernel:
+AHA_ATTN_WAVES=4|8, AHA_ATTN_SCHED=0|1.  `python scripts/bench_attn.py 16384 40980` times causal launches of those lengths.
+(The elimination variants recorded in profiles/r01_attn_prefill_anatomy.md came from a temporary template parameter.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("AHA_ATTN_TIME", "5")
