@@ -80,6 +80,10 @@ SIGNATURES = {
     "aha_hip_img_smart_resize": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32),
                                            C.POINTER(C.c_uint32)]),
     "aha_hip_image_resize": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P]),
+    "aha_hip_debug_resize_taps": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float),
+                                            C.c_int64]),
+    "aha_hip_debug_resample_taps": (C.c_int64, [C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int32),
+                                                C.POINTER(C.c_int32)]),
     "aha_hip_audio_resample": (C.c_int64, [_P, C.POINTER(C.c_float), C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                            C.POINTER(C.c_float), C.c_int64]),
     "aha_hip_cache_len": (C.c_size_t, [_P]),

@@ -9,6 +9,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
 #include <numeric>
 #include <vector>
 
@@ -82,6 +83,21 @@ void sinc_resample_taps(int64_t orig, int64_t new_f, int lowpass_filter_width, d
       taps[(size_t)j * klen + k] = sinc * window * scale;
     }
   }
+}
+
+// host-only view of the polyphase taps (orig / new already divided by their gcd), for the CPU test tier
+int64_t debug_resample_taps(int64_t orig, int64_t new_f, float* taps, int64_t cap, int32_t* width, int32_t* klen) {
+  std::vector<float> t;
+  int w = 0, k = 0;
+  sinc_resample_taps(orig, new_f, 6, 0.99, t, w, k);
+  if ((int64_t)t.size() > cap) {
+    set_error("debug_resample_taps: buffer too small");
+    return AHA_ERR_INVALID;
+  }
+  std::copy(t.begin(), t.end(), taps);
+  *width = w;
+  *klen = k;
+  return (int64_t)t.size();
 }
 
 int64_t resample_output_len(int64_t length, int64_t orig_sr, int64_t target_sr) {

@@ -416,6 +416,26 @@ int aha_hip_image_resize(const uint8_t* src_hwc, int32_t H, int32_t W, uint8_t* 
   API_GUARD_END
 }
 
+int aha_hip_debug_resize_taps(int32_t n_in, int32_t n_out, int32_t* left, int32_t* count, float* weights, int64_t weights_cap) {
+  API_GUARD_BEGIN
+  if (n_in <= 0 || n_out <= 0 || !left || !count || !weights) {
+    set_error("debug_resize_taps: bad arguments");
+    return AHA_ERR_INVALID;
+  }
+  return debug_resize_taps(n_in, n_out, left, count, weights, weights_cap);
+  API_GUARD_END
+}
+
+int64_t aha_hip_debug_resample_taps(int32_t orig, int32_t new_f, float* taps, int64_t cap, int32_t* width, int32_t* klen) {
+  API_GUARD_BEGIN
+  if (orig <= 0 || new_f <= 0 || !taps || !width || !klen) {
+    set_error("debug_resample_taps: bad arguments");
+    return AHA_ERR_INVALID;
+  }
+  return debug_resample_taps(orig, new_f, taps, cap, width, klen);
+  API_GUARD_END
+}
+
 int aha_hip_get_rope_index(const aha_model_desc* desc, const uint32_t* input_ids, size_t n_ids, const uint32_t* image_grid_thw,
                            int32_t n_images, int32_t* pos_out, int64_t* rope_delta_out) {
   API_GUARD_BEGIN

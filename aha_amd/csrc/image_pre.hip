@@ -111,6 +111,19 @@ int upload(const Taps& t, int** d_int, float** d_w, hipStream_t st) {
 
 }  // namespace
 
+// host-only view of the tap tables (tests compare them bit for bit with the restatement without a GPU)
+int debug_resize_taps(int n_in, int n_out, int32_t* left, int32_t* count, float* weights, int64_t weights_cap) {
+  const Taps t = build_taps(n_in, n_out);
+  if ((int64_t)t.w.size() > weights_cap) {
+    set_error("debug_resize_taps: weights buffer too small");
+    return AHA_ERR_INVALID;
+  }
+  std::copy(t.left.begin(), t.left.end(), left);
+  std::copy(t.count.begin(), t.count.end(), count);
+  std::copy(t.w.begin(), t.w.end(), weights);
+  return (int)t.w.size();
+}
+
 // img_smart_resize (img_utils.rs:294-331): f32 beta, round / floor / ceil to a multiple of `factor`
 int img_smart_resize(uint32_t h, uint32_t w, uint32_t factor, uint32_t min_pixels, uint32_t max_pixels, uint32_t* h_out, uint32_t* w_out) {
   if (h == 0 || w == 0 || factor == 0) {

@@ -263,6 +263,11 @@ int aha_hip_img_smart_resize(uint32_t h, uint32_t w, uint32_t factor, uint32_t m
  * restated in oracle/image_pre.py ([unverified] against the crate itself): vertical pass into f32, horizontal pass,
  * CatmullRom taps scaled by max(ratio, 1) and normalised, clamp, round half away from zero.  Synchronises the stream. */
 int aha_hip_image_resize(const uint8_t* src_hwc, int32_t H, int32_t W, uint8_t* dst_hwc, int32_t new_h, int32_t new_w, void* stream);
+/* Host-only debug views (no GPU work) of the tap tables the two pre-processing kernels use, so that the CPU test tier can
+ * compare them bit for bit with the restatements: resize taps of one axis (left[n_out], count[n_out], weights concatenated,
+ * returns their number) and the polyphase resampling taps (new_f x klen floats for rates already divided by their gcd). */
+int aha_hip_debug_resize_taps(int32_t n_in, int32_t n_out, int32_t* left, int32_t* count, float* weights, int64_t weights_cap);
+int64_t aha_hip_debug_resample_taps(int32_t orig, int32_t new_f, float* taps, int64_t cap, int32_t* width, int32_t* klen);
 /* V0: one RGB8 image (H, W, 3) in device memory, H and W multiples of patch*merge -> the processor's pixel_values rows
  * ((H/patch)*(W/patch), 3*2*patch*patch) bf16 in merge-window order with the frame duplicated to T = 2
  * (/root/reference/src/models/qwen3vl/processor.rs:174-251; img_transform, /root/reference/src/utils/img_utils.rs:272-293). */

@@ -82,3 +82,21 @@ def test_channel_mean_and_passthrough():
     np.testing.assert_array_equal(a, ap.resample_simple(mono, 44100, 16000))
     # a trailing partial frame is dropped (audio_vec[0..frame_len * channels])
     assert ap.resample_audio_from_vec_f32(np.ones(7, np.float32), 2, 16000, 16000).shape[0] == 3
+
+
+@pytest.mark.parametrize("orig_sr,new_sr", [(44100, 16000), (48000, 16000), (8000, 16000), (22050, 16000), (11025, 16000), (16000, 24000)])
+def test_library_taps_against_the_restatement(orig_sr, new_sr):
+    """The product's host-side kernel builder (csrc/audio_pre.hip sinc_resample_taps, libm sinf / cosf) against the numpy
+    restatement: same width / length, taps equal to a few f32 ulps of the kernel's scale (sin / cos implementations differ)."""
+    import ctypes as C
+    from aha_amd import _lib
+    g = math.gcd(orig_sr, new_sr)
+    orig, new = orig_sr // g, new_sr // g
+    ref, width = ap.get_sinc_resample_kernel(orig_sr, new_sr, g)
+    cap = ref.size
+    buf = (C.c_float * cap)()
+    w, k = C.c_int32(), C.c_int32()
+    n = _lib.lib().aha_hip_debug_resample_taps(orig, new, buf, cap, C.byref(w), C.byref(k))
+    assert n == ref.size and w.value == width and k.value == ref.shape[1]
+    got = np.frombuffer(buf, dtype=np.float32).reshape(ref.shape)
+    assert np.abs(got - ref).max() <= 4e-7 * max(1.0, float(np.abs(ref).max()))

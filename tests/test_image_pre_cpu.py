@@ -67,3 +67,23 @@ def test_smart_resize_c_abi_matches_python(h, w):
     assert l.aha_hip_img_smart_resize(1, 500, 32, 65536, 16777216, C.byref(ho), C.byref(wo)) < 0      # aspect ratio > 200
     with pytest.raises(ValueError):
         img_smart_resize(1, 500)
+
+
+@pytest.mark.parametrize("n_in,n_out", [(64, 160), (64, 96), (100, 32), (75, 96), (1024, 672), (37, 64), (5, 1), (1, 7), (3000, 2048)])
+def test_library_tap_tables_are_the_restatements_bit_for_bit(n_in, n_out):
+    """The product's host-side tap builder (csrc/image_pre.hip build_taps) against oracle.sample_taps: same left / count and the
+    same f32 weight bits, so the GPU passes (plain f32 multiply + add in tap order) reproduce the restatement exactly."""
+    l = _lib.lib()
+    left = (C.c_int32 * n_out)()
+    count = (C.c_int32 * n_out)()
+    cap = n_out * (int(np.ceil(4 * max(n_in / n_out, 1.0))) + 4)
+    w = (C.c_float * cap)()
+    n = l.aha_hip_debug_resize_taps(n_in, n_out, left, count, w, cap)
+    assert n > 0
+    ws = np.frombuffer(w, dtype=np.float32)[:n]
+    off = 0
+    for o, (rl, rw) in enumerate(ip.sample_taps(n_in, n_out)):
+        assert (left[o], count[o]) == (rl, len(rw))
+        np.testing.assert_array_equal(ws[off: off + len(rw)].view(np.uint32), rw.view(np.uint32))
+        off += len(rw)
+    assert off == n
