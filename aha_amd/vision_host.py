@@ -18,7 +18,10 @@ def img_smart_resize(h: int, w: int, factor: int = 32, min_pixels: int = 65536, 
     """img_smart_resize, /root/reference/src/utils/img_utils.rs:295-331 (f32 beta, round/floor/ceil by factor)."""
     if max(h, w) // min(h, w) > 200:
         raise ValueError(f"absolute aspect ratio mush be smaller than 200, got {max(h, w) // min(h, w)}")
-    rnd = lambda v: int(round(v / factor)) * factor
+    def rnd(v):  # round_by_factor (utils/mod.rs:392-395): f32 quotient, f32::round = half AWAY from zero (Python's round is half-even)
+        q = np.float32(v) / np.float32(factor)
+        fl = np.floor(q)
+        return int(fl + (q - fl >= np.float32(0.5))) * factor
     h_bar, w_bar = max(factor, rnd(h)), max(factor, rnd(w))
     if h_bar * w_bar > max_pixels:
         beta = np.sqrt(np.float32(h * w) / np.float32(max_pixels), dtype=np.float32)

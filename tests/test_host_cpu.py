@@ -103,6 +103,7 @@ def test_img_smart_resize():
     assert img_smart_resize(2048, 2048) == (2048, 2048)
     assert img_smart_resize(100, 100) == (256, 256)             # below min_pixels 65536 -> scaled up, ceil to x32
     assert img_smart_resize(1000, 700) == (992, 704)            # round to the nearest multiple of 32
+    assert img_smart_resize(80, 880) == (96, 896)               # 80 / 32 = 2.5 rounds AWAY from zero (f32::round), not to even
     h, w = img_smart_resize(6000, 5000)
     assert h % 32 == 0 and w % 32 == 0 and h * w <= 16777216
     with pytest.raises(ValueError):

@@ -1,0 +1,75 @@
+"""Property tests (hypothesis) of host-side logic on the request path: smart-resize arithmetic (C ABI and Python mirror), the
+sampler's draw weights, resampler output lengths."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+hyp = pytest.importorskip("hypothesis")
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+from aha_amd import _lib  # noqa: E402
+from aha_amd import sampling as hs  # noqa: E402
+from aha_amd.vision_host import img_smart_resize  # noqa: E402
+from oracle import audio_pre as ap  # noqa: E402
+from oracle import sampling as osamp  # noqa: E402
+
+
+@settings(max_examples=200, deadline=None)
+@given(h=st.integers(1, 6000), w=st.integers(1, 6000))
+def test_smart_resize_invariants(h, w):
+    """img_smart_resize (img_utils.rs:294-331): multiples of 32, area inside [min, max] (up to one factor step of rounding),
+    aspect ratio kept within the rounding granularity; C ABI == Python mirror."""
+    if max(h, w) // min(h, w) > 200:
+        with pytest.raises(ValueError):
+            img_smart_resize(h, w)
+        return
+    mn, mx = 65536, 16777216
+    hb, wb = img_smart_resize(h, w, 32, mn, mx)
+    ho, wo = C.c_uint32(), C.c_uint32()
+    assert _lib.lib().aha_hip_img_smart_resize(h, w, 32, mn, mx, C.byref(ho), C.byref(wo)) == 0
+    assert (ho.value, wo.value) == (hb, wb)
+    assert hb % 32 == 0 and wb % 32 == 0 and hb >= 32 and wb >= 32
+    assert hb * wb <= mx
+    if min(h, w) * 200 >= max(h, w) and h * w >= 4:
+        assert hb * wb >= mn or max(hb, wb) / min(hb, wb) > 50      # extreme strips can stay below the minimum area
+    # scale factors of the two axes agree up to the 32-pixel granularity
+    sh, sw = hb / h, wb / w
+    assert abs(sh - sw) <= 33 / min(h, w) + 1e-6 or min(hb, wb) == 32
+
+
+@settings(max_examples=100, deadline=None)
+@given(seed=st.integers(0, 10_000), k=st.integers(1, 64), p=st.floats(0.05, 0.999), t=st.floats(0.2, 2.0),
+       scale=st.floats(0.2, 8.0))
+def test_sampler_weights_properties(seed, k, p, t, scale):
+    """TopKThenTopP draw weights: non-negative, supported on the k largest logits, the best token always kept, the kept mass at
+    least min(top_p, mass of the top k), and equal to the oracle's weights on the same logits."""
+    V = 512
+    logits = (np.random.default_rng(seed).standard_normal(V) * scale).astype(np.float32)
+    lp = hs.LogitsProcessor(0, hs.Sampling("TopKThenTopP", float(np.float32(t)), k, float(np.float32(p))))
+    vals, idx, mx, se = osamp.topk_candidates(logits, k, lp.sampling.temperature)
+    w = lp.weights_from_candidates(vals, mx, se)
+    assert w is not None and w.shape == (k,) and (w >= 0).all() and w[0] > 0
+    topk_mass = float(np.exp((vals.astype(np.float64) - mx) / lp.sampling.temperature).sum() / se)
+    assert float(w.sum()) >= min(lp.sampling.p, topk_mass) - 1e-4
+    assert (np.diff(np.nonzero(w)[0]) == 1).all()                   # a prefix of the descending candidates survives
+    want = osamp.final_weights(logits, osamp.Sampling("TopKThenTopP", lp.sampling.temperature, k=k, p=lp.sampling.p))
+    got = np.zeros(V, np.float32)
+    got[idx] = w
+    boundary = np.abs(np.cumsum(np.sort(want[want > 0])[::-1]) - lp.sampling.p).min() < 1e-5 if (want > 0).any() else False
+    if not boundary:                                                # a running sum within 1e-5 of top_p may cut one token apart
+        assert set(np.nonzero(got)[0]) == set(np.nonzero(want)[0])
+        np.testing.assert_allclose(got, want, rtol=3e-5, atol=1e-9)
+
+
+@settings(max_examples=60, deadline=None)
+@given(n=st.integers(0, 5000), rates=st.sampled_from([(44100, 16000), (48000, 16000), (8000, 16000), (22050, 16000), (16000, 24000)]))
+def test_resample_length_formula(n, rates):
+    """ceil(new * n / orig), capped by the convolution's output rows (audio_utils.rs:200-207)."""
+    orig_sr, new_sr = rates
+    g = math.gcd(orig_sr, new_sr)
+    orig, new = orig_sr // g, new_sr // g
+    y = ap.resample_simple(np.zeros(n, np.float32), orig_sr, new_sr)
+    assert y.shape[0] == min(math.ceil(new * n / orig), (n // orig + 1) * new)
+    assert abs(y.shape[0] - n * new_sr / orig_sr) < 1 + 1e-9
