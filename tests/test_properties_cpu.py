@@ -73,3 +73,51 @@ def test_resample_length_formula(n, rates):
     y = ap.resample_simple(np.zeros(n, np.float32), orig_sr, new_sr)
     assert y.shape[0] == min(math.ceil(new * n / orig), (n // orig + 1) * new)
     assert abs(y.shape[0] - n * new_sr / orig_sr) < 1 + 1e-9
+
+
+# ---- native JSON / config parser (csrc/json.h, loader.hip) under formatting noise -------------------------------------------------
+json_leaf = st.one_of(st.none(), st.booleans(), st.integers(-2**53, 2**53), st.floats(allow_nan=False, allow_infinity=False, width=64),
+                      st.text(max_size=12))
+json_value = st.recursive(json_leaf, lambda ch: st.one_of(st.lists(ch, max_size=4), st.dictionaries(st.text(max_size=6), ch, max_size=4)),
+                          max_leaves=12)
+
+
+@settings(max_examples=60, deadline=None)
+@given(extras=st.dictionaries(st.text(min_size=1, max_size=8).map(lambda s: "x_" + s), json_value, max_size=5),
+       indent=st.sampled_from([None, 0, 1, 4]), ascii_only=st.booleans(), seed=st.integers(0, 1000),
+       eps_fmt=st.sampled_from(["{:e}", "{:.12f}", "{!r}", "{:E}"]), theta_fmt=st.sampled_from(["{:e}", "{:.1f}", "{!r}", "{:.0f}"]))
+def test_config_parser_ignores_formatting_and_unknown_keys(extras, indent, ascii_only, seed, eps_fmt, theta_fmt):
+    """serde ignores unknown fields and JSON formatting; so must aha_hip_config_parse: shuffled keys, any indentation, escaped or
+    raw unicode, numbers in any JSON spelling and arbitrary extra members leave the parsed description unchanged."""
+    import json
+    import random
+    import tempfile
+
+    import torch
+
+    from aha_amd.checkpoint import config_json, parse_config, save_checkpoint
+    from aha_amd.configs import tiny_qwen3
+    from aha_amd.model import make_desc
+
+    cfg = tiny_qwen3()
+    want = make_desc(cfg)
+    with tempfile.TemporaryDirectory() as d:
+        save_checkpoint(d, cfg, {"dummy": torch.zeros(1)})
+        base = json.load(open(f"{d}/config.json"))
+        items = list(base.items()) + list(extras.items())
+        random.Random(seed).shuffle(items)
+        text = json.dumps(dict(items), indent=indent, ensure_ascii=ascii_only)
+        # respell the two float fields (json.dumps always writes repr)
+        for key, fmt in (("rms_norm_eps", eps_fmt), ("rope_theta", theta_fmt)):
+            val = float(base[key])
+            new = fmt.format(val)
+            if float(new) != val:
+                continue  # this spelling would change the value
+            old = json.dumps(base[key])
+            assert f'"{key}": {old}' in text
+            text = text.replace(f'"{key}": {old}', f'"{key}": {new}')
+        open(f"{d}/config.json", "w", encoding="utf-8").write(text)
+        got = parse_config(d)
+    for name, _ in want._fields_:
+        a, b = getattr(got, name), getattr(want, name)
+        assert (list(a) if hasattr(a, "__len__") else a) == (list(b) if hasattr(b, "__len__") else b), name
