@@ -39,8 +39,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
            [os.path.join(HERE, "..", "include", "aha_hip.h")]
     stamp = os.path.join(CSRC, ".build_stamp")
     dig = _digest(srcs + hdrs)
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+    def fresh() -> bool:
+        return os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig
+
+    if not force and fresh():
         return LIB
+    # one builder at a time: several ranks of one node (bench.py --gpus N) may all find the library missing
+    import fcntl
+    lock = open(os.path.join(CSRC, ".build_lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and fresh():  # another process built it while this one waited
+            return LIB
+        return _build_locked(srcs, stamp, dig, verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(srcs, stamp: str, dig: str, verbose: bool) -> str:
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
@@ -57,11 +74,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(compile_one, srcs))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lrccl",
+    tmp = LIB + ".tmp"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs, "-L/opt/rocm/lib", "-lrccl",
            "-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
+    os.replace(tmp, LIB)  # atomic: a process that dlopens concurrently sees the old or the new file, never a partial one
     with open(stamp, "w") as f:
         f.write(dig)
     return LIB
