@@ -121,3 +121,32 @@ def test_config_parser_ignores_formatting_and_unknown_keys(extras, indent, ascii
     for name, _ in want._fields_:
         a, b = getattr(got, name), getattr(want, name)
         assert (list(a) if hasattr(a, "__len__") else a) == (list(b) if hasattr(b, "__len__") else b), name
+
+
+@settings(max_examples=150, deadline=None)
+@given(seed=st.integers(0, 10**6), n_images=st.integers(0, 6), max_g=st.integers(1, 12))
+def test_rope_index_differential(seed, n_images, max_g):
+    """aha_hip_get_rope_index (host C++, csrc/vision.hip) vs the oracle restatement of Qwen3VLModel::get_rope_index
+    (qwen3vl/model.rs:901-1133) on random prompts: integer work, bit-exact, and the structural invariants of the positions."""
+    from aha_amd.configs import tiny_qwen3vl
+    from aha_amd.vision_host import get_rope_index
+    from oracle import qwen3vl as ov
+    cfg = tiny_qwen3vl()
+    rng = np.random.default_rng(seed)
+    ids, grids = [int(x) for x in rng.integers(0, 1000, size=rng.integers(0, 6))], []
+    for _ in range(n_images):
+        gh, gw = int(rng.integers(1, max_g + 1)), int(rng.integers(1, max_g + 1))
+        grids.append([1, 2 * gh, 2 * gw])
+        ids += [cfg.vision_start_token_id] + [cfg.image_token_id] * (gh * gw) + [cfg.vision_end_token_id]
+        ids += [int(x) for x in rng.integers(0, 1000, size=rng.integers(0, 5))]
+    if not ids:
+        ids = [1]
+    grid = np.asarray(grids, dtype=np.uint32).reshape(-1, 3)
+    pos, delta = get_rope_index(cfg, ids, grid)
+    ref_pos, ref_delta = ov.get_rope_index(ids, grid, cfg)
+    np.testing.assert_array_equal(pos, np.asarray(ref_pos))
+    assert delta == int(ref_delta)
+    assert pos.shape == (3, len(ids)) and (pos >= 0).all()
+    assert int(pos.max()) + 1 - len(ids) == delta and delta <= 0          # rope_deltas = max_pos + 1 - S (model.rs:1128-1131)
+    txt = np.asarray([t != cfg.image_token_id for t in ids])
+    assert (pos[0, txt] == pos[1, txt]).all() and (pos[0, txt] == pos[2, txt]).all()   # text tokens: the same index on T, H, W
