@@ -42,11 +42,14 @@ def get_logit_processor(temperature: Optional[float], top_p: Optional[float], to
     return LogitsProcessor(seed, s)
 
 
-def _topp_mask(prs: np.ndarray, top_p: float) -> np.ndarray:
-    """LogitsProcessor::sample_topp: descending walk, zero everything after the running sum has reached top_p."""
+def _topp_mask(prs: np.ndarray, top_p: float, tie_key: Optional[np.ndarray] = None) -> np.ndarray:
+    """LogitsProcessor::sample_topp: descending walk (candle's `sort_by` is stable: equal probabilities are walked in position
+    order; `tie_key` supplies the vocabulary positions when `prs` is a candidate list in another order), zero everything
+    after the running sum has reached top_p."""
     prs = prs.astype(np.float32).copy()
     cumsum = np.float32(0.0)
-    for i in np.argsort(-prs, kind="stable"):
+    order = np.argsort(-prs, kind="stable") if tie_key is None else np.lexsort((tie_key, -prs.astype(np.float64)))
+    for i in order:
         if cumsum >= np.float32(top_p):
             prs[i] = 0.0
         else:
@@ -66,12 +69,16 @@ class LogitsProcessor:
         if s.kind in ("TopK", "TopKThenTopP"):
             return s.k if 1 <= s.k <= MAX_CANDIDATES and s.k < vocab_size else 0
         if s.kind == "TopP":
-            return min(MAX_CANDIDATES, vocab_size)
+            # candle: `if p <= 0.0 || p >= 1.0 { sample_multinomial(&prs) }` -- the whole distribution, no candidates
+            return 0 if (s.p <= 0.0 or s.p >= 1.0) else min(MAX_CANDIDATES, vocab_size)
         return 0
 
-    def weights_from_candidates(self, vals: np.ndarray, mx: float, sumexp: float) -> Optional[np.ndarray]:
+    def weights_from_candidates(self, vals: np.ndarray, mx: float, sumexp: float, idx: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
         """Weights over the candidates (same order) that candle's sampler would hand to the weighted draw, or None when the
-        candidates do not cover the sampler's support (TopP nucleus wider than the candidate list)."""
+        candidates do not cover the sampler's support (TopP nucleus wider than the candidate list).  The candidates arrive
+        ranked by (logit descending, index ascending), which refines candle's ranking by probability (oracle.topk_order
+        states the tie rule); `idx` (their vocabulary positions) lets the plain TopP walk break equal probabilities by
+        position as candle's stable full-vocabulary sort does."""
         s = self.sampling
         inv_t = np.float32(1.0 / s.temperature)
         prs = (np.exp((vals.astype(np.float32) - np.float32(mx)) * inv_t, dtype=np.float32) / np.float32(sumexp)).astype(np.float32)
@@ -83,7 +90,10 @@ class LogitsProcessor:
         if s.kind == "TopP":
             if prs.sum(dtype=np.float32) < np.float32(s.p):
                 return None  # the nucleus reaches past the candidates
-            return _topp_mask(prs, s.p)
+            w = _topp_mask(prs, s.p, None if idx is None else np.asarray(idx, dtype=np.int64))
+            if w[-1] > 0 and len(w) > 1 and prs[-1] == prs[-2]:
+                return None  # the cut falls inside a run of equal probabilities that may continue past the candidates
+            return w
         raise ValueError(f"{s.kind} does not sample from candidates")
 
     def weights_from_logits(self, logits: np.ndarray) -> np.ndarray:
@@ -99,11 +109,15 @@ class LogitsProcessor:
         prs = (e / e.sum(dtype=np.float32)).astype(np.float32)
         if s.kind == "All":
             return prs
-        if s.kind == "TopP" or (s.kind == "TopKThenTopP" and s.k >= logits.shape[0]):
+        if s.kind == "TopP":
+            return prs if (s.p <= 0.0 or s.p >= 1.0) else _topp_mask(prs, s.p)
+        if s.kind == "TopKThenTopP" and s.k >= logits.shape[0]:
             return _topp_mask(prs, s.p)
         if s.k >= logits.shape[0]:
             return prs
-        keep = np.argsort(-prs, kind="stable")[: s.k]
+        # candle selects the k largest PROBABILITIES (select_nth_unstable_by); equal probabilities: higher logit, then lower
+        # index (the same refinement as the device's ranking by logit)
+        keep = np.lexsort((np.arange(prs.shape[0]), -logits.astype(np.float64), -prs.astype(np.float64)))[: s.k]
         sub = prs[keep]
         if s.kind == "TopKThenTopP" and not (s.p <= 0.0 or s.p >= sub.sum(dtype=np.float32)):
             sub = _topp_mask(sub, s.p)
@@ -157,7 +171,7 @@ def sample_and_push(ctx: GenerationContext, model, argmax_token: int, generated:
             if lp.sampling.kind == "ArgMax":
                 token = int(idx[0])  # arg-max of the penalised logits (first maximal index)
             else:
-                w = lp.weights_from_candidates(vals, mx, se)
+                w = lp.weights_from_candidates(vals, mx, se, idx)
                 if w is not None:
                     token = int(idx[lp.draw(w)])
         if token is None:  # full-vector fallback

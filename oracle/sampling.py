@@ -77,8 +77,9 @@ def softmax_last_dim(x: np.ndarray) -> np.ndarray:
 
 
 def _topp_mask(prs: np.ndarray, top_p: float) -> np.ndarray:
-    """LogitsProcessor::sample_topp: walk the probabilities in descending order; once the running sum has reached top_p the
-    remaining ones are zeroed (the one that crosses the threshold is kept)."""
+    """LogitsProcessor::sample_topp: walk the probabilities in descending order (`sort_by`, a STABLE sort: equal
+    probabilities stay in position order); once the running sum has reached top_p the remaining ones are zeroed (the one
+    that crosses the threshold is kept)."""
     prs = prs.copy()
     order = np.argsort(-prs, kind="stable")
     cumsum = np.float32(0.0)
@@ -88,6 +89,16 @@ def _topp_mask(prs: np.ndarray, top_p: float) -> np.ndarray:
         else:
             cumsum = np.float32(cumsum + prs[i])
     return prs
+
+
+def topk_order(prs: np.ndarray, logits: np.ndarray) -> np.ndarray:
+    """Descending order of the PROBABILITIES (candle's key in sample_topk / sample_topk_topp:
+    `select_nth_unstable_by(k, |i, j| prs[j].total_cmp(&prs[i]))`).  The selection is unstable, so which of several EQUAL
+    f32 probabilities makes the cut at position k is unspecified in the reference; the rule fixed here (and in the host mirror
+    and on the device) is the refinement "higher logit first, then lower index" -- the f32 softmax is monotone in the logit,
+    so this is one of the orders candle's selection may produce, and it is the order a ranking by logit gives."""
+    idx = np.arange(prs.shape[0])
+    return np.lexsort((idx, -np.asarray(logits, dtype=np.float64), -np.asarray(prs, dtype=np.float64)))
 
 
 def final_weights(logits: np.ndarray, s: Sampling) -> np.ndarray:
@@ -104,10 +115,11 @@ def final_weights(logits: np.ndarray, s: Sampling) -> np.ndarray:
     if s.kind == "All":
         return prs
     if s.kind == "TopP":
-        return _topp_mask(prs, s.p)
+        # LogitsProcessor::sample: `if p <= 0.0 || p >= 1.0 { sample_multinomial(&prs) } else { sample_topp(..) }`
+        return prs if (s.p <= 0.0 or s.p >= 1.0) else _topp_mask(prs, s.p)
     if s.k >= V:                                       # sample_topk / sample_topk_topp fall through to the full vector
         return prs if s.kind == "TopK" else _topp_mask(prs, s.p)
-    keep = np.argsort(-prs, kind="stable")[: s.k]      # select_nth_unstable_by(k, descending): the k largest
+    keep = topk_order(prs, logits)[: s.k]              # select_nth_unstable_by(k, descending probability): the k largest
     sub = prs[keep]
     if s.kind == "TopKThenTopP":
         sum_p = sub.sum(dtype=np.float32)

@@ -16,7 +16,7 @@ from oracle import audio_pre as ap  # noqa: E402
 from oracle import sampling as osamp  # noqa: E402
 
 
-@settings(max_examples=200, deadline=None)
+@settings(max_examples=200, deadline=None, derandomize=True)
 @given(h=st.integers(1, 6000), w=st.integers(1, 6000))
 def test_smart_resize_invariants(h, w):
     """img_smart_resize (img_utils.rs:294-331): multiples of 32, area inside [min, max] (up to one factor step of rounding),
@@ -39,7 +39,7 @@ def test_smart_resize_invariants(h, w):
     assert abs(sh - sw) <= 33 / min(h, w) + 1e-6 or min(hb, wb) == 32
 
 
-@settings(max_examples=100, deadline=None)
+@settings(max_examples=100, deadline=None, derandomize=True)
 @given(seed=st.integers(0, 10_000), k=st.integers(1, 64), p=st.floats(0.05, 0.999), t=st.floats(0.2, 2.0),
        scale=st.floats(0.2, 8.0))
 def test_sampler_weights_properties(seed, k, p, t, scale):
@@ -63,7 +63,7 @@ def test_sampler_weights_properties(seed, k, p, t, scale):
         np.testing.assert_allclose(got, want, rtol=3e-5, atol=1e-9)
 
 
-@settings(max_examples=60, deadline=None)
+@settings(max_examples=60, deadline=None, derandomize=True)
 @given(n=st.integers(0, 5000), rates=st.sampled_from([(44100, 16000), (48000, 16000), (8000, 16000), (22050, 16000), (16000, 24000)]))
 def test_resample_length_formula(n, rates):
     """ceil(new * n / orig), capped by the convolution's output rows (audio_utils.rs:200-207)."""
@@ -82,7 +82,7 @@ json_value = st.recursive(json_leaf, lambda ch: st.one_of(st.lists(ch, max_size=
                           max_leaves=12)
 
 
-@settings(max_examples=60, deadline=None)
+@settings(max_examples=60, deadline=None, derandomize=True)
 @given(extras=st.dictionaries(st.text(min_size=1, max_size=8).map(lambda s: "x_" + s), json_value, max_size=5),
        indent=st.sampled_from([None, 0, 1, 4]), ascii_only=st.booleans(), seed=st.integers(0, 1000),
        eps_fmt=st.sampled_from(["{:e}", "{:.12f}", "{!r}", "{:E}"]), theta_fmt=st.sampled_from(["{:e}", "{:.1f}", "{!r}", "{:.0f}"]))
@@ -123,7 +123,7 @@ def test_config_parser_ignores_formatting_and_unknown_keys(extras, indent, ascii
         assert (list(a) if hasattr(a, "__len__") else a) == (list(b) if hasattr(b, "__len__") else b), name
 
 
-@settings(max_examples=150, deadline=None)
+@settings(max_examples=150, deadline=None, derandomize=True)
 @given(seed=st.integers(0, 10**6), n_images=st.integers(0, 6), max_g=st.integers(1, 12))
 def test_rope_index_differential(seed, n_images, max_g):
     """aha_hip_get_rope_index (host C++, csrc/vision.hip) vs the oracle restatement of Qwen3VLModel::get_rope_index

@@ -186,3 +186,61 @@ def test_repeat_penalty_agrees_with_transformers():
     proc = tr.RepetitionPenaltyLogitsProcessor(penalty=1.3)
     want = proc(torch.tensor([ctxt]), torch.tensor(logits)[None].clone())[0].numpy()
     np.testing.assert_array_equal(osamp.apply_repeat_penalty(logits, 1.3, ctxt), want)
+
+
+def test_topk_tie_rule_equal_probabilities_seed49():
+    """Round-1 flake, pinned: logits 0.37142882 (id 420) and 0.37142873 (id 304) collapse to ONE f32 probability at
+    T = 1.03125 and sit across the k = 18 cut.  candle ranks by probability with an UNSTABLE selection, so either id is a
+    legal 18th candidate there; the rule fixed in oracle.topk_order (higher logit, then lower index) is what the device's
+    ranking by logit produces, and the host mirror, the full-vector fallback and the oracle must all pick id 420."""
+    V, k, t, p = 512, 18, float(np.float32(1.03125)), float(np.float32(0.5))
+    logits = (np.random.default_rng(49).standard_normal(V) * 0.203125).astype(np.float32)
+    s = osamp.Sampling("TopK", t, k=k)
+    prs = osamp.softmax_last_dim(logits * np.float32(1.0 / t))
+    assert logits[420] > logits[304] and prs[420] == prs[304]
+    want = osamp.final_weights(logits, s)
+    assert want[420] > 0 and want[304] == 0 and np.count_nonzero(want) == k
+    lp = hs.LogitsProcessor(0, hs.Sampling("TopK", t, k))
+    vals, idx, mx, se = osamp.topk_candidates(logits, k, t)
+    got = np.zeros(V, np.float32)
+    got[idx] = lp.weights_from_candidates(vals, mx, se, idx)
+    assert set(np.nonzero(got)[0]) == set(np.nonzero(want)[0])
+    np.testing.assert_allclose(got, want, rtol=3e-5)
+    np.testing.assert_array_equal(lp.weights_from_logits(logits), want)
+    # the same with the nucleus cut on top (the hypothesis example that failed)
+    want2 = osamp.final_weights(logits, osamp.Sampling("TopKThenTopP", t, k=k, p=p))
+    lp2 = hs.LogitsProcessor(0, hs.Sampling("TopKThenTopP", t, k, p))
+    got2 = np.zeros(V, np.float32)
+    got2[idx] = lp2.weights_from_candidates(vals, mx, se, idx)
+    assert set(np.nonzero(got2)[0]) == set(np.nonzero(want2)[0])
+    np.testing.assert_array_equal(lp2.weights_from_logits(logits), want2)
+
+
+@pytest.mark.parametrize("p", [0.0, 1.0, 1.5, -0.1])
+def test_topp_degenerate_p_samples_the_whole_distribution(p):
+    """candle LogitsProcessor::sample, Sampling::TopP: `if p <= 0.0 || p >= 1.0 { sample_multinomial(&prs) }` -- no nucleus
+    walk, no candidate launch, never an all-zero weight vector."""
+    V = 2048
+    logits = _peaked_logits(V, 11, 2.0)
+    want = osamp.final_weights(logits, osamp.Sampling("TopP", 0.8, p=p))
+    np.testing.assert_array_equal(want, osamp.final_weights(logits, osamp.Sampling("All", 0.8)))
+    lp = hs.LogitsProcessor(3, hs.Sampling("TopP", 0.8, p=p))
+    assert lp.candidates_needed(V) == 0
+    w = lp.weights_from_logits(logits)
+    np.testing.assert_allclose(w, want, rtol=1e-6)
+    assert w.sum() > 0.999 and 0 <= lp.draw(w) < V
+
+
+def test_topp_equal_probabilities_walk_in_position_order():
+    """sample_topp sorts with the STABLE `sort_by`: equal probabilities are walked lowest index first, whatever order the
+    candidate list arrives in."""
+    logits = np.log(np.array([0.1, 0.3, 0.3, 0.3], np.float32))
+    want = osamp.final_weights(logits, osamp.Sampling("TopP", 1.0, p=0.5))
+    np.testing.assert_allclose(want, [0.0, 0.3, 0.3, 0.0], atol=1e-6)
+    lp = hs.LogitsProcessor(0, hs.Sampling("TopP", 1.0, p=0.5))
+    np.testing.assert_allclose(lp.weights_from_logits(logits), want, atol=1e-7)
+    vals, idx = logits[[3, 2, 1, 0]], np.array([3, 2, 1, 0])       # a candidate list in a hostile order
+    w = lp.weights_from_candidates(vals, float(logits.max()), float(np.exp(logits - logits.max()).sum()), idx)
+    got = np.zeros(4, np.float32)
+    got[idx] = w
+    np.testing.assert_allclose(got, want, atol=1e-6)
