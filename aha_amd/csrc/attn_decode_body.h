@@ -1,60 +1,47 @@
-// Body of the fused decode attention, shared by attn_decode_fused_kernel (kernels_attn.hip) and the persistent
-// decode-step kernel (decode_mega.hip).
+// Body of the fused decode attention kernel (attn_decode_fused_kernel, kernels_attn.hip).
 #pragma once
+#include <type_traits>
 #include "attn_common.h"
 
 namespace aha {
 
-constexpr int ATTN_DECODE_FUSED_LDS = 16 * 128 * 2 + 128 * 2 + 128 * 2 + 4 * 128 * 16 * 4 + 2 * 4 * 16 * 4;  // bytes
+constexpr int ATTN_DECODE_NW = 4;  // waves (= KV units) per workgroup
+constexpr int ATTN_DECODE_FUSED_LDS = 16 * 128 * 2 + 128 * 2 + 128 * 2 + ATTN_DECODE_NW * 128 * 16 * 4 + 2 * ATTN_DECODE_NW * 16 * 4;  // bytes
 
 // ---- decode, fused: q/k RMSNorm + (M-)RoPE + KV append + split-KV attention + in-block merge --------------------
-// One launch replaces qknorm_rope_kernel + attn_decode_kernel + most of the combine: every block redoes the (tiny)
-// norm/rope of its kv head's g query heads and of the new key in LDS (QKNormAttention::forward, modules.rs:538-557),
-// block (kvhd, 0) appends the new K/V to the cache page (modules.rs:558-566), all blocks attend over the OLD tokens
-// from the pages, unit 0 adds the new token from LDS, the 4 waves of a block are merged through LDS, and one
-// un-normalised partial per (split, head) is left for the o_proj matvec's prologue to merge (kernels_gemv.hip).
-// smem: ATTN_DECODE_FUSED_LDS bytes, 16-byte aligned.  (kvhd, split) of nsplit: this block's KV head and KV split.
-// after_prefetch() runs after the unit's first page has been requested and before qkv is read.
-// Returns true in the one block per kv head that wrote the final attention output of the head's g query heads.
-// General form: NW waves cooperate as one "block" (wave = 0..NW-1, tid = wave * 64 + lane); sync() is a barrier among exactly
-// those waves (__syncthreads() for a whole workgroup; the chain engine's consumer-wave barrier otherwise); emit(head, d, v)
-// receives the final attention output (called for consecutive d by consecutive tid).  LDS: attn_decode_lds_bytes(NW).
-constexpr int attn_decode_lds_bytes(int nw) { return 16 * 128 * 2 + 128 * 2 + 128 * 2 + nw * 128 * 16 * 4 + 2 * nw * 16 * 4; }
-
-template <bool COH, int NW, class AfterPrefetch, class Sync, class Emit>
-__device__ __forceinline__ bool attn_decode_fused_body_t(const AttnDecodeFusedArgs& a, char* smem, const int kvhd, const int split,
-                                                         const int nsplit, const int wave, const int tid,
-                                                         AfterPrefetch&& after_prefetch, Sync&& sync, Emit&& emit) {
-  constexpr int NT = NW * 64;
+// One launch replaces qknorm_rope_kernel + attn_decode_kernel + the combine: every block redoes the (tiny) norm/rope of
+// its kv head's g query heads and of the new key in LDS (QKNormAttention::forward, modules.rs:538-557), block (kvhd, 0)
+// appends the new K/V to the cache page (modules.rs:558-566), all blocks attend over the OLD tokens from the pages, unit
+// 0 adds the new token from LDS, the 4 waves of a block are merged through LDS, one un-normalised partial per
+// (split, head) is published, and the LAST split block of the kv head to arrive merges the splits and writes the bf16
+// attention output.
+//
+// Latency structure (batch 1: the launch is a chain of dependent round trips, not bandwidth):
+//   * every length-dependent scalar (cache length, slot, rope table of the step) arrives as a kernel ARGUMENT or from a
+//     table the step's first kernel wrote -- no dependent scalar loads, no sincos, in front of the first page request;
+//   * the prologue's own inputs (qkv, norm weights, rope table: L2 hits) are requested first, the unit's first page
+//     right behind them (returns are in order within a wave), and the norm/rope arithmetic runs under the page fetch;
+//   * in the page loop K and V of a page are separate register buffers re-requested as soon as their MFMAs have
+//     consumed them (K(next) right after QK^T, V(next) right after P.V), so a wave always has 16-32 KB in flight.
+// smem: ATTN_DECODE_FUSED_LDS bytes, 16-byte aligned.  Returns true in the one block per kv head that wrote the output.
+__device__ __forceinline__ bool attn_decode_fused_body(const AttnDecodeFusedArgs& a, char* smem, const int kvhd, const int split,
+                                                       const int nsplit) {
+  constexpr int NW = ATTN_DECODE_NW, NT = NW * 64;
   bf16_t* qs = reinterpret_cast<bf16_t*>(smem);                 // [16][128]
   bf16_t* ksn = qs + 16 * 128;                                  // [128]
   bf16_t* vsn = ksn + 128;                                      // [128]
   float* mo = reinterpret_cast<float*>(vsn + 128);              // per wave O^T [NW][d 128][q 16]
   float* mm = mo + NW * 128 * 16;                               // [NW][16]
   float* mlz = mm + NW * 16;                                    // [NW][16]
+  const int tid = (int)threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, G = lane >> 4, c = lane & 15;
   const int g = a.nh / a.kvh;
   const int nunits = nsplit * NW, unit = split * NW + wave;
-  const int L = *a.kv_len, slot_new = *a.kv_start;
+  const int L = a.kv_len_v, slot_new = a.kv_start_v;
   const int L_old = L - 1;  // tokens already in the pages; the new one is handled from LDS
   const int npages = (L_old + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS;
 
-  // This unit's first page goes out BEFORE the norm/rope prologue: its loads do not depend on q, and the prologue's
-  // own dependent chain (qkv -> wave_sum -> sincos -> LDS) then overlaps the page fetch instead of preceding it.
-  u32x4_t kf[4][4], vf[8][2];
-  auto load_page = [&](int page) {
-    const char* base = reinterpret_cast<const char*>(a.kv.page_ptrs[page] + a.kv.layer_off);
-    const char* kb = base + (size_t)kvhd * KV_PAGE_TOKENS * 256;
-    const char* vb = base + (size_t)a.kvh * KV_PAGE_TOKENS * 256 + (size_t)kvhd * 128 * (KV_PAGE_TOKENS * 2);
-#pragma unroll
-    for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) kf[sub][k4] = ld_nt16(kb + (size_t)(sub * 16 + c) * 256 + (k4 * 32 + G * 8) * 2);
-#pragma unroll
-    for (int ds = 0; ds < 8; ++ds)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) vf[ds][kk] = ld_nt16(vb + (size_t)(ds * 16 + c) * (KV_PAGE_TOKENS * 2) + (kk * 32 + G * 8) * 2);
-  };
   // optional timeline (AHA_ATTN_TRACE): block (kv head 0, split 0) and (kv head 0, last split), thread 0, 100 MHz stamps:
   // start, prologue done, pages done, partial published, arrival known, end
   const int tslot = (kvhd == 0 && split == 0) ? 0 : (kvhd == 0 && split == nsplit - 1 ? 1 : -1);
@@ -62,41 +49,99 @@ __device__ __forceinline__ bool attn_decode_fused_body_t(const AttnDecodeFusedAr
     if (a.trace != nullptr && tslot >= 0 && tid == 0) a.trace[tslot * 6 + k] = wall_clock64();
   };
   stamp(0);
-  int page = unit;
-  if (page < npages) load_page(page);
-  after_prefetch();  // grid barrier of the persistent decode kernel: qkv of this step is complete past this point
+
+  // ---- requests, in the order their data is needed ------------------------------------------------------------------
+  const bf16_t* qkv = (const bf16_t*)a.qkv;
+  // first (for most waves: only) prologue item of this wave: hs < g: q head kvhd*g+hs ; hs == g: the k head
+  const bool p_is_k = wave == g;
+  const bool p_have = wave <= g;
+  const bf16_t* p_src = p_is_k ? qkv + (int64_t)(a.nh + kvhd) * 128 : qkv + (int64_t)(kvhd * g + min(wave, g - 1)) * 128;
+  const bf16_t* p_nw = (const bf16_t*)(p_is_k ? a.k_norm_w : a.q_norm_w);
+  const bf16_t px0 = p_src[lane], px1 = p_src[lane + 64];
+  const bf16_t pw0 = p_nw[lane], pw1 = p_nw[lane + 64];
+  const float cs = a.rope[lane], sn = a.rope[64 + lane];   // bf16-representable values (rope_step_kernel)
+  bf16_t vnew = 0;
+  if (tid < 128) vnew = qkv[(int64_t)(a.nh + a.kvh + kvhd) * 128 + tid];
+
+  u32x4_t kf[4][4], vf[8][2];
+  // Addresses: wave-uniform 64-bit base (scalar registers) + ONE 32-bit per-lane offset (lane * 16), the rest immediates:
+  // pages are fragment-major (common.h), every load is `global_load_dwordx4 v, v_off, s[base] offset:frag*1024` = 1 KB
+  // contiguous per wave instruction.
+  typedef const __attribute__((address_space(1))) char* gchar_t;
+  const uint32_t l_off = (uint32_t)lane * 16;
+  auto load_k = [&](uint64_t base) {
+    gchar_t kb = reinterpret_cast<gchar_t>(base + (uint64_t)kvhd * KV_PAGE_TOKENS * 256);
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4)
+        kf[sub][k4] = __builtin_nontemporal_load(reinterpret_cast<gptr16_t>(kb + (sub * 4 + k4) * 1024 + l_off));
+  };
+  auto load_v = [&](uint64_t base) {
+    gchar_t vb = reinterpret_cast<gchar_t>(base + (uint64_t)a.kvh * KV_PAGE_TOKENS * 256 + (uint64_t)kvhd * 128 * (KV_PAGE_TOKENS * 2));
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        vf[ds][kk] = __builtin_nontemporal_load(reinterpret_cast<gptr16_t>(vb + (ds * 2 + kk) * 1024 + l_off));
+  };
+  // This unit's page pointers (pages unit, unit + nunits, ...): ONE vector load up front, lane i holding the i-th of them,
+  // broadcast per iteration with v_readlane.  (A load of page_ptrs[page] inside the loop is a VECTOR load -- the kernel also
+  // stores, so the compiler will not use the scalar cache -- and its wait drains the K/V requests queued behind it.)
+  uint64_t my_pages = 0;
+  auto fetch_page_ptrs = [&](int first_it) {
+    const int pg = unit + (first_it + lane) * nunits;
+    my_pages = pg < npages ? (uint64_t)(a.kv.page_ptrs[pg] + a.kv.layer_off) : 0;
+  };
+  auto page_base = [&](int i) {
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)my_pages, i & 63), hi = __builtin_amdgcn_readlane((uint32_t)(my_pages >> 32), i & 63);
+    return ((uint64_t)hi << 32) | lo;
+  };
+  fetch_page_ptrs(0);
+  int page = unit, it = 0;
+  if (page < npages) {
+    const uint64_t b0 = page_base(0);
+    __builtin_amdgcn_sched_barrier(0);  // K strictly ahead of V (as in the loop): the loop's counted waits assume that order
+    load_k(b0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_v(b0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 
   // ---- prologue: norm + rope of the g q heads and the k head; v raw ------------------------------------------------
   {
-    const bf16_t* qkv = (const bf16_t*)a.qkv;
-    for (int hs = wave; hs <= g; hs += NW) {  // hs < g: q head kvhd*g+hs ; hs == g: the k head
+    auto norm_rope = [&](bf16_t bx0, bf16_t bx1, bf16_t bw0, bf16_t bw1, bf16_t* dst) {
+      float x0 = bf2f(bx0), x1 = bf2f(bx1);
+      const float ss = wave_sum(fmaf(x0, x0, x1 * x1));  // explicit: `a*a + b*b` can be fused two ways
+      const float rinv = 1.0f / sqrtf(ss / 128.0f + a.eps);
+      x0 = rbf(x0 * rinv * bf2f(bw0));
+      x1 = rbf(x1 * rinv * bf2f(bw1));
+      const bf16_t y0 = f2bf(rbf(x0 * cs) + rbf(-x1 * sn));
+      const bf16_t y1 = f2bf(rbf(x1 * cs) + rbf(x0 * sn));
+      dst[lane] = y0;
+      dst[lane + 64] = y1;
+    };
+    if (p_have) norm_rope(px0, px1, pw0, pw1, p_is_k ? ksn : qs + wave * 128);
+    for (int hs = wave + NW; hs <= g; hs += NW) {  // more heads than waves (g >= 4): a second round for some waves
       const bool is_k = hs == g;
       const bf16_t* src = is_k ? qkv + (int64_t)(a.nh + kvhd) * 128 : qkv + (int64_t)(kvhd * g + hs) * 128;
       const bf16_t* nw = (const bf16_t*)(is_k ? a.k_norm_w : a.q_norm_w);
-      float x0 = bf2f(act_ld_bf<COH>(src + lane)), x1 = bf2f(act_ld_bf<COH>(src + lane + 64));
-      const float ss = wave_sum(fmaf(x0, x0, x1 * x1));  // explicit: `a*a + b*b` can be fused two ways
-      const float rinv = 1.0f / sqrtf(ss / 128.0f + a.eps);
-      x0 = rbf(x0 * rinv * bf2f(nw[lane]));
-      x1 = rbf(x1 * rinv * bf2f(nw[lane + 64]));
-      const float ang = (float)a.pos[a.axis_map[lane]] * a.inv_freq[lane];
-      const float cs = rbf(cosf(ang)), sn = rbf(sinf(ang));
-      const bf16_t y0 = f2bf(rbf(x0 * cs) + rbf(-x1 * sn));
-      const bf16_t y1 = f2bf(rbf(x1 * cs) + rbf(x0 * sn));
-      bf16_t* dst = is_k ? ksn : qs + hs * 128;
-      dst[lane] = y0;
-      dst[lane + 64] = y1;
+      norm_rope(src[lane], src[lane + 64], nw[lane], nw[lane + 64], is_k ? ksn : qs + hs * 128);
     }
-    for (int i = tid; i < 128; i += NT) vsn[i] = act_ld_bf<COH>(qkv + (int64_t)(a.nh + a.kvh + kvhd) * 128 + i);
+    if (tid < 128) vsn[tid] = vnew;
   }
-  sync();
+  __syncthreads();
   stamp(1);
   if (split == 0) {  // append (k roped, v raw) for the following steps
+    // global address space spelled out: a flat store here would make every later wait in the kernel a vmcnt(0)
+    typedef __attribute__((address_space(1))) bf16_t* gbf_t;
     const int pg = slot_new / KV_PAGE_TOKENS, t = slot_new % KV_PAGE_TOKENS;
-    bf16_t* base = reinterpret_cast<bf16_t*>(a.kv.page_ptrs[pg] + a.kv.layer_off);
-    bf16_t* vd = base + (int64_t)a.kvh * KV_PAGE_TOKENS * 128 + (int64_t)kvhd * 128 * KV_PAGE_TOKENS;
+    const uint64_t base = (uint64_t)(a.kv.page_ptrs[pg] + a.kv.layer_off);
+    gbf_t kd = reinterpret_cast<gbf_t>(base) + (int64_t)kvhd * KV_PAGE_TOKENS * 128;
+    gbf_t vd = reinterpret_cast<gbf_t>(base) + (int64_t)a.kvh * KV_PAGE_TOKENS * 128 + (int64_t)kvhd * 128 * KV_PAGE_TOKENS;
     for (int i = tid; i < 128; i += NT) {
-      base[((int64_t)kvhd * KV_PAGE_TOKENS + t) * 128 + i] = ksn[i];
-      vd[(int64_t)i * KV_PAGE_TOKENS + v_slot(t)] = vsn[i];
+      kd[kpage_elem(t, i, 4)] = ksn[i];
+      vd[vpage_elem(t, i)] = vsn[i];
     }
   }
 
@@ -112,7 +157,17 @@ __device__ __forceinline__ bool attn_decode_fused_body_t(const AttnDecodeFusedAr
 #pragma unroll
   for (int i = 0; i < 8; ++i) o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  while (page < npages) {
+  // One page of this unit.  MORE (compile time): the unit has another page after this one -- its K is requested right
+  // after QK^T and its V right after P.V, unconditionally, so the register buffers are plain loop-carried values (a
+  // run-time `if (more) load` makes them phis that the compiler resolves with copies and a vmcnt(0) at the loop end).
+  auto do_page = [&](auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    uint64_t nb = 0;
+    if (MORE) {
+      ++it;
+      if ((it & 63) == 0) fetch_page_ptrs(it);  // > 64 pages per unit: next batch of pointers (contexts beyond 1 M tokens)
+      nb = page_base(it);
+    }
     f32x4_t st[4];
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
@@ -120,6 +175,9 @@ __device__ __forceinline__ bool attn_decode_fused_body_t(const AttnDecodeFusedAr
 #pragma unroll
       for (int k4 = 0; k4 < 4; ++k4) st[sub] = mfma16(as_frag(kf[sub][k4]), qf[k4], st[sub]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (MORE) load_k(nb);   // K of the unit's next page: in flight during softmax + P.V of this one
+    __builtin_amdgcn_sched_barrier(0);
     float alpha;
     bf16x8_t pf[2];
     const int t0 = page * KV_PAGE_TOKENS;
@@ -130,8 +188,14 @@ __device__ __forceinline__ bool attn_decode_fused_body_t(const AttnDecodeFusedAr
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) o[ds] = mfma16(as_frag(vf[ds][kk]), pf[kk], o[ds]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (MORE) load_v(nb);   // V of the next page: in flight during its QK^T and softmax
+    __builtin_amdgcn_sched_barrier(0);
     page += nunits;
-    if (page < npages) load_page(page);
+  };
+  if (page < npages) {
+    while (page + nunits < npages) do_page(std::true_type{});
+    do_page(std::false_type{});
   }
   stamp(2);
   if (unit == 0) {  // the new token: score from LDS, one more online-softmax step
@@ -166,7 +230,7 @@ __device__ __forceinline__ bool attn_decode_fused_body_t(const AttnDecodeFusedAr
       mlz[wave * 16 + c] = l;
     }
   }
-  sync();
+  __syncthreads();
   const bool single = nsplit == 1;
   for (int it = tid; it < g * 128; it += NT) {
     const int q = it >> 7, d = it & 127;
@@ -182,8 +246,8 @@ __device__ __forceinline__ bool attn_decode_fused_body_t(const AttnDecodeFusedAr
       ls = fmaf(wt, mlz[w * 16 + q], ls);
     }
     const int head = kvhd * g + q;
-    if (single) {  // the whole cache went through this block: normalise and emit the attention output tensor (bf16)
-      emit(head, d, acc * (1.0f / ls));
+    if (single) {  // the whole cache went through this block: normalise and write the attention output tensor (bf16)
+      ((bf16_t*)a.o)[head * 128 + d] = f2bf(acc * (1.0f / ls));
     } else {
       act_stf<true>(a.part_o + ((int64_t)split * a.nh + head) * 128 + d, acc);
       if (d == 0) {
@@ -199,63 +263,67 @@ __device__ __forceinline__ bool attn_decode_fused_body_t(const AttnDecodeFusedAr
   stamp(3);
 
   // ---- the LAST split block of this kv head to finish merges all splits of its g heads --------------------------------
-  // Partials cross blocks (possibly XCDs) inside one launch: agent-scope stores above, every wave waits for their
-  // acknowledgement, then one relaxed atomic per block on the head's counter decides who arrived last.
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-  sync();
+  // Partials cross blocks (possibly XCDs) inside one launch: write-through (agent-scope) stores above, every wave waits for
+  // their acknowledgement, then one relaxed atomic per block on the head's counter decides who arrived last; the reader
+  // uses agent-scope loads (no fence needed on either side: cdna guide G16 R1, sc1 payload both sides).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   int* s_last = reinterpret_cast<int*>(qs);  // q fragments are in registers since the page loop; LDS region is free
   if (tid == 0) {
     const unsigned prev = __hip_atomic_fetch_add(a.head_ctr + 32 * kvhd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *s_last = (prev + 1u == a.ctr_target) ? 1 : 0;
   }
-  sync();
+  __syncthreads();
   stamp(4);
   if (*s_last == 0) return false;
-  for (int it = tid; it < g * 128; it += NT) {
-    const int q = it >> 7, d = it & 127;
-    const int head = kvhd * g + q;
-    float M = -INFINITY, ls = 0.f, f = 0.f;
-    // 8 splits per round, all 16 loads of a round issued before any is used; running (M, ls, f) rescaled between rounds
-    for (int s0 = 0; s0 < nsplit; s0 += 8) {
-      float2 ml[8];
-      float po[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int sidx = min(s0 + j, nsplit - 1);
-        const size_t hb = (size_t)sidx * a.nh + head;
-        ml[j] = act_ldf2<true>(a.part_ml + hb * 2);
-        po[j] = act_ldf<true>(a.part_o + hb * 128 + d);
-        if (s0 + j >= nsplit) ml[j].x = -INFINITY;
-      }
-      float Mc = M;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) Mc = fmaxf(Mc, ml[j].x);
-      if (Mc == -INFINITY) continue;
-      const float resc = (M == -INFINITY) ? 0.f : __expf(M - Mc);
-      ls *= resc;
-      f *= resc;
-      M = Mc;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float wgt = (ml[j].x == -INFINITY) ? 0.f : __expf(ml[j].x - M);
-        ls = fmaf(wgt, ml[j].y, ls);
-        f = fmaf(wgt, po[j], f);
+  // Weights first, through LDS: the (max, sum) pairs of all splits of the g heads are read ONCE by the block (one load per
+  // thread per 256 pairs), every thread derives the global max and the split weights of its head from LDS, and then its
+  // nsplit partial values are independent loads -- issued 16 at a time with nothing between them but the FMA chain.  (The
+  // previous form re-read the pairs per thread and rescaled round by round: nsplit/8 dependent round trips, ~1 us each.)
+  float* w_lds = mo;            // [g][nsplit] weights  (the per-wave O^T staging area is free again)
+  float* inv_lds = mo + 16 * 256;  // [g] 1 / sum
+  {
+    float2* ml_lds = reinterpret_cast<float2*>(mo + 8 * 256);  // [g][nsplit] (max, sum)
+    for (int i = tid; i < g * nsplit; i += NT) {
+      const int q = i / nsplit, sidx = i - q * nsplit;
+      ml_lds[i] = act_ldf2<true>(a.part_ml + ((size_t)sidx * a.nh + kvhd * g + q) * 2);
+    }
+    __syncthreads();
+    if (tid < g * 64) {  // one wave per head (g <= 16 heads, 4 waves: loop)
+      for (int q = wave; q < g; q += NW) {
+        float M = -INFINITY;
+        for (int sidx = lane; sidx < nsplit; sidx += 64) M = fmaxf(M, ml_lds[q * nsplit + sidx].x);
+        M = wave_max(M);
+        float ls = 0.f;
+        for (int sidx = lane; sidx < nsplit; sidx += 64) {
+          const float2 v = ml_lds[q * nsplit + sidx];
+          const float wgt = (v.x == -INFINITY) ? 0.f : __expf(v.x - M);
+          w_lds[q * nsplit + sidx] = wgt;
+          ls = fmaf(wgt, v.y, ls);
+        }
+        ls = wave_sum(ls);
+        if (lane == 0) inv_lds[q] = 1.0f / ls;
       }
     }
-    emit(head, d, f * (1.0f / ls));  // attention output tensor (rounded to bf16 by the receiver)
+    __syncthreads();
+  }
+  for (int it2 = tid; it2 < g * 128; it2 += NT) {
+    const int q = it2 >> 7, d = it2 & 127;
+    const int head = kvhd * g + q;
+    const float* wq = w_lds + q * nsplit;
+    float f = 0.f;
+    for (int s0 = 0; s0 < nsplit; s0 += 16) {
+      float po[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) po[j] = act_ldf<true>(a.part_o + ((size_t)min(s0 + j, nsplit - 1) * a.nh + head) * 128 + d);
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (s0 + j < nsplit) f = fmaf(wq[s0 + j], po[j], f);
+    }
+    ((bf16_t*)a.o)[head * 128 + d] = f2bf(f * inv_lds[q]);  // attention output tensor
   }
   stamp(5);
   return true;
-}
-
-// The whole-workgroup form used by attn_decode_fused_kernel and the persistent decode-step kernel: 4 waves, __syncthreads,
-// output written to a.o as bf16.
-template <bool COH, class AfterPrefetch>
-__device__ __forceinline__ bool attn_decode_fused_body(const AttnDecodeFusedArgs& a, char* smem, const int kvhd, const int split,
-                                                       const int nsplit, AfterPrefetch&& after_prefetch) {
-  return attn_decode_fused_body_t<COH, 4>(
-      a, smem, kvhd, split, nsplit, (int)(threadIdx.x >> 6), (int)threadIdx.x, after_prefetch, [] { __syncthreads(); },
-      [&](int head, int d, float v) { act_st_bf<COH>((bf16_t*)a.o + head * 128 + d, f2bf(v)); });
 }
 
 }  // namespace aha

@@ -85,6 +85,13 @@ __device__ __forceinline__ u32x4_t ld_nt16(const void* p) {
   return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
 }
 __device__ __forceinline__ u32x4_t ld16(const void* p) { return *reinterpret_cast<const u32x4_t*>(p); }
+// The same for an address that did not come from a kernel argument (KV page pointers are 64-bit integers read from the page
+// table): without the explicit global address space the compiler emits flat_load, which it cannot count (flat may complete
+// out of order with LDS traffic), so every wait becomes vmcnt(0) lgkmcnt(0) and a software pipeline collapses.
+typedef const __attribute__((address_space(1))) u32x4_t* gptr16_t;
+__device__ __forceinline__ u32x4_t ld_nt16_global(uint64_t addr) {
+  return __builtin_nontemporal_load(reinterpret_cast<gptr16_t>(addr));
+}
 
 // ---- activation traffic inside the persistent decode kernel --------------------------------------------------------
 // Blocks on different XCDs exchange activations between grid barriers.  The 8 XCD L2s are not coherent with each other
@@ -135,12 +142,31 @@ __device__ __forceinline__ void act_stf(float* p, float v) {
 
 constexpr int KV_PAGE_TOKENS = 64;  // tokens per KV page
 
-// Slot of token t (0..63) inside a V page row.  The V block is dim-major [d][64] and its 64 token slots are permuted
+// Slot of token t (0..63) inside a V page.  Per dim the 64 token slots of a page are permuted
 // so that the 8 tokens one MFMA lane group needs for the P.V step (two 4-token runs that come out of the S^T = K.Q^T
 // accumulator fragments of token sub-tiles 2kk and 2kk+1) are 16 contiguous bytes: t = kk*32 + sub1*16 + G*4 + j
 // lives at slot kk*32 + G*8 + sub1*4 + j.
 __host__ __device__ __forceinline__ int v_slot(int t) {
   return (t & 32) | (((t >> 2) & 3) << 3) | (((t >> 4) & 1) << 2) | (t & 3);
+}
+
+// ---- KV page layout: FRAGMENT-MAJOR ------------------------------------------------------------------------------------------
+// One kv head's share of a page is stored as the MFMA operand fragments themselves, each a contiguous 1 KB block whose 16-byte
+// piece l is exactly what lane l (G = l >> 4, c = l & 15) of a wave feeds v_mfma_f32_16x16x32_bf16:
+//   K block (4 * KS fragments, KS = padded head dim / 32): fragment (sub, k4) = tokens sub*16.., dims k4*32..;
+//       piece l = dims k4*32 + G*8 .. +8 of token sub*16 + c
+//   V block (2 * DS fragments, DS = padded head dim / 16): fragment (ds, kk) = dims ds*16.., token slots kk*32..;
+//       piece l = slots kk*32 + G*8 .. +8 (v_slot order) of dim ds*16 + c
+// A wave-wide 16-byte-per-lane load of a fragment is 1 KB contiguous = 8 whole 128-byte lines.  With token-major K rows /
+// dim-major V rows the same load touched 16 rows x 64 B -- half lines, twice the address work per byte in the CU's memory
+// pipeline -- and the decode attention kernel streamed at 4.5 TB/s instead of 5.5 (131 k context, measured A/B).
+// Element index (in bf16 elements from the head's block start):
+__host__ __device__ __forceinline__ int kpage_elem(int t, int e, int KS) {
+  return ((((t >> 4) * KS + (e >> 5)) * 64 + ((e >> 3) & 3) * 16 + (t & 15)) << 3) + (e & 7);
+}
+__host__ __device__ __forceinline__ int vpage_elem(int t, int e) {
+  const int s = v_slot(t);
+  return ((((e >> 4) * 2 + (s >> 5)) * 64 + ((s >> 3) & 3) * 16 + (e & 15)) << 3) + (s & 7);
 }
 
 }  // namespace aha

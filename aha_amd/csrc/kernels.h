@@ -7,8 +7,8 @@
 namespace aha {
 
 // Paged KV cache view of ONE layer.  Page p of this layer lives at page_ptrs[p] + layer_off (bytes):
-//   K block  [kvh][KV_PAGE_TOKENS][d]   token-major   (QK^T operand rows are contiguous 2*d bytes)
-//   V block  [kvh][d][KV_PAGE_TOKENS]   dim-major     (P.V operand rows are contiguous in tokens)
+//   K block  [kvh][KV_PAGE_TOKENS * d]   fragment-major (common.h kpage_elem): the QK^T MFMA operand fragments, 1 KB each
+//   V block  [kvh][d * KV_PAGE_TOKENS]   fragment-major (common.h vpage_elem): the P.V operand fragments, slot-permuted
 struct KvLayer {
   const uint64_t* page_ptrs;  // device array, byte addresses of each logical page's layer-0 storage
   uint64_t layer_off;         // byte offset of this layer inside a page's slab slot
@@ -99,12 +99,11 @@ struct AttnDecodeFusedArgs {
   const void* qkv;          // ((nh+2kvh)*128) bf16: output of the fused QKV matvec
   const void* q_norm_w;     // (128) bf16
   const void* k_norm_w;
-  const int32_t* pos;       // (3) rope positions T,H,W of the token
-  const float* inv_freq;    // (64)
-  const int32_t* axis_map;  // (64)
+  const float* rope;        // (128) f32: cos[64], sin[64] of the step's rope angles, already rounded to bf16 values
+                            // (rope_step_kernel: once per step instead of once per layer and block)
   KvLayer kv;
-  const int32_t* kv_start;  // device scalar: cache slot of the token
-  const int32_t* kv_len;    // device scalar: cache length after the append (= kv_start + 1)
+  int kv_start_v;           // cache slot of the token (host value: the step is enqueued with its lengths known)
+  int kv_len_v;             // cache length after the append (= kv_start_v + 1)
   float* part_o;            // (nsplit, nh, 128) f32
   float* part_ml;           // (nsplit, nh, 2) f32
   void* o;                  // (nh*128) bf16 attention output
@@ -155,84 +154,10 @@ struct GemmWorkspaceScope {
 // x[i] = bf16(x[i] + bf16(sum[i])): Linear output tensor (all-reduced f32 partials) -> bf16, then the residual add -> bf16
 void launch_residual_add_f32(void* x, const float* sum, int64_t n, hipStream_t st);
 
-// ---- persistent decode-step kernel (decode_mega.hip) ----------------------------------------------------------------
 struct StepState;  // model.h
-struct DecodeLayerDev {
-  const void *wqkv, *wo, *wgu, *wdown, *in_norm, *post_norm, *q_norm, *k_norm;
-  uint64_t kv_layer_off;  // byte offset of the layer inside a KV page slot
-};
-struct DecodeMegaArgs {
-  const DecodeLayerDev* layers;  // device array
-  int n_layers;
-  const void* embed;             // (vocab, H) bf16
-  const StepState* state;        // device: token, rope positions, cache slot / length of this step
-  void* x;                       // (H) bf16 residual stream
-  void* qkv;                     // ((nh + 2 kvh) * 128) bf16
-  void* act;                     // (I) bf16
-  float* part_o;                 // (nsplit, nh, 128) f32 attention partials
-  float* part_ml;                // (nsplit, nh, 2) f32
-  void* attn;                    // (nh*128) bf16 attention output
-  unsigned head_ctr_target;      // see AttnDecodeFusedArgs::ctr_target
-  const float* inv_freq;
-  const int32_t* axis_map;
-  const uint64_t* page_ptrs;
-  const void* final_norm;
-  const void* lm_head;
-  float* logits;
-  float* blk_max;                // (grid) argmax partials
-  uint32_t* blk_idx;
-  void* h_out;                   // (H) bf16: final-norm output (debug_last_hidden)
-  int H, I, nh, kvh, vocab, nsplit;
-  float eps, scale;
-  unsigned* bar;                 // grid-barrier words (DECODE_MEGA_BAR_BYTES, zeroed once; layout in decode_mega.hip)
-  unsigned bar_done0;            // barriers completed by all previous launches
-  unsigned long long* trace;     // optional (AHA_MEGA_TRACE): [4 blocks][phases][3] 100 MHz timestamps: start, past wait, done
-};
-constexpr size_t DECODE_MEGA_BAR_BYTES = 32768;
-constexpr int DECODE_MEGA_BAR_ERR_WORD = 32;
+// words the fused decode attention synchronises through (zeroed once at model creation, monotonic afterwards)
+constexpr size_t DECODE_SYNC_BYTES = 32768;
 constexpr int DECODE_HEAD_CTR_WORD = 6144;  // + 32 * kv head: split-arrival counters of the fused decode attention
-constexpr int DECODE_AO_CTR_WORD = 2048;  // arrival counter of the attention + o_proj launch (monotonic)
-// barriers one launch passes: the host advances bar_done0 by this
-inline int decode_mega_barriers(int n_layers) { return 5 * n_layers; }
-size_t decode_mega_lds_bytes(int H, int I, int nq);
-int decode_mega_max_blocks_per_cu(int H, size_t lds);
-void launch_decode_mega(const DecodeMegaArgs& a, int grid, size_t lds, hipStream_t st);
-// ---- decode chain engine (decode_chain.hip): up to 4 dependent matvecs of one token in one persistent launch ---------
-constexpr int CH_MAX_OPS = 4;
-struct ChainOp {
-  const void* W;             // weight matrix (for GEMV_SILU_MUL the fused gate/up matrix, 16-row blocks interleaved)
-  const void* norm_w;        // optional fused RMSNorm of the input vector
-  const void* in_plain;      // input vector (K bf16) written by an EARLIER launch; nullptr = the previous op's granules
-  const void* res_plain;     // GEMV_RESIDUAL: residual vector from an earlier launch, or nullptr -> res_own_op
-  void* out_plain;           // optional plain bf16 copy of the output vector (read by later launches)
-  unsigned long long* gran;  // optional granule buffer (n_out / 2 x 8 bytes) the op publishes for the next op
-  const unsigned long long* gran_in;  // in_plain == nullptr: granules to gather the input vector from, tagged tag_base + tag_in
-  int tag_in;
-  int n_out, K, kind;        // kind: GEMV_STORE / GEMV_RESIDUAL / GEMV_SILU_MUL
-  int res_own_op;            // GEMV_RESIDUAL without res_plain: index of the earlier op whose rows (same CU) are the residual
-  float eps;
-};
-struct ChainArgs {
-  // optional attention stage in front of op[0] (has_attn): the first attn.kvh * attn.nsplit workgroups run the fused decode
-  // attention with their three consumer waves and publish the output as granules (attn_gran, tag_base + 7) while every
-  // loader already streams op[0]'s weights
-  AttnDecodeFusedArgs attn;
-  unsigned long long* attn_gran;
-  int has_attn;
-  ChainOp op[CH_MAX_OPS];
-  int n_ops;
-  int kmax;                  // longest input vector of the chain (LDS sizing)
-  unsigned tag_base;         // launch-unique: op i publishes granules tagged tag_base + i
-  unsigned* err;             // device word: a bounded wait gave up
-  unsigned long long* trace; // optional timeline (AHA_CHAIN_TRACE)
-  int exact;                 // 1: fmaf consumer (bit-identical to gemv_body.h); 0: v_dot2c_f32_bf16 consumer (faster)
-  int dbg;                   // experiments (AHA_CHAIN_DBG): 1 = consumers skip the dot products, 2 = loader skips the DMA
-};
-size_t decode_chain_lds_bytes(int kmax);
-bool decode_chain_op_ok(int n_out, int K, int kind, int ncu);
-void launch_decode_chain(const ChainArgs& a, int ncu, hipStream_t st);
-
-void launch_attn_oproj(const AttnDecodeFusedArgs& f, const GemvArgs& g, unsigned* sync, unsigned target, hipStream_t st);
 
 }  // namespace aha
 

@@ -6,13 +6,13 @@
 // q head i reads kv head i / g.  Softmax runs online in f32; P feeds the MFMA as bf16.
 //
 // Fragment scheme (v_mfma_f32_16x16x32_bf16, wave64; G = lane>>4, c = lane&15):
-//   S^T tile = K . Q^T :  A = K   (row = token c, k = dims G*8..+8  -> 16 B straight from a token-major K row)
+//   S^T tile = K . Q^T :  A = K   (row = token c, k = dims G*8..+8  -> 16 B piece `lane` of a fragment-major K fragment)
 //                         B = Q^T (col = q row c, k = dims G*8..+8  -> 16 B straight from a q row)
 //                         C[reg] = S[token G*4+reg][q c]            -> softmax statistics are per lane column
-//   O^T tile = V^T . P^T: A = V^T (row = dim c,  k = 8 token slots  -> 16 B from the dim-major, slot-permuted V page)
+//   O^T tile = V^T . P^T: A = V^T (row = dim c,  k = 8 token slots  -> 16 B piece `lane` of a fragment-major V fragment)
 //                         B = P^T (col = q c,    k = the two S^T fragments of token sub-tiles 2kk, 2kk+1, in registers)
 //                         C[reg] = O[q c][dim G*4+reg]
-// so no operand ever needs a transpose or a cross-lane shuffle; see v_slot() in common.h for the V slot permutation.
+// so no operand ever needs a transpose or a cross-lane shuffle; page layout and the V slot permutation: common.h.
 #include <stdlib.h>
 
 #include "attn_decode_body.h"
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
   // read is ds_read_b128 at base + lane * 16 and a staging store is ds_write_b128 at base + tid * 16: both conflict-free.
   // (A padded row-major tile cannot be: the b128 lane groups {0-3, 12-15, 20-27}, ... put rows 0-3,12-15 of chunk G and rows
   // 4-11 of chunk G+1 in one LDS cycle, which collide for every row pitch -- 8 instead of 4 cycles per read, and the ViT
-  // kernel sat at 76 % LDS-busy.)  The global side of the staging copy reads 16 rows x 64 B per wave instruction.
+  // kernel sat at 76 % LDS-busy.)  The KV pages in HBM have the same fragment-major layout, so the staging copy is linear.
   constexpr int KP = KV_PAGE_TOKENS * DQK / 8, VP = DV * KV_PAGE_TOKENS / 8;  // 16-byte pieces
   constexpr int KI = (KP + NT - 1) / NT, VI = (VP + NT - 1) / NT;
   constexpr int STAGE_BYTES = (KP + VP) * 16;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
     for (int i = 0; i < KI; ++i) {
       const int blk = wave + i * NWV;  // fragment block (sub, k4) = (blk / KS, blk % KS)
       if (KP % NT == 0 || blk < KP / 64)
-        rk[i] = ld16(kb + ((blk / KS) * 16 + c) * (DQK * 2) + ((blk % KS) * 4 + G) * 16);
+        rk[i] = ld16(kb + blk * 1024 + lane * 16);   // pages are fragment-major (common.h): 1 KB contiguous per wave load
     }
   };
   auto gload_v = [&](int tile) {
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
     for (int i = 0; i < VI; ++i) {
       const int blk = wave + i * NWV;  // fragment block (ds, kk) = (blk >> 1, blk & 1)
       if (VP % NT == 0 || blk < VP / 64)
-        rv[i] = ld16(vb + ((blk >> 1) * 16 + c) * (KV_PAGE_TOKENS * 2) + ((blk & 1) * 4 + G) * 16);
+        rv[i] = ld16(vb + blk * 1024 + lane * 16);
     }
   };
   auto lstore_k = [&](int stage) {
@@ -246,11 +246,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) kf[sub][k4] = ld_nt16(kb + (size_t)(sub * 16 + c) * 256 + (k4 * 32 + G * 8) * 2);
+      for (int k4 = 0; k4 < 4; ++k4) kf[sub][k4] = ld_nt16(kb + ((sub * 4 + k4) * 64 + lane) * 16);   // fragment-major pages
 #pragma unroll
     for (int ds = 0; ds < 8; ++ds)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) vf[ds][kk] = ld_nt16(vb + (size_t)(ds * 16 + c) * (KV_PAGE_TOKENS * 2) + (kk * 32 + G * 8) * 2);
+      for (int kk = 0; kk < 2; ++kk) vf[ds][kk] = ld_nt16(vb + ((ds * 2 + kk) * 64 + lane) * 16);
 
     f32x4_t st[4];
 #pragma unroll
@@ -333,9 +333,9 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnDecodeArgs
   ((bf16_t*)a.o)[head * 128 + d] = f2bf(acc / lsum);
 }
 
-__global__ __launch_bounds__(256) void attn_decode_fused_kernel(AttnDecodeFusedArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_decode_fused_kernel(AttnDecodeFusedArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[ATTN_DECODE_FUSED_LDS];
-  attn_decode_fused_body<false>(a, smem, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, [] {});
+  attn_decode_fused_body(a, smem, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
 }
 
 }  // namespace

@@ -166,7 +166,7 @@ void launch_sinus_pe_add(void* x, int64_t rows, int d, int T, hipStream_t st) {
 }
 
 // ---- A2 staging: K / V of a fused qkv activation -> attention pages (head_dim hd, multiple of 32) ----------------------
-// K block [nh][64][hd] token-major, V block [nh][hd][64] dim-major with the v_slot permutation (common.h).
+// Fragment-major page blocks (common.h kpage_elem / vpage_elem): K block [nh][64 * hd], V block [nh][hd * 64].
 __global__ __launch_bounds__(256) void kv_pack_generic_kernel(const bf16_t* __restrict__ src, int64_t ld, int k_off, int v_off,
                                                               KvLayer kv, int N, int nh, int hd) {
   const int lane = threadIdx.x & 63;
@@ -175,14 +175,13 @@ __global__ __launch_bounds__(256) void kv_pack_generic_kernel(const bf16_t* __re
   const int n = (int)(wid / nh), h = (int)(wid % nh);
   const int page = n / KV_PAGE_TOKENS, slot = n % KV_PAGE_TOKENS;
   bf16_t* base = reinterpret_cast<bf16_t*>(kv.page_ptrs[page] + kv.layer_off);
-  bf16_t* kd = base + ((int64_t)h * KV_PAGE_TOKENS + slot) * hd;
+  bf16_t* kd = base + (int64_t)h * KV_PAGE_TOKENS * hd;
   bf16_t* vd = base + (int64_t)nh * KV_PAGE_TOKENS * hd + (int64_t)h * hd * KV_PAGE_TOKENS;
   const bf16_t* ks = src + (int64_t)n * ld + k_off + (int64_t)h * hd;
   const bf16_t* vs = src + (int64_t)n * ld + v_off + (int64_t)h * hd;
-  const int sl = v_slot(slot);
   for (int e = lane; e < hd; e += 64) {
-    kd[e] = ks[e];
-    vd[(int64_t)e * KV_PAGE_TOKENS + sl] = vs[e];
+    kd[kpage_elem(slot, e, hd / 32)] = ks[e];
+    vd[vpage_elem(slot, e)] = vs[e];
   }
 }
 void launch_kv_pack_generic(const void* src, int64_t ld, int k_off, int v_off, KvLayer kv, int N, int nh, int hd, hipStream_t st) {

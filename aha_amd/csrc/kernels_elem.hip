@@ -146,13 +146,13 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(RopeArgs a) {
     const int page = tok / KV_PAGE_TOKENS, t = tok % KV_PAGE_TOKENS;
     char* base = reinterpret_cast<char*>(a.kv.page_ptrs[page] + a.kv.layer_off);
     if (is_k) {
-      bf16_t* dst = reinterpret_cast<bf16_t*>(base) + ((int64_t)h * KV_PAGE_TOKENS + t) * 128;
-      dst[lane] = b0;
-      dst[lane + 64] = b1;
+      bf16_t* dst = reinterpret_cast<bf16_t*>(base) + (int64_t)h * KV_PAGE_TOKENS * 128;
+      dst[kpage_elem(t, lane, 4)] = b0;
+      dst[kpage_elem(t, lane + 64, 4)] = b1;
     } else {
       bf16_t* dst = reinterpret_cast<bf16_t*>(base) + (int64_t)a.kvh * KV_PAGE_TOKENS * 128 + (int64_t)h * 128 * KV_PAGE_TOKENS;
-      dst[(int64_t)lane * KV_PAGE_TOKENS + v_slot(t)] = b0;
-      dst[(int64_t)(lane + 64) * KV_PAGE_TOKENS + v_slot(t)] = b1;
+      dst[vpage_elem(t, lane)] = b0;
+      dst[vpage_elem(t, lane + 64)] = b1;
     }
   }
 }
@@ -175,13 +175,13 @@ __global__ __launch_bounds__(256) void kv_pack_pages_kernel(const bf16_t* __rest
   const int page = tok / KV_PAGE_TOKENS, t = tok % KV_PAGE_TOKENS;
   bf16_t* base = reinterpret_cast<bf16_t*>(kv.page_ptrs[page] + kv.layer_off);
   if (!which) {
-    bf16_t* dst = base + ((int64_t)h * KV_PAGE_TOKENS + t) * 128;
-    dst[lane] = src[lane];
-    dst[lane + 64] = src[lane + 64];
+    bf16_t* dst = base + (int64_t)h * KV_PAGE_TOKENS * 128;
+    dst[kpage_elem(t, lane, 4)] = src[lane];
+    dst[kpage_elem(t, lane + 64, 4)] = src[lane + 64];
   } else {
     bf16_t* dst = base + (int64_t)kv.kvh * KV_PAGE_TOKENS * 128 + (int64_t)h * 128 * KV_PAGE_TOKENS;
-    dst[(int64_t)lane * KV_PAGE_TOKENS + v_slot(t)] = src[lane];
-    dst[(int64_t)(lane + 64) * KV_PAGE_TOKENS + v_slot(t)] = src[lane + 64];
+    dst[vpage_elem(t, lane)] = src[lane];
+    dst[vpage_elem(t, lane + 64)] = src[lane + 64];
   }
 }
 void launch_kv_pack_pages(const void* k, const void* v, KvLayer kv, int L, hipStream_t st) {

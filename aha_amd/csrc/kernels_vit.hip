@@ -124,7 +124,6 @@ __global__ __launch_bounds__(256) void vit_rope_pack_kernel(VitRopeArgs a) {
   const int D = a.nh * hd;
   const int page = a.page_of[n], slot = a.slot_of[n];
   bf16_t* pbase = reinterpret_cast<bf16_t*>(a.kv.page_ptrs[page] + a.kv.layer_off);
-  const int vs = v_slot(slot);
   float c = 0.f, s = 0.f;
   if (lane < half) {
     const int pos = (lane < quarter) ? a.rowcol[2 * n] : a.rowcol[2 * n + 1];
@@ -135,7 +134,7 @@ __global__ __launch_bounds__(256) void vit_rope_pack_kernel(VitRopeArgs a) {
   for (int h = h0; h < min(h0 + VIT_HEADS_PER_WAVE, a.nh); ++h) {
     const bf16_t* src = (const bf16_t*)a.qkv + (int64_t)n * 3 * D + (int64_t)h * hd;
     bf16_t* qd = (bf16_t*)a.q_out + ((int64_t)n * a.nh + h) * VIT_DQK;
-    bf16_t* kd = pbase + ((int64_t)h * KV_PAGE_TOKENS + slot) * VIT_DQK;
+    bf16_t* kd = pbase + (int64_t)h * KV_PAGE_TOKENS * VIT_DQK;   // fragment-major K block of the head (common.h kpage_elem)
     bf16_t* vd = pbase + (int64_t)a.nh * KV_PAGE_TOKENS * VIT_DQK + (int64_t)h * VIT_DV * KV_PAGE_TOKENS;
     if (lane < half) {
       const int e = lane;
@@ -145,19 +144,23 @@ __global__ __launch_bounds__(256) void vit_rope_pack_kernel(VitRopeArgs a) {
         const float x0 = bf2f(p[e]), x1 = bf2f(p[e + half]);
         const bf16_t y0 = f2bf(rbf(x0 * c) + rbf(-x1 * s));
         const bf16_t y1 = f2bf(rbf(x1 * c) + rbf(x0 * s));
-        bf16_t* d = which ? kd : qd;
-        d[e] = y0;
-        d[e + half] = y1;
+        if (which) {
+          kd[kpage_elem(slot, e, VIT_DQK / 32)] = y0;
+          kd[kpage_elem(slot, e + half, VIT_DQK / 32)] = y1;
+        } else {
+          qd[e] = y0;
+          qd[e + half] = y1;
+        }
       }
     }
     // zero the pad lanes of q and k rows [hd, VIT_DQK)
     if (lane < VIT_DQK - hd) {
       qd[hd + lane] = 0;
-      kd[hd + lane] = 0;
+      kd[kpage_elem(slot, hd + lane, VIT_DQK / 32)] = 0;
     }
-    // V: dim-major, slot-permuted (common.h v_slot); pad rows [hd, VIT_DV) zero
+    // V: fragment-major (common.h vpage_elem); pad rows [hd, VIT_DV) zero
     const bf16_t* vp = src + 2 * (int64_t)D;
-    for (int e = lane; e < VIT_DV; e += 64) vd[(int64_t)e * KV_PAGE_TOKENS + vs] = (e < hd) ? vp[e] : (bf16_t)0;
+    for (int e = lane; e < VIT_DV; e += 64) vd[vpage_elem(slot, e)] = (e < hd) ? vp[e] : (bf16_t)0;
   }
 }
 void launch_vit_rope_pack(const VitRopeArgs& a, hipStream_t st) {

@@ -78,6 +78,7 @@ struct aha_model {
   // rope constants
   float* d_inv_freq = nullptr;
   int32_t* d_axis_map = nullptr;
+  float* d_rope = nullptr;       // (128) f32: the current decode step's rope cos/sin table (embed_state_kernel)
   float attn_scale = 0.f;
   // paged KV cache
   std::vector<void*> slabs;
@@ -115,25 +116,10 @@ struct aha_model {
   int lm_rows = 0, lm_row0 = 0; // lm_head rows this rank streams (vocab-parallel under TP) and the first of them
   float* d_partial = nullptr;   // decode: (hidden) f32 partial projection; also the 2T-float argmax pair exchange
   float* p_partial = nullptr;   // prefill: (S, hidden) f32
-  // persistent decode-step kernel (decode_mega.hip): one launch per token
-  bool decode_mega = false;
-  bool decode_chain = false;        // o_proj -> gate/up -> down -> next qkv in one persistent launch (decode_chain.hip)
-  int chain_ncu = 0;                // workgroups (= CUs) of the chain launch
-  unsigned chain_tag = 0;           // launch-unique granule tag base
-  unsigned long long* d_gran[4] = {nullptr, nullptr, nullptr, nullptr};  // granule buffers: x1, act, x2, attention output
-  bool decode_ao = false;           // attention + o_proj in one launch (opt-in)
   unsigned head_ctr_base = 0;       // value every kv head's split-arrival counter has reached after all launches so far
-  unsigned ao_base = 0;             // value the attn_oproj arrival counter has reached after all launches so far
-  aha::DecodeLayerDev* d_layers_dev = nullptr;
-  unsigned* d_bar = nullptr;        // grid-barrier words (kernels.h DECODE_MEGA_BAR_BYTES)
-  unsigned* h_bar_err = nullptr;    // pinned copy of the sticky error word
-  unsigned long long* d_mega_trace = nullptr;  // AHA_MEGA_TRACE timeline
+  unsigned* d_bar = nullptr;        // split-arrival counters of the fused decode attention (kernels.h DECODE_SYNC_BYTES)
   unsigned long long* d_gemv_trace = nullptr;  // AHA_GEMV_TRACE timeline
-  unsigned long long* d_chain_trace = nullptr; // AHA_CHAIN_TRACE timeline
   unsigned long long* d_attn_trace = nullptr;  // AHA_ATTN_TRACE timeline
-  unsigned bar_base = 0;            // barriers completed by all launches so far
-  int mega_grid = 0;
-  size_t mega_lds = 0;
   bool decode_fused = true;  // attention block of a decode step in one launch (kernels_attn.hip attn_decode_fused_kernel)
   float* h_logits = nullptr;  // pinned
   bool have_logits = false;   // d_logits holds the logits of a completed forward call

@@ -2,7 +2,7 @@
 //   create      <- Qwen3Model::new                      /root/reference/src/models/qwen3/model.rs:104-134
 //   prefill     <- Qwen3Model::forward_hidden (S > 1)   /root/reference/src/models/qwen3/model.rs:146-189
 //   decode step <- the same with S == 1, mask = None    (generate.rs:135-143 drives it once per token)
-// The KV cache is paged (64-token pages, K token-major / V dim-major, see kernels.h) and must be indistinguishable from
+// The KV cache is paged (64-token pages, K / V blocks fragment-major, see common.h) and must be indistinguishable from
 // the reference's Tensor::cat growth (modules.rs:558-566).
 #include "model.h"
 
@@ -631,71 +631,13 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
   m->d_part_o = (float*)p;
   if ((rc = dev_alloc(m, (size_t)m->max_nsplit * 4 * c.num_attention_heads * 2 * 4, &p))) return fail(rc);
   m->d_part_ml = (float*)p;
+  if ((rc = dev_alloc(m, 128 * 4, &p, true))) return fail(rc);
+  m->d_rope = (float*)p;
 
-  // words the in-kernel synchronisation uses (kernels.h DECODE_MEGA_BAR_BYTES): zeroed once, only ever grow; all accesses
-  // are agent-scope atomics (ordinary device memory: scripts/bench_barrier.hip saw no stale read in either mapping)
-  if ((rc = dev_alloc(m, DECODE_MEGA_BAR_BYTES, &p, true))) return fail(rc);
+  // split-arrival counters of the fused decode attention (kernels.h DECODE_SYNC_BYTES): zeroed once, only ever grow; all
+  // accesses are agent-scope atomics
+  if ((rc = dev_alloc(m, DECODE_SYNC_BYTES, &p, true))) return fail(rc);
   m->d_bar = (unsigned*)p;
-  AHA_HIP_CHECK(hipHostMalloc((void**)&m->h_bar_err, 4));
-  *m->h_bar_err = 0;
-  // attention + o_proj in one launch (decode_mega.hip attn_oproj_kernel): opt-in (AHA_DECODE_AO=1) -- measured 1.5-3%
-  // slower than two launches (profiles/r01_decode_mega_timeline.md)
-  m->decode_ao = false;
-  if (const char* e = getenv("AHA_DECODE_AO")) m->decode_ao = atoi(e) != 0 && m->tp_size == 1 && d == 128 && m->decode_fused;
-  // decode chain engine (decode_chain.hip): o_proj -> gate/up -> down -> next qkv in one persistent launch per layer
-  {
-    bool want = false;
-    if (const char* e = getenv("AHA_DECODE_CHAIN")) want = atoi(e) != 0;
-    want = want && m->tp_size == 1 && d == 128 && m->decode_fused;
-    if (want) {
-      hipDeviceProp_t prop;
-      AHA_HIP_CHECK(hipGetDeviceProperties(&prop, m->ctx->device));
-      const int kmax = std::max(std::max(H, I), nq);
-      for (int ncu = prop.multiProcessorCount; ncu >= 8 && !m->decode_chain; ncu >>= 1) {
-        if (decode_chain_op_ok(H, nq, GEMV_RESIDUAL, ncu) && decode_chain_op_ok(I, H, GEMV_SILU_MUL, ncu) &&
-            decode_chain_op_ok(H, I, GEMV_RESIDUAL, ncu) && decode_chain_op_ok(nq + 2 * nkv, H, GEMV_STORE, ncu) &&
-            decode_chain_lds_bytes(kmax) <= (size_t)160 * 1024) {
-          m->decode_chain = true;
-          m->chain_ncu = ncu;
-        }
-      }
-      if (m->decode_chain) {
-        for (int k = 0; k < 4; ++k) {
-          if ((rc = dev_alloc(m, (size_t)kmax * 4, &p, true))) return fail(rc);
-          m->d_gran[k] = (unsigned long long*)p;
-        }
-        m->chain_tag = 16;
-      }
-    }
-  }
-  // persistent decode-step kernel: resident grid sized by the occupancy the kernel actually gets on this device
-  {
-    // Opt-in (AHA_DECODE_MEGA=1): measured 6-25% SLOWER than the launch-per-op path on MI355X -- see DESIGN.md and
-    // profiles/r01_decode_mega_timeline.md; kept because it is parity-tested and documents where batch-1 decode time goes.
-    bool want = false;
-    if (const char* e = getenv("AHA_DECODE_MEGA")) want = atoi(e) != 0;
-    want = want && m->tp_size == 1 && d == 128 && m->decode_fused;
-    if (want) {
-      m->mega_lds = decode_mega_lds_bytes(H, I, nq);
-      hipDeviceProp_t prop;
-      AHA_HIP_CHECK(hipGetDeviceProperties(&prop, m->ctx->device));
-      const int per_cu = decode_mega_max_blocks_per_cu(H, m->mega_lds);
-      if (per_cu >= 1) {
-        m->mega_grid = std::min(512, std::min(per_cu, 2) * prop.multiProcessorCount);
-        if (const char* e = getenv("AHA_MEGA_GRID")) m->mega_grid = std::min(atoi(e), per_cu * prop.multiProcessorCount);
-        std::vector<DecodeLayerDev> hl(c.num_hidden_layers);
-        for (int li = 0; li < c.num_hidden_layers; ++li) {
-          const LayerWeights& L = m->layers[li];
-          hl[li] = DecodeLayerDev{L.wqkv, L.wo, L.wgu, L.wdown, L.in_norm, L.post_norm, L.q_norm, L.k_norm,
-                                  (uint64_t)li * m->layer_stride};
-        }
-        if ((rc = dev_alloc(m, hl.size() * sizeof(DecodeLayerDev), &p))) return fail(rc);
-        m->d_layers_dev = (DecodeLayerDev*)p;
-        AHA_HIP_CHECK(hipMemcpy(p, hl.data(), hl.size() * sizeof(DecodeLayerDev), hipMemcpyHostToDevice));
-        m->decode_mega = m->mega_grid >= c.num_key_value_heads;
-      }
-    }
-  }
 
   if (c.arch == AHA_ARCH_QWEN3VL) {
     if ((rc = vision_create(m, w, nw))) return fail(rc);
@@ -722,7 +664,6 @@ void model_destroy(aha_model* m) {
   if (m->h_state) hipHostFree(m->h_state);
   if (m->h_logits) hipHostFree(m->h_logits);
   if (m->h_samp) hipHostFree(m->h_samp);
-  if (m->h_bar_err) hipHostFree(m->h_bar_err);
   delete m;
 }
 
@@ -809,82 +750,7 @@ static void enqueue_lm_head(aha_model* m, const void* x_last) {
   launch_argmax_pick(m->d_partial, m->tp_size, &m->d_state->next_token, m->stream);
 }
 
-// The persistent decode kernel's grid barrier gave up (a block was not scheduled or died): report instead of hanging, and
-// fall back to the multi-kernel path for the rest of the model's life.
-static int mega_check(aha_model* m) {
-  if (*m->h_bar_err == 0) return AHA_OK;
-  m->decode_mega = false;
-  m->decode_ao = false;
-  m->decode_chain = false;
-  *m->h_bar_err = 0;
-  hipMemsetAsync(m->d_bar, 0, DECODE_MEGA_BAR_BYTES, m->stream);
-  m->bar_base = 0;
-  m->ao_base = 0;
-  m->head_ctr_base = 0;
-  set_error("decode: an in-kernel wait timed out (results of this call are invalid); "
-            "falling back to one launch per op");
-  return AHA_ERR_HIP;
-}
-
-// AHA_MEGA_TRACE=1: per phase kind, averaged over layers, for 4 sample blocks (microseconds; clock = 100 MHz):
-// wait = phase start -> barrier passed, work = barrier passed -> compute done, gap = done -> next phase start
 static void gemv_trace_dump(aha_model* m);
-static void chain_trace_dump(aha_model* m) {
-  const int L = m->desc.num_hidden_layers;
-  const size_t LS = 2 * CH_MAX_OPS * 5 + 64;
-  std::vector<unsigned long long> t((size_t)L * LS);
-  if (hipMemcpy(t.data(), m->d_chain_trace, t.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
-  static const char* names[4] = {"o_proj", "gate_up", "down", "qkv"};
-  for (int b = 0; b < 2; ++b) {
-    fprintf(stderr, "[chain trace] block %d (times relative to the loader's first issue, us; avg over layers):", b);
-    for (int oi = 0; oi < 4; ++oi) {
-      double v[5] = {};
-      int n = 0;
-      for (int li = 1; li + 1 < L; ++li) {
-        const unsigned long long* p = t.data() + (size_t)li * LS + ((size_t)b * CH_MAX_OPS + oi) * 5;
-        const unsigned long long t0 = t[(size_t)li * LS + (size_t)b * CH_MAX_OPS * 5];
-        if (p[0] == 0 || p[4] == 0) continue;
-        for (int k = 0; k < 5; ++k) v[k] += (double)(p[k] - t0) * 0.01;
-        ++n;
-      }
-      if (n) fprintf(stderr, " %s: load %.1f-%.1f gathered %.1f normed %.1f done %.1f |", names[oi], v[0] / n, v[1] / n, v[2] / n, v[3] / n, v[4] / n);
-    }
-    fprintf(stderr, "\n");
-  }
-  {  // consumer wave 1 of block 0, gate_up, layer 3: per slot [wait for landed, compute]
-    const unsigned long long* q = t.data() + (size_t)3 * LS + 2 * CH_MAX_OPS * 5;
-    fprintf(stderr, "[chain trace] gate_up consumer 0 slots (wait us / compute us):");
-    for (int i = 0; i < 16; ++i)
-      fprintf(stderr, " %.2f/%.2f(+%.2f)", (double)(q[i * 3 + 1] - q[i * 3]) * 0.01, (double)(q[i * 3 + 2] - q[i * 3 + 1]) * 0.01,
-              i + 1 < 16 ? (double)(q[(i + 1) * 3] - q[i * 3 + 2]) * 0.01 : 0.0);
-    fprintf(stderr, "\n");
-  }
-}
-static void mega_trace_dump(aha_model* m) {
-  const int L = m->desc.num_hidden_layers, np = 5 * L + 1;
-  std::vector<unsigned long long> t((size_t)4 * np * 3);
-  if (hipMemcpy(t.data(), m->d_mega_trace, t.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
-  static const char* names[5] = {"qkv", "attn", "o_proj", "gate_up", "down"};
-  for (int b = 0; b < 4; ++b) {
-    const unsigned long long* tb = t.data() + (size_t)b * np * 3;
-    fprintf(stderr, "[mega trace] block slot %d: total %.1f us |", b, (tb[(np - 1) * 3 + 2] - tb[0]) * 0.01);
-    for (int k = 0; k < 5; ++k) {
-      double w = 0, c = 0, g = 0;
-      int n = 0;
-      for (int li = 0; li < L; ++li) {
-        const unsigned long long* p = tb + (size_t)(li * 5 + k) * 3;
-        if (p[0] == 0 || p[2] == 0) continue;  // block had no unit in this phase (attention)
-        w += (p[1] - p[0]) * 0.01;
-        c += (p[2] - p[1]) * 0.01;
-        g += ((p[3] ? p[3] : p[6]) - p[2]) * 0.01;
-        ++n;
-      }
-      if (n) fprintf(stderr, " %s wait %.2f work %.2f gap %.2f |", names[k], w / n, c / n, g / n);
-    }
-    const unsigned long long* p = tb + (size_t)(np - 1) * 3;
-    fprintf(stderr, " lm_head wait %.2f work %.2f\n", (p[1] - p[0]) * 0.01, (p[2] - p[1]) * 0.01);
-  }
-}
 
 // vocab-parallel lm_head: every rank zeroes the slices it does not own and the all-reduce assembles the full vector
 static int assemble_logits(aha_model* m) {
@@ -909,12 +775,8 @@ static int fetch_outputs(aha_model* m, float* logits_out, uint32_t* argmax_out) 
   }
   if (logits_out) AHA_HIP_CHECK(hipMemcpyAsync(m->h_logits, m->d_logits, (size_t)c.vocab_size * 4, hipMemcpyDeviceToHost, m->stream));
   AHA_HIP_CHECK(hipMemcpyAsync(&m->h_state->next_token, &m->d_state->next_token, 4, hipMemcpyDeviceToHost, m->stream));
-  if (m->decode_mega || m->decode_ao || m->decode_chain) AHA_HIP_CHECK(hipMemcpyAsync(m->h_bar_err, m->d_bar + DECODE_MEGA_BAR_ERR_WORD, 4, hipMemcpyDeviceToHost, m->stream));
   AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
-  if (int e = mega_check(m)) return e;
-  if (m->d_mega_trace) mega_trace_dump(m);
   if (m->d_gemv_trace) gemv_trace_dump(m);
-  if (m->d_chain_trace) chain_trace_dump(m);
   if (m->d_attn_trace) {
     const int L = m->desc.num_hidden_layers;
     std::vector<unsigned long long> t((size_t)L * 12);
@@ -986,10 +848,20 @@ static int gemm_row_parallel(aha_model* m, GemmArgs g) {
 }
 
 // ---- decode: one token through all layers; every length-dependent value is read from d_state on the device ----
-__global__ void embed_state_kernel(const bf16_t* __restrict__ table, const StepState* __restrict__ st, bf16_t* __restrict__ out, int H) {
+// First kernel of a decode step: the token's embedding row (Qwen3Model::embedding_token_id, qwen3/model.rs:191-193) and
+// the step's rope table -- cos/sin of pos[axis]*inv_freq, cast to the model dtype as apply_rotary_pos_emb does
+// (rope.rs:96-132, 454-476), computed ONCE per step here instead of once per layer and block in the attention kernel.
+__global__ void embed_state_kernel(const bf16_t* __restrict__ table, const StepState* __restrict__ st, bf16_t* __restrict__ out, int H,
+                                   const float* __restrict__ inv_freq, const int32_t* __restrict__ axis_map, float* __restrict__ rope) {
   const u32x4_t* src = reinterpret_cast<const u32x4_t*>(table + (size_t)st->token * H);
   u32x4_t* dst = reinterpret_cast<u32x4_t*>(out);
   for (int i = threadIdx.x + blockIdx.x * blockDim.x; i < H / 8; i += blockDim.x * gridDim.x) dst[i] = src[i];
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    const int i = threadIdx.x;
+    const float ang = (float)st->pos[axis_map[i]] * inv_freq[i];
+    rope[i] = rbf(cosf(ang));
+    rope[64 + i] = rbf(sinf(ang));
+  }
 }
 __global__ void advance_state_kernel(StepState* st, uint32_t* token_log) {
   const uint32_t t = st->next_token;
@@ -1050,46 +922,10 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
   const int H = c.hidden_size, I = c.intermediate_size, d = c.head_dim, nh = c.num_attention_heads, kvh = c.num_key_value_heads;
   const int nq = nh * d, nkv = kvh * d;
   hipStream_t st = m->stream;
-  if (m->decode_mega) {
-    const int npg = (int)((kv_len_after + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS);
-    DecodeMegaArgs a{};
-    a.layers = m->d_layers_dev; a.n_layers = c.num_hidden_layers; a.embed = m->embed; a.state = m->d_state;
-    a.x = m->d_x; a.qkv = m->d_qkv; a.act = m->d_act; a.part_o = m->d_part_o; a.part_ml = m->d_part_ml; a.attn = m->d_attn;
-    a.inv_freq = m->d_inv_freq; a.axis_map = m->d_axis_map; a.page_ptrs = m->d_page_ptrs;
-    a.final_norm = m->final_norm; a.lm_head = m->lm_head; a.logits = m->d_logits; a.blk_max = m->d_blk_max;
-    a.blk_idx = m->d_blk_idx; a.h_out = m->d_hlast;
-    a.H = H; a.I = I; a.nh = nh; a.kvh = kvh; a.vocab = c.vocab_size;
-    a.nsplit = std::max(1, std::min(std::min((npg + 3) / 4, m->max_nsplit), m->mega_grid / kvh));
-    a.eps = c.rms_norm_eps; a.scale = m->attn_scale;
-    a.bar = m->d_bar; a.bar_done0 = m->bar_base;
-    static const char* e_trace = getenv("AHA_MEGA_TRACE");
-    if (e_trace && atoi(e_trace)) {
-      const size_t nb = (size_t)4 * (5 * c.num_hidden_layers + 1) * 3 * 8;
-      if (!m->d_mega_trace) {
-        void* tp = nullptr;
-        if (dev_alloc(m, nb, &tp, true) == AHA_OK) m->d_mega_trace = (unsigned long long*)tp;
-      }
-      a.trace = m->d_mega_trace;
-    }
-    static const char* e_ns = getenv("AHA_MEGA_NSPLIT_MAX");
-    if (e_ns) a.nsplit = std::max(1, std::min(a.nsplit, atoi(e_ns)));
-    a.head_ctr_target = m->head_ctr_base + (unsigned)a.nsplit;  // layer 0's target; layer li adds li * nsplit
-    if (a.nsplit > 1) m->head_ctr_base += (unsigned)(c.num_hidden_layers * a.nsplit);  // a single split never touches it
-    {
-      const double wbytes = (double)c.num_hidden_layers * ((double)(nq + 2 * nkv) * H + (double)H * nq + 3.0 * I * H) * 2 +
-                            (double)c.vocab_size * H * 2;
-      const double kvbytes = (double)c.num_hidden_layers * (double)kv_len_after * 2 * nkv * 2;
-      ProfScope ps(m, "decode_step", wbytes + kvbytes, wbytes + 2 * kvbytes * (nh / kvh));
-      launch_decode_mega(a, m->mega_grid, m->mega_lds, st);
-    }
-    m->bar_base += (unsigned)decode_mega_barriers(c.num_hidden_layers);
-    ProfScope ps(m, "argmax", 0, 0);
-    launch_argmax_partials(m->d_blk_max, m->d_blk_idx, m->mega_grid, &m->d_state->next_token, st);
-    return;
-  }
   {
     ProfScope ps(m, "elem", H * 4.0, 0);
-    hipLaunchKernelGGL(embed_state_kernel, dim3(1), dim3(256), 0, st, (const bf16_t*)m->embed, m->d_state, (bf16_t*)m->d_x, H);
+    hipLaunchKernelGGL(embed_state_kernel, dim3(1), dim3(256), 0, st, (const bf16_t*)m->embed, m->d_state, (bf16_t*)m->d_x, H,
+                       m->d_inv_freq, m->d_axis_map, m->d_rope);
   }
   const int npages = (int)((kv_len_after + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS);
   // KV splits of the fused decode attention: one block (4 waves = 4 KV units) per `div` pages
@@ -1099,9 +935,6 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
   nsplit = std::max(1, std::min(nsplit, m->max_nsplit));
   for (int li = 0; li < c.num_hidden_layers; ++li) {
     const LayerWeights& L = m->layers[li];
-    if (m->decode_chain && li > 0) {
-      // qkv of this layer came out of the previous layer's chain launch
-    } else
     {  // h = RMSNorm(x); qkv = h Wqkv^T                      (qwen3/model.rs:79, modules.rs:538-552)
       GemvArgs g{};
       g.W = L.wqkv; g.x = m->d_x; g.norm_w = L.in_norm; g.eps = c.rms_norm_eps; g.y = m->d_qkv; g.N = nq + 2 * nkv; g.K = H;
@@ -1113,8 +946,8 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
       // q/k norm + rope + KV append + attention over the paged cache (modules.rs:544-574, 757-813), then
       // x = x + attn Wo^T with the KV-split partials merged in the matvec prologue (modules.rs:577, qwen3/model.rs:81)
       AttnDecodeFusedArgs a{};
-      a.qkv = m->d_qkv; a.q_norm_w = L.q_norm; a.k_norm_w = L.k_norm; a.pos = m->d_state->pos; a.inv_freq = m->d_inv_freq;
-      a.axis_map = m->d_axis_map; a.kv = model_kv_layer(m, li); a.kv_start = &m->d_state->kv_start; a.kv_len = &m->d_state->kv_len;
+      a.qkv = m->d_qkv; a.q_norm_w = L.q_norm; a.k_norm_w = L.k_norm; a.rope = m->d_rope;
+      a.kv = model_kv_layer(m, li); a.kv_start_v = (int)kv_len_after - 1; a.kv_len_v = (int)kv_len_after;
       a.part_o = m->d_part_o; a.part_ml = m->d_part_ml; a.nh = nh; a.kvh = kvh; a.nsplit = nsplit; a.eps = c.rms_norm_eps;
       a.scale = m->attn_scale; a.o = m->d_attn; a.head_ctr = m->d_bar + DECODE_HEAD_CTR_WORD;
       if (nsplit > 1) m->head_ctr_base += (unsigned)nsplit;  // a single split never touches the counter
@@ -1132,76 +965,12 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
       g.trace = gemv_trace_slot(m, li * 4 + 1);
       const double attn_bytes = (double)kv_len_after * 2 * nkv * 2 + (nq + 2 * nkv) * 2.0 + nsplit * nq * 4.0;
       const double gemv_bytes = (double)g.N * g.K * 2 + g.K * 2.0 + g.N * 4.0;
-      if (m->decode_chain) {
-        static const char* e_ca = getenv("AHA_CHAIN_ATTN");
-        const bool chain_attn = e_ca ? atoi(e_ca) != 0 : false;  // measured: attention inside the launch is slower (101 vs 98 us/layer)
-        const bool has_next = li + 1 < c.num_hidden_layers;
-        ChainArgs ch{};
-        if (chain_attn) {  // attention inside the chain launch: 3 KV units (waves) per workgroup
-          if (nsplit > 1) m->head_ctr_base -= (unsigned)nsplit;  // undo the 4-wave split count taken above
-          int ns3 = (npages + 2) / 3;
-          ns3 = std::max(1, std::min(std::min(ns3, m->max_nsplit), m->chain_ncu / kvh));
-          a.nsplit = ns3;
-          if (ns3 > 1) m->head_ctr_base += (unsigned)ns3;
-          a.ctr_target = m->head_ctr_base;
-          ch.attn = a;
-          ch.attn_gran = m->d_gran[3];
-          ch.has_attn = 1;
-        } else {
-          ProfScope ps(m, "attn_decode", attn_bytes, 4.0 * kv_len_after * nq);
-          launch_attn_decode_fused(a, st);
-        }
-        ch.n_ops = has_next ? 4 : 3;
-        ch.kmax = std::max(std::max(H, I), nq);
-        m->chain_tag += 8;
-        ch.tag_base = m->chain_tag;
-        ch.err = m->d_bar + DECODE_MEGA_BAR_ERR_WORD;
-        ChainOp& o0 = ch.op[0];  // x1 = x + attn Wo^T                               (modules.rs:577, qwen3/model.rs:81)
-        o0.W = L.wo; o0.in_plain = chain_attn ? nullptr : m->d_attn; o0.gran_in = m->d_gran[3]; o0.tag_in = 7;
-        o0.res_plain = m->d_x; o0.gran = m->d_gran[0];
-        o0.n_out = H; o0.K = nq; o0.kind = GEMV_RESIDUAL; o0.res_own_op = -1; o0.eps = c.rms_norm_eps;
-        ChainOp& o1 = ch.op[1];  // act = silu(h Wg^T) * (h Wu^T), h = RMSNorm(x1)       (qwen3/model.rs:83, modules.rs:81-84)
-        o1.W = L.wgu; o1.norm_w = L.post_norm; o1.gran = m->d_gran[1]; o1.gran_in = m->d_gran[0]; o1.tag_in = 0;
-        o1.n_out = I; o1.K = H; o1.kind = GEMV_SILU_MUL; o1.res_own_op = -1; o1.eps = c.rms_norm_eps;
-        ChainOp& o2 = ch.op[2];  // x2 = x1 + act Wd^T                                (modules.rs:85, qwen3/model.rs:86)
-        o2.W = L.wdown; o2.out_plain = m->d_x; o2.gran = has_next ? m->d_gran[2] : nullptr; o2.gran_in = m->d_gran[1]; o2.tag_in = 1;
-        o2.n_out = H; o2.K = I; o2.kind = GEMV_RESIDUAL; o2.res_own_op = 0; o2.eps = c.rms_norm_eps;
-        double bytes = ((double)H * nq + 3.0 * I * H) * 2;
-        if (has_next) {
-          const LayerWeights& Ln = m->layers[li + 1];
-          ChainOp& o3 = ch.op[3];  // next layer: h = RMSNorm(x2); qkv = h Wqkv^T      (qwen3/model.rs:79, modules.rs:538-552)
-          o3.W = Ln.wqkv; o3.norm_w = Ln.in_norm; o3.out_plain = m->d_qkv; o3.gran_in = m->d_gran[2]; o3.tag_in = 2;
-          o3.n_out = nq + 2 * nkv; o3.K = H; o3.kind = GEMV_STORE; o3.res_own_op = -1; o3.eps = c.rms_norm_eps;
-          bytes += (double)(nq + 2 * nkv) * H * 2;
-        }
-        static const char* e_ct = getenv("AHA_CHAIN_TRACE");
-        if (e_ct && atoi(e_ct)) {
-          if (!m->d_chain_trace) {
-            void* tp = nullptr;
-            if (dev_alloc(m, (size_t)c.num_hidden_layers * (2 * CH_MAX_OPS * 5 + 64) * 8, &tp, true) == AHA_OK) m->d_chain_trace = (unsigned long long*)tp;
-          }
-          if (m->d_chain_trace) ch.trace = m->d_chain_trace + (size_t)li * (2 * CH_MAX_OPS * 5 + 64);
-        }
-        static const char* e_dbg = getenv("AHA_CHAIN_DBG");
-        ch.dbg = e_dbg ? atoi(e_dbg) : 0;
-        static const char* e_exact = getenv("AHA_CHAIN_EXACT");
-        ch.exact = e_exact ? atoi(e_exact) : 0;
-        ProfScope ps(m, "decode_chain", bytes, bytes);
-        launch_decode_chain(ch, m->chain_ncu, st);
-        continue;
+      {
+        ProfScope ps(m, "attn_decode", attn_bytes, 4.0 * kv_len_after * nq);
+        launch_attn_decode_fused(a, st);
       }
-      if (m->decode_ao) {  // one launch: attention blocks signal the o_proj grid through a counter
-        m->ao_base += (unsigned)kvh;
-        ProfScope ps(m, "attn_oproj", attn_bytes + gemv_bytes, 4.0 * kv_len_after * nq + 2.0 * g.N * g.K);
-        launch_attn_oproj(a, g, m->d_bar, m->ao_base, st);
-      } else {
-        {
-          ProfScope ps(m, "attn_decode", attn_bytes, 4.0 * kv_len_after * nq);
-          launch_attn_decode_fused(a, st);
-        }
-        ProfScope ps(m, "gemv", gemv_bytes, 2.0 * g.N * g.K);
-        gemv_row_parallel(m, g);
-      }
+      ProfScope ps(m, "gemv", gemv_bytes, 2.0 * g.N * g.K);
+      gemv_row_parallel(m, g);
     } else {  // three-launch variant (A/B knob AHA_DECODE_FUSED=0)
       {  // q/k norm + rope + append                            (modules.rs:544-566)
         RopeArgs r{};
@@ -1298,10 +1067,8 @@ int model_decode_greedy(aha_model* m, uint32_t first_token, size_t offset, size_
     AHA_HIP_CHECK(hipGetLastError());
     if (m->async_rc) { const int e = m->async_rc; m->async_rc = 0; return e; }
     AHA_HIP_CHECK(hipMemcpyAsync(out + produced, m->d_token_log, n * 4, hipMemcpyDeviceToHost, m->stream));
-    if (m->decode_mega || m->decode_ao || m->decode_chain) AHA_HIP_CHECK(hipMemcpyAsync(m->h_bar_err, m->d_bar + DECODE_MEGA_BAR_ERR_WORD, 4, hipMemcpyDeviceToHost, m->stream));
-    AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
-    if (int e = mega_check(m)) return e;
-    size_t used = n;
+      AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+      size_t used = n;
     for (size_t i = 0; i < n && !stop; ++i)
       for (int e = 0; e < c.n_stop_tokens; ++e)
         if (out[produced + i] == c.stop_tokens[e]) {

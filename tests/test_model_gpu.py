@@ -212,80 +212,6 @@ def test_missing_weight_is_an_error(gpu):
         HipInferenceModel(cfg, w)
 
 
-@pytest.mark.parametrize("shape", ["small", "8b-width"])
-@pytest.mark.parametrize("path", ["attn_oproj", "mega", "chain"])
-def test_decode_fused_launches_equal_launch_per_op(gpu, monkeypatch, shape, path):
-    """The decode paths that synchronise inside a launch -- attention + o_proj in one launch (AHA_DECODE_AO=1) and the
-    persistent decode-step kernel (AHA_DECODE_MEGA=1) -- share their device code with the default launch-per-op path: logits
-    must be BIT-identical at every step, across page boundaries and KV-split counts, and so must the device greedy loop."""
-    from aha_amd.model import HipInferenceModel
-    if shape == "small":
-        cfg, w = make()
-        lens = [1, 62, 200, 700]
-    else:
-        cfg = tiny_qwen3(layers=2, hidden=4096, heads=32, kv_heads=8, inter=12288, vocab=2048, tie=False)
-        w = qwen3_text_weights(cfg, seed=3)
-        lens = [97, 1500]
-    monkeypatch.setenv("AHA_DECODE_MEGA", "0")
-    monkeypatch.setenv("AHA_DECODE_AO", "0")
-    monkeypatch.setenv("AHA_DECODE_CHAIN", "0")
-    multi = HipInferenceModel(cfg, w)
-    monkeypatch.setenv("AHA_DECODE_MEGA", "1" if path == "mega" else "0")
-    monkeypatch.setenv("AHA_DECODE_AO", "1" if path != "chain" else "0")
-    monkeypatch.setenv("AHA_DECODE_CHAIN", "1" if path == "chain" else "0")
-    monkeypatch.setenv("AHA_CHAIN_EXACT", "1")   # the fmaf consumer: same arithmetic as gemv_body.h
-    monkeypatch.setenv("AHA_CHAIN_ATTN", "0")    # attention as its own launch (inside the chain its 3-wave units merge in a different order)
-    mega = HipInferenceModel(cfg, w)
-    for S in lens:
-        ids = ids_for(cfg, S, 100 + S)
-        multi.clear_cache(); mega.clear_cache()
-        a, am = multi.forward_initial(ids, 0)
-        b, bm = mega.forward_initial(ids, 0)
-        np.testing.assert_array_equal(a, b)
-        tok, off = am, S
-        for step in range(5):
-            a, am = multi.forward_step(tok, off)
-            b, bm = mega.forward_step(tok, off)
-            np.testing.assert_array_equal(a, b, err_msg=f"S={S} step {step}")
-            assert am == bm
-            tok, off = am, off + 1
-        ta = multi.decode_greedy(tok, off, 40)
-        tb = mega.decode_greedy(tok, off, 40)
-        assert ta == tb and len(tb) == 40
-    multi.close(); mega.close()
-
-
-@pytest.mark.parametrize("attn_in_chain", ["0", "1"])
-def test_decode_chain_dot2c_consumer_close_to_launch_per_op(gpu, monkeypatch, attn_in_chain):
-    """The chain engine's default configuration: v_dot2c_f32_bf16 consumer (packed bf16 pairs, hardware-internal rounding of
-    the pair sum) and, with attn_in_chain, the attention stage inside the launch (3-wave KV units: another merge order).
-    Not bit-identical, but inside the f32-accumulation tolerance every other cross-kernel comparison uses
-    (max |dlogit| <= 0.05 std, rms <= 0.02 std), at the Qwen3-VL-8B layer width, across KV-split counts."""
-    from aha_amd.model import HipInferenceModel
-    cfg = tiny_qwen3(layers=2, hidden=4096, heads=32, kv_heads=8, inter=12288, vocab=2048, tie=False)
-    w = qwen3_text_weights(cfg, seed=3)
-    monkeypatch.setenv("AHA_DECODE_CHAIN", "0")
-    ref = HipInferenceModel(cfg, w)
-    monkeypatch.setenv("AHA_DECODE_CHAIN", "1")
-    monkeypatch.setenv("AHA_CHAIN_EXACT", "0")
-    monkeypatch.setenv("AHA_CHAIN_ATTN", attn_in_chain)
-    ch = HipInferenceModel(cfg, w)
-    for S in (1, 70, 190, 1500):
-        ids = ids_for(cfg, S, 200 + S)
-        ref.clear_cache(); ch.clear_cache()
-        a, tok = ref.forward_initial(ids, 0)
-        ch.forward_initial(ids, 0)
-        for step in range(6):
-            a, am = ref.forward_step(tok, S + step)
-            b, _ = ch.forward_step(tok, S + step)
-            std = float(a.std())
-            assert np.isfinite(b).all()
-            assert float(np.abs(a - b).max()) <= LOGIT_TOL_STD * std, f"S={S} step {step}"
-            assert float(np.sqrt(((a - b) ** 2).mean())) <= LOGIT_RMS_STD * std
-            tok = am
-    ref.close(); ch.close()
-
-
 def test_many_requests_reuse_pages_deterministically(tiny):
     """A serving loop: 150 requests of random lengths through one handle (clear_cache between them, as the reference's
     generate() does): page pool reuse, chunked growth and the device loop must stay deterministic -- the first request,
@@ -311,3 +237,39 @@ def test_many_requests_reuse_pages_deterministically(tiny):
     np.testing.assert_array_equal(again, ref)
     assert tok2 == tok and m.decode_greedy(tok2, 90, 12) == ref_toks
     m.clear_cache()
+
+
+@pytest.mark.parametrize("shape", ["small", "8b-width"])
+def test_fused_decode_attention_equals_three_launch_variant(gpu, monkeypatch, shape):
+    """The fused decode attention (q/k norm + rope from the per-step table + append + split-KV attention + in-launch merge,
+    attn_decode_fused_kernel) against the three-launch variant (qknorm_rope_kernel, attn_decode_kernel, combine;
+    AHA_DECODE_FUSED=0) across page boundaries and KV-split counts: same arithmetic per token, different merge order of the
+    KV units => within the cross-kernel tolerance, and identical greedy tokens on decisive margins."""
+    from aha_amd.model import HipInferenceModel
+    if shape == "small":
+        cfg, w = make()
+        lens = [1, 62, 64, 200, 700, 3000]
+    else:
+        cfg = tiny_qwen3(layers=2, hidden=4096, heads=32, kv_heads=8, inter=12288, vocab=2048, tie=False)
+        w = qwen3_text_weights(cfg, seed=3)
+        lens = [97, 1500, 9000]
+    monkeypatch.setenv("AHA_DECODE_FUSED", "1")
+    fused = HipInferenceModel(cfg, w)
+    monkeypatch.setenv("AHA_DECODE_FUSED", "0")
+    plain = HipInferenceModel(cfg, w)
+    for S in lens:
+        ids = ids_for(cfg, S, 100 + S)
+        fused.clear_cache(); plain.clear_cache()
+        a, tok = plain.forward_initial(ids, 0)
+        b, _ = fused.forward_initial(ids, 0)
+        np.testing.assert_array_equal(a, b)          # prefill does not touch the decode kernels
+        off = S
+        for step in range(5):
+            a, am = plain.forward_step(tok, off)
+            b, bm = fused.forward_step(tok, off)
+            std = float(a.std())
+            assert np.isfinite(b).all()
+            assert float(np.abs(a - b).max()) <= LOGIT_TOL_STD * std, f"S={S} step {step}"
+            assert float(np.sqrt(((a - b) ** 2).mean())) <= LOGIT_RMS_STD * std
+            tok, off = am, off + 1
+    fused.close(); plain.close()
