@@ -232,27 +232,37 @@ __device__ __forceinline__ bool attn_decode_fused_body(const AttnDecodeFusedArgs
   }
   __syncthreads();
   const bool single = nsplit == 1;
-  for (int it = tid; it < g * 128; it += NT) {
-    const int q = it >> 7, d = it & 127;
+  // one thread per (head, 4 dims): the published partial is ONE 16-byte write-through store per thread (a dword sc1 store is
+  // one fabric write each: ~6x the time per byte of a dwordx4 one)
+  const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(a.part_o, 0, (int)((size_t)nsplit * a.nh * 128 * 4), 0x00020000);
+  for (int item = tid; item < g * 32; item += NT) {
+    const int q = item >> 5, d0 = (item & 31) * 4;
     float M = -INFINITY;
 #pragma unroll
     for (int w = 0; w < NW; ++w) M = fmaxf(M, mm[w * 16 + q]);
-    float acc = 0.f, ls = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, ls = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
       const float mw = mm[w * 16 + q];
       const float wt = (mw == -INFINITY) ? 0.f : __expf(mw - M);
-      acc = fmaf(wt, mo[w * (128 * 16) + d * 16 + q], acc);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fmaf(wt, mo[w * (128 * 16) + (d0 + e) * 16 + q], acc[e]);
       ls = fmaf(wt, mlz[w * 16 + q], ls);
     }
     const int head = kvhd * g + q;
     if (single) {  // the whole cache went through this block: normalise and write the attention output tensor (bf16)
-      ((bf16_t*)a.o)[head * 128 + d] = f2bf(acc * (1.0f / ls));
+      const float inv = 1.0f / ls;
+      uint2 w2;
+      w2.x = pack_bf(acc[0] * inv, acc[1] * inv);
+      w2.y = pack_bf(acc[2] * inv, acc[3] * inv);
+      *reinterpret_cast<uint2*>((bf16_t*)a.o + head * 128 + d0) = w2;
     } else {
-      act_stf<true>(a.part_o + ((int64_t)split * a.nh + head) * 128 + d, acc);
-      if (d == 0) {
-        act_stf<true>(a.part_ml + ((int64_t)split * a.nh + head) * 2 + 0, M);
-        act_stf<true>(a.part_ml + ((int64_t)split * a.nh + head) * 2 + 1, ls);
+      const u32x4_t v = {__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3])};
+      __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_w, (uint32_t)(((size_t)split * a.nh + head) * 128 + d0) * 4, 0, 16 /* sc1 */);
+      if (d0 == 0) {
+        const unsigned long long mlp = ((unsigned long long)__float_as_uint(ls) << 32) | __float_as_uint(M);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.part_ml + ((int64_t)split * a.nh + head) * 2), mlp, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
@@ -276,51 +286,76 @@ __device__ __forceinline__ bool attn_decode_fused_body(const AttnDecodeFusedArgs
   __syncthreads();
   stamp(4);
   if (*s_last == 0) return false;
-  // Weights first, through LDS: the (max, sum) pairs of all splits of the g heads are read ONCE by the block (one load per
-  // thread per 256 pairs), every thread derives the global max and the split weights of its head from LDS, and then its
-  // nsplit partial values are independent loads -- issued 16 at a time with nothing between them but the FMA chain.  (The
-  // previous form re-read the pairs per thread and rescaled round by round: nsplit/8 dependent round trips, ~1 us each.)
-  float* w_lds = mo;            // [g][nsplit] weights  (the per-wave O^T staging area is free again)
+  // The merging block is ONE workgroup, so this phase is bound by how many load instructions it issues and by dependent round
+  // trips to memory (the partials were published write-through: they are in memory, not in any L2).  Hence: 16-byte
+  // write-through-coherent (sc1) buffer loads, one thread per (head, 4 dims) -- nsplit wave-loads per wave instead of
+  // 4 * nsplit -- and ONE round for up to 16 splits: the (max, sum) pairs of all splits of the g heads (shared through LDS)
+  // and the thread's first 16 partial vectors are requested together; the global max, the split weights and 1/sum are
+  // derived from LDS while the vectors are in flight.
+  float* w_lds = mo;               // [g][nsplit] weights  (the per-wave O^T staging area is free again)
   float* inv_lds = mo + 16 * 256;  // [g] 1 / sum
-  {
-    float2* ml_lds = reinterpret_cast<float2*>(mo + 8 * 256);  // [g][nsplit] (max, sum)
-    for (int i = tid; i < g * nsplit; i += NT) {
-      const int q = i / nsplit, sidx = i - q * nsplit;
-      ml_lds[i] = act_ldf2<true>(a.part_ml + ((size_t)sidx * a.nh + kvhd * g + q) * 2);
+  float2* ml_lds = reinterpret_cast<float2*>(mo + 8 * 256);  // [g][nsplit] (max, sum)
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.part_o, 0, (int)((size_t)nsplit * a.nh * 128 * 4), 0x00020000);
+  const int nvec = g * 32;                      // (head, 4-dim group) items of this kv head
+  const uint32_t split_stride = (uint32_t)a.nh * 128 * 4;
+  f32x4_t pv[16];
+  auto load_batch = [&](int item, int s0) {     // partial vectors of splits s0 .. s0 + 15 (clamped) for `item`
+    const uint32_t off = (uint32_t)((kvhd * g + (item >> 5)) * 128 + (item & 31) * 4) * 4;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + (uint32_t)min(s0 + j, nsplit - 1) * split_stride, 0, 16 /* sc1 */);
+      pv[j] = f32x4_t{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
     }
-    __syncthreads();
-    if (tid < g * 64) {  // one wave per head (g <= 16 heads, 4 waves: loop)
-      for (int q = wave; q < g; q += NW) {
-        float M = -INFINITY;
-        for (int sidx = lane; sidx < nsplit; sidx += 64) M = fmaxf(M, ml_lds[q * nsplit + sidx].x);
-        M = wave_max(M);
-        float ls = 0.f;
-        for (int sidx = lane; sidx < nsplit; sidx += 64) {
-          const float2 v = ml_lds[q * nsplit + sidx];
-          const float wgt = (v.x == -INFINITY) ? 0.f : __expf(v.x - M);
-          w_lds[q * nsplit + sidx] = wgt;
-          ls = fmaf(wgt, v.y, ls);
-        }
-        ls = wave_sum(ls);
-        if (lane == 0) inv_lds[q] = 1.0f / ls;
+  };
+  {
+    float2 mlv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {   // g * nsplit <= 1024 (host check): up to 4 pairs per thread
+      const int i = tid + r * NT;
+      const int q = min(i / nsplit, g - 1), sidx = i - (i / nsplit) * nsplit;
+      mlv[r] = act_ldf2<true>(a.part_ml + ((size_t)sidx * a.nh + kvhd * g + q) * 2);
+    }
+    if (tid < nvec) load_batch(tid, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = tid + r * NT;
+      if (i < g * nsplit) ml_lds[i] = mlv[r];
+    }
+  }
+  __syncthreads();
+  for (int q = wave; q < g; q += NW) {  // one wave per head
+    float M = -INFINITY;
+    for (int sidx = lane; sidx < nsplit; sidx += 64) M = fmaxf(M, ml_lds[q * nsplit + sidx].x);
+    M = wave_max(M);
+    float ls = 0.f;
+    for (int sidx = lane; sidx < nsplit; sidx += 64) {
+      const float2 v = ml_lds[q * nsplit + sidx];
+      const float wgt = (v.x == -INFINITY) ? 0.f : __expf(v.x - M);
+      w_lds[q * nsplit + sidx] = wgt;
+      ls = fmaf(wgt, v.y, ls);
+    }
+    ls = wave_sum(ls);
+    if (lane == 0) inv_lds[q] = 1.0f / ls;
+  }
+  __syncthreads();
+  for (int item = tid; item < nvec; item += NT) {
+    const int q = item >> 5;
+    const float* wq = w_lds + q * nsplit;
+    f32x4_t f = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < nsplit; s0 += 16) {
+      if (item != tid || s0 > 0) load_batch(item, s0);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float wgt = (s0 + j < nsplit) ? wq[s0 + j] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[e] = fmaf(wgt, pv[j][e], f[e]);
       }
     }
-    __syncthreads();
-  }
-  for (int it2 = tid; it2 < g * 128; it2 += NT) {
-    const int q = it2 >> 7, d = it2 & 127;
-    const int head = kvhd * g + q;
-    const float* wq = w_lds + q * nsplit;
-    float f = 0.f;
-    for (int s0 = 0; s0 < nsplit; s0 += 16) {
-      float po[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) po[j] = act_ldf<true>(a.part_o + ((size_t)min(s0 + j, nsplit - 1) * a.nh + head) * 128 + d);
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (s0 + j < nsplit) f = fmaf(wq[s0 + j], po[j], f);
-    }
-    ((bf16_t*)a.o)[head * 128 + d] = f2bf(f * inv_lds[q]);  // attention output tensor
+    const float inv = inv_lds[q];
+    uint2 w;
+    w.x = pack_bf(f[0] * inv, f[1] * inv);
+    w.y = pack_bf(f[2] * inv, f[3] * inv);
+    *reinterpret_cast<uint2*>((bf16_t*)a.o + (kvhd * g) * 128 + item * 4) = w;   // attention output tensor (bf16)
   }
   stamp(5);
   return true;

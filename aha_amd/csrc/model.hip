@@ -932,7 +932,7 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
   static const char* e_div = getenv("AHA_ATTN_PAGES_PER_BLOCK");
   const int div = e_div ? std::max(1, atoi(e_div)) : 4;
   int nsplit = (npages + div - 1) / div;
-  nsplit = std::max(1, std::min(nsplit, m->max_nsplit));
+  nsplit = std::max(1, std::min(std::min(nsplit, m->max_nsplit), 1024 / (nh / kvh)));  // g * nsplit <= 1024: LDS tables of the split merge
   for (int li = 0; li < c.num_hidden_layers; ++li) {
     const LayerWeights& L = m->layers[li];
     {  // h = RMSNorm(x); qkv = h Wqkv^T                      (qwen3/model.rs:79, modules.rs:538-552)
