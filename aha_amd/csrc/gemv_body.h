@@ -1,5 +1,4 @@
-// Body of the batch-1 weight-streaming matvec, shared by the stand-alone kernel (kernels_gemv.hip) and the persistent
-// decode-step kernel (decode_mega.hip).  See kernels_gemv.hip for the design notes.
+// Body of the batch-1 weight-streaming matvec (kernels_gemv.hip has the design notes).
 #pragma once
 #include "common.h"
 #include "kernels.h"
@@ -22,7 +21,7 @@ __device__ __forceinline__ int xs_index(int k) {
 // xs: LDS, (ceil(K/512)*512 + 16) floats.  bid/nblk: this block's index in, and the size of, the persistent grid.
 // after_issue() runs once the block's first weight tile has been requested and before anything that depends on the
 // activation vector -- the stand-alone kernel passes a no-op, the persistent kernel waits on its grid barrier there.
-template <int R, int U, int EPI, bool COH, class AfterIssue>
+template <int R, int U, int EPI, bool COH, bool FAST, class AfterIssue>
 __device__ __forceinline__ void gemv_body(const GemvArgs& a, float* xs, const int bid, const int nblk, AfterIssue&& after_issue) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.K, N = a.N;
@@ -40,11 +39,21 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, float* xs, const in
   const bf16_t* Wb = (const bf16_t*)a.W;
   const bf16_t* W2b = (const bf16_t*)a.W2;
 
+  // FAST (K a multiple of 512 * U, non-temporal weights): no per-load predicates at all.  A load under a run-time select
+  // (`ok ? load : 0`) makes hipcc branch around it and wait vmcnt(0) at the join, and a buffer refilled under `if (more)`
+  // becomes a phi resolved with copies + vmcnt(0): the two-buffer pipeline then degenerates to one buffer per wave.  In
+  // the FAST form the steady-state loop refills each buffer unconditionally right after it has been consumed, the waits
+  // are counted (the other buffer's R*U*NW loads stay in flight), and the tile's residual values are requested in FRONT of
+  // the tile's last weight group (in-order return) instead of inside the epilogue, where waiting for them drained the queue.
   // issue the R*U*NW 16-byte loads of work item gi (no dependence on x: they go out BEFORE the prologue)
-  auto issue = [&](int gi, u32x4_t (&buf)[U][NW][R]) {
+  auto issue = [&](int gi, u32x4_t (&buf)[U][NW][R], bf16_t (&resv)[R]) {
     const int tile = bid + (gi / gpt) * nblk;
     const int c0 = (gi % gpt) * U;
     const int row0 = tile * ROWS_PER_TILE + wave * R;
+    if (FAST && EPI == GEMV_RESIDUAL) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) resv[r] = ((const bf16_t*)a.residual)[min(row0 + r, n_out - 1)];
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int row = min(row0 + r, n_out - 1);  // clamp: out-of-range rows are computed but never stored
@@ -65,6 +74,11 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, float* xs, const in
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int k = ((c0 + u) << 9) + lane * 8;
+        if (FAST) {
+          buf[u][0][r] = ld_nt16(p0 + k);
+          if (NW == 2) buf[u][NW - 1][r] = ld_nt16(p1 + k);
+          continue;
+        }
         const bool ok = (c0 + u < nchunks) && (k < K);
         buf[u][0][r] = ok ? (a.cached ? ld16(p0 + k) : ld_nt16(p0 + k)) : u32x4_t{0u, 0u, 0u, 0u};
         if (NW == 2) buf[u][NW - 1][r] = ok ? (a.cached ? ld16(p1 + k) : ld_nt16(p1 + k)) : u32x4_t{0u, 0u, 0u, 0u};
@@ -96,7 +110,8 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, float* xs, const in
     }
   }
   u32x4_t bufA[U][NW][R], bufB[U][NW][R];
-  if (ngroups > 0) issue(0, bufA);
+  bf16_t resA[R], resB[R];   // FAST + GEMV_RESIDUAL: the residual values of the buffer's tile, requested with it
+  if (ngroups > 0) issue(0, bufA, resA);
   stamp(1);
   after_issue();  // grid barrier of the persistent decode kernel: the first weight tile is already in flight
 
@@ -171,11 +186,11 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, float* xs, const in
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
 
-  auto consume = [&](int gi, u32x4_t (&buf)[U][NW][R]) {
+  auto consume = [&](int gi, u32x4_t (&buf)[U][NW][R], bf16_t (&resv)[R]) {
     const int c0 = (gi % gpt) * U;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (c0 + u < nchunks) {
+      if (FAST || c0 + u < nchunks) {
         const float4 xlo = *reinterpret_cast<const float4*>(xs + ((c0 + u) << 9) + (lane << 2));
         const float4 xhi = *reinterpret_cast<const float4*>(xs + ((c0 + u) << 9) + 256 + (lane << 2));
 #pragma unroll
@@ -211,7 +226,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, float* xs, const in
           } else if (EPI == GEMV_STORE) {
             act_st_bf<COH>((bf16_t*)a.y + row, f2bf(lin));
           } else if (EPI == GEMV_RESIDUAL) {
-            act_st_bf<COH>((bf16_t*)a.y + row, f2bf(bf2f(act_ld_bf<COH>((const bf16_t*)a.residual + row)) + lin));
+            act_st_bf<COH>((bf16_t*)a.y + row, f2bf(bf2f(FAST ? resv[r] : act_ld_bf<COH>((const bf16_t*)a.residual + row)) + lin));
           } else if (EPI == GEMV_SILU_MUL) {
             const float g = rbf(silu_f(lin));            // gate_proj -> act_fn   (modules.rs:82)
             const float up = rbf(acc[NW - 1][r]);        // up_proj               (modules.rs:83)
@@ -230,12 +245,35 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, float* xs, const in
   };
 
   stamp(2);
-  for (int g = 0; g < ngroups; g += 2) {
-    if (g + 1 < ngroups) issue(g + 1, bufB);
-    consume(g, bufA);
-    if (g == 0) stamp(3);
-    if (g + 2 < ngroups) issue(g + 2, bufA);
-    if (g + 1 < ngroups) consume(g + 1, bufB);
+  if (FAST) {
+    int g = 0;
+    for (; g + 2 < ngroups; g += 2) {   // steady state: both refills unconditional
+      __builtin_amdgcn_sched_barrier(0);
+      issue(g + 1, bufB, resB);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(g, bufA, resA);
+      __builtin_amdgcn_sched_barrier(0);
+      issue(g + 2, bufA, resA);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(g + 1, bufB, resB);
+    }
+    if (g + 1 < ngroups) {
+      __builtin_amdgcn_sched_barrier(0);
+      issue(g + 1, bufB, resB);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(g, bufA, resA);
+      consume(g + 1, bufB, resB);
+    } else if (g < ngroups) {
+      consume(g, bufA, resA);
+    }
+  } else {
+    for (int g = 0; g < ngroups; g += 2) {
+      if (g + 1 < ngroups) issue(g + 1, bufB, resB);
+      consume(g, bufA, resA);
+      if (g == 0) stamp(3);
+      if (g + 2 < ngroups) issue(g + 2, bufA, resA);
+      if (g + 1 < ngroups) consume(g + 1, bufB, resB);
+    }
   }
   stamp(4);
   if (EPI == GEMV_LOGITS) {

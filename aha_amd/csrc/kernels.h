@@ -142,6 +142,7 @@ struct GemmArgs {
   int act;
   void* workspace = nullptr;     // optional f32 scratch for split-K slabs (splitk * M * N * 4 bytes)
   size_t workspace_bytes = 0;
+  int tile_group = 8;            // band width of the grouped tile order inside an XCD's run (kernels_gemm.hip tile_of_block); 0 = plain
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 // split-K scratch used by launch_gemm calls of this THREAD whose GemmArgs carry none (the model sets it per forward)

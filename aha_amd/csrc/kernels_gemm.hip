@@ -14,6 +14,7 @@
 // bias / activation / gate*up pairing / residual are then lane-local and the store is 8 bytes.
 // Rounding points follow the reference op boundaries (Linear matmul -> bf16, + bias -> bf16, act -> bf16, + residual -> bf16).
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -56,15 +57,20 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs& a, int& m0, int& n
   int bid = blockIdx.x;
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  // Within an XCD's run the SHORTER tile dimension varies fastest, so the ~32 tiles in flight on the XCD form a compact
-  // rectangle (few distinct A / W panels in its L2) instead of one long row: PMC FETCH_SIZE of the gate/up GEMM
-  // (7 x 96 tiles) was 1.47 GB per launch with row-major order -- every W panel re-fetched for each of the 7 row tiles.
+  // Within an XCD's run of tiles, the ~32 tiles in flight on the XCD's 32 CUs should form a compact rectangle: per K step
+  // they then pull (rows + columns) operand panels into the XCD's L2 instead of one panel per tile -- an 8 x 4 rectangle
+  // fetches 12 panels for 32 tiles (81 % L2 hits), a 32 x 1 strip 33 (50 %: at 8192^3 that is 4.3 GB per GEMM over the
+  // fabric, which bounds the kernel).  Grouped order: bands of 8 tiles of the SHORTER dimension, the band's tiles varying
+  // fastest.  (PMC FETCH_SIZE of the cfg 3 gate/up GEMM, 7 x 96 tiles, was 1.47 GB per launch in plain row-major order.)
+  const int GRP = a.tile_group > 0 ? a.tile_group : (1 << 20);
   if (ntm <= ntn) {
-    m0 = (bid % ntm) * TBM;
-    n0 = (bid / ntm) * TBN;
+    const int per = GRP * ntn, grp = bid / per, first = grp * GRP, gsz = min(ntm - first, GRP), r = bid - grp * per;
+    m0 = (first + r % gsz) * TBM;
+    n0 = (r / gsz) * TBN;
   } else {
-    m0 = (bid / ntn) * TBM;
-    n0 = (bid % ntn) * TBN;
+    const int per = GRP * ntm, grp = bid / per, first = grp * GRP, gsz = min(ntn - first, GRP), r = bid - grp * per;
+    n0 = (first + r % gsz) * TBN;
+    m0 = (r / gsz) * TBM;
   }
 }
 
@@ -85,73 +91,109 @@ __device__ __forceinline__ void mma_tile(const char* sa, const char* sw, int wm,
   }
 }
 
-// ---- epilogue: lane holds C[m = .. + c][n = .. + G*4 + 0..3] -------------------------------------------------------
-// mb / nb: first row / column of the wave's sub-tile (MI x 4 fragments of 16 x 16)
+// ---- epilogue --------------------------------------------------------------------------------------------------------------
+// Every MFMA variant here is issued as W-fragment x A-fragment, so a lane ends up with groups of 4 consecutive output columns
+// n..n+3 of one row m: bias / activation / gate*up pairing / residual are lane-local and the store is 8 bytes.
+// One group of 4 raw f32 sums -> the reference's rounding chain -> store.
+template <int ACT, bool HAS_BIAS, bool HAS_RES>
+__device__ __forceinline__ void epi_group(const GemmArgs& a, int m, int n, float x0, float x1, float x2, float x3) {
+  if (n >= a.N) return;
+  if (ACT == ACT_PARTIAL_F32) {
+    *reinterpret_cast<float4*>((float*)a.C + (int64_t)m * a.ldc + n) = make_float4(x0, x1, x2, x3);
+    return;
+  }
+  float v[4] = {rbf(x0), rbf(x1), rbf(x2), rbf(x3)};
+  if (HAS_BIAS) {
+    const uint2 b2 = *reinterpret_cast<const uint2*>((const bf16_t*)a.bias + n);
+    v[0] = rbf(v[0] + lo_bf(b2.x)); v[1] = rbf(v[1] + hi_bf(b2.x));
+    v[2] = rbf(v[2] + lo_bf(b2.y)); v[3] = rbf(v[3] + hi_bf(b2.y));
+  }
+  if (ACT == ACT_GELU_TANH) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = rbf(gelu_tanh_f(v[r]));
+  } else if (ACT == ACT_GELU_ERF) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = rbf(gelu_erf_f(v[r]));
+  } else if (ACT == ACT_SILU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = rbf(silu_f(v[r]));
+  }
+  if (HAS_RES) {
+    const uint2 r2 = *reinterpret_cast<const uint2*>((const bf16_t*)a.residual + (int64_t)m * a.ldc + n);
+    v[0] += lo_bf(r2.x); v[1] += hi_bf(r2.x); v[2] += lo_bf(r2.y); v[3] += hi_bf(r2.y);
+  }
+  uint2 w2;
+  w2.x = pack_bf(v[0], v[1]);
+  w2.y = pack_bf(v[2], v[3]);
+  *reinterpret_cast<uint2*>((bf16_t*)a.C + (int64_t)m * a.ldc + n) = w2;
+}
+// ACT_SILU_MUL_PAIRS: W rows come in 16-row blocks, gate rows j..j+15 then up rows j..j+15 (the model loader interleaves them);
+// n = fused-weight row of the 4 gate values, oc = their output column
+__device__ __forceinline__ void epi_pairs(const GemmArgs& a, int m, int n, int oc, const float (&gt)[4], const float (&up)[4]) {
+  if (n >= a.N) return;
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float gte = rbf(silu_f(rbf(gt[r])));  // gate_proj -> bf16, act_fn -> bf16 (modules.rs:82)
+    const float u = rbf(up[r]);                 // up_proj -> bf16 (modules.rs:83)
+    v[r] = gte * u;                             // lhs * rhs -> bf16 (modules.rs:84)
+  }
+  uint2 w2;
+  w2.x = pack_bf(v[0], v[1]);
+  w2.y = pack_bf(v[2], v[3]);
+  *reinterpret_cast<uint2*>((bf16_t*)a.C + (int64_t)m * a.ldc + oc) = w2;
+}
+
+// 16x16x32 fragments: lane holds C[m = .. + c][n = .. + G*4 + 0..3].  mb / nb: first row / column of the wave's sub-tile
+// (MI x 4 fragments of 16 x 16)
 template <int ACT, bool HAS_BIAS, bool HAS_RES, int MI>
 __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x4_t (&acc)[4][MI], int mb, int nb, int G, int c) {
-  bf16_t* C = (bf16_t*)a.C;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = mb + mi * 16 + c;
     if (m >= a.M) continue;
-    if (ACT == ACT_PARTIAL_F32) {
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int n = nb + ni * 16 + G * 4;
-        if (n >= a.N) continue;
-        *reinterpret_cast<float4*>((float*)a.C + (int64_t)m * a.ldc + n) =
-            make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
-      }
-    } else if (ACT == ACT_SILU_MUL_PAIRS) {
-      // W rows come in 16-row blocks: gate rows j..j+15 then up rows j..j+15 (the model loader interleaves them)
+    if (ACT == ACT_SILU_MUL_PAIRS) {
 #pragma unroll
       for (int np = 0; np < 2; ++np) {
-        const int n = nb + np * 32 + G * 4;  // fused-weight row of the gate values
-        if (n >= a.N) continue;
-        const int oc = nb / 2 + np * 16 + G * 4;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float gte = rbf(silu_f(rbf(acc[2 * np][mi][r])));  // gate_proj -> bf16, act_fn -> bf16 (modules.rs:82)
-          const float up = rbf(acc[2 * np + 1][mi][r]);            // up_proj -> bf16 (modules.rs:83)
-          v[r] = gte * up;                                          // lhs * rhs -> bf16 (modules.rs:84)
-        }
-        uint2 w2;
-        w2.x = pack_bf(v[0], v[1]);
-        w2.y = pack_bf(v[2], v[3]);
-        *reinterpret_cast<uint2*>(C + (int64_t)m * a.ldc + oc) = w2;
+        const float gt[4] = {acc[2 * np][mi][0], acc[2 * np][mi][1], acc[2 * np][mi][2], acc[2 * np][mi][3]};
+        const float up[4] = {acc[2 * np + 1][mi][0], acc[2 * np + 1][mi][1], acc[2 * np + 1][mi][2], acc[2 * np + 1][mi][3]};
+        epi_pairs(a, m, nb + np * 32 + G * 4, nb / 2 + np * 16 + G * 4, gt, up);
       }
     } else {
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int n = nb + ni * 16 + G * 4;
-        if (n >= a.N) continue;
-        float v[4];
+      for (int ni = 0; ni < 4; ++ni)
+        epi_group<ACT, HAS_BIAS, HAS_RES>(a, m, nb + ni * 16 + G * 4, acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
+    }
+  }
+}
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+__device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// 32x32x16 fragments (W-fragment x A-fragment): lane l holds row m = .. + (l & 31) and, in register quad q, the columns
+// n = .. + 8 q + 4 (l >> 5) + 0..3.  acc[nf][mf]: NF x MF fragments of 32 x 32.
+template <int ACT, bool HAS_BIAS, bool HAS_RES, int NF, int MF>
+__device__ __forceinline__ void epilogue32(const GemmArgs& a, f32x16_t (&acc)[NF][MF], int mb, int nb, int lane) {
+  const int r32 = lane & 31, h = lane >> 5;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = rbf(acc[ni][mi][r]);
-        if (HAS_BIAS) {
-          const uint2 b2 = *reinterpret_cast<const uint2*>((const bf16_t*)a.bias + n);
-          v[0] = rbf(v[0] + lo_bf(b2.x)); v[1] = rbf(v[1] + hi_bf(b2.x));
-          v[2] = rbf(v[2] + lo_bf(b2.y)); v[3] = rbf(v[3] + hi_bf(b2.y));
+  for (int mf = 0; mf < MF; ++mf) {
+    const int m = mb + mf * 32 + r32;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      const f32x16_t& v = acc[nf][mf];
+      if (ACT == ACT_SILU_MUL_PAIRS) {   // a 32-row W fragment = one gate block (quads 0,1) + its up block (quads 2,3)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float gt[4] = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+          const float up[4] = {v[4 * q + 8], v[4 * q + 9], v[4 * q + 10], v[4 * q + 11]};
+          epi_pairs(a, m, nb + nf * 32 + 8 * q + 4 * h, (nb + nf * 32) / 2 + 8 * q + 4 * h, gt, up);
         }
-        if (ACT == ACT_GELU_TANH) {
+      } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = rbf(gelu_tanh_f(v[r]));
-        } else if (ACT == ACT_GELU_ERF) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = rbf(gelu_erf_f(v[r]));
-        } else if (ACT == ACT_SILU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = rbf(silu_f(v[r]));
-        }
-        if (HAS_RES) {
-          const uint2 r2 = *reinterpret_cast<const uint2*>((const bf16_t*)a.residual + (int64_t)m * a.ldc + n);
-          v[0] += lo_bf(r2.x); v[1] += hi_bf(r2.x); v[2] += lo_bf(r2.y); v[3] += hi_bf(r2.y);
-        }
-        uint2 w2;
-        w2.x = pack_bf(v[0], v[1]);
-        w2.y = pack_bf(v[2], v[3]);
-        *reinterpret_cast<uint2*>(C + (int64_t)m * a.ldc + n) = w2;
+        for (int q = 0; q < 4; ++q)
+          epi_group<ACT, HAS_BIAS, HAS_RES>(a, m, nb + nf * 32 + 8 * q + 4 * h, v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
       }
     }
   }
@@ -350,6 +392,196 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, const void*
   epilogue<ACT, HAS_BIAS, HAS_RES, 8>(a, acc, m0 + wm * 128, n0 + wn * 64, G, c);
 }
 
+// ---- variant 4: the 256 x 256 x 64 tile as a staggered, counted-wait pipeline ----------------------------------------------
+// Same tile, wave layout (2 x 4 waves, 128 x 64 each), LDS image and epilogue as gemm256_kernel; what changes is the K loop:
+//   * a K tile is staged as four 16-KiB HALF-tiles (A rows 0-127 / 128-255, W rows 0-127 / 128-255), one half-tile per
+//     segment (2 LDS-DMA instructions per thread), and nothing in the loop ever waits for all of them: the only wait is a
+//     counted s_waitcnt vmcnt(2) once per K tile, which leaves the newest half-tile in flight (raw s_barrier -- a
+//     __syncthreads() would drain the DMA queue);
+//   * the wave's 128 x 64 output is computed as four 64 x 32 quadrants of 8 v_mfma_f32_32x32x16_bf16 each, fed from registers that were read
+//     from LDS one segment earlier (A half 8 x ds_read_b128, W half 4 x);
+//   * the two wave rows (wm = 0 / 1: one wave of each per SIMD) run the same program ONE barrier interval apart, so in every
+//     interval one wave of a SIMD is in a 16-MFMA segment (s_setprio 1) while its partner reads fragments and issues DMA.
+// Per K tile and wave (L = load segment, C = compute segment; G0 = waves wm 0 at intervals 8t+1.., G1 one interval later):
+//   L1: read A0, W0      C1: quadrant (0,0) + DMA A-lo(t+1)
+//   L2: read W1          C2: quadrant (0,1) + DMA A-hi(t+1)
+//   L3: read A1          C3: quadrant (1,1) + DMA W-lo(t+2)
+//   L4: vmcnt(2)         C4: quadrant (1,0) + DMA W-hi(t+2)
+// (the DMA pieces are issued between the MFMAs of the compute segment: ~60 issue cycles each in the MFMAs' shadow, against
+// 100-185 next to ds_reads)
+// Hazards (intervals; a read issued in interval i is complete once its wave is past the lgkmcnt at the start of its next
+// segment, i.e. before the barrier that ends interval i+1):
+//   WAR  W(t) last read L2 (8t+3 / 8t+4, complete by 8t+5) -> W(t+2) DMA in C3 / C4 (8t+6.. ); A-lo(t) last read by G0 in L3
+//        (8t+5), A-hi(t) by G1 (8t+6) -> A(t+2) DMA in C1 / C2 of tile t+1 (8t+10.. / 8t+12..).
+//   RAW  tile t+1 is first read at 8t+9 (G0) / 8t+10 (G1); its W halves were issued a whole tile earlier, its A halves in C1 /
+//        C2 of tile t; every wave retires them with the vmcnt(2) of its L4 (8t+7 / 8t+8), one barrier before the first read.
+// Half-tiles past the last K tile are issued all the same (from the zero block, into a buffer nobody reads any more) so the
+// counts stay uniform.
+// TRACE (AHA_GEMM_TRACE=1, debug): block 0, waves 0 and 4 stamp s_memtime at every segment boundary of K tiles 8 and 9 into `trace`.
+template <int ACT, bool HAS_BIAS, bool HAS_RES, int MODE = 0>
+__global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs a, const void* zeros, int kt_per_slice, unsigned long long* trace = nullptr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A tile 32 KiB | W tile 32 KiB]
+  const int tid = threadIdx.x, lane = tid & 63, G = lane >> 4, c = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  int m0, n0;
+  tile_of_block<BM2, BN2>(a, m0, n0);
+  const bf16_t* A = (const bf16_t*)a.A;
+  const bf16_t* W = (const bf16_t*)a.W;
+  const int nk_all = (a.K + BK - 1) / BK;
+  const int kt0 = blockIdx.y * kt_per_slice, kt1 = min(nk_all, kt0 + kt_per_slice);
+  if (ACT == ACT_PARTIAL_F32) a.C = (float*)a.C + (int64_t)blockIdx.y * a.M * a.ldc;
+
+  // staging sources: half h (rows h*128..), piece j = 0,1: LDS row group (h*16 + j*8 + wave) of 8 rows (1 KiB)
+  const int kofs = (((lane & 7) ^ (((lane >> 4) + 4 * (wave & 1)) & 7))) * 8;   // logical k offset this lane fetches (source-side swizzle)
+  const bf16_t* ga[2][2];
+  const bf16_t* gw[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = h * 128 + (j * 8 + wave) * 8 + (lane >> 3);
+      ga[h][j] = A + (int64_t)min(m0 + row, a.M - 1) * a.lda + kofs;
+      gw[h][j] = W + (int64_t)min(n0 + row, a.N - 1) * a.ldw + kofs;
+    }
+  auto issue_half = [&](int kt, int stage, int which /* 0 = A, 1 = W */, int h) {
+    if (MODE == 2 && kt > kt0 + 1) return;   // ablation: no DMA in the steady state
+    char* dst = smem + stage * 2 * TILE2_BYTES + which * TILE2_BYTES + h * (TILE2_BYTES / 2);
+    const bool ok = kt < kt1 && kt * BK + kofs < a.K;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const void* src = ok ? (const void*)((which ? gw[h][j] : ga[h][j]) + (int64_t)kt * BK) : zeros;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(dst + (j * 8 + wave) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16_t acc[2][4];  // [n fragment of 32][m fragment of 32]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+// 8 MFMAs (32x32x16) of one 64 x 32 quadrant (W fragments WF, accumulator columns NI0.., rows MI0..) with the segment's half-tile DMA
+// issued in the shadow of the first MFMAs (an LDS-DMA piece costs ~60 issue cycles among MFMAs, 100-185 among ds_reads)
+#define MMA_QUAD(WF, NF, MF0, DMA)                                                                                    \
+  do {                                                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                \
+      _Pragma("unroll") for (int mf = 0; mf < 2; ++mf) {                                                            \
+        if (MODE != 3) acc[NF][MF0 + mf] = mfma32(WF[ks], af[ks][mf], acc[NF][MF0 + mf]);                           \
+        else asm volatile("" :: "v"(WF[ks]), "v"(af[ks][mf]));                                                     \
+      }                                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    DMA;                                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    _Pragma("unroll") for (int ks = 2; ks < 4; ++ks)                                                                \
+      _Pragma("unroll") for (int mf = 0; mf < 2; ++mf) {                                                            \
+        if (MODE != 3) acc[NF][MF0 + mf] = mfma32(WF[ks], af[ks][mf], acc[NF][MF0 + mf]);                           \
+        else asm volatile("" :: "v"(WF[ks]), "v"(af[ks][mf]));                                                     \
+      }                                                                                                              \
+  } while (0)
+
+#define AHA_BAR()                                \
+  do {                                           \
+    __builtin_amdgcn_sched_barrier(0);           \
+    __builtin_amdgcn_s_barrier();                \
+    __builtin_amdgcn_sched_barrier(0);           \
+  } while (0)
+
+  if (MODE == 1 && blockIdx.x == 0 && tid == 0) { trace[40] = __builtin_readcyclecounter(); trace[41] = wall_clock64(); }
+  // prologue: tile kt0 complete + the W halves of tile kt0+1 in flight
+  issue_half(kt0, 0, 1, 0);
+  issue_half(kt0, 0, 1, 1);
+  issue_half(kt0, 0, 0, 0);
+  issue_half(kt0, 0, 0, 1);
+  issue_half(kt0 + 1, 1, 1, 0);
+  issue_half(kt0 + 1, 1, 1, 1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  AHA_BAR();
+  if (wm == 1) AHA_BAR();   // the second wave row runs one interval behind
+
+  bf16x8_t af[4][2], wf0[4], wf1[4];   // [k step of 16][32-row fragment]
+  const int r32 = lane & 31, hk = lane >> 5;
+  int tr_i = 0;
+  auto stamp = [&](int kt) {
+    if (MODE == 1) {
+      if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && (kt == kt0 + 8 || kt == kt0 + 9) && tr_i < 20)
+        trace[(wave >> 2) * 20 + tr_i++] = __builtin_readcyclecounter();
+    }
+  };
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    stamp(kt);
+    const char* sa = smem + cur * 2 * TILE2_BYTES;
+    const char* sw = sa + TILE2_BYTES;
+    // ---- L1
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (MODE != 4 || kt == kt0) wf0[ks] = as_frag(*reinterpret_cast<const u32x4_t*>(sw + swz(wn * 64 + r32, ks * 2 + hk)));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        if (MODE != 4 || kt == kt0) af[ks][i] = as_frag(*reinterpret_cast<const u32x4_t*>(sa + swz(wm * 128 + i * 32 + r32, ks * 2 + hk)));
+    }
+    stamp(kt);
+    AHA_BAR();
+    stamp(kt);
+    // ---- C1: quadrant (0,0)
+    __builtin_amdgcn_s_setprio(1);
+    MMA_QUAD(wf0, 0, 0, issue_half(kt + 1, cur ^ 1, 0, 0));
+    __builtin_amdgcn_s_setprio(0);
+    stamp(kt);
+    AHA_BAR();
+    stamp(kt);
+    // ---- L2
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      if (MODE != 4 || kt == kt0) wf1[ks] = as_frag(*reinterpret_cast<const u32x4_t*>(sw + swz(wn * 64 + 32 + r32, ks * 2 + hk)));
+    stamp(kt);
+    AHA_BAR();
+    stamp(kt);
+    // ---- C2: quadrant (0,1)
+    __builtin_amdgcn_s_setprio(1);
+    MMA_QUAD(wf1, 1, 0, issue_half(kt + 1, cur ^ 1, 0, 1));
+    __builtin_amdgcn_s_setprio(0);
+    stamp(kt);
+    AHA_BAR();
+    stamp(kt);
+    // ---- L3
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        if (MODE != 4 || kt == kt0) af[ks][i] = as_frag(*reinterpret_cast<const u32x4_t*>(sa + swz(wm * 128 + 64 + i * 32 + r32, ks * 2 + hk)));
+    stamp(kt);
+    AHA_BAR();
+    stamp(kt);
+    // ---- C3: quadrant (1,1)
+    __builtin_amdgcn_s_setprio(1);
+    MMA_QUAD(wf1, 1, 2, issue_half(kt + 2, cur, 1, 0));
+    __builtin_amdgcn_s_setprio(0);
+    stamp(kt);
+    AHA_BAR();
+    stamp(kt);
+    // ---- L4
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // A(t+1) has landed (its W halves long before); W-lo(t+2) stays in flight
+    stamp(kt);
+    AHA_BAR();
+    stamp(kt);
+    // ---- C4: quadrant (1,0)
+    __builtin_amdgcn_s_setprio(1);
+    MMA_QUAD(wf0, 0, 2, issue_half(kt + 2, cur, 1, 1));
+    __builtin_amdgcn_s_setprio(0);
+    AHA_BAR();
+  }
+  if (wm == 0) AHA_BAR();   // arrivals of the two wave rows balance
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (dummy) half-tiles
+#undef AHA_BAR
+#undef MMA_QUAD
+  if (MODE == 1 && blockIdx.x == 0 && tid == 0) { trace[42] = __builtin_readcyclecounter(); trace[43] = wall_clock64(); }
+  epilogue32<ACT, HAS_BIAS, HAS_RES, 2, 4>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
+}
+
 // Sums the split-K slabs and runs the same rounding chain as the in-kernel epilogue: Linear output -> bf16, + bias -> bf16,
 // activation -> bf16, + residual -> bf16.  One thread per 4 consecutive columns.  (Not used with ACT_SILU_MUL_PAIRS.)
 template <int ACT, bool HAS_BIAS, bool HAS_RES>
@@ -426,7 +658,52 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st) {
       hipFuncSetAttribute((const void*)gemm256_kernel<ACT, B, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       once = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<ACT, B, R>), dim3(ntm * ntn), dim3(512), lds, st, a, zero_block(), nk);
+    static const bool pipe = [] { const char* e = getenv("AHA_GEMM_PIPE"); return e ? atoi(e) != 0 : true; }();
+    if (pipe) {
+      static bool once2 = false;
+      if (!once2) {
+        hipFuncSetAttribute((const void*)gemm256p_kernel<ACT, B, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        once2 = true;
+      }
+      static const int mode = [] { const char* e = getenv("AHA_GEMM_MODE"); return e ? atoi(e) : 0; }();
+      if (mode >= 2 && mode <= 4 && ACT == ACT_NONE && !B && !R) {   // ablations (debug; results are wrong by construction)
+        static bool once3 = false;
+        if (!once3) {
+          hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_NONE, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_NONE, false, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_NONE, false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          once3 = true;
+        }
+        if (mode == 2) hipLaunchKernelGGL((gemm256p_kernel<ACT_NONE, false, false, 2>), dim3(ntm * ntn), dim3(512), lds, st, a, zero_block(), nk, nullptr);
+        if (mode == 3) hipLaunchKernelGGL((gemm256p_kernel<ACT_NONE, false, false, 3>), dim3(ntm * ntn), dim3(512), lds, st, a, zero_block(), nk, nullptr);
+        if (mode == 4) hipLaunchKernelGGL((gemm256p_kernel<ACT_NONE, false, false, 4>), dim3(ntm * ntn), dim3(512), lds, st, a, zero_block(), nk, nullptr);
+        return;
+      }
+      static const bool tr = [] { const char* e = getenv("AHA_GEMM_TRACE"); return e && atoi(e) != 0; }();
+      if (tr && ACT == ACT_NONE && !B && !R) {
+        static unsigned long long* d_tr = nullptr;
+        if (!d_tr) {
+          hipMalloc((void**)&d_tr, 48 * 8);
+          hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_NONE, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
+        hipMemsetAsync(d_tr, 0, 48 * 8, st);
+        hipLaunchKernelGGL((gemm256p_kernel<ACT_NONE, false, false, 1>), dim3(ntm * ntn), dim3(512), lds, st, a, zero_block(), nk, d_tr);
+        unsigned long long h[48];
+        hipMemcpyAsync(h, d_tr, sizeof(h), hipMemcpyDeviceToHost, st);
+        hipStreamSynchronize(st);
+        for (int w = 0; w < 2; ++w) {
+          fprintf(stderr, "[gemm trace] wave row %d:", w);
+          for (int i = 1; i < 20 && h[w * 20 + i]; ++i) fprintf(stderr, " %llu", h[w * 20 + i] - h[w * 20 + i - 1]);
+          fprintf(stderr, "\n");
+        }
+        fprintf(stderr, "[gemm trace] main loop: %llu shader cycles in %.2f us => %.3f GHz\n", h[42] - h[40], (double)(h[43] - h[41]) * 0.01,
+                (double)(h[42] - h[40]) / ((double)(h[43] - h[41]) * 10.0));
+        return;
+      }
+      hipLaunchKernelGGL((gemm256p_kernel<ACT, B, R>), dim3(ntm * ntn), dim3(512), lds, st, a, zero_block(), nk);
+    } else {
+      hipLaunchKernelGGL((gemm256_kernel<ACT, B, R>), dim3(ntm * ntn), dim3(512), lds, st, a, zero_block(), nk);
+    }
     return;
   }
   (void)attr_done;
@@ -519,6 +796,8 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t st) {
     a.workspace = tl_ws;
     a.workspace_bytes = tl_ws_bytes;
   }
+  static const int e_grp = [] { const char* e = getenv("AHA_GEMM_GROUP"); return e ? atoi(e) : 8; }();
+  a.tile_group = e_grp;
   const GemmPlan plan = plan_gemm(a);
   if (plan.tile == 256) {
     switch (a.act) {

@@ -18,10 +18,10 @@ namespace aha {
 
 namespace {
 
-template <int R, int U, int EPI>
+template <int R, int U, int EPI, bool FAST>
 __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float xs[];  // K f32 + 8 floats reduction scratch
-  gemv_body<R, U, EPI, false>(a, xs, (int)blockIdx.x, (int)gridDim.x, [] {});
+  gemv_body<R, U, EPI, false, FAST>(a, xs, (int)blockIdx.x, (int)gridDim.x, [] {});
 }
 
 struct GemvPlan { int R, U, grid; };
@@ -74,7 +74,14 @@ template <int EPI>
 static void launch_gemv_epi(const GemvArgs& a, const GemvPlan& p, hipStream_t st) {
   const size_t lds = (size_t)((a.K + 511) / 512) * 512 * 4 + 64;
   dim3 grid(p.grid), block(GEMV_THREADS);
-#define GV(RR, UU) hipLaunchKernelGGL((gemv_kernel<RR, UU, EPI>), grid, block, lds, st, a)
+  // FAST form (gemv_body.h): every chunk group full and in range, weights non-temporal
+  static const bool fast_ok = [] { const char* e = getenv("AHA_GEMV_FAST"); return e ? atoi(e) != 0 : true; }();
+  const bool fast = fast_ok && a.K % (512 * p.U) == 0 && !a.cached && a.N >= 1;
+#define GV(RR, UU)                                                                            \
+  do {                                                                                        \
+    if (fast) hipLaunchKernelGGL((gemv_kernel<RR, UU, EPI, true>), grid, block, lds, st, a);  \
+    else hipLaunchKernelGGL((gemv_kernel<RR, UU, EPI, false>), grid, block, lds, st, a);      \
+  } while (0)
   if (p.R == 4) {
     if (p.U >= 4) GV(4, 4); else if (p.U == 2) GV(4, 2); else GV(4, 1);
   } else if (p.R == 2) {

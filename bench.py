@@ -214,23 +214,21 @@ def main():
     # ---- roofline of the dominant kernel (weight-streaming matvec), HIP events on the model's stream ----
     model.set_profiling(True)
     tok, off = run_steps(args.steps, tok, off)
-    prof = {k: model.get_profile(k) for k in ("decode_step", "gemv", "attn_decode", "elem", "argmax")}
+    prof = {k: model.get_profile(k) for k in ("gemv", "attn_decode", "elem", "argmax")}
     model.set_profiling(False)
-    # default path: ONE persistent kernel per token (decode_mega.hip); AHA_DECODE_MEGA=0: the launch-per-op path, whose
-    # dominant kernel class is the weight-streaming matvec
-    mega = prof["decode_step"]["launches"] > 0
-    gv = prof["decode_step"] if mega else prof["gemv"]
-    pmc_file = "r01_pmc_traffic_decode_step.json" if mega else "r01_pmc_traffic_gemv.json"
+    # dominant kernel class of a decode step: the weight-streaming matvec (all projections + lm_head)
+    gv = prof["gemv"]
+    pmc_file = "r02_pmc_traffic_gemv.json"
+    stats_file = "r02_cfg3_kernel_stats.md"
     achieved = gv["bytes"] / (gv["ms"] * 1e-3) / 1e9 if gv["ms"] > 0 else 0.0
     roof = {"bound": "hbm",
-            "kernel": ("decode_step_kernel (persistent: all layers' weight streaming + paged attention + lm_head of one token)"
-                       if mega else "gemv_kernel (batch-1 weight streaming, all projections + lm_head)"),
+            "kernel": "gemv_kernel (batch-1 weight streaming, all projections + lm_head)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "launches": gv["launches"], "avg_us": round(1e3 * gv["ms"] / max(gv["launches"], 1), 2),
             "algorithmic_bytes_per_launch": round(gv["bytes"] / max(gv["launches"], 1))}
     # HBM traffic of the same kernel class from the PMC passes (rocprofv3 cannot run inside this process): the committed
-    # summary profiles/r01_pmc_traffic_gemv.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes).
+    # summary profiles/r02_pmc_traffic_gemv.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes).
     try:
         with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
             pmc = json.load(f)
@@ -242,9 +240,9 @@ def main():
     # kernel-only duration of the same class from the committed rocprofv3 --kernel-trace --stats summary of this command: an event
     # pair also sees the dispatch latency in front of the kernel (~2 us per launch), rocprofv3 times the kernel alone
     try:
-        if not mega and args.workload == "qwen3vl8b":
+        if args.workload == "qwen3vl8b":
             tot_us, calls = 0.0, 0
-            with open(os.path.join(ROOT, "profiles", "r01_cfg3_final_kernel_stats.md")) as f:
+            with open(os.path.join(ROOT, "profiles", stats_file)) as f:
                 for line in f:
                     c = [x.strip() for x in line.split("|")]
                     if len(c) >= 6 and "gemv_kernel" in c[1]:
@@ -254,7 +252,7 @@ def main():
                 avg = tot_us / calls
                 roof["rocprof"] = {"avg_us": round(avg, 2), "achieved": round(roof["algorithmic_bytes_per_launch"] / avg / 1e3, 1),
                                    "frac": round(roof["algorithmic_bytes_per_launch"] / avg / 1e3 / HBM_PEAK_GBS, 4),
-                                   "source": "profiles/r01_cfg3_final_kernel_stats.md"}
+                                   "source": "profiles/" + stats_file}
     except (OSError, ValueError):
         pass
     ad = prof["attn_decode"]
