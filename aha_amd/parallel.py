@@ -2,8 +2,9 @@
 
 BASELINE.json north_star: decode stays single-GPU (weights 15 GB << 288 GB), so N GPUs serve N independent requests
 (replicas, "scaling": "weak"); only the timing is combined across ranks (max over ranks, as the bench contract asks).
-The ViT (per-image) and long-context TP prefill (RCCL reduce-scatter / all-gather) are SURVEY.md section 8(e) rows
-for a later round; `shard_units` is the partitioning they will share.
+The two parts that DO shard are driven from here as well: the ViT by images (independent units,
+one all-gather of the embeddings: `encode_images_sharded`) and the long-context prefill by tensor parallelism inside the
+library (`sharded_prefill`: one TP group over all ranks, all-reduce over RCCL).
 One process per GPU; `torch.distributed` backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
 """
 from __future__ import annotations
@@ -76,3 +77,62 @@ def encode_images_sharded(encode_fn, per_image_inputs: List, tokens_per_image: L
     outs = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(outs, buf)
     return torch.cat([o[:, :c] for o, c in zip(outs, counts) if c > 0], dim=1)
+
+
+def broadcast_bytes(payload, src: int = 0):
+    """Rank `src`'s bytes object on every rank (the 128-byte RCCL unique id travels this way)."""
+    import torch.distributed as dist
+    box = [payload]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def sharded_prefill(cfg, weights, input_ids, data, rank: int, world: int, device_index: int, kv_reserve_tokens: int = 0,
+                    repeats: int = 1):
+    """BASELINE cfg 5's sharded path on `world` GPUs of one node, one process per GPU:
+      * the ranks form ONE tensor-parallel group: every rank passes the full checkpoint, the library keeps its q/k/v heads,
+        gate/up rows and o/down columns, and all-reduces the row-parallel partial sums over RCCL (aha_hip_tp_init_rccl);
+      * the ViT runs image-parallel: rank r encodes images shard_units(n, world, r), one all_gather moves the merged +
+        DeepStack embeddings (encode_images_sharded), and every rank scatters all of them into its prompt;
+      * lm_head is vocabulary-parallel inside the library (arg-max pair exchange).
+    Returns (first greedy token, seconds of the slowest of `repeats` timed prefills on this rank, model).  world == 1 is the
+    plain single-GPU call, so the N = 1 value of a scaling curve is the single-GPU cfg 5 prefill."""
+    import time
+    import numpy as np
+    import torch
+    from .model import HipInferenceModel, MultiModalData, tp_unique_id
+    uid = None
+    if world > 1:
+        uid = broadcast_bytes(tp_unique_id() if rank == 0 else None)
+    model = HipInferenceModel(cfg, weights, device=device_index, kv_reserve_tokens=kv_reserve_tokens,
+                              tp_rank=rank if world > 1 else 0, tp_size=world, rccl_unique_id=uid)
+    grid = None if data is None else np.asarray(data.image_grid_thw, dtype=np.uint32).reshape(-1, 3)
+
+    def one_prefill():
+        model.clear_cache()
+        mm = data
+        if data is not None and world > 1:
+            m2 = cfg.vision.spatial_merge_size ** 2
+            toks = [int(g[0]) * int(g[1]) * int(g[2]) // m2 for g in grid]
+            patches = np.cumsum([0] + [int(g[0]) * int(g[1]) * int(g[2]) for g in grid])
+
+            def enc(idx_range):
+                a, b = idx_range[0], idx_range[-1] + 1
+                return model.vision_encode(MultiModalData(data.pixel_values[patches[a]:patches[b]], grid[a:b]))
+            emb = encode_images_sharded(lambda idx: enc(idx), list(range(len(grid))), toks, world, rank)
+            mm = MultiModalData(image_grid_thw=grid, image_embeds=emb.contiguous())
+        _, tok = model.forward_initial(input_ids, 0, mm, want_logits=False)
+        return tok
+
+    tok = one_prefill()   # warm (page allocation, RCCL channels)
+    worst = 0.0
+    for _ in range(repeats):
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tok = one_prefill()
+        torch.cuda.synchronize()
+        worst = max(worst, time.perf_counter() - t0)
+    return tok, worst, model

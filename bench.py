@@ -33,6 +33,7 @@ METRICS = {
     "qwen3vl8b-cfg5": "decode tokens/s (greedy, batch 1) -- Qwen3-VL-8B, 8 x 2048^2 images + 8192-token prompt (BASELINE cfg 5 on one GPU, S ~ 41k); prefill tok/s alongside",
     "qwen3vl8b-text": "decode tokens/s (greedy, batch 1) -- Qwen3-VL-8B text stack, 1542-token prompt; prefill tok/s alongside",
     "qwen3-0.6b": "decode tokens/s (greedy, batch 1) -- Qwen3-0.6B, 2048-token prompt (BASELINE cfg 2); prefill tok/s alongside",
+    "qwen3vl8b-cfg5-tp": "prefill tokens/s -- Qwen3-VL-8B, 8 x 2048^2 images + 8192-token prompt (BASELINE cfg 5), tensor-parallel decoder stack + image-parallel ViT over all ranks",
     "qwen3-asr": "decode tokens/s (greedy, batch 1) -- Qwen3-ASR-0.6B, 30 s of 16 kHz audio (BASELINE cfg 4); prefill (log-mel + audio encoder + text) alongside",
 }
 
@@ -110,6 +111,39 @@ def cpu_baseline(cfg, sample_secs=20.0):
                       "Candle CPU reference not buildable here"}
 
 
+def sharded_prefill_bench(rank, world, local_rank, n_images=8, image_px=2048, prompt=8192, repeats=1):
+    """BASELINE cfg 5 through the sharded path: one tensor-parallel group over all ranks (RCCL
+    all-reduce over xGMI inside the library), the ViT image-parallel with one all-gather.  Strong scaling: the request is the
+    same for every N, value = prompt tokens / slowest rank's prefill seconds.  N = 1 is the single-GPU cfg 5 prefill."""
+    import torch
+    from aha_amd import configs, parallel
+    from aha_amd import weights as W
+    from aha_amd.vision_host import synthetic_image_request
+    cfg = configs.qwen3vl_8b()
+    dev = f"cuda:{local_rank}"
+    w = W.qwen3vl_weights(cfg, seed=0, device=dev)            # the SAME checkpoint on every rank; the library keeps its shard
+    g = torch.Generator().manual_seed(5)
+    ids, data = synthetic_image_request(cfg, image_px, prompt, g, device=dev, n_images=n_images)
+    torch.cuda.synchronize()
+    tok, secs, model = parallel.sharded_prefill(cfg, w, ids, data, rank, world, local_rank, kv_reserve_tokens=len(ids) + 4096,
+                                                repeats=repeats)
+    del w
+    value, worst = parallel.aggregate_throughput(float(len(ids)) / world, secs, device=dev)   # sum of shares / max seconds
+    toks = torch.tensor([tok], dtype=torch.int64, device=dev)
+    same = True
+    if world > 1:
+        import torch.distributed as dist
+        lst = [torch.zeros_like(toks) for _ in range(world)]
+        dist.all_gather(lst, toks)
+        same = all(int(t.item()) == int(lst[0].item()) for t in lst)
+    model.close()
+    torch.cuda.empty_cache()
+    return {"metric": METRICS["qwen3vl8b-cfg5-tp"], "value": round(value, 1), "unit": "tokens/s", "prefill_s": round(worst, 4),
+            "prompt_tokens": len(ids), "n_images": n_images, "image": image_px, "scaling": "strong",
+            "parallelism": f"tp{world} (RCCL all-reduce of the row-parallel partial sums) + image-parallel ViT (all-gather)",
+            "rccl_ranks": world, "first_token_equal_on_all_ranks": same}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,6 +153,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prompt", type=int, default=0, help="override the workload's text prompt length (diagnostics; the JSON names it)")
     ap.add_argument("--host-loop", action="store_true", help="drive decode with forward_step (one host sync per token)")
+    ap.add_argument("--sharded-prefill", action="store_true",
+                    help="also run BASELINE cfg 5 through the TP + image-parallel path (always done when WORLD_SIZE > 1)")
     args = ap.parse_args()
 
     import numpy as np
@@ -134,6 +170,20 @@ def main():
 
     import __graft_entry__
     __graft_entry__.build()
+    if args.workload == "qwen3vl8b-cfg5-tp":   # the sharded path as the metric itself (strong scaling over --gpus)
+        sp = sharded_prefill_bench(rank, world, local_rank, repeats=max(1, min(args.steps, 3)))
+        if rank == 0:
+            line = {"metric": sp["metric"], "value": sp["value"], "unit": "tokens/s", "n_gpus": world, "steps": max(1, min(args.steps, 3)),
+                    "warmup": 1, "ms_per_step": round(1e3 * sp["prefill_s"], 2), "higher_is_better": True, "scaling": "strong",
+                    "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                    "config": {"workload": args.workload, "prompt_tokens": sp["prompt_tokens"], "image": sp["image"],
+                               "n_images": sp["n_images"], "parallelism": sp["parallelism"], "rccl_ranks": world},
+                    "first_token_equal_on_all_ranks": sp["first_token_equal_on_all_ranks"]}
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     from aha_amd import weights as W
     from aha_amd.model import HipInferenceModel, MultiModalData
 
@@ -277,8 +327,16 @@ def main():
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(line), flush=True)
     model.close()
+    torch.cuda.empty_cache()
+    # The part of the path that SHARDS (north_star: long-context prefill + ViT over the node's GPUs): measured next to the
+    # replica decode number whenever there is more than one rank, so a scaling run of this command covers both.
+    if (world > 1 or args.sharded_prefill) and args.workload == "qwen3vl8b":
+        sp = sharded_prefill_bench(rank, world, local_rank)
+        if rank == 0:
+            line["sharded_prefill"] = sp
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -72,3 +72,36 @@ def test_image_parallel_gather_gloo():
     for rank, shape, col in res:
         assert tuple(shape) == (2, 10, 4)
         assert all(abs(a - b) < 1e-6 for a, b in zip(col, want))
+
+
+def _uid_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from aha_amd import parallel
+    dist = parallel.init_process_group("gloo")
+    # the RCCL unique id of the TP group: made on rank 0 (a host-only call of the library), identical bytes on every rank
+    from aha_amd.model import tp_unique_id
+    uid = parallel.broadcast_bytes(tp_unique_id() if rank == 0 else None)
+    # the strong-scaling aggregation of bench.py's sharded prefill: every rank contributes tokens / world, slowest rank's time
+    value, tmax = parallel.aggregate_throughput(40980.0 / world, 1.5 + 0.25 * rank)
+    out.put((rank, uid, value, tmax))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tp_group_setup_and_strong_scaling_aggregate_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_uid_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, u0, v0, t0), (_, u1, v1, t1) = res
+    assert isinstance(u0, bytes) and len(u0) == 128 and u0 == u1 and any(u0)
+    assert t0 == t1 == 1.75 and abs(v0 - 40980.0 / 1.75) < 1e-6 and v0 == v1

