@@ -40,6 +40,7 @@ class ModelDesc(C.Structure):
         ("aud_output_dim", C.c_int32), ("aud_n_window", C.c_int32),
         ("audio_token_id", C.c_int32),
         ("tp_rank", C.c_int32), ("tp_size", C.c_int32),
+        ("compute_dtype", C.c_int32),
     ]
 
 
@@ -65,6 +66,8 @@ SIGNATURES = {
     "aha_hip_shutdown": (None, [_P]),
     "aha_hip_last_error": (C.c_char_p, []),
     "aha_hip_version": (C.c_char_p, []),
+    "aha_hip_get_dtype": (C.c_int, [C.c_int32, C.c_char_p, C.POINTER(C.c_int32)]),
+    "aha_hip_check_dtype": (C.c_int, [C.c_int32]),
     "aha_hip_model_create": (C.c_int, [_P, C.POINTER(ModelDesc), C.POINTER(TensorView), C.c_size_t, C.POINTER(_P)]),
     "aha_hip_model_destroy": (None, [_P]),
     "aha_hip_forward_initial": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_size_t, C.c_size_t, C.POINTER(MmInput),

@@ -32,6 +32,37 @@ extern "C" {
 const char* aha_hip_last_error(void) { return last_error_cstr(); }
 const char* aha_hip_version(void) { return "aha-hip 0.1 (gfx950)"; }
 
+int aha_hip_get_dtype(int32_t requested, const char* cfg_dtype, int32_t* out) {
+  API_GUARD_BEGIN
+  if (!out) {
+    set_error("aha_hip_get_dtype: out is null");
+    return AHA_ERR_INVALID;
+  }
+  if (requested >= 0) {   // Some(d) => d
+    if (requested != AHA_BF16 && requested != AHA_F16 && requested != AHA_F32) {
+      set_error("aha_hip_get_dtype: not a floating-point model dtype");
+      return AHA_ERR_INVALID;
+    }
+    *out = requested;
+    return AHA_OK;
+  }
+  const std::string c = cfg_dtype ? cfg_dtype : "";
+  if (c == "float32" || c == "float") *out = AHA_F32;
+  else if (c == "float16") *out = AHA_F16;
+  else if (c == "bfloat16") *out = AHA_BF16;
+  else *out = AHA_F32;
+  return AHA_OK;
+  API_GUARD_END
+}
+
+int aha_hip_check_dtype(int32_t dtype) {
+  if (dtype == AHA_BF16) return AHA_OK;
+  set_error(std::string("compute dtype ") + (dtype == AHA_F16 ? "f16" : dtype == AHA_F32 ? "f32" : "?") +
+            " is not supported: the gfx950 kernels compute in bf16 (f16 / f32 checkpoints are cast to bf16 at load); pass "
+            "Some(DType::BF16) or leave the dtype to a bfloat16 checkpoint's config");
+  return AHA_ERR_UNSUPPORTED;
+}
+
 int aha_hip_init(int device, aha_ctx** out) {
   API_GUARD_BEGIN
   if (!out) {
@@ -62,6 +93,10 @@ void aha_hip_shutdown(aha_ctx* ctx) {
 int aha_hip_model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view* weights, size_t n_weights,
                          aha_model** out) {
   API_GUARD_BEGIN
+  if (desc) {
+    const int rc = aha_hip_check_dtype(desc->compute_dtype);
+    if (rc) return rc;
+  }
   return model_create(ctx, desc, weights, n_weights, out);
   API_GUARD_END
 }

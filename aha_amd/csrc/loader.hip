@@ -55,7 +55,15 @@ int need_i32(const JsonValue& o, const char* key, const std::string& where, int3
     set_error(where + ": missing numeric field \"" + key + "\"");
     return AHA_ERR_INVALID;
   }
-  *out = (int32_t)v->as_i64();
+  // serde deserialises these into usize / u32: a fraction, an exponent form that is not integral, a negative value or one
+  // beyond i32 is a parse error there, not a silent truncation (strtoll of "1e3" is 1)
+  // (serde_json classifies any literal with a fraction or an exponent as a float and refuses to put it into an integer)
+  const double x = v->num;
+  if (v->str.find_first_of(".eE") != std::string::npos || !(x >= 0.0) || x > 2147483647.0 || x != (double)(int64_t)x) {
+    set_error(where + ": field \"" + key + "\" is not a non-negative 32-bit integer");
+    return AHA_ERR_INVALID;
+  }
+  *out = (int32_t)(int64_t)x;
   return AHA_OK;
 }
 int need_f32(const JsonValue& o, const char* key, const std::string& where, float* out) {

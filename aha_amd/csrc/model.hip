@@ -460,6 +460,12 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
     set_error("only head_dim == 128 is supported by the decoder kernels (Qwen3 family)");
     return AHA_ERR_UNSUPPORTED;
   }
+  if (cd.hidden_size <= 0 || cd.intermediate_size <= 0 || cd.num_hidden_layers <= 0 || cd.num_attention_heads <= 0 ||
+      cd.num_key_value_heads <= 0 || cd.vocab_size <= 0 || cd.n_stop_tokens < 0 || cd.n_stop_tokens > 8 ||
+      (cd.arch == AHA_ARCH_QWEN3VL && (cd.vis_spatial_merge_size <= 0 || cd.vis_patch_size <= 0 || cd.vis_num_heads <= 0))) {
+    set_error("model_create: sizes must be positive (and at most 8 stop tokens)");   // they divide below: a 0 would be SIGFPE
+    return AHA_ERR_INVALID;
+  }
   if (cd.num_attention_heads % cd.num_key_value_heads || cd.num_attention_heads / cd.num_key_value_heads > 16) {
     set_error("unsupported GQA group size");
     return AHA_ERR_UNSUPPORTED;
@@ -607,8 +613,11 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
   void* p;
   if ((rc = dev_alloc(m, sizeof(StepState), &p, true))) return fail(rc);
   m->d_state = (StepState*)p;
-  AHA_HIP_CHECK(hipHostMalloc((void**)&m->h_state, sizeof(StepState)));
-  AHA_HIP_CHECK(hipHostMalloc((void**)&m->h_logits, (size_t)c.vocab_size * 4));
+  if (hipHostMalloc((void**)&m->h_state, sizeof(StepState)) != hipSuccess ||
+      hipHostMalloc((void**)&m->h_logits, (size_t)c.vocab_size * 4) != hipSuccess) {
+    set_error("model_create: pinned host allocation failed");
+    return fail(AHA_ERR_HIP);
+  }
   m->token_log_cap = 1 << 16;
   if ((rc = dev_alloc(m, m->token_log_cap * 4, &p))) return fail(rc);
   m->d_token_log = (uint32_t*)p;
@@ -645,7 +654,10 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
   if (c.arch == AHA_ARCH_QWEN3ASR) {
     if ((rc = audio_create(m, w, nw))) return fail(rc);
   }
-  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  if (hipStreamSynchronize(m->stream) != hipSuccess) {
+    set_error(std::string("model_create: ") + hipGetErrorString(hipGetLastError()));
+    return fail(AHA_ERR_HIP);
+  }
   *out = m;
   return AHA_OK;
 }
@@ -1248,6 +1260,7 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
   enqueue_lm_head(m, (const char*)m->p_x + (size_t)(S - 1) * H * 2);
   m->cache_len += n;
   AHA_HIP_CHECK(hipGetLastError());
+  if (m->async_rc) { const int e = m->async_rc; m->async_rc = 0; return e; }   // e.g. a failed vocab-parallel all-reduce
   return fetch_outputs(m, logits_out, argmax_out);
 }
 

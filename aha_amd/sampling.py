@@ -203,3 +203,40 @@ def generate_generic_sampled(model, input_ids: Sequence[int], ctx: GenerationCon
         ctx.seqlen_offset += ctx.seq_len
     model.clear_cache()
     return generated
+
+
+def generate_asr(model, audio_datas, temperature: float, top_p: Optional[float] = None, seed: int = 34562,
+                 max_tokens: int = 1024) -> Tuple[List[int], int]:
+    """Qwen3AsrGenerateModel::generate's own loop (src/models/qwen3_asr/generate.rs:130-186), which is NOT generate_generic:
+      * sampler = get_logit_processor(Some(temperature), top_p, None, seed) with the default seed 34562 -- top_k is always
+        None (ArgMax below 1e-7, else Sampling::All / TopP), there is no repeat penalty, and ONE processor (one RNG stream)
+        serves all audio chunks of the request;
+      * `audio_datas` = one (input_ids, MultiModalData) per <= 1200 s chunk (processor.rs:126-179); every chunk runs up to
+        max_tokens forwards -- the audio features only on the first (seqlen_offset 0) -- and stops AFTER pushing either of the
+        model's two eos ids (checked on the very first sampled token too); the KV cache is cleared between chunks;
+      * the tokens of all chunks go into one list (decoded as one string by the reference).
+    Returns (generated ids, prompt token count)."""
+    lp = get_logit_processor(temperature, top_p, None, seed)
+    ctx = GenerationContext(None, None, None, None, None, seed, 0, max_tokens)
+    ctx.logit_processor = lp          # repeat_penalty 1.0: sample_and_push reduces to logit_processor.sample
+    eos = set(model.stop_token_ids()[:2])
+    generated: List[int] = []
+    prompt_tokens = 0
+    for input_ids, data in audio_datas:
+        seq_len, seqlen_offset = len(input_ids), 0
+        prompt_tokens += seq_len
+        tok = None
+        for _ in range(max_tokens):
+            if seqlen_offset == 0:
+                _, am = model.forward_initial(input_ids, 0, data, want_logits=False)
+            else:
+                _, am = model.forward_step(tok, seqlen_offset, want_logits=False)
+            mark = len(generated)
+            tok = sample_and_push(ctx, model, am, generated)
+            assert len(generated) == mark + 1
+            if tok in eos:
+                break
+            seqlen_offset += seq_len
+            seq_len = 1
+        model.clear_cache()
+    return generated, prompt_tokens

@@ -69,6 +69,11 @@ typedef struct aha_model_desc {
    * intermediate_size/tp_size MLP columns; o_proj / down_proj produce f32 partial sums that are all-reduced (RCCL or the
    * host callback below) before the residual add.  tp_size 0 or 1 = off.  Every rank passes the FULL checkpoint tensors. */
   int32_t tp_rank, tp_size;
+  /* Compute dtype the caller asks for (the `dtype: Option<DType>` of XxxGenerateModel::init resolved by get_dtype,
+   * /root/reference/src/utils/mod.rs:77-115; see aha_hip_get_dtype).  AHA_BF16 (= 0, the zero-initialised default) is the
+   * only dtype the kernels compute in: f16 / f32 CHECKPOINTS are accepted and cast to bf16 at load, an f16 / f32 COMPUTE
+   * request is refused by aha_hip_model_create with AHA_ERR_UNSUPPORTED instead of silently running in bf16. */
+  int32_t compute_dtype;
 } aha_model_desc;
 
 /* One checkpoint tensor: HF name, pointer (host memory, e.g. an mmapped safetensors file; or, when on_device != 0,
@@ -110,6 +115,15 @@ int aha_hip_init(int device, aha_ctx** out);
 void aha_hip_shutdown(aha_ctx* ctx);
 const char* aha_hip_last_error(void);
 const char* aha_hip_version(void);
+
+/* get_dtype (/root/reference/src/utils/mod.rs:77-115) as a `hip` cargo feature would extend it: an explicit request wins
+ * (requested = an aha_dtype, or -1 for None); otherwise the checkpoint's config.json "torch_dtype" string decides --
+ * "float32"/"float" -> AHA_F32, "float16" -> AHA_F16, "bfloat16" -> AHA_BF16 (gfx950 has native bf16: the role the
+ * SM >= 8.0 test plays on the reference's cuda branch; its cpu branch maps bfloat16 to F16, mod.rs:107), anything else ->
+ * AHA_F32 like the reference's `_` arm.  Host-only.  aha_hip_check_dtype says whether this library can COMPUTE in a dtype:
+ * AHA_OK for AHA_BF16, AHA_ERR_UNSUPPORTED (with a message) for the others. */
+int aha_hip_get_dtype(int32_t requested, const char* cfg_dtype, int32_t* out);
+int aha_hip_check_dtype(int32_t dtype);
 
 /* Replaces XxxGenerateModel::init's VarBuilder::from_mmaped_safetensors + Qwen3Model::new
  * (/root/reference/src/models/qwen3/generate.rs:22-50, qwen3/model.rs:104-134). */

@@ -113,3 +113,37 @@ def test_asr_token_count_mismatch_is_an_error(asr):
     with pytest.raises(AhaHipError, match="n_audio_tokens"):
         m.forward_initial(ids, 0, MultiModalData(audio_features=feats))
     m.clear_cache()
+
+
+def test_asr_generate_loop_two_chunks_greedy(asr):
+    """A4: the ASR model's own generate loop (qwen3_asr/generate.rs:130-186) through the C ABI, two audio chunks, greedy, against
+    the oracle run chunk by chunk: same tokens wherever the oracle's margin is decisive, both eos ids honoured."""
+    from aha_amd import sampling as hs
+    from aha_amd.model import MultiModalData
+    cfg, m, o = asr
+    chunks, want = [], []
+    for seed, secs in [(31, 2.5), (32, 4.0)]:
+        wave = synth_audio(int(16000 * secs), seed)
+        feats = oa.log_mel(wave)
+        ids = make_ids(cfg, oa.get_feat_extract_output_lengths(feats.shape[1]), seed)
+        chunks.append((ids, MultiModalData(audio_features=feats)))
+        o.clear_cache()
+        lg = o.forward_initial(ids, 0, torch.from_numpy(feats)).reshape(-1).numpy()
+        toks, off = [int(np.argmax(lg))], len(ids)
+        for _ in range(5):
+            lg = o.forward_step([toks[-1]], off).reshape(-1).numpy()
+            toks.append(int(np.argmax(lg)))
+            off += 1
+        want.append(toks)
+    m.clear_cache()
+    got, n_prompt = hs.generate_asr(m, chunks, temperature=0.0, max_tokens=6)
+    assert n_prompt == sum(len(c[0]) for c in chunks) and len(got) == 12
+    agree = sum(int(a == b) for a, b in zip(got, want[0] + want[1]))
+    assert got[0] == want[0][0] and got[6] == want[1][0] and agree >= 10, (got, want)
+    # an eos id stops the chunk after it has been pushed: make the first chunk's first token an eos id
+    real = m.stop_token_ids
+    m.stop_token_ids = lambda: [got[0], 1 << 30]
+    got2, _ = hs.generate_asr(m, chunks, temperature=0.0, max_tokens=6)
+    m.stop_token_ids = real
+    assert got2[0] == got[0] and got2[1:7] == got[6:12]
+    assert m.cache_len() == 0

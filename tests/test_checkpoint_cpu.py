@@ -57,6 +57,21 @@ def test_eos_scalar_and_unicode_and_errors(tmp_path):
         parse_config(str(tmp_path / "nope"))
 
 
+@pytest.mark.parametrize("bad", ["1e3", "2e0", "12.5", "2.0", "-4", "4294967296"])
+def test_config_integers_are_validated_like_serde(tmp_path, bad):
+    """usize / u32 fields: a fraction, a non-integral exponent form, a negative or an over-wide value is a parse error in the
+    reference (serde_json: any literal with a fraction or exponent is a float), never a silent truncation (strtoll("1e3") == 1) or a later division by zero."""
+    cfg = tiny_qwen3()
+    save_checkpoint(str(tmp_path), cfg, {"dummy": torch.zeros(1)})
+    txt = open(tmp_path / "config.json").read()
+    c = json.loads(txt)
+    marker = f'"num_key_value_heads": {c["num_key_value_heads"]}'
+    assert marker in txt
+    open(tmp_path / "config.json", "w").write(txt.replace(marker, f'"num_key_value_heads": {bad}'))
+    with pytest.raises(AhaHipError, match="num_key_value_heads"):
+        parse_config(str(tmp_path))
+
+
 @pytest.mark.parametrize("shards", [1, 3])
 def test_safetensors_reader_bit_exact(tmp_path, shards):
     cfg = tiny_qwen3vl()

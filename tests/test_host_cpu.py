@@ -174,3 +174,49 @@ def test_get_rope_index_hand_checked_and_errors():
         get_rope_index(cfg, ids + ids, [[1, 4, 6]])
     with pytest.raises(AhaHipError, match="longer than the remaining"):   # grid says 12 tokens, prompt has 6
         get_rope_index(cfg, ids, [[1, 4, 12]])
+
+
+def test_get_dtype_and_check_dtype():
+    """C0: get_dtype (utils/mod.rs:77-115) as a hip feature extends it + the explicit bf16-only compute contract."""
+    import ctypes as C
+    from aha_amd import _lib
+    lib = _lib.lib()
+    BF16, F16, F32 = 0, 1, 2
+    out = C.c_int32(-7)
+    for cfg, want in [(b"bfloat16", BF16), (b"float16", F16), (b"float32", F32), (b"float", F32), (b"int8", F32), (b"", F32)]:
+        assert lib.aha_hip_get_dtype(-1, cfg, C.byref(out)) == 0 and out.value == want, cfg
+    assert lib.aha_hip_get_dtype(-1, None, C.byref(out)) == 0 and out.value == F32
+    for req in (BF16, F16, F32):                      # Some(d) => d, whatever the checkpoint says
+        assert lib.aha_hip_get_dtype(req, b"bfloat16", C.byref(out)) == 0 and out.value == req
+    assert lib.aha_hip_get_dtype(4, b"bfloat16", C.byref(out)) < 0      # u8 is not a model dtype
+    assert lib.aha_hip_check_dtype(BF16) == 0
+    for bad in (F16, F32):
+        assert lib.aha_hip_check_dtype(bad) == -6     # AHA_ERR_UNSUPPORTED
+        assert b"bf16" in lib.aha_hip_last_error()
+    assert _lib.ModelDesc.compute_dtype.offset == _lib.ModelDesc.tp_size.offset + 4
+
+
+def test_rust_shim_declares_the_header_symbols():
+    """rust/aha-hip/src/lib.rs cannot be compiled here (no Rust toolchain): keep it honest textually -- every extern "C" function
+    it declares is declared in include/aha_hip.h and exported by the built library, and its #[repr(C)] structs list the fields
+    of the ctypes mirrors (which test_struct_layouts ties to the header) in the same order."""
+    import re
+    from aha_amd import _lib
+    src = open(os.path.join(ROOT, "rust", "aha-hip", "src", "lib.rs")).read()
+    header = open(os.path.join(ROOT, "include", "aha_hip.h")).read()
+    ext = src[src.index('extern "C" {'):]
+    ext = ext[:ext.index("\n    }\n")]
+    fns = re.findall(r"pub fn (aha_hip_\w+)\(", ext)
+    assert len(fns) >= 20 and len(set(fns)) == len(fns)
+    lib = _lib.lib()
+    for f in fns:
+        assert re.search(r"\b%s\s*\(" % f, header), f"{f} is not in include/aha_hip.h"
+        assert hasattr(lib, f), f"{f} is not exported by libaha_hip.so"
+
+    def rust_fields(name):
+        body = src[src.index("pub struct %s {" % name):]
+        body = body[:body.index("\n    }\n")]
+        return re.findall(r"pub (\w+):", body)
+    assert rust_fields("AhaModelDesc") == [n for n, _ in _lib.ModelDesc._fields_]
+    assert rust_fields("AhaTensorView") == [n for n, _ in _lib.TensorView._fields_]
+    assert rust_fields("AhaMmInput") == [n for n, _ in _lib.MmInput._fields_]

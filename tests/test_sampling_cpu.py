@@ -244,3 +244,35 @@ def test_topp_equal_probabilities_walk_in_position_order():
     got = np.zeros(4, np.float32)
     got[idx] = w
     np.testing.assert_allclose(got, want, atol=1e-6)
+
+
+def test_asr_generate_loop_mirror():
+    """qwen3_asr/generate.rs:130-186: per chunk a fresh prefill (features on the first forward only), eos checked on every
+    sampled token including the first, cache cleared between chunks, one token list, top_k always None."""
+    m = _FakeModel(64, eos=0)
+    m.stop_token_ids = lambda: [0, 1]
+    script = iter([5, 7, 1,      # chunk 0: stops on the SECOND eos id after pushing it
+                   0,            # chunk 1: the first sampled token is already an eos id
+                   9, 9, 9])     # chunk 2: runs into max_tokens
+    orig = m._new_logits
+    def scripted():
+        orig(); m.logits[:] = -50.0; m.logits[next(script)] = 50.0
+    m._new_logits = scripted
+    chunks = [([10, 11, 12, 13], "feat0"), ([20, 21], "feat1"), ([30, 31, 32], "feat2")]
+    toks, n_prompt = hs.generate_asr(m, chunks, temperature=0.0, max_tokens=3)
+    assert toks == [5, 7, 1, 0, 9, 9, 9] and n_prompt == 9
+    assert [c for c in m.calls if c[0] != "cand"] == [
+        ("init", 4, 0), ("step", 5, 4), ("step", 7, 5), ("clear",),
+        ("init", 2, 0), ("clear",),
+        ("init", 3, 0), ("step", 9, 3), ("step", 9, 4), ("clear",)]
+    # temperature > 0 without top_k: Sampling::All / TopP -- never a top-k candidate query of size k, seed default 34562
+    lp = hs.get_logit_processor(0.7, 0.9, None, 34562)
+    assert lp.sampling.kind == "TopP" and hs.get_logit_processor(0.7, None, None, 34562).sampling.kind == "All"
+    m2 = _FakeModel(64, eos=63)
+    m2.stop_token_ids = lambda: [63, 62]
+    a, _ = hs.generate_asr(m2, [([1, 2, 3], None)], temperature=0.7, top_p=None, max_tokens=4)
+    m3 = _FakeModel(64, eos=63)
+    m3.stop_token_ids = lambda: [63, 62]
+    b, _ = hs.generate_asr(m3, [([1, 2, 3], None)], temperature=0.7, top_p=None, max_tokens=4)
+    assert a == b and len(a) <= 4                       # same seed, same stream
+    assert len([c for c in m2.calls if c[0] == "logits"]) == len(a)   # Sampling::All draws from the whole vector
