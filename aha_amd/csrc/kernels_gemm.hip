@@ -710,6 +710,7 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st) {
   static bool once_p = false;
   if (!once_p) {
     hipFuncSetAttribute((const void*)gemm256_kernel<ACT_PARTIAL_F32, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_PARTIAL_F32, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     once_p = true;
   }
   GemmArgs p = a;  // pass 1: f32 slabs [splitk][M][N] in the caller's workspace
@@ -719,7 +720,11 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st) {
   p.residual = nullptr;
   p.act = ACT_PARTIAL_F32;
   const int kps = (nk + splitk - 1) / splitk;
-  hipLaunchKernelGGL((gemm256_kernel<ACT_PARTIAL_F32, false, false>), dim3(ntm * ntn, splitk), dim3(512), lds, st, p, zero_block(), kps);
+  static const bool pipe_sk = [] { const char* e = getenv("AHA_GEMM_PIPE"); return e ? atoi(e) != 0 : true; }();
+  if (pipe_sk)
+    hipLaunchKernelGGL((gemm256p_kernel<ACT_PARTIAL_F32, false, false>), dim3(ntm * ntn, splitk), dim3(512), lds, st, p, zero_block(), kps, nullptr);
+  else
+    hipLaunchKernelGGL((gemm256_kernel<ACT_PARTIAL_F32, false, false>), dim3(ntm * ntn, splitk), dim3(512), lds, st, p, zero_block(), kps);
   const int64_t quads = (int64_t)a.M * (a.N >> 2);
   hipLaunchKernelGGL((gemm_splitk_reduce_kernel<ACT, B, R>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, a,
                      (const float*)a.workspace, (nk + kps - 1) / kps);
@@ -760,9 +765,14 @@ GemmPlan plan_gemm(const GemmArgs& a) {
   const bool can_split = a.act != ACT_SILU_MUL_PAIRS && a.act != ACT_PARTIAL_F32 && a.workspace != nullptr && (a.N & 3) == 0;
   GemmPlan best{128, 1};
   double best_cost = cost128;
-  for (int sk = 1; sk <= 4; sk *= 2) {
-    if (sk > 1 && (!can_split || (size_t)sk * a.M * a.N * 4 > a.workspace_bytes || nk / sk < 8)) break;
-    double c = ceil(t256 * sk / 256.0) * ceil(nk / sk) * 2.0;
+  // 256^2 units: tiles x K slices.  A CU retires one 64-deep k step of a 256^2 tile in ~1.75 us with the whole chip busy (it
+  // is clock-bound there: 1.18 us alone on the chip); the last, partly filled round of units costs a full round, so the
+  // split factor is chosen to make tiles * sk land just under a multiple of the CU count -- any factor, not only powers of
+  // two (M = 1542: qkv 168 tiles x 3 = 504 units).  The reduce pass streams (sk + 1) x M x N x 4 bytes.
+  static const int sks[] = {1, 2, 3, 4, 5, 6, 8};
+  for (int sk : sks) {
+    if (sk > 1 && (!can_split || (size_t)sk * a.M * a.N * 4 > a.workspace_bytes || nk / sk < 8)) continue;
+    double c = ceil(t256 * sk / 256.0) * ceil(nk / sk) * 1.75;
     if (sk > 1) c += (double)(sk + 1) * a.M * a.N * 4.0 / 4.0e6 + 3.0;
     if (e_sk && atoi(e_sk) != sk) continue;
     if (c < best_cost || (e_tile && atoi(e_tile) == 256 && best.tile != 256)) {
@@ -770,6 +780,8 @@ GemmPlan plan_gemm(const GemmArgs& a) {
       best_cost = c;
     }
   }
+  static const char* e_dbg = getenv("AHA_GEMM_PLAN_DEBUG");
+  if (e_dbg && atoi(e_dbg)) fprintf(stderr, "[gemm plan] M=%d N=%d K=%d act=%d -> tile %d splitk %d (cost %.1f us, 128^2 %.1f us)\n", a.M, a.N, a.K, a.act, best.tile, best.splitk, best_cost, cost128);
   if (a.M < 256) best = GemmPlan{128, 1};
   if (e_tile && atoi(e_tile) == 128) best = GemmPlan{128, 1};
   return best;

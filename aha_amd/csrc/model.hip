@@ -711,7 +711,7 @@ static int ensure_prefill_scratch(aha_model* m, size_t S) {
   if ((rc = al(cap * nq * 2, &m->p_attn))) return rc;
   if ((rc = al(cap * I * 2, &m->p_act))) return rc;
   if (m->tp_size > 1 && (rc = al(cap * H * 4, (void**)&m->p_partial))) return rc;
-  m->gemm_ws_bytes = std::min((size_t)4 * cap * H * 4, (size_t)512 << 20);  // split-K slabs of the N = hidden GEMMs
+  m->gemm_ws_bytes = std::min((size_t)12 * cap * H * 4, (size_t)1 << 30);  // split-K slabs (up to 8 slices of an N = hidden GEMM, 6 of the qkv one)
   if ((rc = al(m->gemm_ws_bytes, &m->p_gemm_ws))) return rc;
   m->pf_cap = cap;
   return AHA_OK;
