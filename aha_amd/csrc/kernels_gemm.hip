@@ -17,6 +17,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -469,6 +471,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs a, const void
   do {                                                                                                               \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                \
       _Pragma("unroll") for (int mf = 0; mf < 2; ++mf) {                                                            \
+        if (!FULL && MF0 + mf >= nmf) continue;                                                                      \
         if (MODE != 3) acc[NF][MF0 + mf] = mfma32(WF[ks], af[ks][mf], acc[NF][MF0 + mf]);                           \
         else asm volatile("" :: "v"(WF[ks]), "v"(af[ks][mf]));                                                     \
       }                                                                                                              \
@@ -477,6 +480,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs a, const void
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     _Pragma("unroll") for (int ks = 2; ks < 4; ++ks)                                                                \
       _Pragma("unroll") for (int mf = 0; mf < 2; ++mf) {                                                            \
+        if (!FULL && MF0 + mf >= nmf) continue;                                                                      \
         if (MODE != 3) acc[NF][MF0 + mf] = mfma32(WF[ks], af[ks][mf], acc[NF][MF0 + mf]);                           \
         else asm volatile("" :: "v"(WF[ks]), "v"(af[ks][mf]));                                                     \
       }                                                                                                              \
@@ -503,6 +507,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs a, const void
 
   bf16x8_t af[4][2], wf0[4], wf1[4];   // [k step of 16][32-row fragment]
   const int r32 = lane & 31, hk = lane >> 5;
+  // Ragged last row tile (M = 1542: the seventh tile holds 6 rows): a wave skips the MFMAs and fragment reads of its 32-row
+  // fragments that lie entirely past M (wave-uniform), so such a tile costs its DMA + barrier skeleton, not a full tile.
+  const int nmf = __builtin_amdgcn_readfirstlane(max(0, min(4, (a.M - (m0 + wm * 128) + 31) / 32)));
   int tr_i = 0;
   auto stamp = [&](int kt) {
     if (MODE == 1) {
@@ -510,6 +517,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs a, const void
         trace[(wave >> 2) * 20 + tr_i++] = __builtin_readcyclecounter();
     }
   };
+  auto k_loop = [&](auto full_tag) {
+  constexpr bool FULL = decltype(full_tag)::value;   // all four 32-row fragments of this wave hold valid rows: no predicates
   for (int kt = kt0; kt < kt1; ++kt) {
     const int cur = (kt - kt0) & 1;
     stamp(kt);
@@ -521,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs a, const void
       if (MODE != 4 || kt == kt0) wf0[ks] = as_frag(*reinterpret_cast<const u32x4_t*>(sw + swz(wn * 64 + r32, ks * 2 + hk)));
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        if (MODE != 4 || kt == kt0) af[ks][i] = as_frag(*reinterpret_cast<const u32x4_t*>(sa + swz(wm * 128 + i * 32 + r32, ks * 2 + hk)));
+        if ((MODE != 4 || kt == kt0) && (FULL || i < nmf)) af[ks][i] = as_frag(*reinterpret_cast<const u32x4_t*>(sa + swz(wm * 128 + i * 32 + r32, ks * 2 + hk)));
     }
     stamp(kt);
     AHA_BAR();
@@ -552,7 +561,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs a, const void
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        if (MODE != 4 || kt == kt0) af[ks][i] = as_frag(*reinterpret_cast<const u32x4_t*>(sa + swz(wm * 128 + 64 + i * 32 + r32, ks * 2 + hk)));
+        if ((MODE != 4 || kt == kt0) && (FULL || 2 + i < nmf)) af[ks][i] = as_frag(*reinterpret_cast<const u32x4_t*>(sa + swz(wm * 128 + 64 + i * 32 + r32, ks * 2 + hk)));
     stamp(kt);
     AHA_BAR();
     stamp(kt);
@@ -574,6 +583,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs a, const void
     __builtin_amdgcn_s_setprio(0);
     AHA_BAR();
   }
+  };
+  if (nmf == 4) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
   if (wm == 0) AHA_BAR();   // arrivals of the two wave rows balance
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (dummy) half-tiles
 #undef AHA_BAR
