@@ -240,3 +240,52 @@ def generate_asr(model, audio_datas, temperature: float, top_p: Optional[float] 
             seq_len = 1
         model.clear_cache()
     return generated, prompt_tokens
+
+
+def generate_stream_generic_text(model, decode, input_ids: Sequence[int], ctx: GenerationContext, data=None, device_chunk: int = 8):
+    """generate_stream_generic_text (src/models/common/generate.rs:161-229) as a Python generator of decoded text pieces.
+
+    Differences from generate_generic that the reference really has and this mirrors: the loop runs `sample_len` iterations
+    including the prefill one; a piece that decodes to text containing U+FFFD (an incomplete UTF-8 sequence) is held back -- the
+    token joins `error_tokens`, which are decoded together with the next token, and are dropped after more than 3 of them -- and
+    such a held-back token is NOT checked against the eos ids (the `continue` precedes the check); the cache is cleared at the end.
+    `decode(ids) -> str` is the tokenizer hook (TokenizerModel::token_decode, src/tokenizer/mod.rs).
+    Greedy requests without a repeat penalty keep the device-resident loop: tokens are produced `device_chunk` at a time by
+    aha_hip_decode_greedy and still yielded one by one (a token produced past an eos id inside a chunk is discarded)."""
+    eos = set(model.stop_token_ids())
+    lp = ctx.logit_processor
+    generated: List[int] = []
+    error_tokens: List[int] = []
+    greedy_fast = lp.sampling.kind == "ArgMax" and ctx.repeat_penalty == 1.0 and hasattr(model, "decode_greedy")
+    pending: List[int] = []          # tokens already produced on the device, not yet consumed by the loop
+    try:
+        for _ in range(ctx.sample_len):
+            if ctx.seqlen_offset == 0:
+                _, am = model.forward_initial(input_ids, 0, data, want_logits=False)
+                tok = sample_and_push(ctx, model, am, generated)
+            elif greedy_fast:
+                if not pending:
+                    n = max(1, min(device_chunk, ctx.sample_len - len(generated)))
+                    pending = list(model.decode_greedy(generated[-1], ctx.seqlen_offset, n))
+                    if not pending:
+                        break
+                tok = pending.pop(0)
+                generated.append(tok)
+            else:
+                _, am = model.forward_step(generated[-1], ctx.seqlen_offset, want_logits=False)
+                tok = sample_and_push(ctx, model, am, generated)
+            piece = decode(error_tokens + [tok])
+            # prepare_for_next_token (generate.rs:54-66)
+            ctx.seqlen_offset += ctx.seq_len
+            ctx.seq_len = 1
+            if "�" in piece:
+                error_tokens.append(tok)
+                if len(error_tokens) > 3:
+                    error_tokens.clear()
+                continue
+            error_tokens.clear()
+            yield piece
+            if tok in eos:
+                break
+    finally:
+        model.clear_cache()

@@ -276,3 +276,42 @@ def test_asr_generate_loop_mirror():
     b, _ = hs.generate_asr(m3, [([1, 2, 3], None)], temperature=0.7, top_p=None, max_tokens=4)
     assert a == b and len(a) <= 4                       # same seed, same stream
     assert len([c for c in m2.calls if c[0] == "logits"]) == len(a)   # Sampling::All draws from the whole vector
+
+
+def test_stream_loop_mirror_holds_back_incomplete_utf8():
+    """generate_stream_generic_text (common/generate.rs:161-229): sample_len iterations including the prefill one, U+FFFD pieces
+    held back and re-decoded with the next token, eos NOT checked on a held-back token, cache cleared at the end."""
+    m = _FakeModel(64, eos=0)
+    script = iter([5, 40, 41, 7, 0, 9])
+    orig = m._new_logits
+    def scripted():
+        orig(); m.logits[:] = -50.0; m.logits[next(script)] = 50.0
+    m._new_logits = scripted
+
+    def decode(ids):          # ids 40, 41 are the two halves of one character; alone each decodes to U+FFFD
+        out, i = "", 0
+        while i < len(ids):
+            if ids[i] == 40 and i + 1 < len(ids) and ids[i + 1] == 41:
+                out += "é"; i += 2
+            elif ids[i] in (40, 41):
+                out += "�"; i += 1
+            else:
+                out += f"<{ids[i]}>"; i += 1
+        return out
+    ctx = hs.GenerationContext(0.0, None, None, None, None, seed=1, initial_seq_len=4, max_tokens=10)
+    m.decode_greedy = None
+    del m.decode_greedy
+    pieces = list(hs.generate_stream_generic_text(m, decode, [1, 2, 3, 4], ctx))
+    assert pieces == ["<5>", "é", "<7>", "<0>"]            # 40 held back, decoded together with 41; stops after the eos piece
+    assert [c for c in m.calls if c[0] in ("init", "step")] == [("init", 4, 0), ("step", 5, 4), ("step", 40, 5), ("step", 41, 6), ("step", 7, 7)]
+    assert m.calls[-1] == ("clear",)
+    # a held-back token is not checked against the eos ids: eos id 0 decoding to U+FFFD does not stop the loop
+    m2 = _FakeModel(64, eos=0)
+    script2 = iter([0, 6, 8])
+    o2 = m2._new_logits
+    def scripted2():
+        o2(); m2.logits[:] = -50.0; m2.logits[next(script2)] = 50.0
+    m2._new_logits = scripted2
+    ctx2 = hs.GenerationContext(0.0, None, None, None, None, seed=1, initial_seq_len=2, max_tokens=3)
+    pieces2 = list(hs.generate_stream_generic_text(m2, lambda ids: "�" if ids == [0] else "".join(f"<{i}>" for i in ids), [1, 2], ctx2))
+    assert pieces2 == ["<0><6>", "<8>"]                      # sample_len = 3 iterations in total

@@ -118,3 +118,25 @@ def test_sampled_generation_distribution(gpu):
         assert hs.generate_generic_sampled(m, prompt, ctx) == toks
     finally:
         m.close()
+
+
+def test_stream_loop_device_chunks_equal_host_loop(gpu):
+    """generate_stream_generic_text over the C ABI: the greedy fast path (device-resident chunks of aha_hip_decode_greedy, one
+    piece yielded per token) produces exactly the tokens of the host-driven generate_generic loop, for chunk sizes that do and
+    do not divide the token count; the sampled path (top-k / top-p) streams the same tokens as generate_generic_sampled."""
+    from aha_amd.model import generate_generic
+    cfg, m = make(2048)
+    try:
+        ids = [int(x) for x in np.random.default_rng(3).integers(0, 2048, size=37)]
+        want, _ = generate_generic(m, ids, 21)
+        for chunk in (1, 4, 8, 64):
+            ctx = hs.GenerationContext(0.0, None, None, None, None, seed=1, initial_seq_len=len(ids), max_tokens=21)
+            got = [int(p) for p in hs.generate_stream_generic_text(m, lambda t: ",".join(map(str, t)), ids, ctx, device_chunk=chunk)]
+            assert got == want, chunk
+            assert m.cache_len() == 0
+        a = hs.generate_generic_sampled(m, ids, hs.GenerationContext(0.7, 0.9, 20, 1.1, 16, seed=5, initial_seq_len=len(ids), max_tokens=12))
+        ctx = hs.GenerationContext(0.7, 0.9, 20, 1.1, 16, seed=5, initial_seq_len=len(ids), max_tokens=12)
+        b = [int(p) for p in hs.generate_stream_generic_text(m, lambda t: ",".join(map(str, t)), ids, ctx)]
+        assert b[:len(a)] == a and len(b) in (len(a), len(a) + 1)   # the stream loop runs sample_len iterations, the generic one sample_len - 1 steps after the prefill
+    finally:
+        m.close()
