@@ -92,6 +92,7 @@ typedef const __attribute__((address_space(1))) u32x4_t* gptr16_t;
 __device__ __forceinline__ u32x4_t ld_nt16_global(uint64_t addr) {
   return __builtin_nontemporal_load(reinterpret_cast<gptr16_t>(addr));
 }
+__device__ __forceinline__ u32x4_t ld16_global(uint64_t addr) { return *reinterpret_cast<gptr16_t>(addr); }  // cached (re-read by other blocks)
 
 // ---- activation traffic inside the persistent decode kernel --------------------------------------------------------
 // Blocks on different XCDs exchange activations between grid barriers.  The 8 XCD L2s are not coherent with each other

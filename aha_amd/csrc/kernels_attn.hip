@@ -33,6 +33,7 @@ template <int DQK, int DV, int QT, int NWV>
 __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV == 8 || DQK < 128) ? 4 : 3, 4))) void attn_prefill_kernel(AttnPrefillArgs a) {
   constexpr int NT = NWV * 64;
   constexpr int KS = DQK / 32, DS = DV / 16;
+  constexpr int RING = 3;  // LDS fragment reads in flight ahead of the MFMA that consumes them
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x [K tile | V^T tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, c = lane & 15;
   // Block order.  Workgroups go round-robin over the 8 XCDs by linear id, and each XCD has its own 4 MB L2: in the XCD-aware
@@ -90,23 +91,26 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
   constexpr int STAGE_BYTES = (KP + VP) * 16;
   u32x4_t rk[KI], rv[VI];
   auto gload_k = [&](int tile) {
-    const char* base = reinterpret_cast<const char*>(a.kv.page_ptrs[tile] + a.kv.layer_off);
-    const char* kb = base + (size_t)kvhd * KV_PAGE_TOKENS * (DQK * 2);
+    // page addresses are integers from the page table: spelled as global-address-space loads (global_load_dwordx4, counted by
+    // vmcnt only).  As generic pointers they were flat_loads, which also count on lgkmcnt -- every "wait for my LDS fragment" in
+    // front of an MFMA then waited for the NEXT tile's HBM loads as well, i.e. the prefetch was not one.
+    const uint64_t base = a.kv.page_ptrs[tile] + a.kv.layer_off;
+    const uint64_t kb = base + (uint64_t)kvhd * KV_PAGE_TOKENS * (DQK * 2);
 #pragma unroll
     for (int i = 0; i < KI; ++i) {
       const int blk = wave + i * NWV;  // fragment block (sub, k4) = (blk / KS, blk % KS)
       if (KP % NT == 0 || blk < KP / 64)
-        rk[i] = ld16(kb + blk * 1024 + lane * 16);   // pages are fragment-major (common.h): 1 KB contiguous per wave load
+        rk[i] = ld16_global(kb + blk * 1024 + lane * 16);   // pages are fragment-major (common.h): 1 KB contiguous per wave load
     }
   };
   auto gload_v = [&](int tile) {
-    const char* base = reinterpret_cast<const char*>(a.kv.page_ptrs[tile] + a.kv.layer_off);
-    const char* vb = base + (size_t)a.kvh * KV_PAGE_TOKENS * (DQK * 2) + (size_t)kvhd * DV * (KV_PAGE_TOKENS * 2);
+    const uint64_t base = a.kv.page_ptrs[tile] + a.kv.layer_off;
+    const uint64_t vb = base + (uint64_t)a.kvh * KV_PAGE_TOKENS * (DQK * 2) + (uint64_t)kvhd * DV * (KV_PAGE_TOKENS * 2);
 #pragma unroll
     for (int i = 0; i < VI; ++i) {
       const int blk = wave + i * NWV;  // fragment block (ds, kk) = (blk >> 1, blk & 1)
       if (VP % NT == 0 || blk < VP / 64)
-        rv[i] = ld16(vb + blk * 1024 + lane * 16);
+        rv[i] = ld16_global(vb + blk * 1024 + lane * 16);
     }
   };
   auto lstore_k = [&](int stage) {
@@ -129,9 +133,14 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
   auto lstore = [&](int stage) { lstore_k(stage); lstore_v(stage); };
   gload(0);
   lstore(0);
+  // Everything requested so far (the q fragments above all) is retired here, once: otherwise the waits the compiler places in
+  // the loop must assume the q loads may still be the newest requests (on the path that issues no prefetch) and turn into
+  // vmcnt(0) in the middle of the QK^T phase, i.e. wait for the tile prefetch issued a few instructions earlier.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
   for (int tile = 0; tile < ntiles; ++tile) {
-    if (tile + 1 < ntiles) gload(tile + 1);
+    // unconditional prefetch (the last iteration re-requests its own tile and drops it): one code path, exact wait counts
+    gload(min(tile + 1, ntiles - 1));
     const char* ks = smem + (tile & 1) * STAGE_BYTES;
     const char* vs = ks + KP * 16;
     const int t0 = tile * KV_PAGE_TOKENS;
@@ -144,19 +153,42 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
       any |= act[t];
     }
     if (any) {
+    // S^T = K . Q^T: the 4 token sub-tiles are 4 independent accumulators and the fragments are consumed k4-major, so
+    // consecutive MFMAs never depend on each other (sub-major order made chains of KS dependent MFMAs, each stalling for the
+    // previous one's result); fragment reads run RING fragments ahead of their MFMA (a read used to be followed by
+    // s_waitcnt lgkmcnt(0) + its MFMA: one exposed LDS latency per MFMA).
     f32x4_t st[QT][4];
 #pragma unroll
-    for (int sub = 0; sub < 4; ++sub) {
+    for (int t = 0; t < QT; ++t)
 #pragma unroll
-      for (int t = 0; t < QT; ++t) st[t][sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int sub = 0; sub < 4; ++sub) st[t][sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    {
+      constexpr int NF = 4 * KS;
+      auto kread = [&](int f) {  // fragment f = (k4, sub) = (f / 4, f % 4)
+        return *reinterpret_cast<const u32x4_t*>(ks + (((f & 3) * KS + (f >> 2)) * 64 + lane) * 16);
+      };
+      u32x4_t ring[RING];
 #pragma unroll
-      for (int k4 = 0; k4 < KS; ++k4) {
-        const bf16x8_t kf = as_frag(*reinterpret_cast<const u32x4_t*>(ks + ((sub * KS + k4) * 64 + lane) * 16));
+      for (int f = 0; f < RING; ++f) ring[f] = kread(f);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const bf16x8_t kf = as_frag(ring[f % RING]);
 #pragma unroll
         for (int t = 0; t < QT; ++t)
-          if (act[t]) st[t][sub] = mfma16(kf, qf[t][k4], st[t][sub]);
+          if (act[t]) st[t][f & 3] = mfma16(kf, qf[t][f >> 2], st[t][f & 3]);
+        if (f + RING < NF) ring[f % RING] = kread(f + RING);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    // the first V^T fragments travel while the softmax VALU work runs
+    constexpr int NFV = 2 * DS;
+    auto vread = [&](int f) {  // fragment f = (kk, ds) = (f / DS, f % DS)
+      return *reinterpret_cast<const u32x4_t*>(vs + (((f % DS) * 2 + f / DS) * 64 + lane) * 16);
+    };
+    u32x4_t vring[RING];
+#pragma unroll
+    for (int f = 0; f < RING; ++f) vring[f] = vread(f);
+    __builtin_amdgcn_sched_barrier(0);
     float alpha[QT];
     bf16x8_t pf[QT][2];
 #pragma unroll
@@ -177,15 +209,15 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
         for (int ds = 0; ds < DS; ++ds) o[t][ds] *= alpha[t];
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ds = 0; ds < DS; ++ds) {
+    for (int f = 0; f < NFV; ++f) {  // O^T += V^T . P^T, kk-major: DS independent accumulators in a row
+      const bf16x8_t vf = as_frag(vring[f % RING]);
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const bf16x8_t vf = as_frag(*reinterpret_cast<const u32x4_t*>(vs + ((ds * 2 + kk) * 64 + lane) * 16));
-#pragma unroll
-        for (int t = 0; t < QT; ++t)
-          if (act[t]) o[t][ds] = mfma16(vf, pf[t][kk], o[t][ds]);
-      }
+      for (int t = 0; t < QT; ++t)
+        if (act[t]) o[t][f % DS] = mfma16(vf, pf[t][f / DS], o[t][f % DS]);
+      if (f + RING < NFV) vring[f % RING] = vread(f + RING);
+      __builtin_amdgcn_sched_barrier(0);
     }
     }  // any
     if (tile + 1 < ntiles) lstore((tile + 1) & 1);

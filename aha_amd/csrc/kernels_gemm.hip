@@ -594,6 +594,172 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs a, const void
   epilogue32<ACT, HAS_BIAS, HAS_RES, 2, 4>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
+// ---- variant 5: the 256 x 256 x 64 tile on FOUR waves (2 x 2, 128 x 128 each), one wave per SIMD ---------------------------------
+// Each wave owns 128 x 128 of the output as 4 x 4 fragments of v_mfma_f32_32x32x16_bf16: 256 accumulator registers (the
+// accumulation half of the 512-register file) and four register sets of operand fragments (A rows i*64.., W rows j*64.. of the
+// wave's slice, 8 fragments = 32 registers each).  A fragment read from LDS feeds FOUR MFMAs (two in the 8-wave kernels): 128 KiB
+// of fragment reads per K tile and CU instead of 192, half the barriers, no second wave per SIMD to arbitrate with.
+// A K tile is four phases of 16 MFMAs (one 64 x 64 quadrant over the 64-deep K tile); the quadrant order (0,0) (0,1) (1,1) (1,0)
+// changes ONE operand set per phase, and that set is read from LDS during the phase before, k-step by k-step, in the shadow of
+// the MFMAs:
+//     P1: MFMA A0 W0 | read W1(t)   | stage W0(t+2)          P3: MFMA A1 W1 | read A0(t+1) | stage A1(t+2)
+//     P2: MFMA A0 W1 | read A1(t)   | stage W1(t+2)          P4: MFMA A1 W0 | read W0(t+1) | stage A0(t+3)
+// W0(t+1) goes into the register set W1(t) has left (the W sets swap roles every tile: the loop body is two tiles).
+// LDS: two stages of four 16-KiB regions (A half 0 / 1, W half 0 / 1: the 64-row halves of BOTH waves that share the operand).
+// Because a region is copied into registers once per tile, it is free again one phase after it was read and is restaged right
+// away with the tile two further on: every LDS-DMA (buffer_load_dwordx4 ... lds: scalar base + tile offset, one address
+// register per piece, no address arithmetic in the loop) is issued SEVEN phases (~3500 cycles) before its data is read.
+// Synchronisation: one s_waitcnt vmcnt(24) lgkmcnt(0) + one s_barrier per phase.  At the barrier of phase p every wave's DMA
+// for the region read in p has landed (it is the 7th-newest group of 4: 6 x 4 newer ones may stay in flight) and every wave's
+// reads of phase p-1 have returned, so the region they came from is restaged in p.  Tiles past the end of the K range are staged
+// from the last valid tile (never read).
+// The LDS image of a region is [128 rows][64 k] bf16 with the XOR slot swizzle of the other kernels (applied on the DMA source
+// address); image row r of half i = wave slice (r >> 6), tile row (r >> 6) * 128 + i * 64 + (r & 63).
+// Requirements: K a multiple of 64 (other shapes stay on gemm256p_kernel).  Rows past M / N are never fetched: their lanes carry
+// an out-of-range buffer offset and the DMA writes zeros.
+typedef __attribute__((address_space(3))) char* lds_cptr_t;
+
+template <int ACT, bool HAS_BIAS, bool HAS_RES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256q_kernel(GemmArgs a, int kt_per_slice) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [stage][A0 | A1 | W0 | W1] x 16 KiB
+  constexpr int REGION = 128 * 128, STAGE = 4 * REGION;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int m0, n0;
+  tile_of_block<BM2, BN2>(a, m0, n0);
+  const int nk_all = a.K / BK;
+  const int kt0 = blockIdx.y * kt_per_slice, kt1 = min(nk_all, kt0 + kt_per_slice);
+  if (ACT == ACT_PARTIAL_F32) a.C = (float*)a.C + (int64_t)blockIdx.y * a.M * a.ldc;
+
+  // buffer resources: base = first row of this block's panel, offsets below are relative to it (< 2^31: 256 rows)
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)a.A + (int64_t)m0 * a.lda), 0, 0x40000000, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)a.W + (int64_t)n0 * a.ldw), 0, 0x40000000, 0x00020000);
+  // staging: region = 16 pieces of 8 image rows (1 KiB); wave w issues pieces w*4 + q.  Lane L of a piece lands on image row
+  // g*8 + (L >> 3), physical slot L & 7, and therefore fetches logical slot (L & 7) ^ ((row >> 1) & 7).
+  int voA[2][4], voW[2][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int ir = (wave * 4 + q) * 8 + (lane >> 3);
+    const int slot = (lane & 7) ^ ((ir >> 1) & 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int trow = (ir >> 6) * 128 + h * 64 + (ir & 63);
+      voA[h][q] = (m0 + trow < a.M) ? (int)((int64_t)trow * a.lda * 2 + slot * 16) : (int)0x80000000;
+      voW[h][q] = (n0 + trow < a.N) ? (int)((int64_t)trow * a.ldw * 2 + slot * 16) : (int)0x80000000;
+    }
+  }
+  const lds_cptr_t lbase = (lds_cptr_t)smem;
+  // one DMA piece: region R (0..3 = A0 A1 W0 W1) of tile kt, piece q of this wave
+  auto dma = [&](int kt, int R, int q) __attribute__((always_inline)) {
+    const int ktc = min(kt, kt1 - 1);  // past the end: the last valid tile again (into the slot the schedule assigns; never read)
+    const lds_cptr_t dst = lbase + ((kt - kt0) & 1) * STAGE + R * REGION + (wave * 4 + q) * 1024;
+    const int so = ktc * (BK * 2);
+    if (R < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)dst, 16, voA[R & 1][q], so, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)dst, 16, voW[R & 1][q], so, 0, 0);
+  };
+  // fragment reads: set of 8 = [32-row fragment f][k-step ks]; lane (r32, hk) reads image row slice*64 + f*32 + r32, slot ks*2 + hk
+  const int r32 = lane & 31, hk = lane >> 5;
+  int loff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) loff[ks] = r32 * 128 + (((ks * 2 + hk) ^ ((r32 >> 1) & 7)) << 4);
+  auto frag = [&](int stage, int R, int slice, int f, int ks) __attribute__((always_inline)) {
+    return as_frag(*reinterpret_cast<const u32x4_t*>(smem + stage * STAGE + R * REGION + (slice * 64 + f * 32) * 128 + loff[ks]));
+  };
+
+  f32x16_t acc[4][4];  // [n fragment of 32][m fragment of 32]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  bf16x8_t fa[2][2][4], fw[2][2][4];  // [register set][fragment][k-step]; A half i lives in fa[i], W half j of tile t in fw[j ^ parity(t)]
+
+  const int nmf = __builtin_amdgcn_readfirstlane(max(0, min(4, (a.M - (m0 + wm * 128) + 31) / 32)));  // valid 32-row fragments
+
+#define AHA_WAIT(imm) __builtin_amdgcn_s_waitcnt(imm)
+#define AHA_BAR()                                \
+  do {                                           \
+    __builtin_amdgcn_sched_barrier(0);           \
+    __builtin_amdgcn_s_barrier();                \
+    __builtin_amdgcn_sched_barrier(0);           \
+  } while (0)
+  // prologue: tile kt0 and kt0+1 requested in steady-state order; A0 / W0 of kt0 into registers; then A0(kt0+2)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma(kt0, 0, q);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma(kt0, 2, q);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma(kt0, 3, q);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma(kt0, 1, q);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma(kt0 + 1, 0, q);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma(kt0 + 1, 2, q);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma(kt0 + 1, 3, q);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma(kt0 + 1, 1, q);
+  AHA_WAIT(0x4F78);  // vmcnt(24): A0, W0 of kt0 have landed
+  AHA_BAR();
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      fa[0][f][ks] = frag(0, 0, wm, f, ks);
+      fw[0][f][ks] = frag(0, 2, wn, f, ks);
+    }
+  AHA_WAIT(0xC07F);  // lgkmcnt(0)
+  AHA_BAR();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma(kt0 + 2, 0, q);
+
+  // one phase: barrier, then 4 k-steps of { 4 MFMAs, 2 fragment reads for a later phase, 1 DMA piece }
+  auto phase = [&](auto full_tag, int mi, bf16x8_t (&A)[2][4], int nj, bf16x8_t (&Wf)[2][4], bf16x8_t (&dst)[2][4], int rstage, int rR,
+                   int rslice, int dkt, int dR) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    AHA_WAIT(0x4078);  // vmcnt(24) lgkmcnt(0)
+    AHA_BAR();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+          if (FULL || mi * 2 + mf < nmf) acc[nj * 2 + nf][mi * 2 + mf] = mfma32(Wf[nf][ks], A[mf][ks], acc[nj * 2 + nf][mi * 2 + mf]);
+      // the 8 fragment reads go out in the first three k-steps (3, 3, 2): the last ones still have 1.5 k-steps of MFMAs to land in
+      // before the phase's lgkmcnt(0)
+#pragma unroll
+      for (int r = ks * 3; r < min(8, ks * 3 + 3); ++r) dst[r >> 2][r & 3] = frag(rstage, rR, rslice, r >> 2, r & 3);
+      dma(dkt, dR, ks);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto tile = [&](auto full_tag, auto par_tag, int kt) __attribute__((always_inline)) {
+    constexpr int P = decltype(par_tag)::value;  // parity of (kt - kt0): stage of this tile, and which W register set holds W0
+    phase(full_tag, 0, fa[0], 0, fw[P], fw[P ^ 1], P, 3, wn, kt + 2, 2);      // A0 W0 | read W1(t)   | stage W0(t+2)
+    phase(full_tag, 0, fa[0], 1, fw[P ^ 1], fa[1], P, 1, wm, kt + 2, 3);      // A0 W1 | read A1(t)   | stage W1(t+2)
+    phase(full_tag, 1, fa[1], 1, fw[P ^ 1], fa[0], P ^ 1, 0, wm, kt + 2, 1);  // A1 W1 | read A0(t+1) | stage A1(t+2)
+    phase(full_tag, 1, fa[1], 0, fw[P], fw[P ^ 1], P ^ 1, 2, wn, kt + 3, 0);  // A1 W0 | read W0(t+1) | stage A0(t+3)
+  };
+  auto k_loop = [&](auto full_tag) __attribute__((always_inline)) {
+    int kt = kt0;
+    for (; kt + 1 < kt1; kt += 2) {
+      tile(full_tag, std::integral_constant<int, 0>{}, kt);
+      tile(full_tag, std::integral_constant<int, 1>{}, kt + 1);
+    }
+    if (kt < kt1) tile(full_tag, std::integral_constant<int, 0>{}, kt);
+  };
+  if (nmf == 4) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
+  AHA_WAIT(0x0F70);  // vmcnt(0): nothing may still be writing this block's LDS when it retires
+#undef AHA_WAIT
+#undef AHA_BAR
+  epilogue32<ACT, HAS_BIAS, HAS_RES, 4, 4>(a, acc, m0 + wm * 128, n0 + wn * 128, lane);
+}
+
 // Sums the split-K slabs and runs the same rounding chain as the in-kernel epilogue: Linear output -> bf16, + bias -> bf16,
 // activation -> bf16, + residual -> bf16.  One thread per 4 consecutive columns.  (Not used with ACT_SILU_MUL_PAIRS.)
 template <int ACT, bool HAS_BIAS, bool HAS_RES>
@@ -671,6 +837,16 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st) {
       once = true;
     }
     static const bool pipe = [] { const char* e = getenv("AHA_GEMM_PIPE"); return e ? atoi(e) != 0 : true; }();
+    static const bool quad = [] { const char* e = getenv("AHA_GEMM_QUAD"); return e ? atoi(e) != 0 : true; }();
+    if (quad && a.K % BK == 0) {   // four waves x 128 x 128 (gemm256q_kernel)
+      static bool onceq = false;
+      if (!onceq) {
+        hipFuncSetAttribute((const void*)gemm256q_kernel<ACT, B, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        onceq = true;
+      }
+      hipLaunchKernelGGL((gemm256q_kernel<ACT, B, R>), dim3(ntm * ntn), dim3(256), lds, st, a, nk);
+      return;
+    }
     if (pipe) {
       static bool once2 = false;
       if (!once2) {
@@ -733,7 +909,15 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st) {
   p.act = ACT_PARTIAL_F32;
   const int kps = (nk + splitk - 1) / splitk;
   static const bool pipe_sk = [] { const char* e = getenv("AHA_GEMM_PIPE"); return e ? atoi(e) != 0 : true; }();
-  if (pipe_sk)
+  static const bool quad_sk = [] { const char* e = getenv("AHA_GEMM_QUAD"); return e ? atoi(e) != 0 : true; }();
+  if (quad_sk && a.K % BK == 0) {
+    static bool onceq = false;
+    if (!onceq) {
+      hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_PARTIAL_F32, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      onceq = true;
+    }
+    hipLaunchKernelGGL((gemm256q_kernel<ACT_PARTIAL_F32, false, false>), dim3(ntm * ntn, splitk), dim3(256), lds, st, p, kps);
+  } else if (pipe_sk)
     hipLaunchKernelGGL((gemm256p_kernel<ACT_PARTIAL_F32, false, false>), dim3(ntm * ntn, splitk), dim3(512), lds, st, p, zero_block(), kps, nullptr);
   else
     hipLaunchKernelGGL((gemm256_kernel<ACT_PARTIAL_F32, false, false>), dim3(ntm * ntn, splitk), dim3(512), lds, st, p, zero_block(), kps);
