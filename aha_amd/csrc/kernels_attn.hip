@@ -90,27 +90,28 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
   constexpr int KI = (KP + NT - 1) / NT, VI = (VP + NT - 1) / NT;
   constexpr int STAGE_BYTES = (KP + VP) * 16;
   u32x4_t rk[KI], rv[VI];
-  auto gload_k = [&](int tile) {
+  auto gload_k = [&](uint64_t page) {
     // page addresses are integers from the page table: spelled as global-address-space loads (global_load_dwordx4, counted by
     // vmcnt only).  As generic pointers they were flat_loads, which also count on lgkmcnt -- every "wait for my LDS fragment" in
     // front of an MFMA then waited for the NEXT tile's HBM loads as well, i.e. the prefetch was not one.
-    const uint64_t base = a.kv.page_ptrs[tile] + a.kv.layer_off;
+    const uint64_t base = page + a.kv.layer_off;
     const uint64_t kb = base + (uint64_t)kvhd * KV_PAGE_TOKENS * (DQK * 2);
 #pragma unroll
     for (int i = 0; i < KI; ++i) {
-      const int blk = wave + i * NWV;  // fragment block (sub, k4) = (blk / KS, blk % KS)
-      if (KP % NT == 0 || blk < KP / 64)
-        rk[i] = ld16_global(kb + blk * 1024 + lane * 16);   // pages are fragment-major (common.h): 1 KB contiguous per wave load
+      // fragment block (sub, k4) = (blk / KS, blk % KS).  When the piece count is not a multiple of the block size (ViT: 768 / 640
+      // pieces, 512 threads) the surplus waves re-request the last block instead of skipping: a load under a predicate is
+      // compiled as a branch with s_waitcnt vmcnt(0) at the join, which serialises the prefetch with the MFMAs.
+      const int blk = (KP % NT == 0) ? wave + i * NWV : min(wave + i * NWV, KP / 64 - 1);
+      rk[i] = ld16_global(kb + blk * 1024 + lane * 16);   // pages are fragment-major (common.h): 1 KB contiguous per wave load
     }
   };
-  auto gload_v = [&](int tile) {
-    const uint64_t base = a.kv.page_ptrs[tile] + a.kv.layer_off;
+  auto gload_v = [&](uint64_t page) {
+    const uint64_t base = page + a.kv.layer_off;
     const uint64_t vb = base + (uint64_t)a.kvh * KV_PAGE_TOKENS * (DQK * 2) + (uint64_t)kvhd * DV * (KV_PAGE_TOKENS * 2);
 #pragma unroll
     for (int i = 0; i < VI; ++i) {
-      const int blk = wave + i * NWV;  // fragment block (ds, kk) = (blk >> 1, blk & 1)
-      if (VP % NT == 0 || blk < VP / 64)
-        rv[i] = ld16_global(vb + blk * 1024 + lane * 16);
+      const int blk = (VP % NT == 0) ? wave + i * NWV : min(wave + i * NWV, VP / 64 - 1);  // fragment block (ds, kk) = (blk >> 1, blk & 1)
+      rv[i] = ld16_global(vb + blk * 1024 + lane * 16);
     }
   };
   auto lstore_k = [&](int stage) {
@@ -129,18 +130,25 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
       if (VP % NT == 0 || p < VP) *reinterpret_cast<u32x4_t*>(vsw + p * 16) = rv[i];
     }
   };
-  auto gload = [&](int tile) { gload_k(tile); gload_v(tile); };
+  auto gload = [&](uint64_t page) { gload_k(page); gload_v(page); };
   auto lstore = [&](int stage) { lstore_k(stage); lstore_v(stage); };
-  gload(0);
+  // the page table is read through the constant address space with a wave-uniform index: a scalar load (s_load_dwordx2), no
+  // vector-memory request and no VGPRs for the address of the next page
+  typedef const __attribute__((address_space(4))) uint64_t* cptr64_t;
+  const cptr64_t ptab = (cptr64_t)(uintptr_t)a.kv.page_ptrs;
+  gload(ptab[0]);
   lstore(0);
   // Everything requested so far (the q fragments above all) is retired here, once: otherwise the waits the compiler places in
   // the loop must assume the q loads may still be the newest requests (on the path that issues no prefetch) and turn into
   // vmcnt(0) in the middle of the QK^T phase, i.e. wait for the tile prefetch issued a few instructions earlier.
+  uint64_t pg_next = ptab[__builtin_amdgcn_readfirstlane(min(1, ntiles - 1))];
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
   for (int tile = 0; tile < ntiles; ++tile) {
     // unconditional prefetch (the last iteration re-requests its own tile and drops it): one code path, exact wait counts
-    gload(min(tile + 1, ntiles - 1));
+    // (the page address itself was requested one iteration earlier: its latency is not in front of the prefetch)
+    gload(pg_next);
+    pg_next = ptab[__builtin_amdgcn_readfirstlane(min(tile + 2, ntiles - 1))];
     const char* ks = smem + (tile & 1) * STAGE_BYTES;
     const char* vs = ks + KP * 16;
     const int t0 = tile * KV_PAGE_TOKENS;

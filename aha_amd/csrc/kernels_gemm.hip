@@ -619,7 +619,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs a, const void
 // an out-of-range buffer offset and the DMA writes zeros.
 typedef __attribute__((address_space(3))) char* lds_cptr_t;
 
-template <int ACT, bool HAS_BIAS, bool HAS_RES>
+// ABL (debug, results wrong by construction): 1 = no DMA in the steady state, 2 = no fragment reads in the steady state, 3 = no barriers
+template <int ACT, bool HAS_BIAS, bool HAS_RES, bool BAR2 = true, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256q_kernel(GemmArgs a, int kt_per_slice) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [stage][A0 | A1 | W0 | W1] x 16 KiB
   constexpr int REGION = 128 * 128, STAGE = 4 * REGION;
@@ -686,22 +687,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __builtin_amdgcn_sched_barrier(0);           \
   } while (0)
   // prologue: tile kt0 and kt0+1 requested in steady-state order; A0 / W0 of kt0 into registers; then A0(kt0+2)
+  {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) dma(kt0, 0, q);
+    for (int q = 0; q < 4; ++q) dma(kt0, 0, q);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) dma(kt0, 2, q);
+    for (int q = 0; q < 4; ++q) dma(kt0, 2, q);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) dma(kt0, 3, q);
+    for (int q = 0; q < 4; ++q) dma(kt0, 3, q);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) dma(kt0, 1, q);
+    for (int q = 0; q < 4; ++q) dma(kt0, 1, q);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) dma(kt0 + 1, 0, q);
+    for (int q = 0; q < 4; ++q) dma(kt0 + 1, 0, q);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) dma(kt0 + 1, 2, q);
+    for (int q = 0; q < 4; ++q) dma(kt0 + 1, 2, q);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) dma(kt0 + 1, 3, q);
+    for (int q = 0; q < 4; ++q) dma(kt0 + 1, 3, q);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) dma(kt0 + 1, 1, q);
+    for (int q = 0; q < 4; ++q) dma(kt0 + 1, 1, q);
+  }
   AHA_WAIT(0x4F78);  // vmcnt(24): A0, W0 of kt0 have landed
   AHA_BAR();
 #pragma unroll
@@ -712,37 +715,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       fw[0][f][ks] = frag(0, 2, wn, f, ks);
     }
   AHA_WAIT(0xC07F);  // lgkmcnt(0)
-  AHA_BAR();
-#pragma unroll
-  for (int q = 0; q < 4; ++q) dma(kt0 + 2, 0, q);
-
-  // one phase: barrier, then 4 k-steps of { 4 MFMAs, 2 fragment reads for a later phase, 1 DMA piece }
-  auto phase = [&](auto full_tag, int mi, bf16x8_t (&A)[2][4], int nj, bf16x8_t (&Wf)[2][4], bf16x8_t (&dst)[2][4], int rstage, int rR,
-                   int rslice, int dkt, int dR) __attribute__((always_inline)) {
-    constexpr bool FULL = decltype(full_tag)::value;
-    AHA_WAIT(0x4078);  // vmcnt(24) lgkmcnt(0)
+  if (!BAR2) {
     AHA_BAR();
 #pragma unroll
+    for (int q = 0; q < 4; ++q) dma(kt0 + 2, 0, q);
+  }
+
+  // one phase: [barrier,] then 4 k-steps of { 4 MFMAs, fragment reads for a later phase, 1 DMA piece }
+  auto phase = [&](auto full_tag, auto bar_tag, int mi, bf16x8_t (&A)[2][4], int nj, bf16x8_t (&Wf)[2][4], bf16x8_t (&dst)[2][4], int rstage,
+                   int rR, int rslice, int dkt, int dR) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    if (decltype(bar_tag)::value) {
+      if (BAR2) AHA_WAIT(0x4070);  // vmcnt(16) lgkmcnt(0)
+      else AHA_WAIT(0x4078);       // vmcnt(24) lgkmcnt(0)
+      if (ABL != 3) AHA_BAR();
+    }
+#pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
+      auto mm = [&](int nf, int mf) __attribute__((always_inline)) {
+        if (FULL || mi * 2 + mf < nmf) acc[nj * 2 + nf][mi * 2 + mf] = mfma32(Wf[nf][ks], A[mf][ks], acc[nj * 2 + nf][mi * 2 + mf]);
+      };
+      // k-step: MFMA | DMA piece | MFMA | fragment reads | MFMA MFMA.  The 8 fragment reads go out in the first three k-steps (3, 3, 2):
+      // the last ones still have 1.5 k-steps of MFMAs to land in before the next wait.  (Placement A/B on MI355X: the piece in
+      // front of the k-step's MFMAs -1 %; each wave's piece behind a different MFMA under scalar branches -17 %.)
+      mm(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ABL != 1) dma(dkt, dR, ks);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(0, 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int nf = 0; nf < 2; ++nf)
-#pragma unroll
-        for (int mf = 0; mf < 2; ++mf)
-          if (FULL || mi * 2 + mf < nmf) acc[nj * 2 + nf][mi * 2 + mf] = mfma32(Wf[nf][ks], A[mf][ks], acc[nj * 2 + nf][mi * 2 + mf]);
-      // the 8 fragment reads go out in the first three k-steps (3, 3, 2): the last ones still have 1.5 k-steps of MFMAs to land in
-      // before the phase's lgkmcnt(0)
-#pragma unroll
-      for (int r = ks * 3; r < min(8, ks * 3 + 3); ++r) dst[r >> 2][r & 3] = frag(rstage, rR, rslice, r >> 2, r & 3);
-      dma(dkt, dR, ks);
+      for (int r = ks * 3; r < min(8, ks * 3 + 3); ++r)
+        if (ABL != 2) dst[r >> 2][r & 3] = frag(rstage, rR, rslice, r >> 2, r & 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(1, 0);
+      mm(1, 1);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
   auto tile = [&](auto full_tag, auto par_tag, int kt) __attribute__((always_inline)) {
     constexpr int P = decltype(par_tag)::value;  // parity of (kt - kt0): stage of this tile, and which W register set holds W0
-    phase(full_tag, 0, fa[0], 0, fw[P], fw[P ^ 1], P, 3, wn, kt + 2, 2);      // A0 W0 | read W1(t)   | stage W0(t+2)
-    phase(full_tag, 0, fa[0], 1, fw[P ^ 1], fa[1], P, 1, wm, kt + 2, 3);      // A0 W1 | read A1(t)   | stage W1(t+2)
-    phase(full_tag, 1, fa[1], 1, fw[P ^ 1], fa[0], P ^ 1, 0, wm, kt + 2, 1);  // A1 W1 | read A0(t+1) | stage A1(t+2)
-    phase(full_tag, 1, fa[1], 0, fw[P], fw[P ^ 1], P ^ 1, 2, wn, kt + 3, 0);  // A1 W0 | read W0(t+1) | stage A0(t+3)
+    constexpr std::true_type bar{};
+    if (!BAR2) {
+      phase(full_tag, bar, 0, fa[0], 0, fw[P], fw[P ^ 1], P, 3, wn, kt + 2, 2);      // A0 W0 | read W1(t)   | stage W0(t+2)
+      phase(full_tag, bar, 0, fa[0], 1, fw[P ^ 1], fa[1], P, 1, wm, kt + 2, 3);      // A0 W1 | read A1(t)   | stage W1(t+2)
+      phase(full_tag, bar, 1, fa[1], 1, fw[P ^ 1], fa[0], P ^ 1, 0, wm, kt + 2, 1);  // A1 W1 | read A0(t+1) | stage A1(t+2)
+      phase(full_tag, bar, 1, fa[1], 0, fw[P], fw[P ^ 1], P ^ 1, 2, wn, kt + 3, 0);  // A1 W0 | read W0(t+1) | stage A0(t+3)
+    } else {
+      // BAR2: a barrier every SECOND phase.  A region is restaged two phases after it was read (the barrier in between covers
+      // both), its data is read six phases after the request; at a barrier the groups of the two coming reads have landed and
+      // the four newer ones may still be in flight: vmcnt(16).
+      constexpr std::false_type nobar{};
+      phase(full_tag, bar, 0, fa[0], 0, fw[P], fw[P ^ 1], P, 3, wn, kt + 2, 0);        // A0 W0 | read W1(t)   | stage A0(t+2)
+      phase(full_tag, nobar, 0, fa[0], 1, fw[P ^ 1], fa[1], P, 1, wm, kt + 2, 2);      // A0 W1 | read A1(t)   | stage W0(t+2)
+      phase(full_tag, bar, 1, fa[1], 1, fw[P ^ 1], fa[0], P ^ 1, 0, wm, kt + 2, 3);    // A1 W1 | read A0(t+1) | stage W1(t+2)
+      phase(full_tag, nobar, 1, fa[1], 0, fw[P], fw[P ^ 1], P ^ 1, 2, wn, kt + 2, 1);  // A1 W0 | read W0(t+1) | stage A1(t+2)
+    }
   };
   auto k_loop = [&](auto full_tag) __attribute__((always_inline)) {
     int kt = kt0;
@@ -838,11 +866,38 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st) {
     }
     static const bool pipe = [] { const char* e = getenv("AHA_GEMM_PIPE"); return e ? atoi(e) != 0 : true; }();
     static const bool quad = [] { const char* e = getenv("AHA_GEMM_QUAD"); return e ? atoi(e) != 0 : true; }();
-    if (quad && a.K % BK == 0) {   // four waves x 128 x 128 (gemm256q_kernel)
+    // four waves x 128 x 128 (gemm256q_kernel).  Not for short K loops with a bias / GELU epilogue (the ViT projections, K = 1152):
+    // one 4-wave block per CU has nothing to overlap its prologue and epilogue with (in the model: ViT fc1 146 us against 87 us on
+    // the 128^2 kernel at 4 blocks per CU, ViT qkv 49.7 against 43.4 on the 8-wave kernel).
+    if (quad && a.K % BK == 0 && (nk >= 32 || (!B && ACT != ACT_GELU_TANH && ACT != ACT_GELU_ERF))) {
       static bool onceq = false;
       if (!onceq) {
         hipFuncSetAttribute((const void*)gemm256q_kernel<ACT, B, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         onceq = true;
+      }
+      static const bool bar2 = [] { const char* e = getenv("AHA_GEMM_BAR2"); return e ? atoi(e) != 0 : true; }();
+      if (!bar2 && ACT == ACT_NONE && !B && !R) {   // A/B: one barrier per phase
+        static bool once1 = false;
+        if (!once1) {
+          hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_NONE, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          once1 = true;
+        }
+        hipLaunchKernelGGL((gemm256q_kernel<ACT_NONE, false, false, false>), dim3(ntm * ntn), dim3(256), lds, st, a, nk);
+        return;
+      }
+      static const int abl = [] { const char* e = getenv("AHA_GEMM_ABL"); return e ? atoi(e) : 0; }();
+      if (abl >= 1 && abl <= 3 && ACT == ACT_NONE && !B && !R) {   // ablations (debug; results are wrong by construction)
+        static bool once2 = false;
+        if (!once2) {
+          hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_NONE, false, false, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_NONE, false, false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_NONE, false, false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          once2 = true;
+        }
+        if (abl == 1) hipLaunchKernelGGL((gemm256q_kernel<ACT_NONE, false, false, true, 1>), dim3(ntm * ntn), dim3(256), lds, st, a, nk);
+        if (abl == 2) hipLaunchKernelGGL((gemm256q_kernel<ACT_NONE, false, false, true, 2>), dim3(ntm * ntn), dim3(256), lds, st, a, nk);
+        if (abl == 3) hipLaunchKernelGGL((gemm256q_kernel<ACT_NONE, false, false, true, 3>), dim3(ntm * ntn), dim3(256), lds, st, a, nk);
+        return;
       }
       hipLaunchKernelGGL((gemm256q_kernel<ACT, B, R>), dim3(ntm * ntn), dim3(256), lds, st, a, nk);
       return;
@@ -961,14 +1016,15 @@ GemmPlan plan_gemm(const GemmArgs& a) {
   const bool can_split = a.act != ACT_SILU_MUL_PAIRS && a.act != ACT_PARTIAL_F32 && a.workspace != nullptr && (a.N & 3) == 0;
   GemmPlan best{128, 1};
   double best_cost = cost128;
-  // 256^2 units: tiles x K slices.  A CU retires one 64-deep k step of a 256^2 tile in ~1.75 us with the whole chip busy (it
-  // is clock-bound there: 1.18 us alone on the chip); the last, partly filled round of units costs a full round, so the
+  // 256^2 units: tiles x K slices.  A CU retires one 64-deep k step of a 256^2 tile in ~1.5 us with the whole chip busy on the
+  // four-wave kernel (1.75 us on the eight-wave one; both clock-bound there); the last, partly filled round of units costs a full round, so the
   // split factor is chosen to make tiles * sk land just under a multiple of the CU count -- any factor, not only powers of
   // two (M = 1542: qkv 168 tiles x 3 = 504 units).  The reduce pass streams (sk + 1) x M x N x 4 bytes.
   static const int sks[] = {1, 2, 3, 4, 5, 6, 8};
   for (int sk : sks) {
     if (sk > 1 && (!can_split || (size_t)sk * a.M * a.N * 4 > a.workspace_bytes || nk / sk < 8)) continue;
-    double c = ceil(t256 * sk / 256.0) * ceil(nk / sk) * 1.75;
+    const bool q4 = a.K % BK == 0 && (sk > 1 || nk >= 32 || (!a.bias && a.act != ACT_GELU_TANH && a.act != ACT_GELU_ERF));   // gemm256q (launch256_one)
+    double c = ceil(t256 * sk / 256.0) * ceil(nk / sk) * (q4 ? 1.5 : 1.75);
     if (sk > 1) c += (double)(sk + 1) * a.M * a.N * 4.0 / 4.0e6 + 3.0;
     if (e_sk && atoi(e_sk) != sk) continue;
     if (c < best_cost || (e_tile && atoi(e_tile) == 256 && best.tile != 256)) {
