@@ -60,6 +60,8 @@ class MmInput(C.Structure):
 # every symbol include/aha_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
+REDUCE_SCATTER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)   # (buf_f32_dev, count_per_rank, user)
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)       # (buf_dev, bytes_per_rank, user)
 
 SIGNATURES = {
     "aha_hip_init": (C.c_int, [C.c_int, C.POINTER(_P)]),
@@ -118,6 +120,7 @@ SIGNATURES = {
     "aha_hip_weights_close": (None, [_P]),
     "aha_hip_model_load": (C.c_int, [_P, C.c_char_p, C.c_size_t, _P]),
     "aha_hip_set_allreduce": (C.c_int, [_P, _P, _P]),
+    "aha_hip_set_seq_parallel": (C.c_int, [_P, _P, _P, _P]),
     "aha_hip_tp_unique_id": (C.c_int, [_P]),
     "aha_hip_tp_init_rccl": (C.c_int, [_P, _P]),
     "aha_hip_debug_allreduce": (C.c_int, [_P, _P, C.c_size_t]),

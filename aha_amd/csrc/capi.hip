@@ -543,6 +543,20 @@ int aha_hip_set_allreduce(aha_model* m, aha_allreduce_fn fn, void* user) {
   m->allreduce_user = user;
   return AHA_OK;
 }
+int aha_hip_set_seq_parallel(aha_model* m, aha_reduce_scatter_fn reduce_scatter, aha_all_gather_fn all_gather, void* user) {
+  if (!m) {
+    set_error("set_seq_parallel: null model");
+    return AHA_ERR_INVALID;
+  }
+  if ((reduce_scatter == nullptr) != (all_gather == nullptr)) {
+    set_error("set_seq_parallel: install both callbacks or neither");
+    return AHA_ERR_INVALID;
+  }
+  m->reduce_scatter_cb = reduce_scatter;
+  m->all_gather_cb = all_gather;
+  m->sp_user = user;
+  return AHA_OK;
+}
 int aha_hip_tp_unique_id(void* out128) {
   API_GUARD_BEGIN
   if (!out128) return AHA_ERR_INVALID;

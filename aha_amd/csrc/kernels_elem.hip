@@ -293,6 +293,19 @@ __global__ __launch_bounds__(256) void residual_add_f32_kernel(bf16_t* __restric
     *reinterpret_cast<uint2*>(x + i) = xv;
   }
 }
+// sequence-parallel prefill: broadcast of one bf16 row through the f32 all-reduce seam (zeros from the ranks that do not own it)
+__global__ __launch_bounds__(256) void row_to_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[i] = x ? bf2f(x[i]) : 0.f;
+}
+__global__ __launch_bounds__(256) void f32_to_row_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[i] = f2bf(x[i]);
+}
+void launch_row_to_f32(const void* x_or_null, float* out, int n, hipStream_t st) {
+  hipLaunchKernelGGL(row_to_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const bf16_t*)x_or_null, out, n);
+}
+void launch_f32_to_row(const float* x, void* out, int n, hipStream_t st) {
+  hipLaunchKernelGGL(f32_to_row_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, (bf16_t*)out, n);
+}
 void launch_residual_add_f32(void* x, const float* sum, int64_t n, hipStream_t st) {
   if (n <= 0) return;
   const int64_t blocks = (n / 4 + 255) / 256;

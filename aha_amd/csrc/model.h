@@ -111,6 +111,9 @@ struct aha_model {
   int tp_rank = 0, tp_size = 1;
   aha_allreduce_fn allreduce_cb = nullptr;
   void* allreduce_user = nullptr;
+  aha_reduce_scatter_fn reduce_scatter_cb = nullptr;   // sequence-parallel prefill (aha_hip_set_seq_parallel)
+  aha_all_gather_fn all_gather_cb = nullptr;
+  void* sp_user = nullptr;
   void* rccl_comm = nullptr;
   int async_rc = 0;             // first error of an all-reduce issued from inside an enqueue helper
   int lm_rows = 0, lm_row0 = 0; // lm_head rows this rank streams (vocab-parallel under TP) and the first of them
@@ -175,6 +178,8 @@ int config_parse(const char* dir, aha_model_desc* out);
 int weights_open(const char* dir, aha_weights** out);
 int model_load(aha_ctx* ctx, const char* dir, size_t kv_reserve_tokens, aha_model** out);
 int rccl_allreduce(aha_model* m, float* buf, size_t count);  // tp_rccl.hip
+int rccl_reduce_scatter(aha_model* m, float* buf, size_t count_per_rank);   // in place: rank r keeps slice r
+int rccl_all_gather(aha_model* m, void* buf, size_t bytes_per_rank);        // in place: slice r is rank r's contribution
 int tp_unique_id(void* out128);
 int tp_init_rccl(aha_model* m, const void* id128);
 void tp_destroy(aha_model* m);

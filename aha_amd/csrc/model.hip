@@ -705,12 +705,12 @@ static int ensure_prefill_scratch(aha_model* m, size_t S) {
   if ((rc = al(cap * 4, (void**)&m->p_ids))) return rc;
   if ((rc = al(cap * 3 * 4, (void**)&m->p_pos))) return rc;
   if ((rc = al(cap * H * 2, &m->p_x))) return rc;
-  if ((rc = al(cap * H * 2, &m->p_h))) return rc;
+  if ((rc = al((cap + 64) * H * 2, &m->p_h))) return rc;   // + padding rows of the sequence-parallel all-gather (T * ceil(S/T) >= S)
   if ((rc = al(cap * (nq + 2 * nkv) * 2, &m->p_qkv))) return rc;
   if ((rc = al(cap * nq * 2, &m->p_q))) return rc;
   if ((rc = al(cap * nq * 2, &m->p_attn))) return rc;
   if ((rc = al(cap * I * 2, &m->p_act))) return rc;
-  if (m->tp_size > 1 && (rc = al(cap * H * 4, (void**)&m->p_partial))) return rc;
+  if (m->tp_size > 1 && (rc = al((cap + 64) * H * 4, (void**)&m->p_partial))) return rc;
   m->gemm_ws_bytes = std::min((size_t)12 * cap * H * 4, (size_t)1 << 30);  // split-K slabs (up to 8 slices of an N = hidden GEMM, 6 of the qkv one)
   if ((rc = al(m->gemm_ws_bytes, &m->p_gemm_ws))) return rc;
   m->pf_cap = cap;
@@ -832,6 +832,32 @@ int model_allreduce(aha_model* m, float* buf, size_t count) {
   }
   return AHA_OK;
 }
+// Sequence-parallel prefill (include/aha_hip.h aha_hip_set_seq_parallel): in-place reduce-scatter of f32 partial sums over
+// row slices, in-place all-gather of bf16 rows.  RCCL communicator if the library owns one, else the host callbacks.
+static bool seq_parallel_on(const aha_model* m) {
+  static const bool env_on = [] { const char* e = getenv("AHA_TP_SP"); return e ? atoi(e) != 0 : true; }();
+  return env_on && m->tp_size > 1 && (m->rccl_comm || (m->reduce_scatter_cb && m->all_gather_cb));
+}
+static int model_reduce_scatter(aha_model* m, float* buf, size_t count_per_rank) {
+  ProfScope ps(m, "reduce_scatter", (double)count_per_rank * m->tp_size * 4, 0);
+  if (m->rccl_comm) return rccl_reduce_scatter(m, buf, count_per_rank);
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  if (m->reduce_scatter_cb(buf, count_per_rank, m->sp_user) != 0) {
+    set_error("reduce-scatter callback failed");
+    return AHA_ERR_STATE;
+  }
+  return AHA_OK;
+}
+static int model_all_gather(aha_model* m, void* buf, size_t bytes_per_rank) {
+  ProfScope ps(m, "all_gather", (double)bytes_per_rank * m->tp_size, 0);
+  if (m->rccl_comm) return rccl_all_gather(m, buf, bytes_per_rank);
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  if (m->all_gather_cb(buf, bytes_per_rank, m->sp_user) != 0) {
+    set_error("all-gather callback failed");
+    return AHA_ERR_STATE;
+  }
+  return AHA_OK;
+}
 static void gemv_row_parallel(aha_model* m, GemvArgs g) {
   if (m->tp_size <= 1) {
     launch_gemv(g, GEMV_RESIDUAL, m->stream);
@@ -843,7 +869,9 @@ static void gemv_row_parallel(aha_model* m, GemvArgs g) {
   if (rc && !m->async_rc) m->async_rc = rc;
   launch_residual_add_f32(g.y, m->d_partial, g.N, m->stream);
 }
-static int gemm_row_parallel(aha_model* m, GemmArgs g) {
+// rows_per_rank > 0 selects the sequence-parallel form: the partial sums are reduce-scattered over row slices and only this
+// rank's rows [tp_rank * rows_per_rank, ...) of the residual stream are updated (the caller all-gathers the NORMALISED rows).
+static int gemm_row_parallel(aha_model* m, GemmArgs g, int rows_per_rank = 0) {
   if (m->tp_size <= 1) {
     launch_gemm(g, m->stream);
     return AHA_OK;
@@ -853,10 +881,35 @@ static int gemm_row_parallel(aha_model* m, GemmArgs g) {
   g.residual = nullptr;
   g.act = ACT_PARTIAL_F32;
   launch_gemm(g, m->stream);
+  if (rows_per_rank > 0) {
+    int rc = model_reduce_scatter(m, m->p_partial, (size_t)rows_per_rank * g.N);
+    if (rc) return rc;
+    const int64_t r0 = (int64_t)m->tp_rank * rows_per_rank, r1 = std::min<int64_t>(g.M, r0 + rows_per_rank);
+    if (r1 > r0)
+      launch_residual_add_f32((char*)xres + r0 * g.N * 2, m->p_partial + r0 * g.N, (r1 - r0) * g.N, m->stream);
+    return AHA_OK;
+  }
   int rc = model_allreduce(m, m->p_partial, (size_t)g.M * g.N);
   if (rc) return rc;
   launch_residual_add_f32(xres, m->p_partial, (int64_t)g.M * g.N, m->stream);
   return AHA_OK;
+}
+// RMSNorm of the prefill rows into p_h.  Sequence-parallel: each rank normalises its own row slice and the bf16 rows are
+// all-gathered (the slices are the only valid rows of the residual stream on their rank).
+static int prefill_norm(aha_model* m, const void* w, int S, int rows_per_rank) {
+  const aha_model_desc& c = m->desc;
+  const int H = c.hidden_size;
+  if (rows_per_rank <= 0) {
+    ProfScope ps(m, "elem", (double)S * H * 4, 0);
+    launch_rmsnorm_rows(m->p_x, w, m->p_h, S, H, H, H, c.rms_norm_eps, m->stream);
+    return AHA_OK;
+  }
+  const int64_t r0 = (int64_t)m->tp_rank * rows_per_rank, r1 = std::min<int64_t>(S, r0 + rows_per_rank);
+  if (r1 > r0) {
+    ProfScope ps(m, "elem", (double)(r1 - r0) * H * 4, 0);
+    launch_rmsnorm_rows((const char*)m->p_x + r0 * H * 2, w, (char*)m->p_h + r0 * H * 2, r1 - r0, H, H, H, c.rms_norm_eps, m->stream);
+  }
+  return model_all_gather(m, m->p_h, (size_t)rows_per_rank * H * 2);
 }
 
 // ---- decode: one token through all layers; every length-dependent value is read from d_state on the device ----
@@ -1195,12 +1248,11 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
     if ((rc = audio_forward_and_scatter(m, ids, n, mm, m->p_x))) return rc;
   }
   const int kv_off = (int)m->cache_len;
+  // sequence-parallel tensor parallelism: rank r owns rows [r * spr, (r+1) * spr) of the residual stream between the GEMMs
+  const int spr = seq_parallel_on(m) ? (S + m->tp_size - 1) / m->tp_size : 0;
   for (int li = 0; li < c.num_hidden_layers; ++li) {
     const LayerWeights& L = m->layers[li];
-    {
-      ProfScope ps(m, "elem", (double)S * H * 4, 0);
-      launch_rmsnorm_rows(m->p_x, L.in_norm, m->p_h, S, H, H, H, c.rms_norm_eps, st);
-    }
+    if ((rc = prefill_norm(m, L.in_norm, S, spr))) return rc;
     {
       GemmArgs g{};
       g.A = m->p_h; g.W = L.wqkv; g.C = m->p_qkv; g.M = S; g.N = nq + 2 * nkv; g.K = H; g.lda = H; g.ldw = H; g.ldc = g.N; g.act = ACT_NONE;
@@ -1228,12 +1280,9 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
       GemmArgs g{};
       g.A = m->p_attn; g.W = L.wo; g.C = m->p_x; g.residual = m->p_x; g.M = S; g.N = H; g.K = nq; g.lda = nq; g.ldw = nq; g.ldc = H; g.act = ACT_NONE;
       ProfScope ps(m, "gemm", ((double)g.M * g.K + (double)g.N * g.K + 2.0 * g.M * g.N) * 2, 2.0 * g.M * g.N * g.K);
-      if ((rc = gemm_row_parallel(m, g))) return rc;
+      if ((rc = gemm_row_parallel(m, g, spr))) return rc;
     }
-    {
-      ProfScope ps(m, "elem", (double)S * H * 4, 0);
-      launch_rmsnorm_rows(m->p_x, L.post_norm, m->p_h, S, H, H, H, c.rms_norm_eps, st);
-    }
+    if ((rc = prefill_norm(m, L.post_norm, S, spr))) return rc;
     {
       GemmArgs g{};
       g.A = m->p_h; g.W = L.wgu; g.C = m->p_act; g.M = S; g.N = 2 * I; g.K = H; g.lda = H; g.ldw = H; g.ldc = I; g.act = ACT_SILU_MUL_PAIRS;
@@ -1244,20 +1293,30 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
       GemmArgs g{};
       g.A = m->p_act; g.W = L.wdown; g.C = m->p_x; g.residual = m->p_x; g.M = S; g.N = H; g.K = I; g.lda = I; g.ldw = I; g.ldc = H; g.act = ACT_NONE;
       ProfScope ps(m, "gemm", ((double)g.M * g.K + (double)g.N * g.K + 2.0 * g.M * g.N) * 2, 2.0 * g.M * g.N * g.K);
-      if ((rc = gemm_row_parallel(m, g))) return rc;
+      if ((rc = gemm_row_parallel(m, g, spr))) return rc;
     }
     if (has_image) {
       // DeepStack: add visual feature k to the visual rows after decoder layer k (qwen3vl/model.rs:806-822)
       if ((rc = vision_deepstack_add(m, li, m->p_x))) return rc;
     }
   }
+  const void* x_last = (const char*)m->p_x + (size_t)(S - 1) * H * 2;
+  if (spr > 0) {
+    // the last position lives on the rank that owns row S-1: every rank contributes that row as f32 (zeros elsewhere) to one
+    // H-float all-reduce -- a broadcast, exact (bf16 -> f32 -> + 0 -> bf16)
+    const bool mine = (S - 1) / spr == m->tp_rank;
+    launch_row_to_f32(mine ? x_last : nullptr, m->d_partial, H, st);
+    if ((rc = model_allreduce(m, m->d_partial, (size_t)H))) return rc;
+    launch_f32_to_row(m->d_partial, m->d_x, H, st);
+    x_last = m->d_x;
+  }
   if (hidden_only) {  // forward_hidden: final norm of the last position only (qwen3/model.rs:186-188)
-    launch_rmsnorm_rows((const char*)m->p_x + (size_t)(S - 1) * H * 2, m->final_norm, m->d_hlast, 1, H, H, H, c.rms_norm_eps, st);
+    launch_rmsnorm_rows(x_last, m->final_norm, m->d_hlast, 1, H, H, H, c.rms_norm_eps, st);
     m->cache_len += n;
     AHA_HIP_CHECK(hipGetLastError());
     return AHA_OK;
   }
-  enqueue_lm_head(m, (const char*)m->p_x + (size_t)(S - 1) * H * 2);
+  enqueue_lm_head(m, x_last);
   m->cache_len += n;
   AHA_HIP_CHECK(hipGetLastError());
   if (m->async_rc) { const int e = m->async_rc; m->async_rc = 0; return e; }   // e.g. a failed vocab-parallel all-reduce

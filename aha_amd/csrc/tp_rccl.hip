@@ -17,6 +17,28 @@ int rccl_allreduce(aha_model* m, float* buf, size_t count) {
   return AHA_OK;
 }
 
+// Sequence-parallel prefill: the same f32 sums as the all-reduce, but each rank receives only its row slice (in place:
+// recvbuff == sendbuff + rank * recvcount), and the bf16 rows of the next GEMM's input are gathered in place
+// (sendbuff == recvbuff + rank * sendcount).
+int rccl_reduce_scatter(aha_model* m, float* buf, size_t count_per_rank) {
+  ncclResult_t r = ncclReduceScatter(buf, buf + (size_t)m->tp_rank * count_per_rank, count_per_rank, ncclFloat, ncclSum,
+                                     (ncclComm_t)m->rccl_comm, m->stream);
+  if (r != ncclSuccess) {
+    set_error(std::string("ncclReduceScatter failed: ") + ncclGetErrorString(r));
+    return AHA_ERR_HIP;
+  }
+  return AHA_OK;
+}
+int rccl_all_gather(aha_model* m, void* buf, size_t bytes_per_rank) {
+  ncclResult_t r = ncclAllGather((const char*)buf + (size_t)m->tp_rank * bytes_per_rank, buf, bytes_per_rank, ncclUint8,
+                                 (ncclComm_t)m->rccl_comm, m->stream);
+  if (r != ncclSuccess) {
+    set_error(std::string("ncclAllGather failed: ") + ncclGetErrorString(r));
+    return AHA_ERR_HIP;
+  }
+  return AHA_OK;
+}
+
 int tp_unique_id(void* out128) {
   ncclUniqueId id;
   ncclResult_t r = ncclGetUniqueId(&id);

@@ -104,11 +104,14 @@ class HipInferenceModel:
 
     def __init__(self, cfg, weights: Dict[str, torch.Tensor], ctx: Optional[HipContext] = None, device: int = 0,
                  kv_reserve_tokens: int = 0, tp_rank: int = 0, tp_size: int = 1, allreduce=None,
-                 rccl_unique_id: Optional[bytes] = None):
+                 rccl_unique_id: Optional[bytes] = None, reduce_scatter=None, all_gather=None):
         """tp_size > 1 shards the decoder stack (heads / MLP columns) over ranks; every rank passes the FULL weights and
         the library slices them.  The all-reduce is either RCCL (rccl_unique_id: 128 bytes from tp_unique_id(), shared
         by all ranks) or a host callback allreduce(ptr: int, count: int) -> None that sums `count` f32 at device
-        pointer `ptr` over ranks in place (the seam a gloo test or another transport plugs into)."""
+        pointer `ptr` over ranks in place (the seam a gloo test or another transport plugs into).
+        reduce_scatter(ptr, count_per_rank) / all_gather(ptr, bytes_per_rank) (both or neither; in place, semantics in
+        include/aha_hip.h aha_hip_set_seq_parallel) switch the prefill to the sequence-parallel form; with RCCL it is on by
+        itself."""
         self.cfg = cfg
         self.text_cfg: Qwen3Config = cfg.text if isinstance(cfg, (Qwen3VLConfig, Qwen3ASRConfig)) else cfg
         self._own_ctx = ctx is None
@@ -149,6 +152,22 @@ class HipInferenceModel:
                     return 1
             self._allreduce_c = _lib.ALLREDUCE_FN(_cb)
             check(lib().aha_hip_set_allreduce(self.handle, self._allreduce_c, None))
+            if (reduce_scatter is None) != (all_gather is None):
+                raise ValueError("pass both reduce_scatter and all_gather, or neither")
+            if reduce_scatter is not None:
+                def _wrap(fn):
+                    def _c(ptr, n, _user):
+                        try:
+                            fn(int(ptr), int(n))
+                            return 0
+                        except Exception:  # noqa: BLE001
+                            import traceback
+                            traceback.print_exc()
+                            return 1
+                    return _c
+                self._rs_c = _lib.REDUCE_SCATTER_FN(_wrap(reduce_scatter))
+                self._ag_c = _lib.ALL_GATHER_FN(_wrap(all_gather))
+                check(lib().aha_hip_set_seq_parallel(self.handle, self._rs_c, self._ag_c, None))
         self.vocab = self.text_cfg.vocab_size
         self._logits = np.empty(self.vocab, dtype=np.float32)
 

@@ -218,6 +218,20 @@ typedef int (*aha_allreduce_fn)(void* buf_f32_dev, size_t count, void* user);
 int aha_hip_set_allreduce(aha_model* m, aha_allreduce_fn fn, void* user);
 int aha_hip_tp_unique_id(void* out128);
 int aha_hip_tp_init_rccl(aha_model* m, const void* unique_id128);
+/* Sequence-parallel prefill ("reduce-scatter + all-gather, sequence-parallel norms").  With it a
+ * tensor-parallel prefill keeps the residual stream row-sharded (rank r owns rows [r*ceil(S/T), ...)): the f32 partial sums of
+ * o_proj / down_proj are REDUCE-SCATTERED over rows (same f32 sums as the all-reduce: identical numerics), the residual add and
+ * the next RMSNorm run on the owned rows only, and the normalised bf16 rows are ALL-GATHERED for the next column-parallel
+ * GEMM -- (T-1)/T * (4 + 2) bytes per element and rank instead of 2 * (T-1)/T * 4 for the ring all-reduce.
+ * Used automatically when the library owns an RCCL communicator (aha_hip_tp_init_rccl); with the host-callback seam install:
+ *   reduce_scatter(buf, count_per_rank): buf holds T * count_per_rank f32 on the device; on return rank r's slice
+ *       buf[r*count_per_rank ..) must hold the sum over ranks of that slice (the other slices are undefined);
+ *   all_gather(buf, bytes_per_rank): rank r's slice of buf (T * bytes_per_rank bytes) is its contribution; on return every
+ *       slice must be filled on every rank.
+ * Passing NULLs removes them (all-reduce path).  AHA_TP_SP=0 in the environment forces the all-reduce path. */
+typedef int (*aha_reduce_scatter_fn)(void* buf_f32_dev, size_t count_per_rank, void* user);
+typedef int (*aha_all_gather_fn)(void* buf_dev, size_t bytes_per_rank, void* user);
+int aha_hip_set_seq_parallel(aha_model* m, aha_reduce_scatter_fn reduce_scatter, aha_all_gather_fn all_gather, void* user);
 /* Test hook: run the installed all-reduce (RCCL communicator or callback) once on a caller-owned f32 device buffer and
  * wait for it.  Lets a 1-GPU box exercise the RCCL wiring with a communicator of size 1. */
 int aha_hip_debug_allreduce(aha_model* m, void* buf_f32_dev, size_t count);

@@ -42,6 +42,37 @@ class TwoRankSum:
         torch.cuda.synchronize()
         self.bar.wait()
 
+    # sequence-parallel seam (aha_hip_set_seq_parallel): in place; rank r keeps / contributes slice r
+    def reduce_scatter(self, rank, ptr, count_per_rank):
+        self.slots[rank] = self.view(ptr, count_per_rank * self.n)
+        self.bar.wait()
+        if rank == 0:
+            self.total = torch.stack([s for s in self.slots]).sum(0)
+            torch.cuda.synchronize()
+            self.rs_calls = getattr(self, "rs_calls", 0) + 1
+        self.bar.wait()
+        sl = slice(rank * count_per_rank, (rank + 1) * count_per_rank)
+        self.slots[rank].fill_(float("nan"))           # the other slices are undefined by contract: poison them
+        self.slots[rank][sl].copy_(self.total[sl])
+        torch.cuda.synchronize()
+        self.bar.wait()
+
+    def view_bytes(self, ptr, nbytes):
+        iface = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+        holder = type("H", (), {"__cuda_array_interface__": iface})()
+        return torch.as_tensor(holder, device="cuda:0")
+
+    def all_gather(self, rank, ptr, bytes_per_rank):
+        self.slots[rank] = self.view_bytes(ptr, bytes_per_rank * self.n)
+        self.bar.wait()
+        for r in range(self.n):
+            if r != rank:
+                sl = slice(r * bytes_per_rank, (r + 1) * bytes_per_rank)
+                self.slots[rank][sl].copy_(self.slots[r][sl])
+        torch.cuda.synchronize()
+        self.ag_calls = getattr(self, "ag_calls", 0) + 1
+        self.bar.wait()
+
 
 def run_ranks(fns):
     out, err = [None] * len(fns), [None] * len(fns)
@@ -92,6 +123,43 @@ def test_tp2_matches_single_gpu_text(gpu, S):
         tok, off = int(np.argmax(ref)), off + 1
     for m in ranks + [single]:
         m.close()
+
+
+@pytest.mark.parametrize("S", [5, 77, 200, 257])
+def test_tp2_sequence_parallel_prefill_equals_allreduce_prefill(gpu, S):
+    """Sequence-parallel prefill (reduce-scatter of the f32 partial sums over row slices, RMSNorm on the owned rows, all-gather
+    of the normalised bf16 rows): the same f32 sums in the same order as the all-reduce path, so the logits must be
+    bit-identical to it (and close to the single-GPU ones); S = 5 leaves the second rank 2 of 3 rows, 257 is ragged."""
+    from aha_amd.model import HipContext, HipInferenceModel
+    cfg = tiny_qwen3()
+    w = qwen3_text_weights(cfg, seed=0)
+    ids = [int(x) for x in np.random.default_rng(S).integers(0, cfg.vocab_size, size=S)]
+    outs = {}
+    for sp in (False, True):
+        red = TwoRankSum()
+        kw = dict(reduce_scatter=None, all_gather=None)
+        ranks = [HipInferenceModel(cfg, w, tp_rank=r, tp_size=2, allreduce=lambda p, n, r=r: red.allreduce(r, p, n),
+                                   **(dict(reduce_scatter=lambda p, n, r=r: red.reduce_scatter(r, p, n),
+                                           all_gather=lambda p, n, r=r: red.all_gather(r, p, n)) if sp else kw)) for r in range(2)]
+        got = run_ranks([lambda m=m: m.forward_initial(ids, 0)[0].copy() for m in ranks])
+        np.testing.assert_array_equal(got[0], got[1])
+        if sp:
+            assert red.rs_calls == 2 * cfg.num_hidden_layers and red.ag_calls == 2 * 2 * cfg.num_hidden_layers  # ag counted per rank
+        else:
+            assert not hasattr(red, "rs_calls")
+        # decode after a sequence-parallel prefill runs on the all-reduce seam over the same KV cache
+        tok = int(np.argmax(got[0]))
+        step = run_ranks([lambda m=m: m.forward_step(tok, S)[0].copy() for m in ranks])
+        np.testing.assert_array_equal(step[0], step[1])
+        outs[sp] = (got[0], step[0])
+        for m in ranks:
+            m.close()
+    np.testing.assert_array_equal(outs[True][0], outs[False][0])
+    np.testing.assert_array_equal(outs[True][1], outs[False][1])
+    single = HipInferenceModel(cfg, w)
+    ref, _ = single.forward_initial(ids, 0)
+    close(outs[True][0], ref, f"sequence-parallel tp2 prefill S={S}")
+    single.close()
 
 
 def test_tp2_greedy_tokens_and_vl(gpu):

@@ -38,7 +38,33 @@ def main():
         torch.cuda.synchronize()
         calls[0] += 1
 
-    m = HipInferenceModel(cfg, w, tp_rank=rank, tp_size=world, allreduce=allreduce)
+    sp_calls = [0, 0]
+
+    def dev_view(ptr, n, typestr):
+        iface = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+        return torch.as_tensor(type("H", (), {"__cuda_array_interface__": iface})(), device="cuda:0")
+
+    def reduce_scatter(ptr, count_per_rank):   # in place: this rank's slice receives the sum, staged through host memory
+        dev = dev_view(ptr, count_per_rank * world, "<f4")
+        host = dev.cpu()
+        dist.all_reduce(host)                  # gloo has no reduce_scatter: all_reduce on the host copy, keep this rank's slice
+        dev.fill_(float("nan"))                # the other slices are undefined by contract
+        dev[rank * count_per_rank:(rank + 1) * count_per_rank].copy_(host[rank * count_per_rank:(rank + 1) * count_per_rank])
+        torch.cuda.synchronize()
+        sp_calls[0] += 1
+
+    def all_gather(ptr, bytes_per_rank):
+        dev = dev_view(ptr, bytes_per_rank * world, "|u1")
+        mine = dev[rank * bytes_per_rank:(rank + 1) * bytes_per_rank].cpu()
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        dev.copy_(torch.cat(parts))
+        torch.cuda.synchronize()
+        sp_calls[1] += 1
+
+    sp = os.environ.get("TP_WORKER_SP", "1") != "0"
+    m = HipInferenceModel(cfg, w, tp_rank=rank, tp_size=world, allreduce=allreduce,
+                          reduce_scatter=reduce_scatter if sp else None, all_gather=all_gather if sp else None)
     g = np.random.default_rng(7)
     imgs = [g.integers(0, 256, size=(h, wd, 3), dtype=np.uint8) for (h, wd) in [(96, 160), (64, 64), (128, 96)]]
     pv, grid = ov.process_images(Numerics("bf16"), imgs)
@@ -63,6 +89,8 @@ def main():
         dec.append(t)
         off += 1
     assert calls[0] > 0, "the all-reduce seam was never used"
+    if sp:
+        assert sp_calls[0] > 0 and sp_calls[1] > 0, "the sequence-parallel seam was never used"
     all_dec = [None] * world
     dist.all_gather_object(all_dec, dec)
     assert all(d == all_dec[0] for d in all_dec), f"ranks disagree on the greedy tokens: {all_dec}"
@@ -80,7 +108,8 @@ def main():
         s2 = float(rl.std())
         assert float(np.abs(lg - rl).max()) <= 0.03 * s2 or dec != rdec, "TP decode logits drifted"
         margin_ok = dec == rdec
-        print(f"TP_WORKER_OK tokens_equal={margin_ok} allreduce_calls={calls[0]}", flush=True)
+        print(f"TP_WORKER_OK tokens_equal={margin_ok} allreduce_calls={calls[0]} reduce_scatter_calls={sp_calls[0]} "
+              f"all_gather_calls={sp_calls[1]}", flush=True)
         single.close()
     m.close()
     dist.barrier()
