@@ -14,6 +14,8 @@
 // bias / activation / gate*up pairing / residual are then lane-local and the store is 8 bytes.
 // Rounding points follow the reference op boundaries (Linear matmul -> bf16, + bias -> bf16, act -> bf16, + residual -> bf16).
 #include <math.h>
+
+#include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -44,9 +46,13 @@ __device__ __forceinline__ bf16x8_t as_frag(u32x4_t v) {
 __device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-  // candle Tensor::gelu / Activation::GeluPytorchTanh: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
-  const float k = 0.7978845608028654f;
-  return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
+  // candle Tensor::gelu / Activation::GeluPytorchTanh: 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3), written as
+  // x / (1 + e^(-2u)) on the hardware exp2 / rcp (1 ulp each): 8 VALU operations instead of tanhf's ~40.  The ViT fc1 epilogue
+  // applies it to 17.6 M elements per block -- with tanhf that was ~25 us of VALU time per launch, as much as the MFMA time.
+  // The result is rounded to bf16 by the caller; against the tanhf form it differs in < 0.1 % of the elements, by one bf16 ulp.
+  const float k2 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;  // -2 sqrt(2/pi) log2(e)
+  const float u = x * fmaf(0.044715f * x, x, 1.0f);
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(k2 * u));
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
@@ -989,7 +995,7 @@ void launch256_act(const GemmArgs& a, int splitk, hipStream_t st) {
   else launch256_one<ACT, false, false>(a, splitk, st);
 }
 
-struct GemmPlan { int tile, splitk; };
+struct GemmPlan { int tile, splitk; double cost = 0; };
 
 // Tile choice by a two-parameter cost model fitted to scripts/bench_gemm.py on MI355X (256 CUs): a CU retires one
 // (128^2 tile, 64-deep k step) in ~0.68 us when it has two or more 128^2 blocks resident, and one (256^2 tile, k step) in
@@ -1012,7 +1018,9 @@ GemmPlan plan_gemm(const GemmArgs& a) {
   const double nk = (a.K + BK - 1) / BK;
   const double t128 = (double)((a.M + 127) / 128) * ((a.N + 127) / 128);
   const double t256 = (double)((a.M + 255) / 256) * ((a.N + 255) / 256);
-  const double cost128 = ceil(t128 / 256.0) * nk * 0.68;
+  // 128^2 kernel: 0.68 us per tile and k step is the throughput of a CU holding four blocks; a launch that leaves CUs with a single
+  // block (or none) runs at that block's own latency, ~1.4 us per k step
+  const double cost128 = std::max(ceil(t128 / 256.0) * nk * 0.68, t128 < 512.0 ? nk * 1.4 + 4.0 : 0.0);
   const bool can_split = a.act != ACT_SILU_MUL_PAIRS && a.act != ACT_PARTIAL_F32 && a.workspace != nullptr && (a.N & 3) == 0;
   GemmPlan best{128, 1};
   double best_cost = cost128;
@@ -1034,8 +1042,9 @@ GemmPlan plan_gemm(const GemmArgs& a) {
   }
   static const char* e_dbg = getenv("AHA_GEMM_PLAN_DEBUG");
   if (e_dbg && atoi(e_dbg)) fprintf(stderr, "[gemm plan] M=%d N=%d K=%d act=%d -> tile %d splitk %d (cost %.1f us, 128^2 %.1f us)\n", a.M, a.N, a.K, a.act, best.tile, best.splitk, best_cost, cost128);
-  if (a.M < 256) best = GemmPlan{128, 1};
-  if (e_tile && atoi(e_tile) == 128) best = GemmPlan{128, 1};
+  best.cost = best_cost;
+  if (a.M < 256) best = GemmPlan{128, 1, cost128};
+  if (e_tile && atoi(e_tile) == 128) best = GemmPlan{128, 1, cost128};
   return best;
 }
 
@@ -1053,6 +1062,8 @@ void set_gemm_workspace(void* ws, size_t bytes) {
   tl_ws_bytes = bytes;
 }
 
+static void launch_planned(const GemmArgs& a, const GemmPlan& plan, hipStream_t st);
+
 void launch_gemm(const GemmArgs& a_in, hipStream_t st) {
   if (a_in.M <= 0 || a_in.N <= 0) return;
   GemmArgs a = a_in;
@@ -1063,6 +1074,30 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t st) {
   static const int e_grp = [] { const char* e = getenv("AHA_GEMM_GROUP"); return e ? atoi(e) : 8; }();
   a.tile_group = e_grp;
   const GemmPlan plan = plan_gemm(a);
+  // Ragged N (ViT fc1: N = 4304 = 16 x 256 + 208): the 17th column of 256^2 tiles makes 272 units = two rounds on 256 CUs for
+  // 1.06 rounds of work.  Where the model says it pays, the columns up to the last multiple of 256 run as one GEMM and the
+  // remaining columns as a second one (sub-views of W / C / bias / residual: same rounding, same results).
+  static const bool nsplit_on = [] { const char* e = getenv("AHA_GEMM_NSPLIT"); return e ? atoi(e) != 0 : true; }();
+  if (nsplit_on && g_force_tile == 0 && a.act != ACT_SILU_MUL_PAIRS && a.act != ACT_PARTIAL_F32 && a.N > 512 && a.N % 256 != 0 && a.M >= 256) {
+    const int n_main = a.N / 256 * 256;
+    GemmArgs am = a, at = a;
+    am.N = n_main;
+    at.N = a.N - n_main;
+    at.W = (const bf16_t*)a.W + (int64_t)n_main * a.ldw;
+    at.C = (bf16_t*)a.C + n_main;
+    if (a.bias) at.bias = (const bf16_t*)a.bias + n_main;
+    if (a.residual) at.residual = (const bf16_t*)a.residual + n_main;
+    const GemmPlan pm = plan_gemm(am), pt = plan_gemm(at);
+    if (pm.cost + pt.cost + 3.0 < plan.cost) {
+      launch_planned(am, pm, st);
+      launch_planned(at, pt, st);
+      return;
+    }
+  }
+  launch_planned(a, plan, st);
+}
+
+static void launch_planned(const GemmArgs& a, const GemmPlan& plan, hipStream_t st) {
   if (plan.tile == 256) {
     switch (a.act) {
       case ACT_NONE: launch256_act<ACT_NONE>(a, plan.splitk, st); break;

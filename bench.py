@@ -66,18 +66,17 @@ def decode_bytes_per_token(cfg, L):
 
 
 def cpu_baseline(cfg, sample_secs=20.0):
-    """Oracle restatement timed on the host cores: one decoder layer at full width + lm_head, extrapolated to the
-    full depth ("port"; the Candle reference cannot be built here -- BASELINE.md section 2)."""
+    """Oracle restatement timed end to end on the host cores ("port"; the Candle reference cannot be built here -- BASELINE.md
+    section 2): the FULL-depth text stack (every layer its own weights in memory: layer i is layer 0's tensors rotated by a
+    layer-dependent offset -- same statistics, distinct bytes, a memcpy instead of 15 GB of randn) decodes tokens over a short
+    context for about `sample_secs`; value = decoded tokens / seconds.  Falls back to one layer x depth only if the host cannot
+    hold the full stack."""
     import copy
     import torch
     from aha_amd.weights import qwen3_text_weights
     from oracle.numerics import Numerics
     from oracle.qwen3 import OracleQwen3
     t = cfg.text if hasattr(cfg, "text") else cfg
-    one = copy.deepcopy(t)
-    one.num_hidden_layers = 1
-    one.mrope_section = None
-    one.tie_word_embeddings = True   # lm_head timed through the (tied) embedding: same shape
     # 256 logical CPUs on the GPU box: torch's intra-op pool thrashes beyond a few dozen threads on these skinny
     # mat-vecs (measured: 1.9 s/layer at 256 threads vs 26 ms at 16-64), so the port is timed on <= 32 threads.
     try:
@@ -86,11 +85,39 @@ def cpu_baseline(cfg, sample_secs=20.0):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 32))
     torch.set_num_threads(cores)
-    w = qwen3_text_weights(one, seed=0)
-    o = OracleQwen3(one, w, Numerics("bf16"))
+    one = copy.deepcopy(t)
+    one.num_hidden_layers = 1
+    one.mrope_section = None
+    one.tie_word_embeddings = True   # lm_head timed through the (tied) embedding: same shape
+    w1 = qwen3_text_weights(one, seed=0)
+    depth, full = t.num_hidden_layers, None
+    try:
+        full_cfg = copy.deepcopy(one)
+        full_cfg.num_hidden_layers = depth
+        w = {k: v for k, v in w1.items() if ".layers." not in k}
+        for i in range(depth):
+            for k, v in w1.items():
+                if ".layers.0." in k:
+                    w[k.replace(".layers.0.", f".layers.{i}.")] = v if i == 0 else torch.roll(v.flatten(), 7919 * i + 1).view_as(v)
+        full = OracleQwen3(full_cfg, w, Numerics("bf16"))
+    except (MemoryError, RuntimeError):
+        full = None
     ids = torch.randint(0, one.vocab_size, (32,), generator=torch.Generator().manual_seed(0)).tolist()
+    if full is not None:
+        logits = full.forward(ids, 0)           # context (untimed)
+        n, pos = 0, len(ids)
+        t_start = time.perf_counter()
+        while n < 4 or (time.perf_counter() - t_start < sample_secs and n < 64):
+            tok = int(torch.argmax(logits.reshape(-1, logits.shape[-1])[-1]))
+            logits = full.forward([tok], pos)
+            n, pos = n + 1, pos + 1
+        secs = time.perf_counter() - t_start
+        return {"value": round(n / secs, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+                "sample": f"oracle restatement (torch-CPU, bf16 rounding points), {n} greedy decode steps of the full {depth}-layer "
+                          f"text stack + lm_head at a {len(ids)}-token context, timed end to end ({secs:.1f} s); Candle CPU reference "
+                          "not buildable here"}
+    o = OracleQwen3(one, w1, Numerics("bf16"))
     o.forward(ids, 0)
-    # time the single layer (hidden -> hidden) and the lm_head separately over decode steps
     n, t_layer, t_head = 0, 0.0, 0.0
     t_start = time.perf_counter()
     pos = len(ids)
@@ -104,11 +131,10 @@ def cpu_baseline(cfg, sample_secs=20.0):
         t_head += t2 - t1
         n += 1
         pos += 1
-    per_tok = t.num_hidden_layers * (t_layer / n) + t_head / n
+    per_tok = depth * (t_layer / n) + t_head / n
     return {"value": round(1.0 / per_tok, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"oracle restatement (torch-CPU, bf16 rounding points), {n} decode steps of 1 of "
-                      f"{t.num_hidden_layers} layers at full width + lm_head, extrapolated x{t.num_hidden_layers}; "
-                      "Candle CPU reference not buildable here"}
+            "sample": f"oracle restatement (torch-CPU, bf16 rounding points), {n} decode steps of 1 of {depth} layers at full width + "
+                      f"lm_head, extrapolated x{depth} (the host could not hold the full stack); Candle CPU reference not buildable here"}
 
 
 def sharded_prefill_bench(rank, world, local_rank, n_images=8, image_px=2048, prompt=8192, repeats=1):

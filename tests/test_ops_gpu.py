@@ -111,6 +111,26 @@ def test_gemm_every_tile_kernel(gpu, tile, splitk, M, N, K):
     assert_close_ulps(plain, NM.linear(A.float(), W.float()), 1, 0.98, f"plain gemm tile {tile} splitk {splitk}")
 
 
+@pytest.mark.parametrize("splitk", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(289, 512, 192), (130, 256, 320), (700, 328, 448), (608, 1024, 2048), (1542, 768, 4160)])
+def test_gemm_four_wave_kernel_edges(gpu, splitk, M, N, K):
+    """gemm256q_kernel (K a multiple of 64): odd K-tile counts (3, 5, 7, 65: the two-tile loop body's tail), uneven split-K slices,
+    every count of valid 32-row fragments in the last row tile (289 -> 2, 130 -> 1 / 0, 700 -> 2 / 0 of the second wave row, 1542 -> 1 / 0),
+    ragged N (328), the bias + residual epilogue on the deep-K route (K = 2048)."""
+    from aha_amd import ops, _lib
+    A, W, b, res = rnd((M, K), 41), rnd((N, K), 42, 0.02), rnd((N,), 43, 0.5), rnd((M, N), 44)
+    ref_plain = NM.linear(A.float(), W.float())
+    ref = NM.r(res.float() + NM.linear(A.float(), W.float(), b.float()))
+    ops.gemm_plan(256, splitk)
+    try:
+        plain = ops.gemm(A.to(gpu), W.to(gpu))
+        full = ops.gemm(A.to(gpu), W.to(gpu), b.to(gpu), res.to(gpu), _lib.ACT_NONE)
+    finally:
+        ops.gemm_plan(0, 0)
+    assert_close_ulps(plain, ref_plain, 1, 0.98, f"gemm256q plain splitk {splitk}")
+    assert_close_ulps(full, ref, 2, 0.97, f"gemm256q bias+residual splitk {splitk}")
+
+
 def test_gemm_gate_up_pairs_256_tile(gpu):
     from aha_amd import ops, _lib
     M, I, K = 700, 1024, 512
