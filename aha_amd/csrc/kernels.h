@@ -74,8 +74,13 @@ struct RopeArgs {
   void* v_out;
   int S, nh, kvh, d;
   float eps;
+  int kv_start_host = -1;   // the same value as *kv_start when the caller knows it on the host (prefill): selects the row-vectorised kernel
+  const void* rope_tab = nullptr;  // optional (S, 128) bf16: cos[64] | sin[64] of every token's angles (launch_rope_table), else computed in place
 };
 void launch_qknorm_rope(const RopeArgs& a, hipStream_t st);
+// cos / sin of pos[axis(i)] * inv_freq[i], rounded to bf16 as apply_rotary_pos_emb casts them (rope.rs:96-132): computed ONCE per
+// prefill for all layers (precise cosf / sinf of angles up to 1e5 rad cost more than the rest of the rope kernel)
+void launch_rope_table(const int32_t* pos, int64_t pos_ld, const float* inv_freq, const int32_t* axis_map, int S, void* tab, hipStream_t st);
 
 // contiguous token-major (L, kvh*d) K,V -> pages (op-level tests and TP KV gather)
 void launch_kv_pack_pages(const void* k, const void* v, KvLayer kv, int L, hipStream_t st);
@@ -182,8 +187,13 @@ struct VitRopeArgs {
   void* q_out;              // (N, nh, VIT_DQK) bf16, zero padded
   KvLayer kv;               // pages: K block [nh][64][VIT_DQK], V block [nh][VIT_DV][64]
   int N, nh, hd;
+  const float* cs_tab = nullptr;   // (N, hd/2, 2) f32: bf16-rounded (cos, sin) per patch and rotary lane (launch_vit_rope_table)
+  const int32_t* page_first = nullptr;  // (n_pages) first token of each page (a page holds consecutive tokens of one segment)
+  const int32_t* page_cnt = nullptr;    // (n_pages) tokens in the page (64 except a segment's last page)
+  int n_pages = 0;
 };
 void launch_vit_rope_pack(const VitRopeArgs& a, hipStream_t st);
+void launch_vit_rope_table(const int32_t* rowcol, const float* inv_freq, int N, int hd, float* tab, hipStream_t st);
 void launch_scatter_rows(void* dst, const void* src, const int32_t* rows, int64_t n, int D, int add, hipStream_t st);
 // image_pre.hip (V0-pre): img_smart_resize (img_utils.rs:294-331) and resize_exact(.., CatmullRom) of an RGB8 image on the device
 int img_smart_resize(uint32_t h, uint32_t w, uint32_t factor, uint32_t min_pixels, uint32_t max_pixels, uint32_t* h_out, uint32_t* w_out);

@@ -156,7 +156,185 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(RopeArgs a) {
     }
   }
 }
+// ---- the same op for a prefill (many tokens, paged destination, cache offset known on the host), 16 bytes per lane -------------
+// qknorm_rope_kernel moves 2 bytes per lane and instruction (lane l owns elements l and l+64 of a head) and recomputes cosf / sinf
+// of every angle in every layer: 23 us per call on 38 MB.  Here a 16-lane group owns one head of one token (lane sub holds dims
+// 8 sub .. 8 sub + 7: one 16-byte load and one 16-byte store, the store being a whole piece of the fragment-major K page), a wave
+// covers 4 tokens x a run of head slots, the rotate_half partner (dims +-64) is the lane 8 further on in the 16-lane row (DPP
+// row_ror:8), and cos / sin come from a table computed once per prefill (launch_rope_table): 16.5 us.
+// Bit-identical to qknorm_rope_kernel by construction: the sum of squares adds the same 64 partial terms
+// fma(x[l], x[l], x[l+64]^2) along the same butterfly (partners l^32, l^16, l^8, l^4, l^2, l^1: here rows of 8 lanes x 8
+// registers, i.e. three DPP steps then three in-register steps), and every later expression is the old one
+// (tests/test_model_gpu.py::test_row_vectorised_rope_kernel_is_bit_identical).
+// V rows take a second block role: 128 lanes per (page, kv head) load 8 tokens x 8 dims each, transpose 8 x 8 in registers
+// and store eight 16-byte pieces of the fragment-major V page (a piece = one dim x 8 token slots); pieces that
+// are only partly covered by this call's tokens fall back to 2-byte stores.
+constexpr int ROPE_ROWS_CHUNK = 10;  // head slots per wave in the q / k role
+template <int CTRL>
+__device__ __forceinline__ float dpp_rot(float v) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+__global__ __launch_bounds__(256) void qknorm_rope_rows_kernel(RopeArgs a, int n_qk_blocks) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nqk = a.nh + a.kvh;
+  if ((int)blockIdx.x < n_qk_blocks) {
+    // ---- role A: q / k heads ----
+    const int nchunk = (nqk + ROPE_ROWS_CHUNK - 1) / ROPE_ROWS_CHUNK;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    const int tg = (int)(wid / nchunk), chunk = (int)(wid % nchunk);
+    const int tq = lane >> 4, sub = lane & 15, sp = sub & 7;
+    const int tok = tg * 4 + tq;
+    if (tg * 4 >= a.S) return;
+    const bool tok_ok = tok < a.S;
+    const int tokc = tok_ok ? tok : a.S - 1;
+    float c[8], sn[8], qw[8], kw[8];
+    if (a.rope_tab) {
+      const bf16_t* tp = (const bf16_t*)a.rope_tab + (int64_t)tokc * 128 + sp * 8;
+      const u32x4_t c4 = ld16(tp), s4 = ld16(tp + 64);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        c[2 * j] = lo_bf(c4[j]); c[2 * j + 1] = hi_bf(c4[j]);
+        sn[2 * j] = lo_bf(s4[j]); sn[2 * j + 1] = hi_bf(s4[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = sp * 8 + j;
+        const float ang = (float)a.pos[(int64_t)a.axis_map[i] * a.pos_ld + tokc] * a.inv_freq[i];
+        c[j] = rbf(cosf(ang));
+        sn[j] = rbf(sinf(ang));
+      }
+    }
+    {
+      const u32x4_t q4 = ld16((const bf16_t*)a.q_norm_w + sub * 8), k4 = ld16((const bf16_t*)a.k_norm_w + sub * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        qw[2 * j] = lo_bf(q4[j]); qw[2 * j + 1] = hi_bf(q4[j]);
+        kw[2 * j] = lo_bf(k4[j]); kw[2 * j + 1] = hi_bf(k4[j]);
+      }
+    }
+    const bf16_t* row = (const bf16_t*)a.qkv + (int64_t)tokc * a.ld + sub * 8;
+    const int slot0 = chunk * ROPE_ROWS_CHUNK, slot1 = min(nqk, slot0 + ROPE_ROWS_CHUNK);
+    const int ctok = a.kv_start_host + tokc;
+    const int page = ctok / KV_PAGE_TOKENS, t = ctok % KV_PAGE_TOKENS;
+    char* kbase = reinterpret_cast<char*>(a.kv.page_ptrs[page] + a.kv.layer_off);
+    const bool hi_half = sub >= 8;
+    u32x4_t raw[ROPE_ROWS_CHUNK];
+#pragma unroll
+    for (int i = 0; i < ROPE_ROWS_CHUNK; ++i)
+      if (slot0 + i < slot1) raw[i] = ld16(row + (int64_t)(slot0 + i) * 128);
+#pragma unroll
+    for (int i = 0; i < ROPE_ROWS_CHUNK; ++i) {
+      const int slot = slot0 + i;
+      if (slot >= slot1) break;
+      const bool is_q = slot < a.nh;
+      float x[8], px[8], s[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { x[2 * j] = lo_bf(raw[i][j]); x[2 * j + 1] = hi_bf(raw[i][j]); }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) px[j] = dpp_rot<0x128>(x[j]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float lo = hi_half ? px[j] : x[j], hi = hi_half ? x[j] : px[j];
+        s[j] = fmaf(lo, lo, hi * hi);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += dpp_rot<0x124>(s[j]);   // partner l ^ 32
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += dpp_rot<0x122>(s[j]);   // l ^ 16
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += dpp_rot<0x121>(s[j]);   // l ^ 8
+      const float u0 = s[0] + s[4], u1 = s[1] + s[5], u2 = s[2] + s[6], u3 = s[3] + s[7];   // l ^ 4
+      const float v0 = u0 + u2, v1 = u1 + u3;                                                // l ^ 2
+      const float ss = v0 + v1;                                                              // l ^ 1
+      const float rinv = 1.0f / sqrtf(ss / 128.0f + a.eps);
+      float xn[8], pn[8], y[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xn[j] = rbf(x[j] * rinv * (is_q ? qw[j] : kw[j]));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pn[j] = dpp_rot<0x128>(xn[j]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[j] = rbf(rbf(xn[j] * c[j]) + rbf((hi_half ? pn[j] : -pn[j]) * sn[j]));
+      u32x4_t o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = pack_bf(y[2 * j], y[2 * j + 1]);
+      if (!tok_ok) continue;
+      if (is_q) {
+        *reinterpret_cast<u32x4_t*>((bf16_t*)a.q_out + ((int64_t)tok * a.nh + slot) * 128 + sub * 8) = o;
+      } else {
+        bf16_t* dst = reinterpret_cast<bf16_t*>(kbase) + (int64_t)(slot - a.nh) * KV_PAGE_TOKENS * 128;
+        *reinterpret_cast<u32x4_t*>(dst + kpage_elem(t, sub * 8, 4)) = o;
+      }
+    }
+    return;
+  }
+  // ---- role B: V rows, 128 lanes per (page of this call, kv head) ----
+  const int64_t u = ((int64_t)(blockIdx.x - n_qk_blocks) * 256 + threadIdx.x);
+  const int unit = (int)(u >> 7), lu = (int)(u & 127);
+  const int p0 = a.kv_start_host / KV_PAGE_TOKENS, p1 = (a.kv_start_host + a.S - 1) / KV_PAGE_TOKENS;
+  const int page = p0 + unit / a.kvh, h = unit % a.kvh;
+  if (page > p1) return;
+  const int kk = lu >> 6, G = (lu >> 4) & 3, dchunk = lu & 15;
+  uint32_t in[8][4];
+  bool ok[8];
+  bool all = true;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {   // slot order inside the piece: e = sub1 * 4 + j  <->  token kk*32 + sub1*16 + G*4 + j
+    const int tokp = kk * 32 + (e >> 2) * 16 + G * 4 + (e & 3);
+    const int srow = page * KV_PAGE_TOKENS + tokp - a.kv_start_host;
+    ok[e] = srow >= 0 && srow < a.S;
+    all &= ok[e];
+    const u32x4_t v = ld16((const bf16_t*)a.qkv + (int64_t)min(max(srow, 0), a.S - 1) * a.ld + (int64_t)(a.nh + a.kvh + h) * 128 + dchunk * 8);
+    in[e][0] = v[0]; in[e][1] = v[1]; in[e][2] = v[2]; in[e][3] = v[3];
+  }
+  bf16_t* vb = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(a.kv.page_ptrs[page] + a.kv.layer_off)) +
+               (int64_t)a.kvh * KV_PAGE_TOKENS * 128 + (int64_t)h * 128 * KV_PAGE_TOKENS;
+#pragma unroll
+  for (int dd = 0; dd < 8; ++dd) {   // dim d = dchunk*8 + dd: word dd>>1, half dd&1 of every token's 16 bytes
+    const int d = dchunk * 8 + dd;
+    u32x4_t o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t a0 = in[2 * w][dd >> 1], a1 = in[2 * w + 1][dd >> 1];
+      o[w] = (dd & 1) ? ((a0 >> 16) | (a1 & 0xffff0000u)) : ((a0 & 0xffffu) | (a1 << 16));
+    }
+    bf16_t* dst = vb + ((((d >> 4) * 2 + kk) * 64 + G * 16 + (d & 15)) << 3);
+    if (all) {
+      *reinterpret_cast<u32x4_t*>(dst) = o;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (ok[e]) dst[e] = (bf16_t)((e & 1) ? (o[e >> 1] >> 16) : (o[e >> 1] & 0xffffu));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void rope_table_kernel(const int32_t* __restrict__ pos, int64_t pos_ld, const float* __restrict__ inv_freq,
+                                                         const int32_t* __restrict__ axis_map, int S, bf16_t* __restrict__ tab) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= (int64_t)S * 64) return;
+  const int tok = (int)(g >> 6), i = (int)(g & 63);
+  const float ang = (float)pos[(int64_t)axis_map[i] * pos_ld + tok] * inv_freq[i];
+  tab[(int64_t)tok * 128 + i] = f2bf(cosf(ang));
+  tab[(int64_t)tok * 128 + 64 + i] = f2bf(sinf(ang));
+}
+void launch_rope_table(const int32_t* pos, int64_t pos_ld, const float* inv_freq, const int32_t* axis_map, int S, void* tab, hipStream_t st) {
+  if (S <= 0) return;
+  hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)(((int64_t)S * 64 + 255) / 256)), dim3(256), 0, st, pos, pos_ld, inv_freq, axis_map, S,
+                     (bf16_t*)tab);
+}
+
 void launch_qknorm_rope(const RopeArgs& a, hipStream_t st) {
+  static const bool rows_on = [] { const char* e = getenv("AHA_ROPE_ROWS"); return e ? atoi(e) != 0 : true; }();
+  if (rows_on && a.kv_start_host >= 0 && a.kv.page_ptrs != nullptr && a.d == 128 && a.S >= 16) {
+    const int nqk = a.nh + a.kvh, nchunk = (nqk + ROPE_ROWS_CHUNK - 1) / ROPE_ROWS_CHUNK;
+    const int64_t qk_waves = (int64_t)((a.S + 3) / 4) * nchunk;
+    const int n_qk_blocks = (int)((qk_waves + 3) / 4);
+    const int npages = (a.kv_start_host + a.S - 1) / KV_PAGE_TOKENS - a.kv_start_host / KV_PAGE_TOKENS + 1;
+    const int n_v_blocks = (npages * a.kvh * 128 + 255) / 256;
+    hipLaunchKernelGGL(qknorm_rope_rows_kernel, dim3((unsigned)(n_qk_blocks + n_v_blocks)), dim3(256), 0, st, a, n_qk_blocks);
+    return;
+  }
   const int64_t waves = (int64_t)a.S * ((a.nh + 2 * a.kvh + ROPE_SLOTS_PER_WAVE - 1) / ROPE_SLOTS_PER_WAVE);
   if (waves <= 0) return;
   hipLaunchKernelGGL(qknorm_rope_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);

@@ -139,6 +139,7 @@ struct aha_model {
   uint32_t* p_ids = nullptr;
   int32_t* p_pos = nullptr;
   void *p_x = nullptr, *p_h = nullptr, *p_qkv = nullptr, *p_q = nullptr, *p_attn = nullptr, *p_act = nullptr;
+  void* p_rope = nullptr;       // (S, 128) bf16 cos | sin table of the prefill's positions (kernels.h launch_rope_table)
   void* p_gemm_ws = nullptr;    // f32 split-K slabs (kernels_gemm.hip)
   size_t gemm_ws_bytes = 0;
   std::vector<void*> pf_owned;

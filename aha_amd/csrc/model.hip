@@ -704,6 +704,7 @@ static int ensure_prefill_scratch(aha_model* m, size_t S) {
   int rc;
   if ((rc = al(cap * 4, (void**)&m->p_ids))) return rc;
   if ((rc = al(cap * 3 * 4, (void**)&m->p_pos))) return rc;
+  if ((rc = al(cap * 128 * 2, &m->p_rope))) return rc;
   if ((rc = al(cap * H * 2, &m->p_x))) return rc;
   if ((rc = al((cap + 64) * H * 2, &m->p_h))) return rc;   // + padding rows of the sequence-parallel all-gather (T * ceil(S/T) >= S)
   if ((rc = al(cap * (nq + 2 * nkv) * 2, &m->p_qkv))) return rc;
@@ -1248,6 +1249,7 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
     if ((rc = audio_forward_and_scatter(m, ids, n, mm, m->p_x))) return rc;
   }
   const int kv_off = (int)m->cache_len;
+  if (d == 128) launch_rope_table(m->p_pos, S, m->d_inv_freq, m->d_axis_map, S, m->p_rope, st);   // cos / sin once for all layers
   // sequence-parallel tensor parallelism: rank r owns rows [r * spr, (r+1) * spr) of the residual stream between the GEMMs
   const int spr = seq_parallel_on(m) ? (S + m->tp_size - 1) / m->tp_size : 0;
   for (int li = 0; li < c.num_hidden_layers; ++li) {
@@ -1265,6 +1267,8 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
       r.pos = m->p_pos; r.pos_ld = S; r.inv_freq = m->d_inv_freq; r.axis_map = m->d_axis_map;
       r.q_out = m->p_q; r.kv = model_kv_layer(m, li); r.kv_start = &m->d_state->kv_start;
       r.S = S; r.nh = nh; r.kvh = kvh; r.d = d; r.eps = c.rms_norm_eps;
+      r.kv_start_host = kv_off;   // == d_state->kv_start (push_state above)
+      r.rope_tab = m->p_rope;
       ProfScope ps(m, "elem", (double)S * (nq + 2 * nkv) * 4, 0);
       launch_qknorm_rope(r, st);
     }

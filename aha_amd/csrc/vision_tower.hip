@@ -36,6 +36,8 @@ struct VisionModel {
   std::vector<void*> owned;
   void *pix = nullptr, *x = nullptr, *h = nullptr, *qkv = nullptr, *q = nullptr, *attn = nullptr, *mlp = nullptr, *mh = nullptr;
   int32_t *d_idx = nullptr, *d_rowcol = nullptr, *d_page_of = nullptr, *d_slot_of = nullptr, *d_vis_rows = nullptr;
+  float* d_cs_tab = nullptr;   // rotary (cos, sin) per patch and lane, shared by all blocks (launch_vit_rope_table)
+  int32_t *d_page_first = nullptr, *d_page_cnt = nullptr;   // per page: first token / token count (vit_rope_pack_kernel's V role)
   float* d_wt = nullptr;
   void* page_store = nullptr;
   uint64_t* d_page_ptrs = nullptr;
@@ -182,11 +184,14 @@ static int vision_ensure_scratch(aha_model* m, size_t N, size_t npages) {
   if ((rc = al(cap * 4 * 4, (void**)&v->d_idx))) return rc;
   if ((rc = al(cap * 4 * 4, (void**)&v->d_wt))) return rc;
   if ((rc = al(cap * 2 * 4, (void**)&v->d_rowcol))) return rc;
+  if ((rc = al(cap * (size_t)v->hd * 4, (void**)&v->d_cs_tab))) return rc;   // (cap, hd/2, 2) f32
   if ((rc = al(cap * 4, (void**)&v->d_page_of))) return rc;
   if ((rc = al(cap * 4, (void**)&v->d_slot_of))) return rc;
   if ((rc = al(n4 * 4, (void**)&v->d_vis_rows))) return rc;
   if ((rc = al(pcap * v->page_bytes, &v->page_store, true))) return rc;  // zero: pad slots of tail pages must stay finite
   if ((rc = al(pcap * 8, (void**)&v->d_page_ptrs))) return rc;
+  if ((rc = al(pcap * 4, (void**)&v->d_page_first))) return rc;
+  if ((rc = al(pcap * 4, (void**)&v->d_page_cnt))) return rc;
   {
     std::vector<uint64_t> ptrs(pcap);
     for (size_t i = 0; i < pcap; ++i) ptrs[i] = (uint64_t)(uintptr_t)v->page_store + i * v->page_bytes;
@@ -359,6 +364,14 @@ int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, cons
   AHA_HIP_CHECK(hipMemcpyAsync(v->d_rowcol, rowcol.data(), rowcol.size() * 4, hipMemcpyHostToDevice, st));
   AHA_HIP_CHECK(hipMemcpyAsync(v->d_page_of, page_of.data(), page_of.size() * 4, hipMemcpyHostToDevice, st));
   AHA_HIP_CHECK(hipMemcpyAsync(v->d_slot_of, slot_of.data(), slot_of.size() * 4, hipMemcpyHostToDevice, st));
+  std::vector<int32_t> page_first((size_t)pages), page_cnt((size_t)pages);
+  for (const Seg& sg : segs)
+    for (int64_t p = 0; p * KV_PAGE_TOKENS < sg.len; ++p) {
+      page_first[(size_t)(sg.page0 + p)] = (int32_t)(sg.start + p * KV_PAGE_TOKENS);
+      page_cnt[(size_t)(sg.page0 + p)] = (int32_t)std::min<int64_t>(KV_PAGE_TOKENS, sg.len - p * KV_PAGE_TOKENS);
+    }
+  AHA_HIP_CHECK(hipMemcpyAsync(v->d_page_first, page_first.data(), page_first.size() * 4, hipMemcpyHostToDevice, st));
+  AHA_HIP_CHECK(hipMemcpyAsync(v->d_page_cnt, page_cnt.data(), page_cnt.size() * 4, hipMemcpyHostToDevice, st));
   AHA_HIP_CHECK(hipMemcpyAsync(v->d_vis_rows, vis_rows.data(), vis_rows.size() * 4, hipMemcpyHostToDevice, st));
   AHA_HIP_CHECK(hipStreamSynchronize(st));  // host vectors are pageable
 
@@ -373,6 +386,7 @@ int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, cons
   kv.layer_off = 0;
   kv.kvh = v->nh;
   kv.d = v->hd;
+  launch_vit_rope_table(v->d_rowcol, v->d_inv_freq, (int)N, v->hd, v->d_cs_tab, st);
   for (int li = 0; li < v->depth; ++li) {
     const VisBlockW& b = v->blocks[li];
     {
@@ -383,7 +397,8 @@ int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, cons
     {
       VitRopeArgs r{};
       r.qkv = v->qkv; r.rowcol = v->d_rowcol; r.inv_freq = v->d_inv_freq; r.page_of = v->d_page_of; r.slot_of = v->d_slot_of;
-      r.q_out = v->q; r.kv = kv; r.N = (int)N; r.nh = v->nh; r.hd = v->hd;
+      r.q_out = v->q; r.kv = kv; r.N = (int)N; r.nh = v->nh; r.hd = v->hd; r.cs_tab = v->d_cs_tab;
+      r.page_first = v->d_page_first; r.page_cnt = v->d_page_cnt; r.n_pages = (int)pages;
       ProfScope ps(m, "elem", (double)N * v->D * 3 * 4, 0);
       launch_vit_rope_pack(r, st);
     }

@@ -273,3 +273,22 @@ def test_fused_decode_attention_equals_three_launch_variant(gpu, monkeypatch, sh
             assert float(np.sqrt(((a - b) ** 2).mean())) <= LOGIT_RMS_STD * std
             tok, off = am, off + 1
     fused.close(); plain.close()
+
+
+def test_row_vectorised_rope_kernel_is_bit_identical(gpu):
+    """The prefill's q/k-norm + rope + KV-append kernel (16 bytes per lane, 4 tokens x a run of heads per wave, V through an 8 x 8
+    register transpose) must produce exactly the bits of the per-element kernel it replaces: same logits for a chunked prefill that
+    enters a KV page in the middle, an M-RoPE prefill and the decode steps on top (tests/tools/rope_rows_worker.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for flag in ("0", "1"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "rope_rows_worker.py")],
+                           env=dict(os.environ, AHA_ROPE_ROWS=flag), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("ROPE_ROWS_DIGEST")]
+        assert line, r.stdout[-2000:]
+        digests.append(line[0].split()[1])
+    assert digests[0] == digests[1], "the row-vectorised rope kernel changed the logits"
