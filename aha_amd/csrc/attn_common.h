@@ -34,9 +34,12 @@ __device__ __forceinline__ float group_sum(float v) {
 
 // Online-softmax update for one 64-token tile.  st[sub][reg] holds raw S for token sub*16+G*4+reg, column c.
 // valid(tok_in_tile) masks both causality and the tail of the last page.  Returns the two P^T fragments.
+// Two halves (the prefill kernel starts the V^T fragment reads between them):
+//   softmax_scores: the reference's rounding chain on the scores, the mask, the tile maximum, the new running maximum and the
+//                   rescale factor alpha of everything accumulated so far; st is left holding the rounded, masked scores;
+//   softmax_probs:  p = e^(s - m) (one fma + one v_exp_f32 per score), the row sum, the bf16 P^T fragments.
 template <typename ValidFn>
-__device__ __forceinline__ void softmax_tile(f32x4_t (&st)[4], float scale, ValidFn valid, int G, float& m, float& l,
-                                             float& alpha, bf16x8_t (&pf)[2]) {
+__device__ __forceinline__ void softmax_scores(f32x4_t (&st)[4], float scale, ValidFn valid, int G, float& m, float& alpha, float& m2) {
   float tmax = -INFINITY;
 #pragma unroll
   for (int sub = 0; sub < 4; ++sub)
@@ -52,7 +55,11 @@ __device__ __forceinline__ void softmax_tile(f32x4_t (&st)[4], float scale, Vali
   const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: keep everything at zero
   alpha = __expf(m - m_use);                               // m = -inf -> 0
   constexpr float LOG2E = 1.4426950408889634f;
-  const float m2 = m_use * LOG2E;
+  m2 = m_use * LOG2E;
+  m = m_new;
+}
+__device__ __forceinline__ void softmax_probs(const f32x4_t (&st)[4], float m2, float alpha, float& l, bf16x8_t (&pf)[2]) {
+  constexpr float LOG2E = 1.4426950408889634f;
   float psum = 0.f;
   uint32_t pk[2][4];
 #pragma unroll
@@ -67,12 +74,18 @@ __device__ __forceinline__ void softmax_tile(f32x4_t (&st)[4], float scale, Vali
     pk[sub >> 1][(sub & 1) * 2 + 1] = pack_bf(p[2], p[3]);
   }
   l = l * alpha + psum;
-  m = m_new;
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
     u32x4_t u = {pk[kk][0], pk[kk][1], pk[kk][2], pk[kk][3]};
     pf[kk] = as_frag(u);
   }
+}
+template <typename ValidFn>
+__device__ __forceinline__ void softmax_tile(f32x4_t (&st)[4], float scale, ValidFn valid, int G, float& m, float& l,
+                                             float& alpha, bf16x8_t (&pf)[2]) {
+  float m2;
+  softmax_scores(st, scale, valid, G, m, alpha, m2);
+  softmax_probs(st, m2, alpha, l, pf);
 }
 
 }  // namespace aha

@@ -13,6 +13,7 @@
 //                         B = P^T (col = q c,    k = the two S^T fragments of token sub-tiles 2kk, 2kk+1, in registers)
 //                         C[reg] = O[q c][dim G*4+reg]
 // so no operand ever needs a transpose or a cross-lane shuffle; page layout and the V slot permutation: common.h.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "attn_decode_body.h"
@@ -29,11 +30,13 @@ namespace {
 // NWV waves per block (4 or 8) share every staged K / V^T tile (8 waves = 128 q rows per tile halve the staging traffic).
 // The waves of a block move in lockstep (one barrier per tile), so MFMA, softmax VALU and LDS phases only overlap ACROSS
 // blocks: the kernel is held to 128 VGPRs (amdgpu_waves_per_eu 4) so that two 8-wave blocks are resident per CU.
-template <int DQK, int DV, int QT, int NWV>
-__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV == 8 || DQK < 128) ? 4 : 3, 4))) void attn_prefill_kernel(AttnPrefillArgs a) {
+// TRACE (debug, AHA_ATTN_PTRACE=1): waves 0 and 4 of the middle block add up the shader cycles they spend in each part of the loop body
+// ABL (debug, AHA_ATTN_ABL, results wrong by construction): 2 = no softmax arithmetic, 3 = no staging of the next tile, 4 = no MFMAs
+template <int DQK, int DV, int QT, int NWV, bool TRACE = false, int ABL = 0>
+__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV == 8 || DQK < 128) ? 4 : 3, 4))) void attn_prefill_kernel(AttnPrefillArgs a, unsigned long long* trace = nullptr) {
   constexpr int NT = NWV * 64;
   constexpr int KS = DQK / 32, DS = DV / 16;
-  constexpr int RING = 3;  // LDS fragment reads in flight ahead of the MFMA that consumes them
+  constexpr int RING = (DQK >= 128) ? 6 : 4;  // LDS fragment reads in flight ahead of the MFMA that consumes them
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x [K tile | V^T tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, c = lane & 15;
   // Block order.  Workgroups go round-robin over the 8 XCDs by linear id, and each XCD has its own 4 MB L2: in the XCD-aware
@@ -78,94 +81,82 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
     for (int i = 0; i < DS; ++i) o[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
 
-  // Software pipeline over KV pages: the next page travels global -> registers while the MFMAs of the current one run
-  // from LDS, and is written to the other LDS buffer afterwards (one barrier per page).
+  // Software pipeline over KV pages: the next page travels global -> LDS by LDS-DMA (global_load_lds_dwordx4: no register round
+  // trip, no ds_write pass) into the other stage while the MFMAs of the current one run (one vmcnt(0) + barrier per page).
   // LDS layout: fragment-major.  Every K (16 tokens x 32 dims) and V^T (16 dims x 32 token slots) MFMA operand is one
   // contiguous 1 KB block whose 16-byte piece l belongs to lane l (row c = l & 15, 8-element chunk G = l >> 4), so a fragment
-  // read is ds_read_b128 at base + lane * 16 and a staging store is ds_write_b128 at base + tid * 16: both conflict-free.
-  // (A padded row-major tile cannot be: the b128 lane groups {0-3, 12-15, 20-27}, ... put rows 0-3,12-15 of chunk G and rows
-  // 4-11 of chunk G+1 in one LDS cycle, which collide for every row pitch -- 8 instead of 4 cycles per read, and the ViT
-  // kernel sat at 76 % LDS-busy.)  The KV pages in HBM have the same fragment-major layout, so the staging copy is linear.
+  // read is ds_read_b128 at base + lane * 16: conflict-free.  The KV pages in HBM have the same fragment-major layout (common.h),
+  // so the LDS image of a tile is a byte copy of the kv head's K and V blocks of the page and a wave-wide DMA piece is 1 KB
+  // contiguous on both sides.
+  // (A padded row-major tile cannot be conflict-free: the b128 lane groups {0-3, 12-15, 20-27}, ... put rows 0-3,12-15 of chunk
+  // G and rows 4-11 of chunk G+1 in one LDS cycle, which collide for every row pitch.)
+  // The staging registers this frees (4 x 16 bytes per lane) pay for a deeper fragment-read ring: the MFMA phases were bound by
+  // the LDS round trip times the reads in flight per wave (3: ~23 cycles per 16-cycle MFMA).
   constexpr int KP = KV_PAGE_TOKENS * DQK / 8, VP = DV * KV_PAGE_TOKENS / 8;  // 16-byte pieces
-  constexpr int KI = (KP + NT - 1) / NT, VI = (VP + NT - 1) / NT;
+  constexpr int KB = KP / 64, VB = VP / 64;                                    // 1-KB fragment blocks
   constexpr int STAGE_BYTES = (KP + VP) * 16;
-  u32x4_t rk[KI], rv[VI];
-  auto gload_k = [&](uint64_t page) {
-    // page addresses are integers from the page table: spelled as global-address-space loads (global_load_dwordx4, counted by
-    // vmcnt only).  As generic pointers they were flat_loads, which also count on lgkmcnt -- every "wait for my LDS fragment" in
-    // front of an MFMA then waited for the NEXT tile's HBM loads as well, i.e. the prefetch was not one.
-    const uint64_t base = page + a.kv.layer_off;
-    const uint64_t kb = base + (uint64_t)kvhd * KV_PAGE_TOKENS * (DQK * 2);
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  auto gload = [&](uint64_t page, int stage) __attribute__((always_inline)) {
+    const uint64_t kb = page + a.kv.layer_off + (uint64_t)kvhd * KV_PAGE_TOKENS * (DQK * 2);
+    const uint64_t vb = page + a.kv.layer_off + (uint64_t)a.kvh * KV_PAGE_TOKENS * (DQK * 2) + (uint64_t)kvhd * DV * (KV_PAGE_TOKENS * 2);
+    char* dst = smem + stage * STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < KI; ++i) {
-      // fragment block (sub, k4) = (blk / KS, blk % KS).  When the piece count is not a multiple of the block size (ViT: 768 / 640
-      // pieces, 512 threads) the surplus waves re-request the last block instead of skipping: a load under a predicate is
-      // compiled as a branch with s_waitcnt vmcnt(0) at the join, which serialises the prefetch with the MFMAs.
-      const int blk = (KP % NT == 0) ? wave + i * NWV : min(wave + i * NWV, KP / 64 - 1);
-      rk[i] = ld16_global(kb + blk * 1024 + lane * 16);   // pages are fragment-major (common.h): 1 KB contiguous per wave load
+    for (int i = 0; i < (KB + NWV - 1) / NWV; ++i) {
+      const int blk = wave + i * NWV;   // wave-uniform: the surplus waves of a ragged count (ViT: 12 + 10 blocks, 8 waves) skip
+      if (KB % NWV == 0 || blk < KB)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(kb + blk * 1024 + lane * 16), (lds_ptr_t)(dst + blk * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < (VB + NWV - 1) / NWV; ++i) {
+      const int blk = wave + i * NWV;
+      if (VB % NWV == 0 || blk < VB)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(vb + blk * 1024 + lane * 16), (lds_ptr_t)(dst + KP * 16 + blk * 1024), 16, 0, 0);
     }
   };
-  auto gload_v = [&](uint64_t page) {
-    const uint64_t base = page + a.kv.layer_off;
-    const uint64_t vb = base + (uint64_t)a.kvh * KV_PAGE_TOKENS * (DQK * 2) + (uint64_t)kvhd * DV * (KV_PAGE_TOKENS * 2);
-#pragma unroll
-    for (int i = 0; i < VI; ++i) {
-      const int blk = (VP % NT == 0) ? wave + i * NWV : min(wave + i * NWV, VP / 64 - 1);  // fragment block (ds, kk) = (blk >> 1, blk & 1)
-      rv[i] = ld16_global(vb + blk * 1024 + lane * 16);
-    }
-  };
-  auto lstore_k = [&](int stage) {
-    char* ksw = smem + stage * STAGE_BYTES;
-#pragma unroll
-    for (int i = 0; i < KI; ++i) {
-      const int p = tid + i * NT;
-      if (KP % NT == 0 || p < KP) *reinterpret_cast<u32x4_t*>(ksw + p * 16) = rk[i];
-    }
-  };
-  auto lstore_v = [&](int stage) {
-    char* vsw = smem + stage * STAGE_BYTES + KP * 16;
-#pragma unroll
-    for (int i = 0; i < VI; ++i) {
-      const int p = tid + i * NT;
-      if (VP % NT == 0 || p < VP) *reinterpret_cast<u32x4_t*>(vsw + p * 16) = rv[i];
-    }
-  };
-  auto gload = [&](uint64_t page) { gload_k(page); gload_v(page); };
-  auto lstore = [&](int stage) { lstore_k(stage); lstore_v(stage); };
   // the page table is read through the constant address space with a wave-uniform index: a scalar load (s_load_dwordx2), no
   // vector-memory request and no VGPRs for the address of the next page
   typedef const __attribute__((address_space(4))) uint64_t* cptr64_t;
   const cptr64_t ptab = (cptr64_t)(uintptr_t)a.kv.page_ptrs;
-  gload(ptab[0]);
-  lstore(0);
+  gload(ptab[0], 0);
   // Everything requested so far (the q fragments above all) is retired here, once: otherwise the waits the compiler places in
   // the loop must assume the q loads may still be the newest requests (on the path that issues no prefetch) and turn into
   // vmcnt(0) in the middle of the QK^T phase, i.e. wait for the tile prefetch issued a few instructions earlier.
   uint64_t pg_next = ptab[__builtin_amdgcn_readfirstlane(min(1, ntiles - 1))];
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
-  for (int tile = 0; tile < ntiles; ++tile) {
-    // unconditional prefetch (the last iteration re-requests its own tile and drops it): one code path, exact wait counts
-    // (the page address itself was requested one iteration earlier: its latency is not in front of the prefetch)
-    gload(pg_next);
-    pg_next = ptab[__builtin_amdgcn_readfirstlane(min(tile + 2, ntiles - 1))];
+  unsigned tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_prev = 0;   // wave-uniform (scalar registers)
+  const bool tr_on = TRACE && blockIdx.x == gridDim.x / 2 && (wave == 0 || wave == 4);
+  auto stamp = [&](int k) __attribute__((always_inline)) {
+    if (TRACE) {
+      if (tr_on) {
+        const unsigned now = __builtin_amdgcn_readfirstlane((unsigned)__builtin_readcyclecounter());
+        if (k >= 0) tr_acc[k] += now - tr_prev;
+        tr_prev = now;
+      }
+    }
+  };
+  // State of a tile between its two halves:
+  f32x4_t st[QT][4];      // raw S^T, then the rounded + masked scores
+  float alpha[QT], m2[QT];
+  bool act[QT];           // wave-uniform: the q sub-tile sees anything of the tile (causal)
+  bool any = false;
+  constexpr int NFV = 2 * DS;
+
+  // first half of a tile: S^T = K . Q^T and the score side of the softmax (rounding chain, mask, running maximum)
+  auto scores_part = [&](int tile) __attribute__((always_inline)) {
     const char* ks = smem + (tile & 1) * STAGE_BYTES;
-    const char* vs = ks + KP * 16;
     const int t0 = tile * KV_PAGE_TOKENS;
-    // wave-uniform activity of each q sub-tile (causal: its 16 rows may see nothing of this tile)
-    bool act[QT];
-    bool any = false;
+    any = false;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
       act[t] = !a.causal || t0 <= a.kv_offset + q0 + t * 16 + 15;
       any |= act[t];
     }
-    if (any) {
-    // S^T = K . Q^T: the 4 token sub-tiles are 4 independent accumulators and the fragments are consumed k4-major, so
-    // consecutive MFMAs never depend on each other (sub-major order made chains of KS dependent MFMAs, each stalling for the
-    // previous one's result); fragment reads run RING fragments ahead of their MFMA (a read used to be followed by
-    // s_waitcnt lgkmcnt(0) + its MFMA: one exposed LDS latency per MFMA).
-    f32x4_t st[QT][4];
+    if (!any) return;
+    // the 4 token sub-tiles are 4 independent accumulators and the fragments are consumed k4-major, so consecutive MFMAs never
+    // depend on each other (sub-major order made chains of KS dependent MFMAs, each stalling for the previous one's result);
+    // fragment reads run RING fragments ahead of their MFMA (a read used to be followed by s_waitcnt lgkmcnt(0) + its MFMA)
 #pragma unroll
     for (int t = 0; t < QT; ++t)
 #pragma unroll
@@ -183,22 +174,15 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
         const bf16x8_t kf = as_frag(ring[f % RING]);
 #pragma unroll
         for (int t = 0; t < QT; ++t)
-          if (act[t]) st[t][f & 3] = mfma16(kf, qf[t][f >> 2], st[t][f & 3]);
+          if (act[t]) {
+            if (ABL != 4) st[t][f & 3] = mfma16(kf, qf[t][f >> 2], st[t][f & 3]);
+            else asm volatile("" :: "v"(kf));
+          }
         if (f + RING < NF) ring[f % RING] = kread(f + RING);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // the first V^T fragments travel while the softmax VALU work runs
-    constexpr int NFV = 2 * DS;
-    auto vread = [&](int f) {  // fragment f = (kk, ds) = (f / DS, f % DS)
-      return *reinterpret_cast<const u32x4_t*>(vs + (((f % DS) * 2 + f / DS) * 64 + lane) * 16);
-    };
-    u32x4_t vring[RING];
-#pragma unroll
-    for (int f = 0; f < RING; ++f) vring[f] = vread(f);
-    __builtin_amdgcn_sched_barrier(0);
-    float alpha[QT];
-    bf16x8_t pf[QT][2];
+    stamp(1);   // QK^T
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
       if (!act[t]) continue;
@@ -207,10 +191,36 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
       // Interior tiles (every token visible to every q row of the sub-tile: all but the diagonal / last tile) skip the
       // per-element predicate -- two compares and a select per score in a VALU-bound softmax.
       const int lim_min = a.causal ? min(a.kv_offset + q0 + t * 16, a.kv_total - 1) : a.kv_total - 1;
+      if (ABL == 2) { alpha[t] = 1.f; m2[t] = 0.f; continue; }
       if (t0 + KV_PAGE_TOKENS - 1 <= lim_min)
-        softmax_tile(st[t], a.scale, [](int) { return true; }, G, m[t], l[t], alpha[t], pf[t]);
+        softmax_scores(st[t], a.scale, [](int) { return true; }, G, m[t], alpha[t], m2[t]);
       else
-        softmax_tile(st[t], a.scale, [&](int tk) { return t0 + tk <= lim; }, G, m[t], l[t], alpha[t], pf[t]);
+        softmax_scores(st[t], a.scale, [&](int tk) { return t0 + tk <= lim; }, G, m[t], alpha[t], m2[t]);
+    }
+    stamp(2);   // scores
+  };
+  // second half: p = e^(s - m), row sums, O^T = O^T * alpha + V^T . P^T
+  auto probs_part = [&](int tile) __attribute__((always_inline)) {
+    if (!any) return;
+    const char* vs = smem + (tile & 1) * STAGE_BYTES + KP * 16;
+    auto vread = [&](int f) {  // fragment f = (kk, ds) = (f / DS, f % DS)
+      return *reinterpret_cast<const u32x4_t*>(vs + (((f % DS) * 2 + f / DS) * 64 + lane) * 16);
+    };
+    u32x4_t vring[RING];   // the first V^T fragments travel while the exponentials run
+#pragma unroll
+    for (int f = 0; f < RING; ++f) vring[f] = vread(f);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8_t pf[QT][2];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      if (!act[t]) continue;
+      if (ABL == 2) {
+        u32x4_t u0 = {__float_as_uint(st[t][0][0]), __float_as_uint(st[t][0][1]), __float_as_uint(st[t][1][0]), __float_as_uint(st[t][1][1])};
+        u32x4_t u1 = {__float_as_uint(st[t][2][0]), __float_as_uint(st[t][2][1]), __float_as_uint(st[t][3][0]), __float_as_uint(st[t][3][1])};
+        pf[t][0] = as_frag(u0); pf[t][1] = as_frag(u1);
+        l[t] += 1.f;
+      } else
+      softmax_probs(st[t], m2[t], alpha[t], l[t], pf[t]);
       // once the running max has settled alpha is exactly 1 in every lane of the wave: skip the DS*4 multiplies (x * 1 == x)
       if (__builtin_amdgcn_ballot_w64(alpha[t] != 1.f) != 0) {
 #pragma unroll
@@ -218,18 +228,51 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    stamp(3);   // probabilities
 #pragma unroll
-    for (int f = 0; f < NFV; ++f) {  // O^T += V^T . P^T, kk-major: DS independent accumulators in a row
+    for (int f = 0; f < NFV; ++f) {  // kk-major: DS independent accumulators in a row
       const bf16x8_t vf = as_frag(vring[f % RING]);
 #pragma unroll
       for (int t = 0; t < QT; ++t)
-        if (act[t]) o[t][f % DS] = mfma16(vf, pf[t][f / DS], o[t][f % DS]);
+        if (act[t]) {
+          if (ABL != 4) o[t][f % DS] = mfma16(vf, pf[t][f / DS], o[t][f % DS]);
+          else asm volatile("" :: "v"(vf), "v"(pf[t][f / DS]));
+        }
       if (f + RING < NFV) vring[f % RING] = vread(f + RING);
       __builtin_amdgcn_sched_barrier(0);
     }
-    }  // any
-    if (tile + 1 < ntiles) lstore((tile + 1) & 1);
+    stamp(4);   // P.V
+  };
+  auto prefetch = [&](int tile) __attribute__((always_inline)) {
+    // unconditional prefetch (the last iteration re-requests its own tile into the free stage and nobody reads it): one code path
+    // (the page address itself was requested one iteration earlier: its latency is not in front of the prefetch)
+    if (ABL != 3) gload(pg_next, (tile + 1) & 1);
+    pg_next = ptab[__builtin_amdgcn_readfirstlane(min(tile + 2, ntiles - 1))];
+    stamp(0);   // loop top
+  };
+  auto stage_and_barrier = [&](int) __attribute__((always_inline)) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's share of the next tile has landed
+    stamp(5);   // wait for the staging DMA
     __syncthreads();
+    stamp(6);   // barrier
+  };
+  stamp(-1);
+  // (A "ping-pong" schedule -- the two wave rows of a block half a tile apart, two barriers per tile, so that one row's
+  // MFMA + fragment-read phase meets the other's softmax VALU phase -- was built and measured on MI355X: parity-green, 0.785 vs
+  // 0.791 ms at S = 8192 causal, 14.87 vs 14.89 ms at 41 k: no gain, the halves do not balance and the second barrier costs what
+  // the overlap returns.  Ablations of this kernel at S = 8192 (0.775 ms): no softmax arithmetic 0.48, no staging 0.66, no MFMAs
+  // 0.38 -- the parts add up, whatever the phase alignment.)
+  for (int tile = 0; tile < ntiles; ++tile) {
+    prefetch(tile);
+    scores_part(tile);
+    probs_part(tile);
+    stage_and_barrier(tile);
+  }
+  if (TRACE) {
+    if (tr_on && lane == 0) {
+      for (int k = 0; k < 7; ++k) trace[(wave >> 2) * 8 + k] = tr_acc[k];
+      trace[(wave >> 2) * 8 + 7] = (unsigned long long)ntiles;
+    }
   }
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
@@ -404,15 +447,39 @@ void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
   dim3 grid = a.nqb ? dim3(nqb * a.nh) : dim3(nqb, a.nh), block(nwv * 64);
   if (a.d == 128) {
     const size_t lds = 2 * KV_PAGE_TOKENS * 2 * (128 + 128);
-    if (nwv == 8) hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 1, 8>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 1, 4>), grid, block, lds, st, a);
+    static const bool ptrace = [] { const char* e = getenv("AHA_ATTN_PTRACE"); return e && atoi(e) != 0; }();
+    if (ptrace && nwv == 8) {   // debug: per-part cycle sums of two waves of the middle block
+      static unsigned long long* d_tr = nullptr;
+      if (!d_tr) (void)hipMalloc((void**)&d_tr, 16 * 8);
+      (void)hipMemsetAsync(d_tr, 0, 16 * 8, st);
+      hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 1, 8, true>), grid, block, lds, st, a, d_tr);
+      unsigned long long h[16];
+      (void)hipMemcpyAsync(h, d_tr, sizeof(h), hipMemcpyDeviceToHost, st);
+      (void)hipStreamSynchronize(st);
+      static const char* names[7] = {"top", "QK^T", "scores", "probs", "P.V", "stage", "barriers"};
+      for (int w = 0; w < 2; ++w) {
+        fprintf(stderr, "[attn ptrace] wave %d, %llu tiles, cycles per tile:", w * 4, h[w * 8 + 7]);
+        for (int k = 0; k < 7; ++k) fprintf(stderr, " %s %.0f", names[k], h[w * 8 + 7] ? (double)h[w * 8 + k] / (double)h[w * 8 + 7] : 0.0);
+        fprintf(stderr, "\n");
+      }
+      return;
+    }
+    static const int abl = [] { const char* e = getenv("AHA_ATTN_ABL"); return e ? atoi(e) : 0; }();
+    if (abl && nwv == 8) {
+      if (abl == 2) hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 1, 8, false, 2>), grid, block, lds, st, a, nullptr);
+      if (abl == 3) hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 1, 8, false, 3>), grid, block, lds, st, a, nullptr);
+      if (abl == 4) hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 1, 8, false, 4>), grid, block, lds, st, a, nullptr);
+      return;
+    }
+    if (nwv == 8) hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 1, 8>), grid, block, lds, st, a, nullptr);
+    else hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 1, 4>), grid, block, lds, st, a, nullptr);
   } else if (a.d == 64) {  // Qwen3-ASR audio encoder
     const size_t lds = 2 * KV_PAGE_TOKENS * 2 * (64 + 64);
-    hipLaunchKernelGGL((attn_prefill_kernel<64, 64, 1, 4>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((attn_prefill_kernel<64, 64, 1, 4>), grid, block, lds, st, a, nullptr);
   } else {  // head_dim 72 (Qwen3-VL ViT): Q/K rows padded to 96, V block to 80
     const size_t lds = 2 * KV_PAGE_TOKENS * 2 * (96 + 80);
-    if (nwv == 8) hipLaunchKernelGGL((attn_prefill_kernel<96, 80, 1, 8>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((attn_prefill_kernel<96, 80, 1, 4>), grid, block, lds, st, a);
+    if (nwv == 8) hipLaunchKernelGGL((attn_prefill_kernel<96, 80, 1, 8>), grid, block, lds, st, a, nullptr);
+    else hipLaunchKernelGGL((attn_prefill_kernel<96, 80, 1, 4>), grid, block, lds, st, a, nullptr);
   }
 }
 
