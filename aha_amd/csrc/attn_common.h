@@ -60,20 +60,23 @@ __device__ __forceinline__ void softmax_scores(f32x4_t (&st)[4], float scale, Va
 }
 __device__ __forceinline__ void softmax_probs(const f32x4_t (&st)[4], float m2, float alpha, float& l, bf16x8_t (&pf)[2]) {
   constexpr float LOG2E = 1.4426950408889634f;
-  float psum = 0.f;
+  // two scores per instruction where the ISA has a packed f32 form: e^(s - m) = exp2(fma(s, log2 e, -m log2 e)) as v_pk_fma_f32,
+  // the row sum as v_pk_add_f32 on two running halves (8 + 8 instead of 16 + 16 issue slots of a VALU-bound loop)
+  const f32x2_t k2 = {LOG2E, LOG2E}, nm2 = {-m2, -m2};
+  f32x2_t psum2 = {0.f, 0.f};
   uint32_t pk[2][4];
 #pragma unroll
   for (int sub = 0; sub < 4; ++sub) {
-    float p[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      p[r] = __builtin_amdgcn_exp2f(fmaf(st[sub][r], LOG2E, -m2));  // e^(s - m): one fma + one v_exp_f32
-      psum += p[r];
-    }
-    pk[sub >> 1][(sub & 1) * 2 + 0] = pack_bf(p[0], p[1]);
-    pk[sub >> 1][(sub & 1) * 2 + 1] = pack_bf(p[2], p[3]);
+    const f32x2_t s01 = {st[sub][0], st[sub][1]}, s23 = {st[sub][2], st[sub][3]};
+    const f32x2_t a01 = __builtin_elementwise_fma(s01, k2, nm2), a23 = __builtin_elementwise_fma(s23, k2, nm2);
+    const f32x2_t p01 = {__builtin_amdgcn_exp2f(a01[0]), __builtin_amdgcn_exp2f(a01[1])};
+    const f32x2_t p23 = {__builtin_amdgcn_exp2f(a23[0]), __builtin_amdgcn_exp2f(a23[1])};
+    psum2 += p01;
+    psum2 += p23;
+    pk[sub >> 1][(sub & 1) * 2 + 0] = pack_bf(p01[0], p01[1]);
+    pk[sub >> 1][(sub & 1) * 2 + 1] = pack_bf(p23[0], p23[1]);
   }
-  l = l * alpha + psum;
+  l = l * alpha + (psum2[0] + psum2[1]);
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
     u32x4_t u = {pk[kk][0], pk[kk][1], pk[kk][2], pk[kk][3]};
