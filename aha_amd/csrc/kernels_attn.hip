@@ -435,8 +435,9 @@ void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
     return e ? atoi(e) : 0;
   }();
   constexpr int qt = 1;  // 2 q sub-tiles per wave were measured slower (300 registers: one wave per SIMD)
-  // 8 waves (128 q rows) per staged tile once there are enough q rows for every CU to get a block that way
-  int nwv = (a.d != 64 && (int64_t)((a.S + 127) / 128) * a.nh >= 256) ? 8 : 4;
+  // 8 waves (128 q rows) per staged tile once that still fills the chip's 512 block slots (two 8-wave blocks per CU); below
+  // that, 64-row blocks balance a causal launch better (S = 1542 x 32 heads: 44 vs 48 us; equal at 2048, 8 waves ahead from there)
+  int nwv = (a.d != 64 && (int64_t)((a.S + 127) / 128) * a.nh >= 512) ? 8 : 4;
   if (nw_env == 4 || (nw_env == 8 && a.d != 64)) nwv = nw_env;
   static const int sched_env = [] {
     const char* e = getenv("AHA_ATTN_SCHED");
