@@ -131,6 +131,22 @@ def test_gemm_four_wave_kernel_edges(gpu, splitk, M, N, K):
     assert_close_ulps(full, ref, 2, 0.97, f"gemm256q bias+residual splitk {splitk}")
 
 
+def test_gemm_ragged_n_is_split_by_the_automatic_plan(gpu):
+    """N = 4304 = 16 x 256 + 208 at M >= 256 (the ViT fc1 shape): the automatic plan runs the columns up to 4096 and the 208-column
+    tail as two GEMMs over sub-views of W / C / bias / residual.  Same bound against the oracle as any other plan, and the two
+    halves must meet exactly at the seam (a wrong view offset shows up as garbage in columns 4096.. or in the last rows)."""
+    from aha_amd import ops, _lib
+    M, N, K = 600, 4304, 1152
+    A, W, b, res = rnd((M, K), 51), rnd((N, K), 52, 0.02), rnd((N,), 53, 0.5), rnd((M, N), 54)
+    y = NM.r(torch.nn.functional.gelu(NM.linear(A.float(), W.float(), b.float()), approximate="tanh"))
+    ref = NM.r(res.float() + y)
+    got = ops.gemm(A.to(gpu), W.to(gpu), b.to(gpu), res.to(gpu), _lib.ACT_GELU_TANH)
+    assert_close_ulps(got, ref, 2, 0.97, "ragged-N gemm, automatic plan")
+    assert_close_ulps(got[:, 4000:], ref[:, 4000:], 2, 0.97, "ragged-N gemm around the seam")
+    plain = ops.gemm(A.to(gpu), W.to(gpu))
+    assert_close_ulps(plain, NM.linear(A.float(), W.float()), 1, 0.98, "ragged-N plain gemm")
+
+
 def test_gemm_gate_up_pairs_256_tile(gpu):
     from aha_amd import ops, _lib
     M, I, K = 700, 1024, 512
