@@ -5,11 +5,10 @@
 // Both operands are K-contiguous (activations row-major, candle_nn::Linear weights (out,in) row-major), which is the
 // natural MFMA feed on CDNA: every fragment is a 16-byte run of one row.  v_mfma_f32_16x16x32_bf16, 128x128x64 block
 // tile, 4 waves (2x2, 64x64 each), XOR-swizzled 16-byte LDS slots (conflict-free ds_read_b128).
-// Two staging variants:
-//   gemm_glds_kernel (default): global_load_lds_dwordx4 straight into a 32-KiB LDS tile (no VGPR round trip, no
+// Staging:
+//   gemm_glds_kernel: global_load_lds_dwordx4 straight into a 32-KiB LDS tile (no VGPR round trip, no
 //       ds_write pass); the swizzle is applied on the per-lane SOURCE address because the DMA destination is
 //       lane-linear; 32 KiB LDS and ~110 VGPRs let 4 blocks share a CU, which is what overlaps load and MFMA.
-//   gemm_kernel (AHA_GEMM_GLDS=0): register-staged double buffer, kept for A/B.
 // The MFMA is issued as W-fragment x A-fragment so that each lane ends up with 4 consecutive output columns of one row:
 // bias / activation / gate*up pairing / residual are then lane-local and the store is 8 bytes.
 // Rounding points follow the reference op boundaries (Linear matmul -> bf16, + bias -> bf16, act -> bf16, + residual -> bf16).
@@ -259,149 +258,17 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs a, const void* 
   epilogue<ACT, HAS_BIAS, HAS_RES, 4>(a, acc, m0 + wm * 64, n0 + wn * 64, G, c);
 }
 
-// ---- variant 2: register-staged double buffer ----------------------------------------------------------------------
-template <int ACT, bool HAS_BIAS, bool HAS_RES>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A tile | W tile]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, c = lane & 15;
-  const int wm = wave >> 1, wn = wave & 1;
-  int m0, n0;
-  tile_of_block(a, m0, n0);
-  const bf16_t* A = (const bf16_t*)a.A;
-  const bf16_t* W = (const bf16_t*)a.W;
-  const int nk = (a.K + BK - 1) / BK;
-
-  // staging assignment: 1024 16-byte pieces per operand tile, 4 per thread; piece p -> row p>>3, slot p&7
-  const bf16_t* ga[4];
-  const bf16_t* gw[4];
-  int lds_off[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int p = tid + i * 256, row = p >> 3, slot = p & 7;
-    ga[i] = A + (int64_t)min(m0 + row, a.M - 1) * a.lda + slot * 8;
-    gw[i] = W + (int64_t)min(n0 + row, a.N - 1) * a.ldw + slot * 8;
-    lds_off[i] = swz(row, slot);
-  }
-  const int kslot = (tid & 7) * 8;  // k offset of this thread's pieces inside a K tile
-
-  u32x4_t ra[4], rw[4];
-  auto gload = [&](int kt) {
-    const bool ok = kt * BK + kslot < a.K;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = ok ? ld16(ga[i] + kt * BK) : u32x4_t{0u, 0u, 0u, 0u};
-      rw[i] = ok ? ld16(gw[i] + kt * BK) : u32x4_t{0u, 0u, 0u, 0u};
-    }
-  };
-  auto lstore = [&](int stage) {
-    char* sa = smem + stage * 2 * TILE_BYTES;
-    char* sw = sa + TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<u32x4_t*>(sa + lds_off[i]) = ra[i];
-      *reinterpret_cast<u32x4_t*>(sw + lds_off[i]) = rw[i];
-    }
-  };
-
-  f32x4_t acc[4][4];  // [ni][mi]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-    const char* sa = smem + cur * 2 * TILE_BYTES;
-    mma_tile(sa, sa + TILE_BYTES, wm, wn, G, c, acc);
-    if (kt + 1 < nk) lstore(cur ^ 1);
-    __syncthreads();
-  }
-  epilogue<ACT, HAS_BIAS, HAS_RES, 4>(a, acc, m0 + wm * 64, n0 + wn * 64, G, c);
-}
-
-// ---- variant 3: 256 x 256 x 64 tile, 8 waves (2 x 4, 128 x 64 each), two LDS stages, one barrier per K tile -------------
-// For M >= ~1k.  Per K tile a wave issues 4 + 4 global_load_lds_dwordx4 for tile kt+1 into the other stage, then runs
-// 64 MFMAs (8 A fragments x 4 W fragments x 2 k-steps) on stage kt; __syncthreads() drains the DMA (vmcnt(0)) and is the
-// only barrier of the iteration.  128 KiB LDS, ~210 VGPRs => 1 block (8 waves) per CU; each LDS byte read feeds 2.7
-// MFMAs (2 in the 128^2 kernel).  gridDim.y > 1 = split-K: slice z accumulates k tiles [z*kps, (z+1)*kps) and writes an
-// f32 slab a.C + z*M*ldc (ACT_PARTIAL_F32); gemm_splitk_reduce_kernel sums the slabs and applies the epilogue chain.
+// ---- 256 x 256 x 64 tiles ----------------------------------------------------------------------------------------------------
+// (The first 256^2 kernel -- 8 waves, one __syncthreads per K tile with the LDS-DMA drained in front of it, 16x16x32 MFMA: 1.41 us
+// per K step alone on the chip, 1.03-1.06 PF at 8192^3 -- was the A/B reference of the two below through round 2 and is retired;
+// its measurements are in profiles/r01_gemm_tile_ab.md and profiles/r02_gemm_anatomy.md.)
+// gridDim.y > 1 = split-K: slice z accumulates k tiles [z*kps, (z+1)*kps) and writes an f32 slab a.C + z*M*ldc (ACT_PARTIAL_F32);
+// gemm_splitk_reduce_kernel sums the slabs and applies the epilogue chain.
 constexpr int BM2 = 256, BN2 = 256;
 constexpr int TILE2_BYTES = 256 * BK * 2;  // 32 KiB per operand per stage
 
-template <int ACT, bool HAS_BIAS, bool HAS_RES>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, const void* zeros, int kt_per_slice) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A tile | W tile]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, c = lane & 15;
-  const int wm = wave >> 2, wn = wave & 3;
-  int m0, n0;
-  tile_of_block<BM2, BN2>(a, m0, n0);
-  const bf16_t* A = (const bf16_t*)a.A;
-  const bf16_t* W = (const bf16_t*)a.W;
-  const int nk_all = (a.K + BK - 1) / BK;
-  const int kt0 = blockIdx.y * kt_per_slice, kt1 = min(nk_all, kt0 + kt_per_slice);
-  if (ACT == ACT_PARTIAL_F32) a.C = (float*)a.C + (int64_t)blockIdx.y * a.M * a.ldc;
-
-  // staging: a stage's operand tile is 32 row groups of 8 rows (1 KiB each); wave w fills groups j*8 + w, j = 0..3
-  const bf16_t* ga[4];
-  const bf16_t* gw[4];
-  int kofs[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (j * 8 + wave) * 8 + (lane >> 3);
-    const int s = (lane & 7) ^ ((row >> 1) & 7);  // logical k-slot this lane fetches (source-side swizzle)
-    kofs[j] = s * 8;
-    ga[j] = A + (int64_t)min(m0 + row, a.M - 1) * a.lda + s * 8;
-    gw[j] = W + (int64_t)min(n0 + row, a.N - 1) * a.ldw + s * 8;
-  }
-  auto issue = [&](int kt, int stage) {
-    char* sa = smem + stage * 2 * TILE2_BYTES;
-    char* sw = sa + TILE2_BYTES;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bool ok = kt * BK + kofs[j] < a.K;
-      const void* pa = ok ? (const void*)(ga[j] + kt * BK) : zeros;
-      const void* pw = ok ? (const void*)(gw[j] + kt * BK) : zeros;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)pa, (lds_ptr_t)(sa + (j * 8 + wave) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)pw, (lds_ptr_t)(sw + (j * 8 + wave) * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x4_t acc[4][8];  // [ni][mi]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  if (kt0 < kt1) issue(kt0, 0);
-  __syncthreads();
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int cur = (kt - kt0) & 1;
-    if (kt + 1 < kt1) issue(kt + 1, cur ^ 1);
-    const char* sa = smem + cur * 2 * TILE2_BYTES;
-    const char* sw = sa + TILE2_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t af[8], wf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wf[i] = as_frag(*reinterpret_cast<const u32x4_t*>(sw + swz(wn * 64 + i * 16 + c, ks * 4 + G)));
-#pragma unroll
-      for (int i = 0; i < 8; ++i) af[i] = as_frag(*reinterpret_cast<const u32x4_t*>(sa + swz(wm * 128 + i * 16 + c, ks * 4 + G)));
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[ni][mi] = mfma16(wf[ni], af[mi], acc[ni][mi]);
-    }
-    __syncthreads();  // stage cur is free again, and tile kt+1 has landed (the fence in front of the barrier is vmcnt(0))
-  }
-  epilogue<ACT, HAS_BIAS, HAS_RES, 8>(a, acc, m0 + wm * 128, n0 + wn * 64, G, c);
-}
-
-// ---- variant 4: the 256 x 256 x 64 tile as a staggered, counted-wait pipeline ----------------------------------------------
-// Same tile, wave layout (2 x 4 waves, 128 x 64 each), LDS image and epilogue as gemm256_kernel; what changes is the K loop:
+// ---- the 256 x 256 x 64 tile on eight waves as a staggered, counted-wait pipeline (gemm256p_kernel) ------------------------------
+// 2 x 4 waves, 128 x 64 each; two LDS stages of [A tile | W tile], rows of 128 B with the XOR slot swizzle of the 128^2 kernel:
 //   * a K tile is staged as four 16-KiB HALF-tiles (A rows 0-127 / 128-255, W rows 0-127 / 128-255), one half-tile per
 //     segment (2 LDS-DMA instructions per thread), and nothing in the loop ever waits for all of them: the only wait is a
 //     counted s_waitcnt vmcnt(2) once per K tile, which leaves the newest half-tile in flight (raw s_barrier -- a
@@ -845,17 +712,16 @@ const void* zero_block() {
 }
 
 template <int ACT, bool B, bool R>
-void launch_one(const GemmArgs& a, dim3 grid, bool glds, hipStream_t st) {
-  if (glds) hipLaunchKernelGGL((gemm_glds_kernel<ACT, B, R>), grid, dim3(256), 2 * TILE_BYTES, st, a, zero_block());
-  else hipLaunchKernelGGL((gemm_kernel<ACT, B, R>), grid, dim3(256), 4 * TILE_BYTES, st, a);
+void launch_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
+  hipLaunchKernelGGL((gemm_glds_kernel<ACT, B, R>), grid, dim3(256), 2 * TILE_BYTES, st, a, zero_block());
 }
 
 template <int ACT>
-void launch_act(const GemmArgs& a, dim3 grid, bool glds, hipStream_t st) {
-  if (a.bias && a.residual) launch_one<ACT, true, true>(a, grid, glds, st);
-  else if (a.bias) launch_one<ACT, true, false>(a, grid, glds, st);
-  else if (a.residual) launch_one<ACT, false, true>(a, grid, glds, st);
-  else launch_one<ACT, false, false>(a, grid, glds, st);
+void launch_act(const GemmArgs& a, dim3 grid, hipStream_t st) {
+  if (a.bias && a.residual) launch_one<ACT, true, true>(a, grid, st);
+  else if (a.bias) launch_one<ACT, true, false>(a, grid, st);
+  else if (a.residual) launch_one<ACT, false, true>(a, grid, st);
+  else launch_one<ACT, false, false>(a, grid, st);
 }
 
 template <int ACT, bool B, bool R>
@@ -863,14 +729,8 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st) {
   const int ntm = (a.M + BM2 - 1) / BM2, ntn = (a.N + BN2 - 1) / BN2;
   const int nk = (a.K + BK - 1) / BK;
   const size_t lds = 4 * TILE2_BYTES;
-  static bool attr_done = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
+  // (> 64 KiB of dynamic LDS needs the opt-in once per kernel instance)
   if (splitk <= 1) {
-    static bool once = false;
-    if (!once) {
-      hipFuncSetAttribute((const void*)gemm256_kernel<ACT, B, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      once = true;
-    }
-    static const bool pipe = [] { const char* e = getenv("AHA_GEMM_PIPE"); return e ? atoi(e) != 0 : true; }();
     static const bool quad = [] { const char* e = getenv("AHA_GEMM_QUAD"); return e ? atoi(e) != 0 : true; }();
     // four waves x 128 x 128 (gemm256q_kernel).  Not for short K loops with a bias / GELU epilogue (the ViT projections, K = 1152):
     // one 4-wave block per CU has nothing to overlap its prologue and epilogue with (in the model: ViT fc1 146 us against 87 us on
@@ -908,7 +768,7 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st) {
       hipLaunchKernelGGL((gemm256q_kernel<ACT, B, R>), dim3(ntm * ntn), dim3(256), lds, st, a, nk);
       return;
     }
-    if (pipe) {
+    {
       static bool once2 = false;
       if (!once2) {
         hipFuncSetAttribute((const void*)gemm256p_kernel<ACT, B, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -950,15 +810,11 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st) {
         return;
       }
       hipLaunchKernelGGL((gemm256p_kernel<ACT, B, R>), dim3(ntm * ntn), dim3(512), lds, st, a, zero_block(), nk);
-    } else {
-      hipLaunchKernelGGL((gemm256_kernel<ACT, B, R>), dim3(ntm * ntn), dim3(512), lds, st, a, zero_block(), nk);
     }
     return;
   }
-  (void)attr_done;
   static bool once_p = false;
   if (!once_p) {
-    hipFuncSetAttribute((const void*)gemm256_kernel<ACT_PARTIAL_F32, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_PARTIAL_F32, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     once_p = true;
   }
@@ -969,7 +825,6 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st) {
   p.residual = nullptr;
   p.act = ACT_PARTIAL_F32;
   const int kps = (nk + splitk - 1) / splitk;
-  static const bool pipe_sk = [] { const char* e = getenv("AHA_GEMM_PIPE"); return e ? atoi(e) != 0 : true; }();
   static const bool quad_sk = [] { const char* e = getenv("AHA_GEMM_QUAD"); return e ? atoi(e) != 0 : true; }();
   if (quad_sk && a.K % BK == 0) {
     static bool onceq = false;
@@ -978,10 +833,9 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st) {
       onceq = true;
     }
     hipLaunchKernelGGL((gemm256q_kernel<ACT_PARTIAL_F32, false, false>), dim3(ntm * ntn, splitk), dim3(256), lds, st, p, kps);
-  } else if (pipe_sk)
+  } else {
     hipLaunchKernelGGL((gemm256p_kernel<ACT_PARTIAL_F32, false, false>), dim3(ntm * ntn, splitk), dim3(512), lds, st, p, zero_block(), kps, nullptr);
-  else
-    hipLaunchKernelGGL((gemm256_kernel<ACT_PARTIAL_F32, false, false>), dim3(ntm * ntn, splitk), dim3(512), lds, st, p, zero_block(), kps);
+  }
   const int64_t quads = (int64_t)a.M * (a.N >> 2);
   hipLaunchKernelGGL((gemm_splitk_reduce_kernel<ACT, B, R>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, a,
                      (const float*)a.workspace, (nk + kps - 1) / kps);
@@ -1109,19 +963,15 @@ static void launch_planned(const GemmArgs& a, const GemmPlan& plan, hipStream_t 
     }
     return;
   }
-  static const bool glds = [] {
-    const char* e = getenv("AHA_GEMM_GLDS");
-    return e ? atoi(e) != 0 : true;
-  }();
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
   dim3 grid(ntm * ntn);
   switch (a.act) {
-    case ACT_NONE: launch_act<ACT_NONE>(a, grid, glds, st); break;
-    case ACT_GELU_TANH: launch_act<ACT_GELU_TANH>(a, grid, glds, st); break;
-    case ACT_GELU_ERF: launch_act<ACT_GELU_ERF>(a, grid, glds, st); break;
-    case ACT_SILU: launch_act<ACT_SILU>(a, grid, glds, st); break;
-    case ACT_SILU_MUL_PAIRS: launch_one<ACT_SILU_MUL_PAIRS, false, false>(a, grid, glds, st); break;
-    case ACT_PARTIAL_F32: launch_one<ACT_PARTIAL_F32, false, false>(a, grid, glds, st); break;
+    case ACT_NONE: launch_act<ACT_NONE>(a, grid, st); break;
+    case ACT_GELU_TANH: launch_act<ACT_GELU_TANH>(a, grid, st); break;
+    case ACT_GELU_ERF: launch_act<ACT_GELU_ERF>(a, grid, st); break;
+    case ACT_SILU: launch_act<ACT_SILU>(a, grid, st); break;
+    case ACT_SILU_MUL_PAIRS: launch_one<ACT_SILU_MUL_PAIRS, false, false>(a, grid, st); break;
+    case ACT_PARTIAL_F32: launch_one<ACT_PARTIAL_F32, false, false>(a, grid, st); break;
   }
 }
 

@@ -1,4 +1,4 @@
-"""GPU microbenchmark of the MFMA GEMM at the cfg3 prefill / ViT shapes.  AHA_GEMM_GLDS=0/1 selects the staging variant."""
+"""GPU microbenchmark of the MFMA GEMM at the cfg3 prefill / ViT shapes (automatic plan).  AHA_GEMM_QUAD=0 forces the 8-wave 256^2 kernel, AHA_GEMM_ONLY=a,b picks shapes."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
