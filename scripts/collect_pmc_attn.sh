@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export AHA_ATTN_TIME=1
 i=0
-for grp in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES"; do
+for grp in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   timeout 120 rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/pmc_attn_$i -o pmc -- python $R/scripts/bench_attn.py 8192 > $R/gpurun_out/pmc_attn_$i.log 2>&1 || true
 done
