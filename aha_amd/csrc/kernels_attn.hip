@@ -34,7 +34,6 @@ namespace {
 // ABL (debug, AHA_ATTN_ABL, results wrong by construction): 2 = no softmax arithmetic, 3 = no staging of the next tile, 4 = no MFMAs
 template <int DQK, int DV, int QT, int NWV, bool TRACE = false, int ABL = 0>
 __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV == 8 || DQK < 128) ? 4 : 3, 4))) void attn_prefill_kernel(AttnPrefillArgs a, unsigned long long* trace = nullptr) {
-  constexpr int NT = NWV * 64;
   constexpr int KS = DQK / 32, DS = DV / 16;
   constexpr int RING = (DQK >= 128) ? 6 : 4;  // LDS fragment reads in flight ahead of the MFMA that consumes them
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x [K tile | V^T tile]

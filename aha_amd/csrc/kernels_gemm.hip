@@ -296,7 +296,7 @@ constexpr int TILE2_BYTES = 256 * BK * 2;  // 32 KiB per operand per stage
 template <int ACT, bool HAS_BIAS, bool HAS_RES, int MODE = 0>
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs a, const void* zeros, int kt_per_slice, unsigned long long* trace = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A tile 32 KiB | W tile 32 KiB]
-  const int tid = threadIdx.x, lane = tid & 63, G = lane >> 4, c = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   int m0, n0;
