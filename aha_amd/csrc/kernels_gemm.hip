@@ -206,6 +206,98 @@ __device__ __forceinline__ void epilogue32(const GemmArgs& a, f32x16_t (&acc)[NF
   }
 }
 
+// The same epilogue for the four-wave 256^2 kernel (4 x 4 fragments per wave), with the stores in ROW order.  epilogue32's lanes
+// own 4 columns of 32 different rows, so each of its 8-byte stores (and residual loads) touches 32 rows x 16 B: with all CUs in
+// their epilogues at once the L2 takes ~8k partial-line requests per block and the epilogue costs ~11 us per 256^2 tile
+// (in-kernel timestamps, profiles/r02_gemm_anatomy.md).  Here a wave passes each 32-row band of its sub-tile through 8 KiB of LDS
+// (the first rounding -- Linear output -> bf16 -- happens before, so the band is bf16 and the chain's values are unchanged):
+// lanes write their 4-column groups (pitch 264 B: conflict-free), then read 16 B of ONE row each, 16 lanes per row, run the rest
+// of the chain on 8 consecutive columns (16-byte bias / residual loads) and store 16 B: 4 whole 256-byte rows per instruction.
+// ACT_SILU_MUL_PAIRS: the band is the finished 64-column output (8 lanes per row).  wbuf: this wave's 32 x 264 B of LDS, free
+// once every wave of the block has left the k loop.
+template <int ACT, bool HAS_BIAS, bool HAS_RES>
+__device__ __forceinline__ void epilogue32_rows(const GemmArgs& a, f32x16_t (&acc)[4][4], int mb, int nb, int lane, char* wbuf) {
+  constexpr bool PAIRS = ACT == ACT_SILU_MUL_PAIRS;
+  constexpr int COLS = PAIRS ? 64 : 128, PITCH = COLS * 2 + 8, LPR = COLS / 8, RPI = 64 / LPR, NIT = 32 / RPI;
+  static_assert(ACT != ACT_PARTIAL_F32, "f32 partial sums keep the fragment-order epilogue");
+  const int r32 = lane & 31, h = lane >> 5;
+  const int rr = lane / LPR, cc = lane % LPR;
+  const int n = (PAIRS ? nb / 2 : nb) + cc * 8;   // this lane's 8 output columns in the row pass
+  const int ncols = PAIRS ? a.N / 2 : a.N;
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf) {
+#pragma unroll
+    for (int nf0 = 0; nf0 < 4; nf0 += 2) {
+      f32x16_t sum[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum[j][r] = acc[nf0 + j][mf][r];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (PAIRS) {   // a 32-row W fragment = one gate block (quads 0,1) + its up block (quads 2,3) -> 16 output columns
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float gte = rbf(silu_f(rbf(sum[j][4 * q + r])));  // gate_proj -> bf16, act_fn -> bf16 (modules.rs:82)
+              const float u = rbf(sum[j][4 * q + 8 + r]);             // up_proj -> bf16 (modules.rs:83)
+              v[r] = gte * u;                                         // lhs * rhs -> bf16 (modules.rs:84)
+            }
+            uint2 w2;
+            w2.x = pack_bf(v[0], v[1]);
+            w2.y = pack_bf(v[2], v[3]);
+            *reinterpret_cast<uint2*>(wbuf + r32 * PITCH + ((nf0 + j) * 16 + 8 * q + 4 * h) * 2) = w2;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            uint2 w2;
+            w2.x = pack_bf(sum[j][4 * q], sum[j][4 * q + 1]);   // Linear output -> bf16
+            w2.y = pack_bf(sum[j][4 * q + 2], sum[j][4 * q + 3]);
+            *reinterpret_cast<uint2*>(wbuf + r32 * PITCH + ((nf0 + j) * 32 + 8 * q + 4 * h) * 2) = w2;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = it * RPI + rr, m = mb + mf * 32 + row;
+      const uint2 lo = *reinterpret_cast<const uint2*>(wbuf + row * PITCH + cc * 16);
+      const uint2 hi = *reinterpret_cast<const uint2*>(wbuf + row * PITCH + cc * 16 + 8);
+      uint32_t d[4] = {lo.x, lo.y, hi.x, hi.y};
+      if (m < a.M && n < ncols) {
+        if (!PAIRS) {
+          if (HAS_BIAS) {
+            const uint4 b4 = *reinterpret_cast<const uint4*>((const bf16_t*)a.bias + n);
+            const uint32_t b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = pack_bf(lo_bf(d[k]) + lo_bf(b[k]), hi_bf(d[k]) + hi_bf(b[k]));
+          }
+          if (ACT == ACT_GELU_TANH) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = pack_bf(gelu_tanh_f(lo_bf(d[k])), gelu_tanh_f(hi_bf(d[k])));
+          } else if (ACT == ACT_GELU_ERF) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = pack_bf(gelu_erf_f(lo_bf(d[k])), gelu_erf_f(hi_bf(d[k])));
+          } else if (ACT == ACT_SILU) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = pack_bf(silu_f(lo_bf(d[k])), silu_f(hi_bf(d[k])));
+          }
+          if (HAS_RES) {
+            const uint4 r4 = *reinterpret_cast<const uint4*>((const bf16_t*)a.residual + (int64_t)m * a.ldc + n);
+            const uint32_t r[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = pack_bf(lo_bf(d[k]) + lo_bf(r[k]), hi_bf(d[k]) + hi_bf(r[k]));
+          }
+        }
+        *reinterpret_cast<uint4*>((bf16_t*)a.C + (int64_t)m * a.ldc + n) = make_uint4(d[0], d[1], d[2], d[3]);
+      }
+    }
+  }
+}
+
 // ---- variant 1: direct-to-LDS staging -------------------------------------------------------------------------------
 // Per K tile each wave issues 4 + 4 global_load_lds_dwordx4 (1 KiB each: 8 rows x 128 B of the LDS image).  Lane i of
 // round j writes LDS row (j*4+wave)*8 + i/8, slot position i%8; it therefore READS logical slot (i%8) ^ f(row) from
@@ -655,10 +747,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
   if (nmf == 4) k_loop(std::true_type{});
   else k_loop(std::false_type{});
-  AHA_WAIT(0x0F70);  // vmcnt(0): nothing may still be writing this block's LDS when it retires
+  AHA_WAIT(0x0F70);  // vmcnt(0): nothing may still be writing this block's LDS when it retires (or reuses it below)
 #undef AHA_WAIT
 #undef AHA_BAR
-  epilogue32<ACT, HAS_BIAS, HAS_RES, 4, 4>(a, acc, m0 + wm * 128, n0 + wn * 128, lane);
+  if (ACT == ACT_PARTIAL_F32) {
+    epilogue32<ACT, HAS_BIAS, HAS_RES, 4, 4>(a, acc, m0 + wm * 128, n0 + wn * 128, lane);
+  } else {
+    __syncthreads();   // every wave has left the k loop (and waited for its own DMAs): the stages are free
+    epilogue32_rows<ACT == ACT_PARTIAL_F32 ? ACT_NONE : ACT, HAS_BIAS, HAS_RES>(a, acc, m0 + wm * 128, n0 + wn * 128, lane, smem + wave * 8448);
+  }
 }
 
 // Sums the split-K slabs and runs the same rounding chain as the in-kernel epilogue: Linear output -> bf16, + bias -> bf16,
@@ -735,7 +832,9 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st) {
     // four waves x 128 x 128 (gemm256q_kernel).  Not for short K loops with a bias / GELU epilogue (the ViT projections, K = 1152):
     // one 4-wave block per CU has nothing to overlap its prologue and epilogue with (in the model: ViT fc1 146 us against 87 us on
     // the 128^2 kernel at 4 blocks per CU, ViT qkv 49.7 against 43.4 on the 8-wave kernel).
-    if (quad && a.K % BK == 0 && (nk >= 32 || (!B && ACT != ACT_GELU_TANH && ACT != ACT_GELU_ERF))) {
+    // (its staging addresses are 32-bit offsets from the block's first row: 256 rows of an operand must span < 1 GiB)
+    const bool q_addr_ok = 256.0 * 2.0 * (double)std::max(a.lda, a.ldw) < 1.0e9;
+    if (quad && q_addr_ok && a.K % BK == 0 && (nk >= 32 || (!B && ACT != ACT_GELU_TANH && ACT != ACT_GELU_ERF))) {
       static bool onceq = false;
       if (!onceq) {
         hipFuncSetAttribute((const void*)gemm256q_kernel<ACT, B, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -826,7 +925,7 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st) {
   p.act = ACT_PARTIAL_F32;
   const int kps = (nk + splitk - 1) / splitk;
   static const bool quad_sk = [] { const char* e = getenv("AHA_GEMM_QUAD"); return e ? atoi(e) != 0 : true; }();
-  if (quad_sk && a.K % BK == 0) {
+  if (quad_sk && a.K % BK == 0 && 256.0 * 2.0 * (double)std::max(a.lda, a.ldw) < 1.0e9) {
     static bool onceq = false;
     if (!onceq) {
       hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_PARTIAL_F32, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
