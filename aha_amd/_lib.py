@@ -54,7 +54,9 @@ class MmInput(C.Structure):
                 ("image_grid_thw", C.POINTER(C.c_uint32)), ("n_images", C.c_int32),
                 ("audio_features", C.POINTER(C.c_float)), ("n_frames", C.c_int64),
                 ("audio_samples", C.POINTER(C.c_float)), ("n_samples", C.c_int64),
-                ("image_embeds", C.c_void_p), ("n_image_tokens", C.c_int64)]
+                ("image_embeds", C.c_void_p), ("n_image_tokens", C.c_int64),
+                ("pixel_values_video", C.c_void_p), ("n_patches_video", C.c_int64),
+                ("video_grid_thw", C.POINTER(C.c_uint32)), ("n_videos", C.c_int32)]
 
 
 # every symbol include/aha_hip.h declares: name -> (restype, argtypes)
@@ -112,6 +114,7 @@ SIGNATURES = {
     "aha_hip_logmel": (C.c_int, [_P, C.c_int64, _P, _P]),
     "aha_hip_debug_gemm_plan": (C.c_int, [C.c_int32, C.c_int32]),
     "aha_hip_get_rope_index": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int32, _P, _P]),
+    "aha_hip_get_rope_index_mm": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int32, _P, C.c_int32, _P, _P]),
     "aha_hip_embed": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "aha_hip_config_parse": (C.c_int, [C.c_char_p, _P]),
     "aha_hip_weights_open": (C.c_int, [C.c_char_p, _P]),
@@ -127,6 +130,8 @@ SIGNATURES = {
     "aha_hip_vision_encode": (C.c_int, [_P, C.POINTER(MmInput), _P, C.POINTER(C.c_int64)]),
     "aha_hip_debug_audio_embeds": (C.c_int, [_P, C.POINTER(C.c_float), C.c_size_t]),
     "aha_hip_image_to_patches": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float),
+                                           C.POINTER(C.c_float), _P]),
+    "aha_hip_video_to_patches": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float),
                                            C.POINTER(C.c_float), _P]),
 }
 

@@ -430,6 +430,17 @@ int aha_hip_image_to_patches(const uint8_t* img_hwc, void* out, int32_t H, int32
   return AHA_OK;
 }
 
+int aha_hip_video_to_patches(const uint8_t* frames_thwc, void* out, int32_t T, int32_t H, int32_t W, int32_t patch, int32_t merge,
+                             const float mean[3], const float std[3], void* stream) {
+  if (!frames_thwc || !out || !mean || !std || T <= 0 || patch <= 0 || merge <= 0 || H % (patch * merge) || W % (patch * merge)) {
+    set_error("video_to_patches: T > 0 frames, H and W multiples of patch*merge");
+    return AHA_ERR_INVALID;
+  }
+  launch_video_to_patches(frames_thwc, out, T, H, W, patch, merge, mean, std, (hipStream_t)stream);
+  AHA_HIP_CHECK(hipGetLastError());
+  return AHA_OK;
+}
+
 int aha_hip_img_smart_resize(uint32_t h, uint32_t w, uint32_t factor, uint32_t min_pixels, uint32_t max_pixels, uint32_t* h_out,
                              uint32_t* w_out) {
   API_GUARD_BEGIN
@@ -471,21 +482,26 @@ int64_t aha_hip_debug_resample_taps(int32_t orig, int32_t new_f, float* taps, in
   API_GUARD_END
 }
 
-int aha_hip_get_rope_index(const aha_model_desc* desc, const uint32_t* input_ids, size_t n_ids, const uint32_t* image_grid_thw,
-                           int32_t n_images, int32_t* pos_out, int64_t* rope_delta_out) {
+int aha_hip_get_rope_index_mm(const aha_model_desc* desc, const uint32_t* input_ids, size_t n_ids, const uint32_t* image_grid_thw,
+                              int32_t n_images, const uint32_t* video_grid_thw, int32_t n_videos, int32_t* pos_out,
+                              int64_t* rope_delta_out) {
   API_GUARD_BEGIN
-  if (!desc || !input_ids || !pos_out || !rope_delta_out || (n_images > 0 && !image_grid_thw)) {
+  if (!desc || !input_ids || !pos_out || !rope_delta_out || (n_images > 0 && !image_grid_thw) || (n_videos > 0 && !video_grid_thw)) {
     set_error("aha_hip_get_rope_index: null argument");
     return AHA_ERR_INVALID;
   }
-  if (n_images <= 0) {
+  if (n_images <= 0 && n_videos <= 0) {
     for (int a = 0; a < 3; ++a)
       for (size_t i = 0; i < n_ids; ++i) pos_out[a * n_ids + i] = (int32_t)i;
     *rope_delta_out = 0;
     return AHA_OK;
   }
-  return rope_index_core(*desc, input_ids, n_ids, image_grid_thw, n_images, pos_out, rope_delta_out);
+  return rope_index_core(*desc, input_ids, n_ids, image_grid_thw, n_images, video_grid_thw, n_videos, pos_out, rope_delta_out);
   API_GUARD_END
+}
+int aha_hip_get_rope_index(const aha_model_desc* desc, const uint32_t* input_ids, size_t n_ids, const uint32_t* image_grid_thw,
+                           int32_t n_images, int32_t* pos_out, int64_t* rope_delta_out) {
+  return aha_hip_get_rope_index_mm(desc, input_ids, n_ids, image_grid_thw, n_images, nullptr, 0, pos_out, rope_delta_out);
 }
 int aha_hip_embed(aha_model* m, const uint32_t* input_ids, size_t n_ids, float* out) {
   API_GUARD_BEGIN

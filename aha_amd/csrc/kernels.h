@@ -199,6 +199,8 @@ void launch_scatter_rows(void* dst, const void* src, const int32_t* rows, int64_
 int img_smart_resize(uint32_t h, uint32_t w, uint32_t factor, uint32_t min_pixels, uint32_t max_pixels, uint32_t* h_out, uint32_t* w_out);
 int image_resize(const uint8_t* src, int H, int W, uint8_t* dst, int new_h, int new_w, hipStream_t st);
 int debug_resize_taps(int n_in, int n_out, int32_t* left, int32_t* count, float* weights, int64_t weights_cap);
+void launch_video_to_patches(const uint8_t* frames, void* out, int T, int H, int W, int patch, int merge, const float* mean,
+                             const float* stdv, hipStream_t st);
 void launch_image_to_patches(const uint8_t* img, void* out, int H, int W, int patch, int merge, const float* mean,
                              const float* stdv, hipStream_t st);
 }  // namespace aha

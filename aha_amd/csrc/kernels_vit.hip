@@ -280,6 +280,39 @@ __global__ __launch_bounds__(192) void image_to_patches_kernel(const uint8_t* __
     o[pp] = b;   // temporal slot 1 (duplicated frame, processor.rs:240)
   }
 }
+// Video frames -> patch rows (Qwen3VLProcessor::process_videos, processor.rs:253-281): (T, H, W, 3) u8 RGB frames -> rows
+// (t, bh, bw, ih, iw) x columns (c, frame-in-pair, py, px), a temporal patch = 2 consecutive frames, an odd last frame repeated
+// (process_vision_tensor, processor.rs:176-186).  Unlike img_transform (f32 until the final cast) the reference normalises videos
+// in the MODEL dtype: u8 -> bf16, affine(1/255, 0), broadcast_sub(mean), broadcast_div(std), every op rounding to bf16
+// (scalars cast to bf16 first) -- restated op by op here.
+__global__ __launch_bounds__(192) void video_to_patches_kernel(const uint8_t* __restrict__ frames, bf16_t* __restrict__ out, int T,
+                                                               int H, int W, int patch, int merge, float m0, float m1, float m2,
+                                                               float s0, float s1, float s2) {
+  const int gw = W / patch, gh = H / patch, bwn = gw / merge;
+  const int t = blockIdx.x / (gh * gw), n = blockIdx.x % (gh * gw);
+  const int iw = n % merge, ih = (n / merge) % merge, bw = (n / (merge * merge)) % bwn, bh = n / (merge * merge * bwn);
+  const int y0 = (bh * merge + ih) * patch, x0 = (bw * merge + iw) * patch;
+  const int pp = patch * patch;
+  const float inv255 = rbf(1.0f / 255.0f);
+  for (int e = threadIdx.x; e < 3 * pp; e += blockDim.x) {
+    const int c = e / pp, py = (e % pp) / patch, px = e % patch;
+    const float mean = rbf(c == 0 ? m0 : (c == 1 ? m1 : m2)), sd = rbf(c == 0 ? s0 : (c == 1 ? s1 : s2));
+    bf16_t* o = out + (size_t)blockIdx.x * (6 * pp) + (size_t)c * 2 * pp + py * patch + px;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int f = min(2 * t + k, T - 1);
+      const float v = (float)frames[(((size_t)f * H + (y0 + py)) * W + (x0 + px)) * 3 + c];
+      o[k * pp] = f2bf(rbf(rbf(rbf(v * inv255) + 0.0f) - mean) / sd);
+    }
+  }
+}
+void launch_video_to_patches(const uint8_t* frames, void* out, int T, int H, int W, int patch, int merge, const float* mean,
+                             const float* stdv, hipStream_t st) {
+  const int n = ((T + 1) / 2) * (H / patch) * (W / patch);
+  if (n <= 0) return;
+  hipLaunchKernelGGL(video_to_patches_kernel, dim3(n), dim3(192), 0, st, frames, (bf16_t*)out, T, H, W, patch, merge, mean[0],
+                     mean[1], mean[2], stdv[0], stdv[1], stdv[2]);
+}
 void launch_image_to_patches(const uint8_t* img, void* out, int H, int W, int patch, int merge, const float* mean,
                              const float* stdv, hipStream_t st) {
   const int n = (H / patch) * (W / patch);

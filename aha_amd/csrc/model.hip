@@ -1219,7 +1219,7 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
 
   // positions: 1-D arange(offset, offset+S) on all three rows (rope.rs:599-604), or get_rope_index for Qwen3-VL
   std::vector<int32_t> pos(3 * (size_t)S);
-  const bool has_image = mm && (mm->n_images > 0 || mm->image_embeds);
+  const bool has_image = mm && (mm->n_images > 0 || mm->n_videos > 0 || mm->image_embeds);   // images and / or videos
   if (has_image && (c.arch != AHA_ARCH_QWEN3VL || !m->vision)) {
     set_error("image input given but this model has no vision tower (arch / model.visual.* weights)");
     return AHA_ERR_UNSUPPORTED;

@@ -9,8 +9,8 @@ int vision_create(aha_model* m, const aha_tensor_view* w, size_t nw);
 void vision_destroy(aha_model* m);
 // get_rope_index (/root/reference/src/models/qwen3vl/model.rs:901-1133): fills pos (3, n) rows T,H,W and sets
 // m->rope_delta.  mm == nullptr => text only: rows = arange(n) + offset, delta 0.
-int rope_index_core(const aha_model_desc& c, const uint32_t* ids, size_t S, const uint32_t* grid_thw, int n_images, int32_t* pos,
-                    int64_t* rope_delta);
+int rope_index_core(const aha_model_desc& c, const uint32_t* ids, size_t S, const uint32_t* grid_thw, int n_images,
+                    const uint32_t* video_grid_thw, int n_videos, int32_t* pos, int64_t* rope_delta);
 int vl_rope_index(aha_model* m, const uint32_t* ids, size_t n, size_t offset, const aha_mm_input* mm, int32_t* pos);
 int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, const aha_mm_input* mm, void* x);
 int vision_deepstack_add(aha_model* m, int layer, void* x);

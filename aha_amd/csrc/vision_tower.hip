@@ -246,9 +246,11 @@ int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, cons
     // Embeddings computed elsewhere (another rank's share of the images, gathered over RCCL -- aha_amd/parallel.py):
     // layout (1 + n_deepstack, n_image_tokens, out_hidden) bf16 in device memory.  Skip the tower, keep the scatter.
     const int64_t n4 = mm->n_image_tokens;
-    std::vector<int32_t> rows;
+    std::vector<int32_t> rows;   // the images' tokens first, then the videos' (the order the rows were encoded in)
     for (size_t i = 0; i < n; ++i)
       if (ids[i] == (uint32_t)c.image_token_id) rows.push_back((int32_t)i);
+    for (size_t i = 0; i < n; ++i)
+      if (ids[i] == (uint32_t)c.video_token_id) rows.push_back((int32_t)i);
     if ((int64_t)rows.size() != n4 || n4 <= 0) {
       set_error("n_image_token num: " + std::to_string(rows.size()) + " not equal to image_embed len: " + std::to_string(n4));
       return AHA_ERR_SHAPE;
@@ -267,32 +269,54 @@ int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, cons
     AHA_HIP_CHECK(hipGetLastError());
     return AHA_OK;
   }
-  if (!mm->pixel_values || !mm->image_grid_thw || mm->n_images <= 0) {
-    set_error("forward_initial: image input without pixel_values / image_grid_thw");
+  const bool has_img = mm->n_images > 0, has_vid = mm->n_videos > 0;
+  if ((!has_img && !has_vid) || (has_img && (!mm->pixel_values || !mm->image_grid_thw)) ||
+      (has_vid && (!mm->pixel_values_video || !mm->video_grid_thw))) {
+    set_error("forward_initial: image / video input without pixel values / grid_thw");
     return AHA_ERR_INVALID;
   }
   const bool encode_only = ids == nullptr;
   // ---- host index construction ------------------------------------------------------------------------------
-  int64_t N = 0;
-  for (int i = 0; i < mm->n_images; ++i) {
-    const uint32_t* g = mm->image_grid_thw + 3 * i;
+  // The reference encodes the images and the videos in two get_vision_features calls (model.rs:1150-1187); every (grid, frame) is
+  // its own attention segment and every other op of the tower is row-wise, so here both lists go through ONE pass: rows =
+  // image patches, then video patches; merged rows = image tokens, then video tokens.
+  std::vector<const uint32_t*> grids;
+  for (int i = 0; i < (has_img ? mm->n_images : 0); ++i) grids.push_back(mm->image_grid_thw + 3 * i);
+  for (int i = 0; i < (has_vid ? mm->n_videos : 0); ++i) grids.push_back(mm->video_grid_thw + 3 * i);
+  int64_t N = 0, N_img = 0;
+  for (size_t i = 0; i < grids.size(); ++i) {
+    const uint32_t* g = grids[i];
     if (g[1] % ms || g[2] % ms || g[0] == 0) {
-      set_error("image_grid_thw: h and w must be multiples of spatial_merge_size");
+      set_error("grid_thw: h and w must be multiples of spatial_merge_size");
       return AHA_ERR_SHAPE;
     }
     N += (int64_t)g[0] * g[1] * g[2];
+    if (has_img && (int)i == mm->n_images - 1) N_img = N;
   }
-  if (N != mm->n_patches) {
-    set_error("pixel_values has " + std::to_string(mm->n_patches) + " rows, image_grid_thw describes " + std::to_string(N));
+  const int64_t N_vid = N - N_img;
+  if (N_img != (has_img ? mm->n_patches : 0)) {
+    set_error("pixel_values has " + std::to_string(mm->n_patches) + " rows, image_grid_thw describes " + std::to_string(N_img));
+    return AHA_ERR_SHAPE;
+  }
+  if (N_vid != (has_vid ? mm->n_patches_video : 0)) {
+    set_error("pixel_values_video has " + std::to_string(mm->n_patches_video) + " rows, video_grid_thw describes " + std::to_string(N_vid));
     return AHA_ERR_SHAPE;
   }
   const int64_t n4 = N / (ms * ms);
   std::vector<int32_t> vis_rows;
-  for (size_t i = 0; i < n; ++i)
-    if (ids[i] == (uint32_t)c.image_token_id) vis_rows.push_back((int32_t)i);
-  if (!encode_only && (int64_t)vis_rows.size() != n4) {  // model.rs:1158-1164
-    set_error("n_image_token num: " + std::to_string(vis_rows.size()) + " not equal to image_embed len: " + std::to_string(n4));
-    return AHA_ERR_SHAPE;
+  if (!encode_only) {
+    for (size_t i = 0; i < n; ++i)
+      if (ids[i] == (uint32_t)c.image_token_id) vis_rows.push_back((int32_t)i);
+    if ((int64_t)vis_rows.size() != N_img / (ms * ms)) {  // model.rs:1158-1164
+      set_error("n_image_token num: " + std::to_string(vis_rows.size()) + " not equal to image_embed len: " + std::to_string(N_img / (ms * ms)));
+      return AHA_ERR_SHAPE;
+    }
+    for (size_t i = 0; i < n; ++i)
+      if (ids[i] == (uint32_t)c.video_token_id) vis_rows.push_back((int32_t)i);
+    if ((int64_t)vis_rows.size() != n4) {  // model.rs:1176-1183 (the reference reuses the image wording)
+      set_error("n_image_token num: " + std::to_string(vis_rows.size() - N_img / (ms * ms)) + " not equal to image_embed len: " + std::to_string(N_vid / (ms * ms)));
+      return AHA_ERR_SHAPE;
+    }
   }
   std::vector<int32_t> idx(4 * N), rowcol(2 * N), page_of(N), slot_of(N);
   std::vector<float> wt(4 * N);
@@ -300,8 +324,8 @@ int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, cons
   std::vector<Seg> segs;
   int64_t off = 0, pages = 0;
   const float Gm1 = (float)(v->G - 1);
-  for (int im = 0; im < mm->n_images; ++im) {
-    const uint32_t* g = mm->image_grid_thw + 3 * im;
+  for (size_t im = 0; im < grids.size(); ++im) {
+    const uint32_t* g = grids[im];
     const int t = g[0], h = g[1], w = g[2];
     // linspace(0, G-1, h) in f32 (tensor_utils.rs:354-365), floor by u32 truncation, ceil clamped (model.rs:520-548)
     auto lin = [&](int steps, std::vector<float>& val, std::vector<int>& fl, std::vector<int>& ce) {
@@ -349,11 +373,17 @@ int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, cons
   hipStream_t st = m->stream;
   // ---- uploads ---------------------------------------------------------------------------------------------------
   if (mm->pixel_dtype == AHA_BF16) {
-    AHA_HIP_CHECK(hipMemcpyAsync(v->pix, mm->pixel_values, (size_t)N * v->patch_dim * 2, hipMemcpyDefault, st));
+    if (N_img) AHA_HIP_CHECK(hipMemcpyAsync(v->pix, mm->pixel_values, (size_t)N_img * v->patch_dim * 2, hipMemcpyDefault, st));
+    if (N_vid)
+      AHA_HIP_CHECK(hipMemcpyAsync((char*)v->pix + (size_t)N_img * v->patch_dim * 2, mm->pixel_values_video, (size_t)N_vid * v->patch_dim * 2,
+                                   hipMemcpyDefault, st));
   } else if (mm->pixel_dtype == AHA_F32) {
     std::vector<uint16_t> tmp((size_t)N * v->patch_dim);
     const float* f = (const float*)mm->pixel_values;
-    for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = f2bf_host(f[i]);
+    const float* fv = (const float*)mm->pixel_values_video;
+    const size_t n_img_el = (size_t)N_img * v->patch_dim;
+    for (size_t i = 0; i < n_img_el; ++i) tmp[i] = f2bf_host(f[i]);
+    for (size_t i = n_img_el; i < tmp.size(); ++i) tmp[i] = f2bf_host(fv[i - n_img_el]);
     AHA_HIP_CHECK(hipMemcpy(v->pix, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
   } else {
     set_error("pixel_values must be bf16 or f32");

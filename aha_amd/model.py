@@ -39,9 +39,12 @@ class HipContext:
 
 @dataclass
 class MultiModalData:
-    """data_vec = [pixel_values, image_grid_thw, None, None, cache_position] (qwen3vl/generate.rs:79-101)."""
+    """data_vec = [pixel_values, image_grid_thw, pixel_values_video, video_grid_thw, cache_position]
+    (qwen3vl/generate.rs:79-101, model.rs:1292-1308)."""
     pixel_values: Optional[torch.Tensor] = None    # (n_patches, C*T*P*P) bf16 or f32, processor row order
     image_grid_thw: Optional[np.ndarray] = None    # (n_images, 3) uint32
+    pixel_values_video: Optional[torch.Tensor] = None   # the same for the sampled frames of the videos (process_videos)
+    video_grid_thw: Optional[np.ndarray] = None    # (n_videos, 3) uint32, t = temporal patches (frame pairs)
     # Qwen3-ASR: data_vec = [input_features] (qwen3_asr/generate.rs:100-125): log-mel (128, F) f32, or raw 16 kHz samples
     audio_features: Optional[np.ndarray] = None
     audio_samples: Optional[np.ndarray] = None
@@ -207,15 +210,30 @@ class HipInferenceModel:
                 mm.n_patches = pv.shape[0]
                 mm.image_grid_thw = grid.ctypes.data_as(C.POINTER(C.c_uint32))
                 mm.n_images = grid.shape[0]
+            if data.pixel_values_video is not None:
+                pvv = data.pixel_values_video.detach().contiguous()
+                if pvv.is_cuda:
+                    torch.cuda.current_stream(pvv.device).synchronize()
+                assert data.pixel_values is None or pvv.dtype == data.pixel_values.dtype, "image and video pixel values share a dtype"
+                vgrid = np.ascontiguousarray(np.asarray(data.video_grid_thw, dtype=np.uint32).reshape(-1, 3))
+                mm.pixel_values_video = pvv.data_ptr()
+                mm.pixel_dtype = _DT[pvv.dtype]
+                mm.n_patches_video = pvv.shape[0]
+                mm.video_grid_thw = vgrid.ctypes.data_as(C.POINTER(C.c_uint32))
+                mm.n_videos = vgrid.shape[0]
             if data.image_embeds is not None:
                 ie = data.image_embeds.detach().contiguous()
                 assert ie.is_cuda and ie.dtype == torch.bfloat16 and ie.dim() == 3
                 torch.cuda.current_stream(ie.device).synchronize()
-                grid = np.ascontiguousarray(np.asarray(data.image_grid_thw, dtype=np.uint32).reshape(-1, 3))
+                grid = np.ascontiguousarray(np.asarray(data.image_grid_thw if data.image_grid_thw is not None else [], dtype=np.uint32).reshape(-1, 3))
                 mm.image_embeds = ie.data_ptr()
                 mm.n_image_tokens = ie.shape[1]
-                mm.image_grid_thw = grid.ctypes.data_as(C.POINTER(C.c_uint32))
+                mm.image_grid_thw = grid.ctypes.data_as(C.POINTER(C.c_uint32)) if grid.shape[0] else None
                 mm.n_images = grid.shape[0]
+                if data.video_grid_thw is not None and data.pixel_values_video is None:   # (the grids still drive get_rope_index)
+                    vgrid = np.ascontiguousarray(np.asarray(data.video_grid_thw, dtype=np.uint32).reshape(-1, 3))
+                    mm.video_grid_thw = vgrid.ctypes.data_as(C.POINTER(C.c_uint32))
+                    mm.n_videos = vgrid.shape[0]
             if data.audio_features is not None:
                 af = np.ascontiguousarray(np.asarray(data.audio_features, dtype=np.float32))
                 mm.audio_features = af.ctypes.data_as(C.POINTER(C.c_float))
@@ -318,16 +336,30 @@ class HipInferenceModel:
         return out
 
     def vision_encode(self, data: "MultiModalData") -> torch.Tensor:
-        """ViT only (aha_hip_vision_encode): -> (1 + n_deepstack, n_tokens, hidden) bf16 on this model's GPU."""
-        pv = data.pixel_values.detach().contiguous()
-        if pv.is_cuda:
-            torch.cuda.current_stream(pv.device).synchronize()
-        grid = np.ascontiguousarray(np.asarray(data.image_grid_thw, dtype=np.uint32).reshape(-1, 3))
+        """ViT only (aha_hip_vision_encode): -> (1 + n_deepstack, n_tokens, hidden) bf16 on this model's GPU; the images' tokens
+        first, then the videos'."""
         mm = MmInput()
-        mm.pixel_values, mm.pixel_dtype, mm.n_patches = pv.data_ptr(), _DT[pv.dtype], pv.shape[0]
-        mm.image_grid_thw, mm.n_images = grid.ctypes.data_as(C.POINTER(C.c_uint32)), grid.shape[0]
         m2 = self.cfg.vision.spatial_merge_size ** 2
-        n_tok = int(sum(int(g[0]) * int(g[1]) * int(g[2]) for g in grid) // m2)
+        n_tok = 0
+        keep = []
+        if data.pixel_values is not None:
+            pv = data.pixel_values.detach().contiguous()
+            if pv.is_cuda:
+                torch.cuda.current_stream(pv.device).synchronize()
+            grid = np.ascontiguousarray(np.asarray(data.image_grid_thw, dtype=np.uint32).reshape(-1, 3))
+            mm.pixel_values, mm.pixel_dtype, mm.n_patches = pv.data_ptr(), _DT[pv.dtype], pv.shape[0]
+            mm.image_grid_thw, mm.n_images = grid.ctypes.data_as(C.POINTER(C.c_uint32)), grid.shape[0]
+            n_tok += int(sum(int(g[0]) * int(g[1]) * int(g[2]) for g in grid) // m2)
+            keep += [pv, grid]
+        if data.pixel_values_video is not None:
+            pvv = data.pixel_values_video.detach().contiguous()
+            if pvv.is_cuda:
+                torch.cuda.current_stream(pvv.device).synchronize()
+            vgrid = np.ascontiguousarray(np.asarray(data.video_grid_thw, dtype=np.uint32).reshape(-1, 3))
+            mm.pixel_values_video, mm.pixel_dtype, mm.n_patches_video = pvv.data_ptr(), _DT[pvv.dtype], pvv.shape[0]
+            mm.video_grid_thw, mm.n_videos = vgrid.ctypes.data_as(C.POINTER(C.c_uint32)), vgrid.shape[0]
+            n_tok += int(sum(int(g[0]) * int(g[1]) * int(g[2]) for g in vgrid) // m2)
+            keep += [pvv, vgrid]
         k = 1 + len(self.cfg.vision.deepstack_visual_indexes)
         out = torch.empty(k, n_tok, self.text_cfg.hidden_size, dtype=torch.bfloat16, device=f"cuda:{self.ctx.device}")
         nt = C.c_int64()

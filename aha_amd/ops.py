@@ -142,6 +142,21 @@ def image_to_patches(img_u8_hwc: torch.Tensor, patch: int = 16, merge: int = 2, 
     return out
 
 
+def video_to_patches(frames_u8_thwc: torch.Tensor, patch: int = 16, merge: int = 2, mean=(0.5, 0.5, 0.5),
+                     std=(0.5, 0.5, 0.5)) -> torch.Tensor:
+    """process_videos: (T, H, W, 3) uint8 GPU frames -> (ceil(T/2)*N, 3*2*patch*patch) bf16 rows (frame pairs, an odd last frame
+    repeated; normalised in bf16 op by op like the reference's video path)."""
+    import ctypes as C
+    _chk(frames_u8_thwc)
+    assert frames_u8_thwc.dtype == torch.uint8 and frames_u8_thwc.dim() == 4 and frames_u8_thwc.shape[3] == 3
+    T, H, W = (int(x) for x in frames_u8_thwc.shape[:3])
+    out = torch.empty(((T + 1) // 2) * (H // patch) * (W // patch), 6 * patch * patch, dtype=torch.bfloat16, device=frames_u8_thwc.device)
+    m = (C.c_float * 3)(*mean)
+    s = (C.c_float * 3)(*std)
+    check(lib().aha_hip_video_to_patches(_ptr(frames_u8_thwc), _ptr(out), T, H, W, patch, merge, m, s, _stream()))
+    return out
+
+
 def image_resize(img_u8_hwc: torch.Tensor, new_h: int, new_w: int) -> torch.Tensor:
     """V0-pre: DynamicImage::resize_exact(new_w, new_h, CatmullRom) of an RGB8 (H, W, 3) image on the GPU."""
     _chk(img_u8_hwc)

@@ -50,6 +50,112 @@ def process_images(imgs_u8: List[torch.Tensor], cfg: Qwen3VLConfig) -> MultiModa
     return MultiModalData(torch.cat(pv, 0), np.asarray(grids, dtype=np.uint32))
 
 
+# ---- video path (the part of get_video_data / process_info that is the reference's own arithmetic; decoding the container and
+# the swscale BILINEAR|ACCURATE_RND resize are ffmpeg's and stay with the caller) ------------------------------------------------
+def _f32_round(q) -> int:
+    """f32::round (half away from zero) of a non-negative f32."""
+    q = np.float32(q)
+    fl = np.floor(q)
+    return int(fl) + (1 if np.float32(q - fl) >= np.float32(0.5) else 0)
+
+
+def video_smart_resize(num_frames: int, height: int, width: int, temporal_factor: int = 2, factor: int = 32, min_pixels: int = 4096,
+                       max_pixels: int = 25165824, video_ratio: int | None = 16) -> Tuple[int, int]:
+    """video_smart_resize, /root/reference/src/utils/video_utils.rs:9-59: the frame size get_video_data scales to
+    (processor.rs:496-505: factor = patch_size * merge_size, min / max_pixels = the video preprocessor's shortest / longest edge,
+    video_ratio = 16 so that swscale gets a multiple of 16)."""
+    if num_frames < temporal_factor:
+        raise ValueError(f"{num_frames} must be larger than temporal_factor {temporal_factor}")
+    if height < factor or width < factor:
+        raise ValueError(f"height:{height} or width:{width} must be larger than factor:{factor}")
+    if max(height, width) // min(height, width) > 200:
+        raise ValueError(f"absolute aspect ratio mush be smaller than 200, got {max(height, width) // min(height, width)}")
+    f = factor if video_ratio is None else math.lcm(factor, video_ratio)
+    by = lambda v, k: _f32_round(np.float32(v) / np.float32(k)) * k   # round_by_factor
+    h_bar, w_bar, t_bar = by(height, f), by(width, f), by(num_frames, temporal_factor)
+    vol = np.float32(num_frames * height * width)
+    if t_bar * h_bar * w_bar > max_pixels:
+        beta = np.sqrt(vol / np.float32(max_pixels), dtype=np.float32)
+        h_bar = max(f, int(math.floor(np.float32(height) / beta / np.float32(f))) * f)
+        w_bar = max(f, int(math.floor(np.float32(width) / beta / np.float32(f))) * f)
+    elif t_bar * h_bar * w_bar < min_pixels:
+        beta = np.sqrt(np.float32(min_pixels) / vol, dtype=np.float32)
+        h_bar = int(math.ceil(np.float32(height) * beta / np.float32(f))) * f
+        w_bar = int(math.ceil(np.float32(width) * beta / np.float32(f))) * f
+    return h_bar, w_bar
+
+
+def sample_video_frames(total_frames: int, rate: float, fps: int = 2, min_frames: int = 4, max_frames: int = 768) -> Tuple[int, int, List[int]]:
+    """Which decoded frames get_video_data keeps (processor.rs:481-489,518-535): (nframes, sample_interval, frame_indices).
+    nframes only sizes the resize; the kept frames are the multiples of round(frames / nframes)."""
+    fr, rt = np.float32(total_frames), np.float32(rate)
+    nframes = min(min(max(_f32_round(fr / rt * np.float32(fps)), min_frames), max_frames), total_frames)
+    interval = _f32_round(fr / np.float32(nframes))
+    return nframes, interval, list(range(0, total_frames, interval))
+
+
+def calculate_timestamps(frame_indices: List[int], fps: float, t_merge_size: int = 2) -> List[float]:
+    """calculate_timestamps (processor.rs:283-307): seconds of every temporal patch = mean of its first and last frame time."""
+    idx = list(frame_indices)
+    if len(idx) % t_merge_size:
+        idx += [idx[-1]] * (t_merge_size - len(idx) % t_merge_size)
+    ts = [np.float32(i) / np.float32(fps) for i in idx]
+    return [float((ts[i] + ts[i + t_merge_size - 1]) / np.float32(2.0)) for i in range(0, len(ts), t_merge_size)]
+
+
+def process_videos(videos_u8: List[torch.Tensor], cfg: Qwen3VLConfig) -> Tuple[torch.Tensor, np.ndarray]:
+    """process_videos (processor.rs:253-281) on the GPU: per video (T, H, W, 3) uint8 frames (already sampled and resized) ->
+    pixel_values_video rows and the (t, h, w) grids."""
+    v = cfg.vision
+    pv, grids = [], []
+    for fr in videos_u8:
+        T, H, W = (int(x) for x in fr.shape[:3])
+        pv.append(ops.video_to_patches(fr, v.patch_size, v.spatial_merge_size))
+        grids.append([(T + v.temporal_patch_size - 1) // v.temporal_patch_size, H // v.patch_size, W // v.patch_size])
+    return torch.cat(pv, 0), np.asarray(grids, dtype=np.uint32)
+
+
+def expand_vision_placeholders(text: str, image_grid_thw, video_grid_thw, video_meta, merge_size: int = 2,
+                               image_token: str = "<|image_pad|>", video_token: str = "<|video_pad|>",
+                               vision_start: str = "<|vision_start|>", vision_end: str = "<|vision_end|>") -> str:
+    """process_info's rewrite of the rendered chat text (processor.rs:386-431): every <|image_pad|> becomes t*h*w/merge^2 of
+    them; every <|vision_start|><|video_pad|><|vision_end|> (or bare <|video_pad|>) becomes, per temporal patch,
+    "<{:.1} seconds>" + <|vision_start|> + h*w/merge^2 x <|video_pad|> + <|vision_end|>.  video_meta[k] = (frame_indices, fps) of
+    video k (VideoMetadata, processor.rs:39-46)."""
+    m2 = merge_size * merge_size
+    if image_grid_thw is not None:
+        k = 0
+        while image_token in text:
+            t, h, w = (int(x) for x in image_grid_thw[k])
+            text = text.replace(image_token, "<|placeholder|>" * (t * h * w // m2), 1)
+            k += 1
+        text = text.replace("<|placeholder|>", image_token)
+    if video_grid_thw is not None:
+        k = 0
+        while video_token in text:
+            t, h, w = (int(x) for x in video_grid_thw[k])
+            stamps = calculate_timestamps(video_meta[k][0], video_meta[k][1], merge_size)
+            block = "".join(f"<{stamps[f]:.1f} seconds>{vision_start}{'<|placeholder|>' * (h * w // m2)}{vision_end}" for f in range(t))
+            three = vision_start + video_token + vision_end
+            text = text.replace(three, block, 1) if three in text else text.replace(video_token, block, 1)
+            k += 1
+        text = text.replace("<|placeholder|>", video_token)
+    return text
+
+
+def video_prompt_ids(cfg: Qwen3VLConfig, video_grids: np.ndarray, stamp_ids: List[List[int]] | None = None) -> List[int]:
+    """The token layout expand_vision_placeholders produces for the videos, on ids: per temporal patch the (tokenised) timestamp,
+    <|vision_start|>, h*w/merge^2 x <|video_pad|>, <|vision_end|>.  stamp_ids[j] = ids of the j-th timestamp text."""
+    m2 = cfg.vision.spatial_merge_size ** 2
+    ids, j = [], 0
+    for g in np.asarray(video_grids).tolist():
+        for _ in range(g[0]):
+            ids += list(stamp_ids[j]) if stamp_ids is not None else []
+            ids += [cfg.vision_start_token_id] + [cfg.video_token_id] * (g[1] * g[2] // m2) + [cfg.vision_end_token_id]
+            j += 1
+    return ids
+
+
 def image_prompt_ids(cfg: Qwen3VLConfig, grids: np.ndarray, prefix: List[int], suffix: List[int]) -> List[int]:
     """prefix + for each image: <|vision_start|> + N/4 x <|image_pad|> + <|vision_end|> (processor.rs:386-399) + suffix."""
     m2 = cfg.vision.spatial_merge_size ** 2
@@ -71,17 +177,20 @@ def synthetic_image_request(cfg: Qwen3VLConfig, image_px: int, prompt_tokens: in
     return image_prompt_ids(cfg, data.image_grid_thw, prefix, suffix), data
 
 
-def get_rope_index(cfg: Qwen3VLConfig, input_ids, image_grid_thw):
+def get_rope_index(cfg: Qwen3VLConfig, input_ids, image_grid_thw, video_grid_thw=None):
     """Qwen3VLModel::get_rope_index through the library's host code (csrc/vision.hip rope_index_core): (3, S) int32
     positions and rope_delta.  No GPU involved."""
     import ctypes as C
     from ._lib import check, lib
     from .model import make_desc
     ids = np.ascontiguousarray(np.asarray(input_ids, dtype=np.uint32).reshape(-1))
-    grid = np.ascontiguousarray(np.asarray(image_grid_thw, dtype=np.uint32).reshape(-1, 3))
+    grid = np.ascontiguousarray(np.asarray(image_grid_thw if image_grid_thw is not None else [], dtype=np.uint32).reshape(-1, 3))
+    vgrid = np.ascontiguousarray(np.asarray(video_grid_thw if video_grid_thw is not None else [], dtype=np.uint32).reshape(-1, 3))
     pos = np.empty((3, ids.size), dtype=np.int32)
     delta = C.c_int64()
     desc = make_desc(cfg)
-    check(lib().aha_hip_get_rope_index(C.byref(desc), ids.ctypes.data_as(C.c_void_p), ids.size, grid.ctypes.data_as(C.c_void_p),
-                                       grid.shape[0], pos.ctypes.data_as(C.c_void_p), C.byref(delta)))
+    check(lib().aha_hip_get_rope_index_mm(C.byref(desc), ids.ctypes.data_as(C.c_void_p), ids.size,
+                                          grid.ctypes.data_as(C.c_void_p) if grid.shape[0] else None, grid.shape[0],
+                                          vgrid.ctypes.data_as(C.c_void_p) if vgrid.shape[0] else None, vgrid.shape[0],
+                                          pos.ctypes.data_as(C.c_void_p), C.byref(delta)))
     return pos, int(delta.value)

@@ -108,6 +108,15 @@ typedef struct aha_mm_input {
    * pixel_values is ignored (image_grid_thw is still needed for the M-RoPE positions). */
   const void* image_embeds;
   int64_t n_image_tokens;
+  /* Qwen3-VL video input (data_vec[2..3] = pixel_values_video, video_grid_thw, /root/reference/src/models/qwen3vl/model.rs:
+   * 1169-1187,1299-1307): patch rows of the sampled frames in processor order (process_videos, processor.rs:253-281) and one
+   * (t, h, w) grid per video, t = temporal patches (frame pairs).  Host pointers; same dtype as pixel_values.  Frame decoding
+   * and the swscale resize (get_video_data, processor.rs:447-571, ffmpeg) stay on the caller's side.  With image_embeds set,
+   * the precomputed rows are the images' tokens followed by the videos' tokens. */
+  const void* pixel_values_video;
+  int64_t n_patches_video;
+  const uint32_t* video_grid_thw; /* host, (n_videos, 3) */
+  int32_t n_videos;
 } aha_mm_input;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------------------- */
@@ -137,6 +146,11 @@ void aha_hip_model_destroy(aha_model* m);
  * arithmetic can be tested (and reused by a host) without a GPU. */
 int aha_hip_get_rope_index(const aha_model_desc* desc, const uint32_t* input_ids, size_t n_ids, const uint32_t* image_grid_thw,
                            int32_t n_images, int32_t* pos_out, int64_t* rope_delta_out);
+/* The same with videos (model.rs:908-925,973-981): every (t, h, w) video grid stands for t frames of (1, h, w), one per
+ * <|vision_start|><|video_pad|> run (the processor writes a timestamp and one such run per temporal patch, processor.rs:397-426). */
+int aha_hip_get_rope_index_mm(const aha_model_desc* desc, const uint32_t* input_ids, size_t n_ids, const uint32_t* image_grid_thw,
+                              int32_t n_images, const uint32_t* video_grid_thw, int32_t n_videos, int32_t* pos_out,
+                              int64_t* rope_delta_out);
 
 /* ---- Qwen3-Embedding / Qwen3-Reranker ------------------------------------------------
  * == Qwen3Embedding::embed_one after tokenisation (/root/reference/src/models/qwen3_embedding/mod.rs:50-64):
@@ -300,6 +314,12 @@ int64_t aha_hip_debug_resample_taps(int32_t orig, int32_t new_f, float* taps, in
  * ((H/patch)*(W/patch), 3*2*patch*patch) bf16 in merge-window order with the frame duplicated to T = 2
  * (/root/reference/src/models/qwen3vl/processor.rs:174-251; img_transform, /root/reference/src/utils/img_utils.rs:272-293). */
 int aha_hip_image_to_patches(const uint8_t* img_hwc, void* out, int32_t H, int32_t W, int32_t patch, int32_t merge,
+                             const float mean[3], const float std[3], void* stream);
+/* The video counterpart (process_videos, /root/reference/src/models/qwen3vl/processor.rs:253-281): T RGB8 frames (T, H, W, 3) in
+ * device memory, already sampled and resized (get_video_data's output) -> (ceil(T/2)*(H/patch)*(W/patch), 3*2*patch*patch) bf16
+ * rows, a temporal patch = two consecutive frames (an odd last frame is repeated, processor.rs:176-186).  The normalisation
+ * runs in bf16 op by op as the reference's does for videos (to_dtype, affine(1/255, 0), broadcast_sub, broadcast_div). */
+int aha_hip_video_to_patches(const uint8_t* frames_thwc, void* out, int32_t T, int32_t H, int32_t W, int32_t patch, int32_t merge,
                              const float mean[3], const float std[3], void* stream);
 /* A0: Whisper log-mel frontend on the GPU (extract_fbank_features, feature_extraction_whisper.rs:93-115): n_samples f32
  * device samples -> out (128, n_samples/160) f32 device (n_fft 400, hop 160, symmetric Hann, Slaney mel, log10, max-8 clamp,

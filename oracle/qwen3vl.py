@@ -5,7 +5,10 @@ tests/test_oracle_vs_hf.py.  Reference files restated:
   src/models/qwen3vl/model.rs:32-104 (patch embed), 106-185 (merger), 232-278 (vision attention), 346-370 (block),
       512-639 (fast_pos_embed_interpolate), 641-690 (rot_pos_emb), 692-740 (vision forward),
       775-828 (text model + DeepStack), 901-1133 (get_rope_index), 1135-1277 (forward)
-  src/models/qwen3vl/processor.rs:174-251 (process_vision_tensor / process_images)
+  src/models/qwen3vl/processor.rs:174-251 (process_vision_tensor / process_images), 253-281 (process_videos),
+      283-307 (calculate_timestamps), 386-431 (placeholder expansion), 481-535 (frame sampling of get_video_data; the ffmpeg
+      decode + swscale resize around it is third-party and not restated)
+  src/utils/video_utils.rs:9-59 (video_smart_resize)
   src/utils/img_utils.rs:272-293 (img_transform)
   src/position_embed/rope.rs:75-94 (apply_rotary_pos_emb_vision), 423-476, 541-580 (vision rotary, interleaved M-RoPE)
   src/utils/tensor_utils.rs:294-321 (masked_scatter_dim0), 354-365 (linspace), 466-470 (mask_index_add)
@@ -56,15 +59,111 @@ def process_images(nm: Numerics, imgs_u8: List[np.ndarray], patch=16, tps=2, mer
     return torch.cat(pv, 0), np.concatenate(grids, 0)
 
 
+def process_videos(nm: Numerics, videos_u8: List[np.ndarray], patch=16, tps=2, merge=2, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)):
+    """processor.rs:253-281: each video (T, H, W, 3) u8 (get_video_data's frames, already at the resize size) -> model dtype,
+    affine(1/255, 0), broadcast_sub(mean), broadcast_div(std) -- every op in T, scalars / constants cast to T first (the image
+    path normalises in f32 instead) -- then process_vision_tensor with the real frame pairs."""
+    pv, grids = [], []
+    for v in videos_u8:
+        x = torch.from_numpy(np.ascontiguousarray(v)).permute(0, 3, 1, 2).to(torch.float32)   # (t, c, h, w); u8 is exact in T
+        x = nm.r(nm.r(x * nm.r(torch.tensor(1.0 / 255.0))) + 0.0)
+        m = nm.r(torch.tensor(mean, dtype=torch.float32)).reshape(1, 3, 1, 1)
+        sd = nm.r(torch.tensor(std, dtype=torch.float32)).reshape(1, 3, 1, 1)
+        x = nm.r(nm.r(x - m) / sd)
+        p, g = process_vision_tensor(x, patch, tps, merge)
+        pv.append(p)
+        grids.append(g)
+    return torch.cat(pv, 0), np.concatenate(grids, 0)
+
+
+def _round_half_away(q) -> int:
+    """f32::round."""
+    q = np.float32(q)
+    fl = np.floor(q)
+    return int(fl + (np.float32(q - fl) >= np.float32(0.5)))
+
+
+def video_smart_resize(num_frames, height, width, temporal_factor=2, factor=32, min_pixels=0, max_pixels=0, video_ratio=16):
+    """utils/video_utils.rs:9-59 (round/floor/ceil_by_factor: utils/mod.rs:392-405, f32 quotients; u32 products)."""
+    if num_frames < temporal_factor:
+        raise ValueError(f"{num_frames} must be larger than temporal_factor {temporal_factor}")
+    if height < factor or width < factor:
+        raise ValueError(f"height:{height} or width:{width} must be larger than factor:{factor}")
+    if max(height, width) // min(height, width) > 200:
+        raise ValueError("absolute aspect ratio mush be smaller than 200")
+    f = factor if video_ratio is None else factor * video_ratio // math.gcd(factor, video_ratio)
+    rnd = lambda v, k: _round_half_away(np.float32(v) / np.float32(k)) * k
+    h_bar, w_bar, t_bar = rnd(height, f), rnd(width, f), rnd(num_frames, temporal_factor)
+    if t_bar * h_bar * w_bar > max_pixels:
+        beta = np.sqrt(np.float32(num_frames * height * width) / np.float32(max_pixels), dtype=np.float32)
+        h_bar = max(f, int(np.floor(np.float32(height) / beta / np.float32(f))) * f)
+        w_bar = max(f, int(np.floor(np.float32(width) / beta / np.float32(f))) * f)
+    elif t_bar * h_bar * w_bar < min_pixels:
+        beta = np.sqrt(np.float32(min_pixels) / np.float32(num_frames * height * width), dtype=np.float32)
+        h_bar = int(np.ceil(np.float32(height) * beta / np.float32(f))) * f
+        w_bar = int(np.ceil(np.float32(width) * beta / np.float32(f))) * f
+    return h_bar, w_bar
+
+
+def sample_frame_indices(total_frames: int, rate: float, fps=2, min_frames=4, max_frames=768):
+    """processor.rs:481-489,518-535: nframes = round(frames / rate * fps) clamped to [min_frames, max_frames] and to the frame
+    count; sample_interval = round(frames / nframes); every decoded frame whose id is a multiple of the interval is kept."""
+    frames32, rate32 = np.float32(total_frames), np.float32(rate)
+    nframes = _round_half_away(frames32 / rate32 * np.float32(fps))
+    nframes = min(min(max(nframes, min_frames), max_frames), total_frames)
+    interval = _round_half_away(frames32 / np.float32(nframes))
+    return nframes, interval, [i for i in range(total_frames) if i % interval == 0]
+
+
+def calculate_timestamps(frame_indices: List[int], fps: float, t_merge_size=2) -> List[float]:
+    """processor.rs:283-307 (f32): pad to a multiple of t_merge_size with the last index, index / fps, mean of the first and last
+    of every group."""
+    idx = list(frame_indices)
+    if len(idx) % t_merge_size:
+        idx += [idx[-1]] * (t_merge_size - len(idx) % t_merge_size)
+    ts = [np.float32(i) / np.float32(fps) for i in idx]
+    return [float((ts[i] + ts[i + t_merge_size - 1]) / np.float32(2.0)) for i in range(0, len(ts), t_merge_size)]
+
+
+def expand_placeholders(text: str, image_grids, video_grids, video_meta, merge=2, image_token="<|image_pad|>", video_token="<|video_pad|>",
+                        vs="<|vision_start|>", ve="<|vision_end|>") -> str:
+    """process_info's text rewrite (processor.rs:386-431).  video_meta: per video (frame_indices, fps)."""
+    m2 = merge * merge
+    if image_grids is not None:
+        k = 0
+        while image_token in text:
+            n = int(np.prod(np.asarray(image_grids[k], dtype=np.int64))) // m2
+            text = text.replace(image_token, "<|placeholder|>" * n, 1)
+            k += 1
+        text = text.replace("<|placeholder|>", image_token)
+    if video_grids is not None:
+        k = 0
+        while video_token in text:
+            t, h, w = (int(x) for x in video_grids[k])
+            stamps = calculate_timestamps(video_meta[k][0], video_meta[k][1], merge)
+            ph = ""
+            for f in range(t):
+                ph += "<%.1f seconds>" % stamps[f] + vs + "<|placeholder|>" * (h * w // m2) + ve
+            three = vs + video_token + ve
+            text = text.replace(three, ph, 1) if three in text else text.replace(video_token, ph, 1)
+            k += 1
+        text = text.replace("<|placeholder|>", video_token)
+    return text
+
+
 # ---- M2: get_rope_index -------------------------------------------------------------------------------------------
-def get_rope_index(ids: List[int], grid_thw: Optional[np.ndarray], cfg) -> Tuple[np.ndarray, int]:
-    """qwen3vl/model.rs:901-1133 for B=1, images only.  Returns position_ids (3,S) int64 and rope_delta."""
+def get_rope_index(ids: List[int], grid_thw: Optional[np.ndarray], cfg, video_grid_thw: Optional[np.ndarray] = None) -> Tuple[np.ndarray, int]:
+    """qwen3vl/model.rs:901-1133 for B=1, no attention mask.  Returns position_ids (3,S) int64 and rope_delta."""
     S = len(ids)
-    if grid_thw is None or len(grid_thw) == 0:
+    has_img = grid_thw is not None and len(grid_thw) > 0
+    has_vid = video_grid_thw is not None and len(video_grid_thw) > 0
+    if not has_img and not has_vid:
         return np.tile(np.arange(S, dtype=np.int64), (3, 1)), 0
+    # model.rs:908-925: every (t, h, w) video grid is replaced by t rows (1, h, w)
+    vrows = [[1, int(g[1]), int(g[2])] for g in (video_grid_thw if has_vid else []) for _ in range(int(g[0]))]
     merge = cfg.vision.spatial_merge_size
     blocks: List[np.ndarray] = []
-    text_start, image_index = 0, 0
+    text_start, image_index, video_index = 0, 0, 0
     ids_a = np.asarray(ids)
 
     def next_start():   # llm_pos_ids_list.last().max_all() + 1, or 0 for an empty list (model.rs:984-991)
@@ -73,10 +172,14 @@ def get_rope_index(ids: List[int], grid_thw: Optional[np.ndarray], cfg) -> Tuple
 
     nxt = [j + 1 for j in range(S - 1) if ids_a[j] == cfg.vision_start_token_id]   # get_vision_next_indices
     for e in nxt:
-        if ids_a[e] != cfg.image_token_id:
-            continue  # video tokens: out of scope (component 2)
-        thw = grid_thw[image_index]
-        image_index += 1
+        if ids_a[e] == cfg.image_token_id:
+            thw = grid_thw[image_index]
+            image_index += 1
+        elif ids_a[e] == cfg.video_token_id:
+            thw = vrows[video_index]
+            video_index += 1
+        else:
+            continue  # (the reference reuses the previous grid here -- or panics on an empty one; never in a processor-made prompt)
         text_end = e
         t, gh, gw = int(thw[0]), int(thw[1]) // merge, int(thw[2]) // merge
         text_len = text_end - text_start
@@ -281,17 +384,38 @@ class OracleQwen3VL:
         x = t.embed_tokens(ids)
         vis_rows, deep = None, None
         grid = None
+        vgrid = None
         if mm is not None:
-            pv, grid = mm
-            img, deep = self.vision.forward(pv, grid)
-            vis_rows = [i for i, tok in enumerate(ids) if tok == self.cfg.image_token_id]
-            if len(vis_rows) != img.shape[0]:
-                raise ValueError(f"n_image_token num: {len(vis_rows)} not equal to image_embed len: {img.shape[0]}")
+            pv, grid, pvv, vgrid = (tuple(mm) + (None, None))[:4]
             x = x.clone()
-            x[0, vis_rows] = img                                  # masked_scatter_dim0
-            self.last_image_embeds, self.last_deepstack = img, deep
+            img_rows, vid_rows, deep_i, deep_v = [], [], None, None
+            if pv is not None:                                    # model.rs:1150-1168
+                img, deep_i = self.vision.forward(pv, grid)
+                img_rows = [i for i, tok in enumerate(ids) if tok == self.cfg.image_token_id]
+                if len(img_rows) != img.shape[0]:
+                    raise ValueError(f"n_image_token num: {len(img_rows)} not equal to image_embed len: {img.shape[0]}")
+                x[0, img_rows] = img                              # masked_scatter_dim0
+                self.last_image_embeds, self.last_deepstack = img, deep_i
+            if pvv is not None:                                   # model.rs:1169-1187: a second pass of the same tower
+                vid, deep_v = self.vision.forward(pvv, vgrid)
+                vid_rows = [i for i, tok in enumerate(ids) if tok == self.cfg.video_token_id]
+                if len(vid_rows) != vid.shape[0]:
+                    raise ValueError(f"n_image_token num: {len(vid_rows)} not equal to image_embed len: {vid.shape[0]}")
+                x[0, vid_rows] = vid
+                self.last_video_embeds, self.last_video_deepstack = vid, deep_v
+            # model.rs:1188-1225: deepstack rows of images and videos joined in position order (index_add into zeros)
+            vis_rows = sorted(img_rows + vid_rows)
+            if deep_i is not None and deep_v is not None:
+                deep = []
+                for di, dv in zip(deep_i, deep_v):
+                    j = torch.zeros(len(vis_rows), di.shape[-1])
+                    j[[vis_rows.index(r) for r in img_rows]] = di
+                    j[[vis_rows.index(r) for r in vid_rows]] = dv
+                    deep.append(j)
+            else:
+                deep = deep_i if deep_i is not None else deep_v
         if self.rope_delta is None:                               # model.rs:1229-1236
-            pos, self.rope_delta = get_rope_index(ids, grid, self.cfg)
+            pos, self.rope_delta = get_rope_index(ids, grid, self.cfg, vgrid)
         else:
             pos = np.tile(np.arange(S, dtype=np.int64) + seqlen_offset + self.rope_delta, (3, 1))
         cs = mrope_cos_sin(t.inv_freq, pos, self.cfg.text.mrope_section)

@@ -104,6 +104,10 @@ pub mod sys {
         pub n_samples: i64,
         pub image_embeds: *const c_void,
         pub n_image_tokens: i64,
+        pub pixel_values_video: *const c_void,
+        pub n_patches_video: i64,
+        pub video_grid_thw: *const u32,
+        pub n_videos: i32,
     }
     impl AhaMmInput {
         pub fn empty() -> Self {
@@ -119,6 +123,10 @@ pub mod sys {
                 n_samples: 0,
                 image_embeds: std::ptr::null(),
                 n_image_tokens: 0,
+                pixel_values_video: std::ptr::null(),
+                n_patches_video: 0,
+                video_grid_thw: std::ptr::null(),
+                n_videos: 0,
             }
         }
     }
@@ -220,6 +228,9 @@ pub enum MmInput<'a> {
     None,
     /// Qwen3-VL: processor output `(n_patches, 1536)` f32 + `image_grid_thw` `(n_images, 3)` (qwen3vl/generate.rs:79-101)
     Image { pixel_values: &'a [f32], n_patches: usize, grid_thw: &'a [u32] },
+    /// Qwen3-VL with videos: `data_vec[0..4]` = pixel_values, image_grid_thw, pixel_values_video, video_grid_thw, each pair
+    /// optional (qwen3vl/model.rs:1292-1308); rows `(n, 1536)` f32, grids `(n, 3)`
+    Vision { image: Option<(&'a [f32], usize, &'a [u32])>, video: Option<(&'a [f32], usize, &'a [u32])> },
     /// Qwen3-ASR: Whisper log-mel `(num_mel_bins, n_frames)` f32 (qwen3_asr/generate.rs:100-125)
     AudioFeatures { features: &'a [f32], n_frames: usize },
     /// Qwen3-ASR: raw 16 kHz mono samples; the library computes the log-mel features on the GPU
@@ -307,6 +318,22 @@ impl Model {
                 c.n_patches = n_patches as i64;
                 c.image_grid_thw = grid_thw.as_ptr();
                 c.n_images = (grid_thw.len() / 3) as i32;
+                &c
+            }
+            MmInput::Vision { image, video } => {
+                c.pixel_dtype = sys::AHA_F32;
+                if let Some((pv, n, grid)) = image {
+                    c.pixel_values = pv.as_ptr() as *const _;
+                    c.n_patches = n as i64;
+                    c.image_grid_thw = grid.as_ptr();
+                    c.n_images = (grid.len() / 3) as i32;
+                }
+                if let Some((pv, n, grid)) = video {
+                    c.pixel_values_video = pv.as_ptr() as *const _;
+                    c.n_patches_video = n as i64;
+                    c.video_grid_thw = grid.as_ptr();
+                    c.n_videos = (grid.len() / 3) as i32;
+                }
                 &c
             }
             MmInput::AudioFeatures { features, n_frames } => {
@@ -434,8 +461,26 @@ pub mod inference_model {
             let mut logits = vec![0f32; self.model.vocab_size()];
             let first = data.data_vec.first().cloned().flatten();
             let second = data.data_vec.get(1).cloned().flatten();
-            let (host_a, host_b);
+            let third = data.data_vec.get(2).cloned().flatten();
+            let fourth = data.data_vec.get(3).cloned().flatten();
+            let (host_a, host_b, host_c, host_d);
             let mm = match (first, second) {
+                // Qwen3-VL with a video: data_vec = [pixel_values?, image_grid_thw?, pixel_values_video, video_grid_thw,
+                // cache_position] (qwen3vl/model.rs:1292-1308)
+                (img, igrid) if third.is_some() && fourth.is_some() => {
+                    let (pvv, vgrid) = (third.unwrap(), fourth.unwrap());
+                    host_c = pvv.to_dtype(DType::F32)?.flatten_all()?.to_vec1::<f32>()?;
+                    host_d = vgrid.flatten_all()?.to_vec1::<u32>()?;
+                    let image = match (img, igrid) {
+                        (Some(pv), Some(grid)) => {
+                            host_a = pv.to_dtype(DType::F32)?.flatten_all()?.to_vec1::<f32>()?;
+                            host_b = grid.flatten_all()?.to_vec1::<u32>()?;
+                            Some((&host_a[..], pv.dim(0)?, &host_b[..]))
+                        }
+                        _ => None,
+                    };
+                    MmInput::Vision { image, video: Some((&host_c[..], pvv.dim(0)?, &host_d[..])) }
+                }
                 // Qwen3-VL: data_vec = [pixel_values, image_grid_thw, None, None, cache_position] (qwen3vl/generate.rs:79-101)
                 (Some(pv), Some(grid)) => {
                     host_a = pv.to_dtype(DType::F32)?.flatten_all()?.to_vec1::<f32>()?;

@@ -79,10 +79,8 @@ def qwen3_embedding_case():
                         hidden=np.stack(hid).astype(np.float32), embedding=np.stack(emb).astype(np.float32))
 
 
-def qwen3vl_case():
+def _hf_qwen3vl():
     from transformers.models.qwen3_vl import Qwen3VLConfig as HFC, Qwen3VLForConditionalGeneration
-    from oracle.numerics import Numerics
-    from oracle.qwen3vl import process_images
     cfg = tiny_qwen3vl()
     w = qwen3vl_weights(cfg, seed=0, dtype=torch.float32)
     t, v = cfg.text, cfg.vision
@@ -104,6 +102,13 @@ def qwen3vl_case():
     m = Qwen3VLForConditionalGeneration(hf).eval().float()
     r = m.load_state_dict(w, strict=False)
     assert not r.missing_keys and not r.unexpected_keys
+    return cfg, m
+
+
+def qwen3vl_case():
+    from oracle.numerics import Numerics
+    from oracle.qwen3vl import process_images
+    cfg, m = _hf_qwen3vl()
     g = np.random.default_rng(3)
     imgs = [g.integers(0, 256, size=(96, 64, 3), dtype=np.uint8), g.integers(0, 256, size=(64, 128, 3), dtype=np.uint8)]
     pv, grid = process_images(Numerics("f32"), imgs)
@@ -129,10 +134,50 @@ def qwen3vl_case():
                         tokens=np.asarray(toks, dtype=np.int64), seed=0)
 
 
+def qwen3vl_video_case():
+    """One image and one 5-frame video (3 temporal patches, the odd last frame repeated) in one prompt, in the layout the
+    reference's processor writes (timestamp text, <|vision_start|>, video pads, <|vision_end|> per temporal patch): HF's
+    get_rope_index for video grids, its second visual pass and the joint DeepStack rows, prefill + 3 greedy steps."""
+    from oracle.numerics import Numerics
+    from oracle.qwen3vl import process_images, process_videos
+    cfg, m = _hf_qwen3vl()
+    g = np.random.default_rng(11)
+    img = g.integers(0, 256, size=(64, 96, 3), dtype=np.uint8)
+    vid = g.integers(0, 256, size=(5, 64, 64, 3), dtype=np.uint8)
+    nm = Numerics("f32")
+    pv, grid = process_images(nm, [img])
+    pvv, vgrid = process_videos(nm, [vid])
+    assert vgrid.tolist() == [[3, 4, 4]]
+    ids = [5, 6]
+    ids += [cfg.vision_start_token_id] + [cfg.image_token_id] * (int(np.prod(grid[0])) // 4) + [cfg.vision_end_token_id, 9]
+    for f in range(3):   # stand-ins for the tokenised "<x.x seconds>" texts
+        ids += [20 + f, 30 + f] + [cfg.vision_start_token_id] + [cfg.video_token_id] * 4 + [cfg.vision_end_token_id]
+    ids += [int(x) for x in g.integers(0, 1900, size=7)]
+    mmt = torch.tensor([[1 if t_ == cfg.image_token_id else (2 if t_ == cfg.video_token_id else 0) for t_ in ids]])
+    with torch.no_grad():
+        out = m(input_ids=torch.tensor([ids]), pixel_values=pv, image_grid_thw=torch.tensor(grid.astype(np.int64)),
+                pixel_values_videos=pvv, video_grid_thw=torch.tensor(vgrid.astype(np.int64)), mm_token_type_ids=mmt, use_cache=True)
+        logits = [out.logits[0, -1].numpy()]
+        toks = [int(out.logits[0, -1].argmax())]
+        past = out.past_key_values
+        for t_ in range(3):
+            out = m(input_ids=torch.tensor([[toks[-1]]]), past_key_values=past, use_cache=True,
+                    cache_position=torch.tensor([len(ids) + t_]))
+            past = out.past_key_values
+            logits.append(out.logits[0, -1].numpy())
+            toks.append(int(out.logits[0, -1].argmax()))
+        pos, delta = m.model.get_rope_index(torch.tensor([ids]), mm_token_type_ids=mmt, image_grid_thw=torch.tensor(grid.astype(np.int64)),
+                                            video_grid_thw=torch.tensor(vgrid.astype(np.int64)))
+    np.savez_compressed(os.path.join(OUT, "qwen3vl_video_tiny_f32.npz"), ids=np.asarray(ids, dtype=np.int64), img=img, vid=vid,
+                        grid=grid, vgrid=vgrid, logits=np.stack(logits).astype(np.float32), tokens=np.asarray(toks, dtype=np.int64),
+                        pos=pos[:, 0].numpy().astype(np.int64), delta=int(delta.reshape(-1)[0]), seed=0)
+
+
 if __name__ == "__main__":
     qwen3_case()
     qwen3_embedding_case()
     qwen3vl_case()
+    qwen3vl_video_case()
     print("wrote", [f for f in os.listdir(OUT) if f.endswith(".npz")])
 
 

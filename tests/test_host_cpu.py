@@ -31,9 +31,10 @@ def test_library_exports_every_declared_symbol(hip_lib):
 
 def test_struct_layout_matches_header(hip_lib):
     from aha_amd import _lib
-    # aha_tensor_view: ptr, ptr, i32, i32, i64[5], i32 (+pad) ; aha_mm_input: ptr, i32, i64, ptr, i32 (+pad)
+    # aha_tensor_view: ptr, ptr, i32, i32, i64[5], i32 (+pad) ; aha_mm_input: 11 eight-byte slots + the video fields (ptr, i64, ptr, i32 + pad)
     assert ctypes.sizeof(_lib.TensorView) == 8 + 8 + 4 + 4 + 40 + 8
-    assert ctypes.sizeof(_lib.MmInput) == 8 * 11
+    assert ctypes.sizeof(_lib.MmInput) == 8 * 15
+    assert _lib.MmInput.pixel_values_video.offset == 8 * 11 and _lib.MmInput.n_videos.offset == 8 * 14
     assert ctypes.sizeof(_lib.ModelDesc) % 4 == 0 and _lib.ModelDesc.stop_tokens.offset > _lib.ModelDesc.kv_reserve_tokens.offset
 
 

@@ -56,6 +56,36 @@ def test_qwen3vl_oracle_matches_golden_f32():
         off += 1
 
 
+def test_qwen3vl_oracle_matches_golden_f32_with_video():
+    """One image + one 5-frame video in a prompt (tests/golden/make_golden.py qwen3vl_video_case): HF's positions for the video
+    frames, its separate visual pass for the video, the joint DeepStack rows; prefill logits and 3 greedy steps."""
+    g = np.load(os.path.join(GOLD, "qwen3vl_video_tiny_f32.npz"))
+    cfg = tiny_qwen3vl()
+    w = qwen3vl_weights(cfg, seed=int(g["seed"]), dtype=torch.float32)
+    nm = Numerics("f32")
+    o = ov.OracleQwen3VL(cfg, w, nm)
+    pv, grid = ov.process_images(nm, [g["img"]])
+    pvv, vgrid = ov.process_videos(nm, [g["vid"]])
+    assert np.array_equal(grid, g["grid"]) and np.array_equal(vgrid, g["vgrid"])
+    ids = g["ids"].tolist()
+    pos, delta = ov.get_rope_index(ids, grid, cfg, vgrid)
+    assert np.array_equal(pos, g["pos"]) and delta == int(g["delta"])
+    lg = o.forward_initial(ids, 0, (pv, grid, pvv, vgrid)).reshape(-1).numpy()
+    assert np.abs(lg - g["logits"][0]).max() < 3e-5
+    toks = g["tokens"].tolist()
+    off = len(ids)
+    for t in range(len(toks) - 1):
+        lg = o.forward_step([toks[t]], off).reshape(-1).numpy()
+        assert np.abs(lg - g["logits"][t + 1]).max() < 3e-5, t
+        assert int(np.argmax(lg)) == toks[t + 1]
+        off += 1
+    # video only (no image): the video rows alone carry the DeepStack adds
+    o.clear_cache()
+    vid_ids = [5] + ids[ids.index(9) + 1:]
+    lg_v = o.forward_initial(vid_ids, 0, (None, None, pvv, vgrid)).reshape(-1)
+    assert torch.isfinite(lg_v).all()
+
+
 def test_decode_equals_prefill_suffix_and_gqa_mapping():
     cfg = tiny_qwen3(layers=2, hidden=256, heads=4, kv_heads=2, inter=512, vocab=512)
     w = qwen3_text_weights(cfg, seed=2, dtype=torch.float32)

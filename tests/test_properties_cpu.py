@@ -124,6 +124,63 @@ def test_config_parser_ignores_formatting_and_unknown_keys(extras, indent, ascii
 
 
 @settings(max_examples=150, deadline=None, derandomize=True)
+@given(seed=st.integers(0, 10**6), n_items=st.integers(1, 6), max_g=st.integers(1, 8))
+def test_rope_index_with_videos_differential(seed, n_items, max_g):
+    """The same differential with videos mixed in (model.rs:908-925,973-981): a (t, h, w) video grid stands for t frames (1, h, w),
+    each behind its own <|vision_start|> after some timestamp tokens -- images and videos interleaved in random order."""
+    from aha_amd.configs import tiny_qwen3vl
+    from aha_amd.vision_host import get_rope_index, video_prompt_ids
+    from oracle import qwen3vl as ov
+    cfg = tiny_qwen3vl()
+    rng = np.random.default_rng(seed)
+    ids, grids, vgrids = [int(x) for x in rng.integers(0, 1000, size=rng.integers(0, 4))], [], []
+    for _ in range(n_items):
+        gh, gw = int(rng.integers(1, max_g + 1)), int(rng.integers(1, max_g + 1))
+        if rng.integers(0, 2):
+            t = int(rng.integers(1, 5))
+            vgrids.append([t, 2 * gh, 2 * gw])
+            stamps = [[int(x) for x in rng.integers(0, 1000, size=rng.integers(0, 4))] for _ in range(t)]
+            ids += video_prompt_ids(cfg, np.asarray([vgrids[-1]]), stamps)
+        else:
+            grids.append([1, 2 * gh, 2 * gw])
+            ids += [cfg.vision_start_token_id] + [cfg.image_token_id] * (gh * gw) + [cfg.vision_end_token_id]
+        ids += [int(x) for x in rng.integers(0, 1000, size=rng.integers(0, 5))]
+    grid = np.asarray(grids, dtype=np.uint32).reshape(-1, 3)
+    vgrid = np.asarray(vgrids, dtype=np.uint32).reshape(-1, 3)
+    pos, delta = get_rope_index(cfg, ids, grid, vgrid)
+    ref_pos, ref_delta = ov.get_rope_index(ids, grid, cfg, vgrid)
+    np.testing.assert_array_equal(pos, np.asarray(ref_pos))
+    assert delta == int(ref_delta) and int(pos.max()) + 1 - len(ids) == delta
+    vis = np.asarray([t in (cfg.image_token_id, cfg.video_token_id) for t in ids])
+    assert (pos[0, ~vis] == pos[1, ~vis]).all() and (pos[0, ~vis] == pos[2, ~vis]).all()
+    # every video frame is a t = 1 grid: its T row is constant over the frame's tokens
+    j = 0
+    while j < len(ids):
+        if ids[j] == cfg.video_token_id:
+            k = j
+            while k < len(ids) and ids[k] == cfg.video_token_id:
+                k += 1
+            assert len(set(pos[0, j:k].tolist())) == 1
+            j = k
+        else:
+            j += 1
+
+
+def test_rope_index_video_errors():
+    """More <|vision_start|><|video_pad|> runs than frames in the grids, or a frame longer than the rest of the prompt: an error,
+    not a read past the grid (the reference indexes out of bounds / fails the final reshape there)."""
+    from aha_amd._lib import AhaHipError
+    from aha_amd.configs import tiny_qwen3vl
+    from aha_amd.vision_host import get_rope_index, video_prompt_ids
+    cfg = tiny_qwen3vl()
+    ids = video_prompt_ids(cfg, np.asarray([[3, 2, 2]]))
+    with pytest.raises(AhaHipError):
+        get_rope_index(cfg, ids, None, np.asarray([[2, 2, 2]], dtype=np.uint32))
+    with pytest.raises(AhaHipError):
+        get_rope_index(cfg, ids[:-3], None, np.asarray([[3, 4, 4]], dtype=np.uint32))
+
+
+@settings(max_examples=150, deadline=None, derandomize=True)
 @given(seed=st.integers(0, 10**6), n_images=st.integers(0, 6), max_g=st.integers(1, 12))
 def test_rope_index_differential(seed, n_images, max_g):
     """aha_hip_get_rope_index (host C++, csrc/vision.hip) vs the oracle restatement of Qwen3VLModel::get_rope_index

@@ -1,0 +1,99 @@
+"""Host arithmetic of the Qwen3-VL video path (aha_amd/vision_host.py) against the oracle restatement and against values worked
+out by hand from the reference's formulas (/root/reference/src/utils/video_utils.rs:9-59, src/models/qwen3vl/processor.rs:283-307,
+386-431, 481-535).  The ffmpeg decode / swscale resize around it is third-party and is not mirrored."""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from aha_amd import vision_host as vh
+from oracle import qwen3vl as ov
+
+
+def test_video_smart_resize_known_answers():
+    # factor = lcm(32, 16) = 32; 360 / 32 = 11.25 -> 11 -> 352; 20 * 352 * 640 pixels is inside [min, max]
+    assert vh.video_smart_resize(20, 360, 640) == (352, 640)
+    # over max_pixels: beta = sqrt(8 * 360 * 640 / 786432) = 1.53093; floor(360 / beta / 32) = 7, floor(640 / beta / 32) = 13
+    assert vh.video_smart_resize(8, 360, 640, 2, 32, 4096, 786432, 16) == (224, 416)
+    # under min_pixels: beta = sqrt(4194304 / (4 * 64 * 64)) = 16; ceil(64 * 16 / 32) * 32 = 1024
+    assert vh.video_smart_resize(4, 64, 64, 2, 32, 4194304, 25165824, 16) == (1024, 1024)
+    # video_ratio = 24: factor lcm(32, 24) = 96; 360 / 96 = 3.75 -> 4 -> 384; 640 / 96 = 6.67 -> 7 -> 672
+    assert vh.video_smart_resize(20, 360, 640, 2, 32, 4096, 25165824, 24) == (384, 672)
+    with pytest.raises(ValueError):
+        vh.video_smart_resize(1, 360, 640)          # fewer frames than a temporal patch
+    with pytest.raises(ValueError):
+        vh.video_smart_resize(8, 16, 640)           # smaller than the factor
+    with pytest.raises(ValueError):
+        vh.video_smart_resize(8, 32, 32 * 201)      # aspect ratio > 200
+
+
+def test_frame_sampling_and_timestamps_known_answers():
+    # 10 s at 25 fps, 2 frames per second: 20 frames; interval = round(12.5) = 13 (f32::round: half away from zero)
+    n, iv, idx = vh.sample_video_frames(250, 25.0)
+    assert (n, iv) == (20, 13) and idx == list(range(0, 250, 13)) and len(idx) == 20
+    # 1 s clip: round(2) = 2 -> min_frames 4; interval = round(7.5) = 8
+    assert vh.sample_video_frames(30, 30.0) == (4, 8, [0, 8, 16, 24])
+    # fewer frames than min_frames: clamped to the frame count, every frame kept
+    assert vh.sample_video_frames(3, 30.0) == (3, 1, [0, 1, 2])
+    # long clip: capped at max_frames = 768
+    n, iv, idx = vh.sample_video_frames(100000, 25.0)
+    assert n == 768 and iv == 130 and idx[:3] == [0, 130, 260]
+    # timestamps: [0, 13, 26] padded with 26; (0 + 0.52) / 2 = 0.26, (1.04 + 1.04) / 2 = 1.04 (f32)
+    ts = vh.calculate_timestamps([0, 13, 26], 25.0)
+    assert ts == [float(np.float32(0.52) / np.float32(2)), float(np.float32(26) / np.float32(25))]
+    assert ["%.1f" % t for t in ts] == ["0.3", "1.0"]
+
+
+def test_placeholder_expansion_known_answer():
+    text = "u<|vision_start|><|image_pad|><|vision_end|>v<|vision_start|><|video_pad|><|vision_end|>w"
+    out = vh.expand_vision_placeholders(text, [[1, 4, 6]], [[2, 4, 4]], [([0, 13, 26], 25.0)])
+    frame = lambda s: f"<{s} seconds><|vision_start|>" + "<|video_pad|>" * 4 + "<|vision_end|>"
+    assert out == "u<|vision_start|>" + "<|image_pad|>" * 6 + "<|vision_end|>v" + frame("0.3") + frame("1.0") + "w"
+    # a bare <|video_pad|> (no surrounding start / end in the template) gets the same block in its place
+    assert vh.expand_vision_placeholders("a<|video_pad|>b", None, [[1, 2, 2]], [([0, 5], 10.0)]) == \
+        "a<0.2 seconds><|vision_start|><|video_pad|><|vision_end|>b"
+
+
+@settings(max_examples=300, deadline=None, derandomize=True)
+@given(nf=st.integers(2, 900), h=st.integers(32, 2200), w=st.integers(32, 4000), max_pix=st.sampled_from([786432, 25165824, 4194304]),
+       min_pix=st.sampled_from([4096, 262144]), ratio=st.sampled_from([None, 16, 24]))
+def test_video_smart_resize_differential(nf, h, w, max_pix, min_pix, ratio):
+    if max(h, w) // min(h, w) > 200:
+        return
+    a = vh.video_smart_resize(nf, h, w, 2, 32, min_pix, max_pix, ratio)
+    b = ov.video_smart_resize(nf, h, w, 2, 32, min_pix, max_pix, ratio)
+    assert a == b
+    f = 32 if ratio is None else int(np.lcm(32, ratio))
+    assert a[0] % f == 0 and a[1] % f == 0 and a[0] >= f and a[1] >= f
+
+
+@settings(max_examples=300, deadline=None, derandomize=True)
+@given(frames=st.integers(1, 200000), rate=st.sampled_from([23.976, 24.0, 25.0, 29.97, 30.0, 50.0, 60.0, 12.5]), fps=st.integers(1, 4))
+def test_frame_sampling_differential(frames, rate, fps):
+    n, iv, idx = vh.sample_video_frames(frames, rate, fps)
+    assert (n, iv, idx) == ov.sample_frame_indices(frames, rate, fps)
+    assert 1 <= n <= min(768, frames) and iv >= 1 and idx[0] == 0 and all(b - a == iv for a, b in zip(idx, idx[1:])) and idx[-1] < frames
+    ts = vh.calculate_timestamps(idx, rate)
+    assert ts == ov.calculate_timestamps(idx, rate) and len(ts) == (len(idx) + 1) // 2
+    assert all(b > a for a, b in zip(ts, ts[1:])) or len(idx) % 2 == 1
+
+
+@settings(max_examples=100, deadline=None, derandomize=True)
+@given(seed=st.integers(0, 10**6))
+def test_placeholder_expansion_differential(seed):
+    rng = np.random.default_rng(seed)
+    n_img, n_vid = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+    igrid = [[1, 2 * int(rng.integers(1, 5)), 2 * int(rng.integers(1, 5))] for _ in range(n_img)]
+    vgrid, meta = [], []
+    for _ in range(n_vid):
+        t = int(rng.integers(1, 5))
+        nfr = 2 * t - int(rng.integers(0, 2))
+        vgrid.append([t, 2 * int(rng.integers(1, 4)), 2 * int(rng.integers(1, 4))])
+        meta.append((sorted(int(x) for x in rng.choice(500, size=nfr, replace=False)), float(rng.choice([24.0, 25.0, 29.97]))))
+    parts = ["<|vision_start|><|image_pad|><|vision_end|>"] * n_img + ["<|vision_start|><|video_pad|><|vision_end|>"] * n_vid
+    rng.shuffle(parts)
+    text = "sys " + " and ".join(parts) + " end"
+    a = vh.expand_vision_placeholders(text, igrid or None, vgrid or None, meta)
+    assert a == ov.expand_placeholders(text, igrid or None, vgrid or None, meta)
+    assert a.count("<|image_pad|>") == sum(g[0] * g[1] * g[2] // 4 for g in igrid)
+    assert a.count("<|video_pad|>") == sum(g[0] * g[1] * g[2] // 4 for g in vgrid)
+    assert a.count(" seconds>") == sum(g[0] for g in vgrid)

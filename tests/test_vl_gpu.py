@@ -53,6 +53,103 @@ def test_image_to_patches_bit_exact(gpu, hw):
     assert torch.equal(got.float().cpu(), ref)
 
 
+@pytest.mark.parametrize("thw", [(2, 64, 64), (5, 96, 64), (3, 32, 160), (1, 64, 32)])
+def test_video_to_patches_bit_exact(gpu, thw):
+    """process_videos normalises in the model dtype op by op (u8 -> bf16, * bf16(1/255), - mean, / std, each rounded), pairs
+    consecutive frames and repeats an odd last frame: elementwise, so bit-identical to the restatement."""
+    from aha_amd import ops
+    g = np.random.default_rng(6)
+    vid = g.integers(0, 256, size=(thw[0], thw[1], thw[2], 3), dtype=np.uint8)
+    ref, grid = ov.process_videos(NM, [vid])
+    got = ops.video_to_patches(torch.from_numpy(vid).to(gpu))
+    assert tuple(grid[0]) == ((thw[0] + 1) // 2, thw[1] // 16, thw[2] // 16) and got.shape == ref.shape
+    assert torch.equal(got.float().cpu(), ref)
+    # not the image path's arithmetic: the f32 chain with one final rounding gives different bits somewhere
+    img_like = ov.process_images(NM, [vid[0]])[0]
+    if thw[0] == 1:
+        assert not torch.equal(ref, img_like)
+
+
+def make_video_request(cfg, img_sizes, vid_shapes, n_text, seed):
+    """Prompt in the processor's layout (processor.rs:386-431): images, then per video and temporal patch some timestamp tokens,
+    <|vision_start|>, h*w/4 video pads, <|vision_end|>."""
+    from aha_amd.vision_host import image_prompt_ids, video_prompt_ids
+    g = np.random.default_rng(seed)
+    imgs = [g.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for (h, w) in img_sizes]
+    vids = [g.integers(0, 256, size=(t, h, w, 3), dtype=np.uint8) for (t, h, w) in vid_shapes]
+    pv, grid = ov.process_images(NM, imgs) if imgs else (None, None)
+    pvv, vgrid = ov.process_videos(NM, vids)
+    ids = [int(x) for x in g.integers(0, 1900, size=3)]
+    if imgs:
+        ids = image_prompt_ids(cfg, grid, ids, [int(x) for x in g.integers(0, 1900, size=2)])
+    stamps = [[int(x) for x in g.integers(0, 1900, size=3)] for _ in range(int(vgrid[:, 0].sum()))]
+    ids += video_prompt_ids(cfg, vgrid, stamps)
+    ids += [int(x) for x in g.integers(0, 1900, size=n_text)]
+    return imgs, vids, pv, grid, pvv, vgrid, ids
+
+
+@pytest.mark.parametrize("img_sizes,vid_shapes", [([(64, 96)], [(5, 64, 64)]), ([], [(4, 96, 64)]), ([(64, 64), (32, 96)], [(2, 64, 64), (3, 32, 64)])])
+def test_vl_video_prefill_and_decode(vl, gpu, img_sizes, vid_shapes):
+    """Videos (model.rs:1169-1225): the frames' patch rows through the same tower, scattered at the <|video_pad|> rows, DeepStack
+    rows of images and videos joined in position order, one (1, h, w) M-RoPE block per temporal patch.  The library encodes images
+    and videos in one pass (row-wise ops + per-frame attention segments), the oracle in two like the reference."""
+    from aha_amd.model import MultiModalData
+    cfg, m, o = vl
+    imgs, vids, pv, grid, pvv, vgrid, ids = make_video_request(cfg, img_sizes, vid_shapes, 7, 29)
+    m.clear_cache(); o.clear_cache()
+    data = MultiModalData(pv.to(torch.bfloat16) if pv is not None else None, grid, pixel_values_video=pvv.to(torch.bfloat16), video_grid_thw=vgrid)
+    got, am = m.forward_initial(ids, 0, data)
+    ref = o.forward_initial(ids, 0, (pv, grid, pvv, vgrid)).reshape(-1).numpy()
+    ref_emb = [o.last_video_embeds] if pv is None else [o.last_image_embeds, o.last_video_embeds]
+    ref_emb = torch.cat(ref_emb, 0).numpy()
+    emb = m.debug_image_embeds(0, ref_emb.shape[0])
+    e_max, e_rms = rel_err(emb, ref_emb)
+    assert e_max < 0.08 and e_rms < 0.02, f"visual embeds off: max {e_max:.4f} rms {e_rms:.4f} (in std units)"
+    for k in range(len(cfg.vision.deepstack_visual_indexes)):
+        rd = o.last_video_deepstack[k] if pv is None else torch.cat([o.last_deepstack[k], o.last_video_deepstack[k]], 0)
+        d_max, d_rms = rel_err(m.debug_image_embeds(k + 1, ref_emb.shape[0]), rd.numpy())
+        assert d_max < 0.08 and d_rms < 0.02, f"deepstack {k} off: max {d_max:.4f} rms {d_rms:.4f}"
+    l_max, l_rms = rel_err(got, ref)
+    assert l_max < 0.05 and l_rms < 0.02, f"prefill logits off: max {l_max:.4f} rms {l_rms:.4f}"
+    assert am == int(np.argmax(got))
+    tok, off = int(np.argmax(ref)), len(ids)
+    for step in range(4):
+        got, _ = m.forward_step(tok, off)
+        ref = o.forward_step([tok], off).reshape(-1).numpy()
+        l_max, l_rms = rel_err(got, ref)
+        assert l_max < 0.05 and l_rms < 0.02, f"decode step {step}: max {l_max:.4f} rms {l_rms:.4f}"
+        tok, off = int(np.argmax(ref)), off + 1
+    assert o.rope_delta < 0
+    # the frames patchified on the GPU give the same logits as the host-side rows
+    from aha_amd import vision_host
+    m.clear_cache()
+    a, _ = m.forward_initial(ids, 0, data)
+    pvv_dev, vgrid_dev = vision_host.process_videos([torch.from_numpy(v).to(gpu) for v in vids], cfg)
+    assert np.array_equal(vgrid_dev, vgrid)
+    m.clear_cache()
+    b, _ = m.forward_initial(ids, 0, MultiModalData(pv.to(torch.bfloat16) if pv is not None else None, grid, pixel_values_video=pvv_dev, video_grid_thw=vgrid))
+    assert np.array_equal(a, b)
+    # encode-only + precomputed rows (the image-parallel entry) with videos in the request
+    emb_dev = m.vision_encode(data)
+    m.clear_cache()
+    c, _ = m.forward_initial(ids, 0, MultiModalData(image_grid_thw=grid, image_embeds=emb_dev, video_grid_thw=vgrid))
+    assert np.array_equal(a, c)
+    m.clear_cache()
+
+
+def test_vl_video_token_count_mismatch_is_an_error(vl):
+    """model.rs:1176-1183: the number of <|video_pad|> tokens must equal the video rows."""
+    from aha_amd._lib import AhaHipError
+    from aha_amd.model import MultiModalData
+    cfg, m, o = vl
+    imgs, vids, pv, grid, pvv, vgrid, ids = make_video_request(cfg, [], [(2, 64, 64)], 3, 31)
+    ids.remove(cfg.video_token_id)
+    m.clear_cache()
+    with pytest.raises(AhaHipError, match="n_image_token"):
+        m.forward_initial(ids, 0, MultiModalData(pixel_values_video=pvv.to(torch.bfloat16), video_grid_thw=vgrid))
+    m.clear_cache()
+
+
 @pytest.mark.parametrize("sizes", [[(64, 64)], [(96, 160)], [(160, 96), (64, 128)]])
 def test_vl_prefill_and_decode(vl, gpu, sizes):
     from aha_amd.model import MultiModalData
