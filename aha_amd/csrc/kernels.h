@@ -145,6 +145,12 @@ struct GemmArgs {
   int M, N, K;
   int64_t lda, ldw, ldc;
   int act;
+  // RMSNorm of the finished output rows as part of the call (candle_nn::RmsNorm over N, weight norm_w (N) bf16): norm_out (M, N)
+  // bf16, row pitch N.  Where the plan ends in a split-K reduce pass the norm runs inside it (the pass holds the finished row in
+  // registers); otherwise launch_gemm appends launch_rmsnorm_rows -- the same values either way.
+  const void* norm_w = nullptr;
+  void* norm_out = nullptr;
+  float norm_eps = 0.f;
   void* workspace = nullptr;     // optional f32 scratch for split-K slabs (splitk * M * N * 4 bytes)
   size_t workspace_bytes = 0;
   int tile_group = 8;            // band width of the grouped tile order inside an XCD's run (kernels_gemm.hip tile_of_block); 0 = plain

@@ -799,6 +799,84 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs a, con
   *reinterpret_cast<uint2*>(C + (int64_t)m * a.ldc + n) = w2;
 }
 
+// The reduce pass with the RMSNorm of the finished rows folded in (prefill: o_proj / down_proj + residual, then the next
+// RMSNorm, /root/reference/src/models/qwen3/model.rs:79-90): one wave per row, lane L owns the 8-column vectors i * 64 + L exactly
+// as rmsnorm_rows_kernel does, so the sum of squares is accumulated and reduced in the same order and the normalised rows are
+// bit-identical to gemm_splitk_reduce_kernel followed by rmsnorm_rows_kernel -- one launch and one read of the row less.
+// N = VPL * 512 (no predicated loads); ACT_NONE, no bias.  All slab loads of a row are issued before the first store.
+template <bool HAS_RES, int VPL>
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_norm_kernel(GemmArgs a, const float* __restrict__ slabs, int nsl) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.M) return;
+  const int64_t slab = (int64_t)a.M * a.N;
+  const float* sp = slabs + row * a.N;
+  float4 s[VPL][2];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int n = (i * 64 + lane) * 8;
+    s[i][0] = *reinterpret_cast<const float4*>(sp + n);
+    s[i][1] = *reinterpret_cast<const float4*>(sp + n + 4);
+  }
+  for (int z = 1; z < nsl; ++z) {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int n = (i * 64 + lane) * 8;
+      const float4 t0 = *reinterpret_cast<const float4*>(sp + z * slab + n), t1 = *reinterpret_cast<const float4*>(sp + z * slab + n + 4);
+      s[i][0].x += t0.x; s[i][0].y += t0.y; s[i][0].z += t0.z; s[i][0].w += t0.w;
+      s[i][1].x += t1.x; s[i][1].y += t1.y; s[i][1].z += t1.z; s[i][1].w += t1.w;
+    }
+  }
+  u32x4_t v[VPL];
+  float ss = 0.f;
+  bf16_t* C = (bf16_t*)a.C + row * a.ldc;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int n = (i * 64 + lane) * 8;
+    float x[8] = {rbf(s[i][0].x), rbf(s[i][0].y), rbf(s[i][0].z), rbf(s[i][0].w), rbf(s[i][1].x), rbf(s[i][1].y), rbf(s[i][1].z), rbf(s[i][1].w)};
+    if (HAS_RES) {
+      const u32x4_t r = ld16((const bf16_t*)a.residual + row * a.ldc + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { x[2 * j] += lo_bf(r[j]); x[2 * j + 1] += hi_bf(r[j]); }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[i][j] = pack_bf(x[2 * j], x[2 * j + 1]);
+  }
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    *reinterpret_cast<u32x4_t*>(C + (i * 64 + lane) * 8) = v[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float p = lo_bf(v[i][j]), q = hi_bf(v[i][j]);
+      ss += p * p + q * q;
+    }
+  }
+  ss = wave_sum(ss);
+  const float rinv = 1.0f / sqrtf(ss / (float)a.N + a.norm_eps);
+  bf16_t* Y = (bf16_t*)a.norm_out + row * a.N;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int n = (i * 64 + lane) * 8;
+    const u32x4_t wv = ld16((const bf16_t*)a.norm_w + n);
+    u32x4_t o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack_bf(lo_bf(v[i][j]) * rinv * lo_bf(wv[j]), hi_bf(v[i][j]) * rinv * hi_bf(wv[j]));
+    *reinterpret_cast<u32x4_t*>(Y + n) = o;
+  }
+}
+template <bool HAS_RES>
+bool launch_reduce_norm(const GemmArgs& a, const float* slabs, int nsl, hipStream_t st) {
+  const dim3 grid((unsigned)((a.M + 3) / 4)), block(256);
+  switch (a.N / 512) {
+    case 2: hipLaunchKernelGGL((gemm_splitk_reduce_norm_kernel<HAS_RES, 2>), grid, block, 0, st, a, slabs, nsl); return true;
+    case 4: hipLaunchKernelGGL((gemm_splitk_reduce_norm_kernel<HAS_RES, 4>), grid, block, 0, st, a, slabs, nsl); return true;
+    case 5: hipLaunchKernelGGL((gemm_splitk_reduce_norm_kernel<HAS_RES, 5>), grid, block, 0, st, a, slabs, nsl); return true;
+    case 8: hipLaunchKernelGGL((gemm_splitk_reduce_norm_kernel<HAS_RES, 8>), grid, block, 0, st, a, slabs, nsl); return true;
+    case 10: hipLaunchKernelGGL((gemm_splitk_reduce_norm_kernel<HAS_RES, 10>), grid, block, 0, st, a, slabs, nsl); return true;
+    default: return false;
+  }
+}
+
 const void* zero_block() {
   static void* z = nullptr;
   if (!z) {
@@ -822,7 +900,7 @@ void launch_act(const GemmArgs& a, dim3 grid, hipStream_t st) {
 }
 
 template <int ACT, bool B, bool R>
-void launch256_one(const GemmArgs& a, int splitk, hipStream_t st) {
+void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fused = nullptr) {
   const int ntm = (a.M + BM2 - 1) / BM2, ntn = (a.N + BN2 - 1) / BN2;
   const int nk = (a.K + BK - 1) / BK;
   const size_t lds = 4 * TILE2_BYTES;
@@ -936,16 +1014,22 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st) {
     hipLaunchKernelGGL((gemm256p_kernel<ACT_PARTIAL_F32, false, false>), dim3(ntm * ntn, splitk), dim3(512), lds, st, p, zero_block(), kps, nullptr);
   }
   const int64_t quads = (int64_t)a.M * (a.N >> 2);
+  if (norm_fused != nullptr) *norm_fused = false;
+  if (a.norm_w != nullptr && norm_fused != nullptr && ACT == ACT_NONE && !B && a.N % 512 == 0 &&
+      launch_reduce_norm<R>(a, (const float*)a.workspace, (nk + kps - 1) / kps, st)) {
+    *norm_fused = true;
+    return;
+  }
   hipLaunchKernelGGL((gemm_splitk_reduce_kernel<ACT, B, R>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, a,
                      (const float*)a.workspace, (nk + kps - 1) / kps);
 }
 
 template <int ACT>
-void launch256_act(const GemmArgs& a, int splitk, hipStream_t st) {
-  if (a.bias && a.residual) launch256_one<ACT, true, true>(a, splitk, st);
-  else if (a.bias) launch256_one<ACT, true, false>(a, splitk, st);
-  else if (a.residual) launch256_one<ACT, false, true>(a, splitk, st);
-  else launch256_one<ACT, false, false>(a, splitk, st);
+void launch256_act(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fused) {
+  if (a.bias && a.residual) launch256_one<ACT, true, true>(a, splitk, st, norm_fused);
+  else if (a.bias) launch256_one<ACT, true, false>(a, splitk, st, norm_fused);
+  else if (a.residual) launch256_one<ACT, false, true>(a, splitk, st, norm_fused);
+  else launch256_one<ACT, false, false>(a, splitk, st, norm_fused);
 }
 
 struct GemmPlan { int tile, splitk; double cost = 0; };
@@ -1015,7 +1099,7 @@ void set_gemm_workspace(void* ws, size_t bytes) {
   tl_ws_bytes = bytes;
 }
 
-static void launch_planned(const GemmArgs& a, const GemmPlan& plan, hipStream_t st);
+static void launch_planned(const GemmArgs& a, const GemmPlan& plan, hipStream_t st, bool* norm_fused = nullptr);
 
 void launch_gemm(const GemmArgs& a_in, hipStream_t st) {
   if (a_in.M <= 0 || a_in.N <= 0) return;
@@ -1044,19 +1128,24 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t st) {
     if (pm.cost + pt.cost + 3.0 < plan.cost) {
       launch_planned(am, pm, st);
       launch_planned(at, pt, st);
+      if (a.norm_w) launch_rmsnorm_rows(a.C, a.norm_w, a.norm_out, a.M, a.N, a.ldc, a.N, a.norm_eps, st);
       return;
     }
   }
-  launch_planned(a, plan, st);
+  static const bool fuse_norm = [] { const char* e = getenv("AHA_GEMM_FUSE_NORM"); return e ? atoi(e) != 0 : true; }();
+  bool norm_fused = false;
+  launch_planned(a, plan, st, a.norm_w && fuse_norm ? &norm_fused : nullptr);
+  if (a.norm_w && !norm_fused) launch_rmsnorm_rows(a.C, a.norm_w, a.norm_out, a.M, a.N, a.ldc, a.N, a.norm_eps, st);
 }
 
-static void launch_planned(const GemmArgs& a, const GemmPlan& plan, hipStream_t st) {
+static void launch_planned(const GemmArgs& a, const GemmPlan& plan, hipStream_t st, bool* norm_fused) {
+  if (norm_fused != nullptr) *norm_fused = false;
   if (plan.tile == 256) {
     switch (a.act) {
-      case ACT_NONE: launch256_act<ACT_NONE>(a, plan.splitk, st); break;
-      case ACT_GELU_TANH: launch256_act<ACT_GELU_TANH>(a, plan.splitk, st); break;
-      case ACT_GELU_ERF: launch256_act<ACT_GELU_ERF>(a, plan.splitk, st); break;
-      case ACT_SILU: launch256_act<ACT_SILU>(a, plan.splitk, st); break;
+      case ACT_NONE: launch256_act<ACT_NONE>(a, plan.splitk, st, norm_fused); break;
+      case ACT_GELU_TANH: launch256_act<ACT_GELU_TANH>(a, plan.splitk, st, norm_fused); break;
+      case ACT_GELU_ERF: launch256_act<ACT_GELU_ERF>(a, plan.splitk, st, norm_fused); break;
+      case ACT_SILU: launch256_act<ACT_SILU>(a, plan.splitk, st, norm_fused); break;
       case ACT_SILU_MUL_PAIRS: launch256_one<ACT_SILU_MUL_PAIRS, false, false>(a, 1, st); break;
       case ACT_PARTIAL_F32: launch256_one<ACT_PARTIAL_F32, false, false>(a, 1, st); break;
     }

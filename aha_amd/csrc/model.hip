@@ -1252,9 +1252,15 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
   if (d == 128) launch_rope_table(m->p_pos, S, m->d_inv_freq, m->d_axis_map, S, m->p_rope, st);   // cos / sin once for all layers
   // sequence-parallel tensor parallelism: rank r owns rows [r * spr, (r+1) * spr) of the residual stream between the GEMMs
   const int spr = seq_parallel_on(m) ? (S + m->tp_size - 1) / m->tp_size : 0;
+  // Single GPU: the RMSNorm that follows o_proj / down_proj + residual rides on the GEMM call (GemmArgs::norm_w: inside the
+  // split-K reduce pass where the plan has one, a separate launch otherwise -- the same values).  Not across a DeepStack add,
+  // which changes the rows between down_proj and the next layer's norm.
+  const bool norm_in_gemm = m->tp_size <= 1;
+  bool in_norm_done = false;
   for (int li = 0; li < c.num_hidden_layers; ++li) {
     const LayerWeights& L = m->layers[li];
-    if ((rc = prefill_norm(m, L.in_norm, S, spr))) return rc;
+    if (!in_norm_done && (rc = prefill_norm(m, L.in_norm, S, spr))) return rc;
+    in_norm_done = false;
     {
       GemmArgs g{};
       g.A = m->p_h; g.W = L.wqkv; g.C = m->p_qkv; g.M = S; g.N = nq + 2 * nkv; g.K = H; g.lda = H; g.ldw = H; g.ldc = g.N; g.act = ACT_NONE;
@@ -1283,10 +1289,11 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
     {
       GemmArgs g{};
       g.A = m->p_attn; g.W = L.wo; g.C = m->p_x; g.residual = m->p_x; g.M = S; g.N = H; g.K = nq; g.lda = nq; g.ldw = nq; g.ldc = H; g.act = ACT_NONE;
+      if (norm_in_gemm) { g.norm_w = L.post_norm; g.norm_out = m->p_h; g.norm_eps = c.rms_norm_eps; }
       ProfScope ps(m, "gemm", ((double)g.M * g.K + (double)g.N * g.K + 2.0 * g.M * g.N) * 2, 2.0 * g.M * g.N * g.K);
       if ((rc = gemm_row_parallel(m, g, spr))) return rc;
     }
-    if ((rc = prefill_norm(m, L.post_norm, S, spr))) return rc;
+    if (!norm_in_gemm && (rc = prefill_norm(m, L.post_norm, S, spr))) return rc;
     {
       GemmArgs g{};
       g.A = m->p_h; g.W = L.wgu; g.C = m->p_act; g.M = S; g.N = 2 * I; g.K = H; g.lda = H; g.ldw = H; g.ldc = I; g.act = ACT_SILU_MUL_PAIRS;
@@ -1296,6 +1303,10 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
     {
       GemmArgs g{};
       g.A = m->p_act; g.W = L.wdown; g.C = m->p_x; g.residual = m->p_x; g.M = S; g.N = H; g.K = I; g.lda = I; g.ldw = I; g.ldc = H; g.act = ACT_NONE;
+      if (norm_in_gemm && li + 1 < c.num_hidden_layers && !(has_image && vision_has_deepstack(m, li))) {
+        g.norm_w = m->layers[li + 1].in_norm; g.norm_out = m->p_h; g.norm_eps = c.rms_norm_eps;
+        in_norm_done = true;
+      }
       ProfScope ps(m, "gemm", ((double)g.M * g.K + (double)g.N * g.K + 2.0 * g.M * g.N) * 2, 2.0 * g.M * g.N * g.K);
       if ((rc = gemm_row_parallel(m, g, spr))) return rc;
     }

@@ -14,6 +14,7 @@ int rope_index_core(const aha_model_desc& c, const uint32_t* ids, size_t S, cons
 int vl_rope_index(aha_model* m, const uint32_t* ids, size_t n, size_t offset, const aha_mm_input* mm, int32_t* pos);
 int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, const aha_mm_input* mm, void* x);
 int vision_deepstack_add(aha_model* m, int layer, void* x);
+bool vision_has_deepstack(aha_model* m, int layer);   // vision_deepstack_add(layer) would change rows
 int vision_debug_embeds(aha_model* m, int which, float* out, size_t n);
 int vision_encode(aha_model* m, const aha_mm_input* mm, void* out_dev, int64_t* n_tokens);
 

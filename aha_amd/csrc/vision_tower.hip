@@ -485,6 +485,11 @@ int vision_encode(aha_model* m, const aha_mm_input* mm, void* out_dev, int64_t* 
   return AHA_OK;
 }
 
+bool vision_has_deepstack(aha_model* m, int layer) {
+  VisionModel* v = m->vision;
+  return v && layer < (int)v->deep.size();
+}
+
 int vision_deepstack_add(aha_model* m, int layer, void* x) {
   VisionModel* v = m->vision;
   if (!v || layer >= (int)v->deep.size()) return AHA_OK;

@@ -292,3 +292,23 @@ def test_row_vectorised_rope_kernel_is_bit_identical(gpu):
         assert line, r.stdout[-2000:]
         digests.append(line[0].split()[1])
     assert digests[0] == digests[1], "the row-vectorised rope kernel changed the logits"
+
+
+def test_norm_inside_the_split_k_reduce_is_bit_identical(gpu):
+    """Prefill on one GPU hands the RMSNorm after o_proj / down_proj + residual to the GEMM call; where the plan ends in a split-K
+    reduce pass the norm runs inside it (one wave per row, the sum of squares in rmsnorm_rows_kernel's order).  Same logits, bit for
+    bit, as the reduce pass followed by the separate norm kernel -- text model and a VL prefill whose DeepStack adds sit between
+    down_proj and the next norm (tests/tools/fuse_norm_worker.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for flag in ("0", "1"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "fuse_norm_worker.py")],
+                           env=dict(os.environ, AHA_GEMM_FUSE_NORM=flag), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("FUSE_NORM_DIGEST")]
+        assert line, r.stdout[-2000:]
+        digests.append(line[0].split()[1])
+    assert digests[0] == digests[1], "the norm inside the reduce pass changed the logits"

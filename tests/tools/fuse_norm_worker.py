@@ -1,0 +1,45 @@
+"""Worker of tests/test_model_gpu.py::test_norm_inside_the_split_k_reduce_is_bit_identical: a text prefill (hidden 1024, 2 + 1
+layers) and a Qwen3-VL prefill with DeepStack adds (no fusion across them), each followed by a decode step, with every GEMM forced
+onto the 256^2 tile in 2 K slices so that o_proj / down_proj end in the reduce pass; prints a digest of the logits.  Run with
+AHA_GEMM_FUSE_NORM=0 (reduce pass, then rmsnorm_rows_kernel) and =1 (gemm_splitk_reduce_norm_kernel): the digests must be equal."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    from aha_amd import ops
+    from aha_amd.configs import tiny_qwen3, tiny_qwen3vl
+    from aha_amd.model import HipInferenceModel
+    from aha_amd.weights import qwen3_text_weights, qwen3vl_weights
+    from aha_amd.vision_host import synthetic_image_request
+    h = hashlib.sha256()
+    ops.gemm_plan(256, 2)
+    cfg = tiny_qwen3(layers=3, hidden=1024, heads=8, kv_heads=2, inter=2048, vocab=2048)
+    m = HipInferenceModel(cfg, qwen3_text_weights(cfg, seed=5))
+    ids = [int(x) for x in np.random.default_rng(2).integers(0, cfg.vocab_size, size=300)]
+    lg, tok = m.forward_initial(ids, 0)
+    h.update(lg.tobytes())
+    lg, _ = m.forward_step(tok, len(ids))
+    h.update(lg.tobytes())
+    m.close()
+    vcfg = tiny_qwen3vl()
+    vm = HipInferenceModel(vcfg, qwen3vl_weights(vcfg, seed=0))
+    vids, data = synthetic_image_request(vcfg, 128, 230, torch.Generator().manual_seed(4))
+    lg, tok = vm.forward_initial(vids, 0, data)
+    h.update(lg.tobytes())
+    lg, _ = vm.forward_step(tok, len(vids))
+    h.update(lg.tobytes())
+    vm.close()
+    ops.gemm_plan(0, 0)
+    print("FUSE_NORM_DIGEST", h.hexdigest(), flush=True)
+
+
+if __name__ == "__main__":
+    main()
