@@ -907,12 +907,13 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
   // (> 64 KiB of dynamic LDS needs the opt-in once per kernel instance)
   if (splitk <= 1) {
     static const bool quad = [] { const char* e = getenv("AHA_GEMM_QUAD"); return e ? atoi(e) != 0 : true; }();
-    // four waves x 128 x 128 (gemm256q_kernel).  Not for short K loops with a bias / GELU epilogue (the ViT projections, K = 1152):
-    // one 4-wave block per CU has nothing to overlap its prologue and epilogue with (in the model: ViT fc1 146 us against 87 us on
-    // the 128^2 kernel at 4 blocks per CU, ViT qkv 49.7 against 43.4 on the 8-wave kernel).
+    // four waves x 128 x 128 (gemm256q_kernel).  Not for short K loops (< 32 K tiles) whose epilogue reads a residual on top of a
+    // bias / GELU (ViT proj, K = 1152: 37.5 us against 35.6 us on the 128^2 kernel at 4 blocks per CU, which overlap each other's
+    // prologue and epilogue).  With the row-order epilogue the other ViT projections moved here: qkv 44.8 -> 39.1 us, fc1
+    // (bias + GELU) 49.1 -> 47.1 us against the 8-wave kernel (rocprofv3 averages inside bench.py, same box).
     // (its staging addresses are 32-bit offsets from the block's first row: 256 rows of an operand must span < 1 GiB)
     const bool q_addr_ok = 256.0 * 2.0 * (double)std::max(a.lda, a.ldw) < 1.0e9;
-    if (quad && q_addr_ok && a.K % BK == 0 && (nk >= 32 || (!B && ACT != ACT_GELU_TANH && ACT != ACT_GELU_ERF))) {
+    if (quad && q_addr_ok && a.K % BK == 0 && (nk >= 32 || !R || (!B && ACT != ACT_GELU_TANH && ACT != ACT_GELU_ERF))) {
       static bool onceq = false;
       if (!onceq) {
         hipFuncSetAttribute((const void*)gemm256q_kernel<ACT, B, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1068,7 +1069,7 @@ GemmPlan plan_gemm(const GemmArgs& a) {
   static const int sks[] = {1, 2, 3, 4, 5, 6, 8};
   for (int sk : sks) {
     if (sk > 1 && (!can_split || (size_t)sk * a.M * a.N * 4 > a.workspace_bytes || nk / sk < 8)) continue;
-    const bool q4 = a.K % BK == 0 && (sk > 1 || nk >= 32 || (!a.bias && a.act != ACT_GELU_TANH && a.act != ACT_GELU_ERF));   // gemm256q (launch256_one)
+    const bool q4 = a.K % BK == 0 && (sk > 1 || nk >= 32 || !a.residual || (!a.bias && a.act != ACT_GELU_TANH && a.act != ACT_GELU_ERF));   // gemm256q (launch256_one)
     double c = ceil(t256 * sk / 256.0) * ceil(nk / sk) * (q4 ? 1.5 : 1.75);
     if (sk > 1) c += (double)(sk + 1) * a.M * a.N * 4.0 / 4.0e6 + 3.0;
     if (e_sk && atoi(e_sk) != sk) continue;

@@ -131,6 +131,30 @@ def test_gemm_four_wave_kernel_edges(gpu, splitk, M, N, K):
     assert_close_ulps(full, ref, 2, 0.97, f"gemm256q bias+residual splitk {splitk}")
 
 
+@pytest.mark.parametrize("M,N,K", [(600, 512, 1152), (4096, 3456, 1152), (300, 768, 192)])
+def test_gemm_four_wave_kernel_short_k_bias_gelu(gpu, M, N, K):
+    """Short K loops (18 and 3 K tiles) with a bias / bias + GELU epilogue and no residual run on the four-wave 256^2 kernel (the
+    ViT qkv and fc1 shapes): automatic plan and the forced 256^2 tile, against the oracle chain."""
+    from aha_amd import ops, _lib
+    A, W, b = rnd((M, K), 81), rnd((N, K), 82, 0.02), rnd((N,), 83, 0.5)
+    ref_b = NM.linear(A.float(), W.float(), b.float())
+    ref_g = NM.r(torch.nn.functional.gelu(ref_b, approximate="tanh"))
+    for plan in ((0, 0), (256, 1)):
+        ops.gemm_plan(*plan)
+        try:
+            got_b = ops.gemm(A.to(gpu), W.to(gpu), b.to(gpu))
+            got_g = ops.gemm(A.to(gpu), W.to(gpu), b.to(gpu), None, _lib.ACT_GELU_TANH)
+        finally:
+            ops.gemm_plan(0, 0)
+        assert_close_ulps(got_b, ref_b, 2, 0.97, f"bias, plan {plan}")          # (two roundings: the bounds of the chained cases above)
+        # GELU on exp2 / rcp (kernels_gemm.hip gelu_tanh_f) behind a reordered f32 sum: at 14 M outputs a handful land 3 ulps
+        # away (4 of 14 155 776 measured); the bound is 3 ulps with at most two per million beyond 2
+        assert_close_ulps(got_g, ref_g, 3, 0.97, f"bias + GELU, plan {plan}")
+        g32, r32 = got_g.float().cpu(), ref_g.float().cpu()
+        tol2 = 2 * ulp_bf16(torch.maximum(r32.abs(), r32.pow(2).mean().sqrt()))
+        assert ((g32 - r32).abs() > tol2).float().mean().item() < 2e-6, f"bias + GELU, plan {plan}: too many outputs beyond 2 ulps"
+
+
 def test_gemm_ragged_n_is_split_by_the_automatic_plan(gpu):
     """N = 4304 = 16 x 256 + 208 at M >= 256 (the ViT fc1 shape): the automatic plan runs the columns up to 4096 and the 208-column
     tail as two GEMMs over sub-views of W / C / bias / residual.  Same bound against the oracle as any other plan, and the two
