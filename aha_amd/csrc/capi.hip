@@ -30,7 +30,7 @@ using namespace aha;
 extern "C" {
 
 const char* aha_hip_last_error(void) { return last_error_cstr(); }
-const char* aha_hip_version(void) { return "aha-hip 0.1 (gfx950)"; }
+const char* aha_hip_version(void) { return "aha-hip 0.2 (gfx950)"; }   // 0.2: aha_mm_input grew (video fields)
 
 int aha_hip_get_dtype(int32_t requested, const char* cfg_dtype, int32_t* out) {
   API_GUARD_BEGIN

@@ -90,6 +90,8 @@ typedef struct aha_tensor_view {
 /* MultiModalData for Qwen3-VL (/root/reference/src/models/qwen3vl/generate.rs:79-101: data_vec =
  * [pixel_values, image_grid_thw, None, None, cache_position]).  pixel_values is the processor output
  * (N_patches, C*T*P*P) in merge-window row order (/root/reference/src/models/qwen3vl/processor.rs:174-227). */
+/* (Layout history: the four video fields at the end were added in library version 0.2 -- aha_hip_version(); a caller built
+ * against the 0.1 header must be recompiled, the library reads all fields.  Zero-initialise the struct and set what applies.) */
 typedef struct aha_mm_input {
   const void* pixel_values;     /* host, (n_patches, patch_dim) */
   int32_t pixel_dtype;          /* AHA_BF16 or AHA_F32 */
