@@ -97,3 +97,49 @@ def test_placeholder_expansion_differential(seed):
     assert a.count("<|image_pad|>") == sum(g[0] * g[1] * g[2] // 4 for g in igrid)
     assert a.count("<|video_pad|>") == sum(g[0] * g[1] * g[2] // 4 for g in vgrid)
     assert a.count(" seconds>") == sum(g[0] for g in vgrid)
+
+
+def test_request_pipeline_text_to_positions(tmp_path):
+    """The host side of a Qwen3-VL request with an image and a video, end to end without a GPU: rendered chat text ->
+    expand_vision_placeholders (process_info) -> tokenizer (TokenizerModel mirror, special tokens as added tokens) -> ids ->
+    get_rope_index through the C ABI -- the ids must carry exactly the pads the grids promise, one <|vision_start|> per image and per
+    temporal patch, the timestamps must survive tokenisation, and the library's positions must equal the oracle's."""
+    import dataclasses
+    import json
+    tokenizers = pytest.importorskip("tokenizers")
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers, trainers
+    from aha_amd import text_host as th
+    from aha_amd.configs import tiny_qwen3vl
+    corpus = ["describe the clip and the picture", "<0.3 seconds> <12.5 seconds> <7.0 seconds>", "user assistant system 0123456789 ."] * 4
+    tok = Tokenizer(models.BPE())
+    tok.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False, use_regex=False)
+    tok.decoder = decoders.ByteLevel()
+    tok.train_from_iterator(corpus, trainers.BpeTrainer(vocab_size=350, initial_alphabet=pre_tokenizers.ByteLevel.alphabet(), special_tokens=[]))
+    tok.model.save(str(tmp_path))
+    base = tok.get_vocab_size()
+    names = ["<|im_start|>", "<|im_end|>", "<|vision_start|>", "<|vision_end|>", "<|image_pad|>", "<|video_pad|>"]
+    json.dump({"added_tokens_decoder": {str(base + i): {"content": n, "special": True} for i, n in enumerate(names)}},
+              open(tmp_path / "tokenizer_config.json", "w"))
+    t = th.TokenizerModel.init(str(tmp_path))
+    tid = {n: t.tokenizer.token_to_id(n) for n in names}
+    cfg = dataclasses.replace(tiny_qwen3vl(), vision_start_token_id=tid["<|vision_start|>"], vision_end_token_id=tid["<|vision_end|>"],
+                              image_token_id=tid["<|image_pad|>"], video_token_id=tid["<|video_pad|>"])
+    # a 10 s clip at 25 fps: 20 sampled frames -> 10 temporal patches; frames scaled to what video_smart_resize names
+    nframes, interval, idx = vh.sample_video_frames(250, 25.0)
+    rh, rw = vh.video_smart_resize(nframes, 360, 640, 2, 32, 4096, 786432, 16)
+    igrid = np.asarray([[1, 8, 12]], dtype=np.uint32)
+    vgrid = np.asarray([[(len(idx) + 1) // 2, rh // 16, rw // 16]], dtype=np.uint32)
+    text = ("<|im_start|>user\n<|vision_start|><|image_pad|><|vision_end|><|vision_start|><|video_pad|><|vision_end|>"
+            "describe the clip and the picture<|im_end|>\n<|im_start|>assistant\n")
+    full = vh.expand_vision_placeholders(text, igrid, vgrid, [(idx, 25.0)])
+    ids = t.text_encode(full)
+    n_img_pads, n_vid_pads = int(np.prod(igrid[0])) // 4, int(np.prod(vgrid[0])) // 4
+    assert ids.count(cfg.image_token_id) == n_img_pads and ids.count(cfg.video_token_id) == n_vid_pads
+    assert ids.count(cfg.vision_start_token_id) == 1 + int(vgrid[0, 0]) == ids.count(cfg.vision_end_token_id)
+    back = t.token_decode_with_special(ids)
+    assert back == full and "<0.3 seconds>" in back and back.count(" seconds>") == int(vgrid[0, 0])
+    pos, delta = vh.get_rope_index(cfg, ids, igrid, vgrid)
+    ref_pos, ref_delta = ov.get_rope_index(ids, igrid, cfg, vgrid)
+    assert np.array_equal(pos, ref_pos) and delta == ref_delta
+    # positions advance by max(h, w) / 2 per frame, not by its token count: the prompt is far shorter in position space
+    assert delta == int(pos.max()) + 1 - len(ids) and delta < -(n_vid_pads // 2)
