@@ -31,6 +31,7 @@ MFMA_PEAK_TFLOPS = 2500.0  # bf16 dense
 METRICS = {
     "qwen3vl8b": "decode tokens/s (greedy, batch 1) -- Qwen3-VL-8B, 1x1024^2 image + 512-token prompt; prefill tok/s alongside",
     "qwen3vl8b-cfg5": "decode tokens/s (greedy, batch 1) -- Qwen3-VL-8B, 8 x 2048^2 images + 8192-token prompt (BASELINE cfg 5 on one GPU, S ~ 41k); prefill tok/s alongside",
+    "qwen3vl8b-video": "decode tokens/s (greedy, batch 1) -- Qwen3-VL-8B, 16 video frames of 448^2 (8 temporal patches, 1568 video tokens) + 512-token prompt; prefill tok/s and the video patchify kernel alongside",
     "qwen3vl8b-text": "decode tokens/s (greedy, batch 1) -- Qwen3-VL-8B text stack, 1542-token prompt; prefill tok/s alongside",
     "qwen3-0.6b": "decode tokens/s (greedy, batch 1) -- Qwen3-0.6B, 2048-token prompt (BASELINE cfg 2); prefill tok/s alongside",
     "qwen3vl8b-cfg5-tp": "prefill tokens/s -- Qwen3-VL-8B, 8 x 2048^2 images + 8192-token prompt (BASELINE cfg 5), tensor-parallel decoder stack + image-parallel ViT over all ranks",
@@ -44,6 +45,8 @@ def build_workload(name: str):
         return configs.qwen3vl_8b(), dict(image=1024, prompt=512)
     if name == "qwen3vl8b-cfg5":   # BASELINE.md section 4 cfg 5 on ONE GPU: 8 images of 2048^2 + 8192 text ids (S ~ 41k); prefill-dominated
         return configs.qwen3vl_8b(), dict(image=2048, prompt=8192, n_images=8)
+    if name == "qwen3vl8b-video":   # the video path (not a BASELINE config): 16 sampled frames of 448^2 = 8 temporal patches x 784
+        return configs.qwen3vl_8b(), dict(image=0, prompt=512, video=(16, 448, 448))   # patches -> 1568 video tokens + timestamps + 512 text ids
     if name == "qwen3vl8b-text":
         return configs.qwen3vl_8b(), dict(image=0, prompt=1542)
     if name == "qwen3-0.6b":
@@ -224,7 +227,7 @@ def main():
     if is_asr:
         w = W.qwen3_asr_weights(cfg, seed=rank, device=dev)
     elif is_vl:
-        w = W.qwen3vl_weights(cfg, seed=rank, device=dev) if wl["image"] else \
+        w = W.qwen3vl_weights(cfg, seed=rank, device=dev) if (wl["image"] or wl.get("video")) else \
             W.qwen3_text_weights(tcfg, seed=rank, prefix="model.language_model.", device=dev)
     else:
         w = W.qwen3_text_weights(tcfg, seed=rank, device=dev)
@@ -240,6 +243,28 @@ def main():
     if wl["image"]:
         from aha_amd.vision_host import synthetic_image_request
         ids, data = synthetic_image_request(cfg, wl["image"], wl["prompt"], g, n_images=wl.get("n_images", 1))
+    elif wl.get("video"):
+        # frames as get_video_data hands them over (RGB24 at the resize size); patchified on the GPU (process_videos), prompt in the
+        # processor's layout: per temporal patch 3 stand-in timestamp ids, <|vision_start|>, h*w/4 video pads, <|vision_end|>
+        from aha_amd import ops, vision_host
+        T, VH, VW = wl["video"]
+        frames = torch.randint(0, 256, (T, VH, VW, 3), generator=g, dtype=torch.uint8).to(dev)
+        pvv, vgrid = vision_host.process_videos([frames], cfg)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(20):
+            ops.video_to_patches(frames, cfg.vision.patch_size, cfg.vision.spatial_merge_size)
+        e1.record()
+        torch.cuda.synchronize()
+        video_patchify = {"us": round(e0.elapsed_time(e1) * 1e3 / 20, 2),
+                          "GBs": round((frames.numel() + pvv.numel() * 2) / (e0.elapsed_time(e1) * 1e-3 / 20) / 1e9, 1),
+                          "algorithmic_bytes": int(frames.numel() + pvv.numel() * 2)}
+        hi = min(tcfg.vocab_size, 151643)
+        stamps = [torch.randint(0, hi, (3,), generator=g).tolist() for _ in range(int(vgrid[:, 0].sum()))]
+        ids = torch.randint(0, hi, (4,), generator=g).tolist() + vision_host.video_prompt_ids(cfg, vgrid, stamps) + \
+            torch.randint(0, hi, (wl["prompt"],), generator=g).tolist()
+        data = MultiModalData(pixel_values_video=pvv, video_grid_thw=vgrid)
     elif is_asr:
         # seed-4 N(0, 0.1^2) clipped to [-1, 1]; the library computes the log-mel features on the GPU from the raw samples
         n = wl["audio_samples"]
@@ -351,6 +376,9 @@ def main():
             "load_s": round(t_load, 1),
             "roofline": roof,
         }
+        if wl.get("video"):
+            line["config"]["video_frames_hw"] = list(wl["video"])
+            line["video_to_patches"] = video_patchify
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
     model.close()
