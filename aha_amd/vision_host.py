@@ -156,6 +156,105 @@ def video_prompt_ids(cfg: Qwen3VLConfig, video_grids: np.ndarray, stamp_ids: Lis
     return ids
 
 
+# ---- process_info / get_data: the request-level orchestration ---------------------------------------------------------------------
+def extract_vision_info(messages) -> dict:
+    """extract_vision_info (processor.rs:126-149): the image / video URLs of the USER messages whose content is a list of parts, in
+    message order.  Parts are an untagged serde enum (params/chat.rs:608-615): the first variant whose fields are present wins --
+    Text (type + text), Image (type + image_url), Audio (type + audio_url), Video (type + video_url) -- the `type` string itself is
+    not looked at."""
+    out = {"image": [], "video": []}
+    for m in messages:
+        if m.get("role") != "user" or not isinstance(m.get("content"), list):
+            continue
+        for part in m["content"]:
+            if not isinstance(part, dict) or "type" not in part:
+                continue
+            if "text" in part:
+                continue
+            if isinstance(part.get("image_url"), dict) and "url" in part["image_url"]:
+                out["image"].append(part["image_url"]["url"])
+            elif "audio_url" in part:
+                continue
+            elif isinstance(part.get("video_url"), dict) and "url" in part["video_url"]:
+                out["video"].append(part["video_url"]["url"])
+    return out
+
+
+def plan_video(total_frames: int, rate: float, height: int, width: int, cfg: Qwen3VLConfig, fps: int = 2, min_frames: int = 4,
+               max_frames: int = 768, min_pixels: int = 4096, max_pixels: int = 25165824) -> dict:
+    """What get_video_data decides before it decodes (processor.rs:481-505): how many frames size the resize, which decoded frames
+    are kept, and the size swscale scales them to."""
+    nframes, interval, idx = sample_video_frames(total_frames, rate, fps, min_frames, max_frames)
+    v = cfg.vision
+    rh, rw = video_smart_resize(nframes, height, width, v.temporal_patch_size, v.patch_size * v.spatial_merge_size, min_pixels, max_pixels, 16)
+    return {"nframes": nframes, "sample_interval": interval, "frame_indices": idx, "resize_hw": (rh, rw)}
+
+
+class Qwen3VLProcessor:
+    """Qwen3VLProcessor::process_info (processor.rs:310-444) for the Python host: collect the request's images and videos, turn them
+    into patch rows + grids, rewrite the rendered chat text.  `image_loader(url) -> (H, W, 3) uint8` defaults to media_host.get_image;
+    `video_loader(url, plan) -> (frames (T, H, W, 3) uint8 at plan(...)["resize_hw"], frame_indices, fps)` has no default: decoding
+    the container and the swscale resize are ffmpeg's (plan = lambda total_frames, rate, height, width: plan_video(...)).
+    `image_fn` / `video_fn` turn the decoded arrays into (rows, grids); the defaults run on the GPU (process_images /
+    process_videos).  As in the reference a source that fails to load is reported and skipped (processor.rs:330-336,359-366)."""
+
+    def __init__(self, cfg: Qwen3VLConfig, image_loader=None, video_loader=None, image_fn=None, video_fn=None, device: str = "cuda",
+                 fps: int = 2, min_frames: int = 4, max_frames: int = 768, video_min_pixels: int = 4096, video_max_pixels: int = 25165824):
+        from . import media_host
+        self.cfg, self.device = cfg, device
+        self.image_loader = image_loader or media_host.get_image
+        self.video_loader = video_loader
+        self.image_fn = image_fn or (lambda imgs: (lambda d: (d.pixel_values, d.image_grid_thw))(
+            process_images([torch.from_numpy(np.ascontiguousarray(i)).to(device) for i in imgs], cfg)))
+        self.video_fn = video_fn or (lambda vids: process_videos([torch.as_tensor(np.ascontiguousarray(v)).to(device) for v in vids], cfg))
+        self.fps, self.min_frames, self.max_frames = fps, min_frames, max_frames
+        self.video_min_pixels, self.video_max_pixels = video_min_pixels, video_max_pixels
+        self.warnings: List[str] = []
+
+    def plan(self, total_frames: int, rate: float, height: int, width: int) -> dict:
+        return plan_video(total_frames, rate, height, width, self.cfg, self.fps, self.min_frames, self.max_frames,
+                          self.video_min_pixels, self.video_max_pixels)
+
+    def process_info(self, messages, text: str) -> dict:
+        """-> GeneralInput as a dict: replace_text, pixel_values, image_grid_thw, pixel_values_video, video_grid_thw."""
+        info = extract_vision_info(messages)
+        out = {"replace_text": text, "pixel_values": None, "image_grid_thw": None, "pixel_values_video": None, "video_grid_thw": None}
+        imgs = []
+        for url in info["image"]:
+            try:
+                imgs.append(self.image_loader(url))
+            except Exception as e:  # noqa: BLE001  (println!("get_image err: {e:?}") and carry on)
+                self.warnings.append(f"get_image err: {e}")
+        if imgs:
+            out["pixel_values"], out["image_grid_thw"] = self.image_fn(imgs)
+        vids, meta = [], []
+        for url in info["video"]:
+            try:
+                if self.video_loader is None:
+                    raise RuntimeError("no video loader: decoding is the caller's (ffmpeg)")
+                frames, idx, fps = self.video_loader(url, self.plan)
+                vids.append(frames)
+                meta.append((list(idx), float(fps)))
+            except Exception as e:  # noqa: BLE001
+                self.warnings.append(f"get_video_data err: {e}")
+        if vids:
+            out["pixel_values_video"], out["video_grid_thw"] = self.video_fn(vids)
+        out["replace_text"] = expand_vision_placeholders(text, out["image_grid_thw"], out["video_grid_thw"], meta,
+                                                         self.cfg.vision.spatial_merge_size)
+        return out
+
+
+def get_data(messages, chat_template, tokenizer, processor: Qwen3VLProcessor, tools=None, enable_thinking=None):
+    """Qwen3VLGenerateModel::get_data (qwen3vl/generate.rs:79-101): render the chat template, run the processor, tokenise the
+    rewritten text -> (input_ids, MultiModalData) for forward_initial.  (cache_position is arange(len) and implicit here.)"""
+    rendered = chat_template.apply_chat_template(messages, tools, enable_thinking)
+    inp = processor.process_info(messages, rendered)
+    ids = tokenizer.text_encode(inp["replace_text"])
+    data = MultiModalData(inp["pixel_values"], inp["image_grid_thw"], pixel_values_video=inp["pixel_values_video"],
+                          video_grid_thw=inp["video_grid_thw"])
+    return ids, data
+
+
 def image_prompt_ids(cfg: Qwen3VLConfig, grids: np.ndarray, prefix: List[int], suffix: List[int]) -> List[int]:
     """prefix + for each image: <|vision_start|> + N/4 x <|image_pad|> + <|vision_end|> (processor.rs:386-399) + suffix."""
     m2 = cfg.vision.spatial_merge_size ** 2

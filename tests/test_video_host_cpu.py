@@ -143,3 +143,80 @@ def test_request_pipeline_text_to_positions(tmp_path):
     assert np.array_equal(pos, ref_pos) and delta == ref_delta
     # positions advance by max(h, w) / 2 per frame, not by its token count: the prompt is far shorter in position space
     assert delta == int(pos.max()) + 1 - len(ids) and delta < -(n_vid_pads // 2)
+
+
+def test_process_info_and_get_data_orchestration(tmp_path):
+    """Qwen3VLProcessor::process_info + Qwen3VLGenerateModel::get_data mirrors (processor.rs:126-149,310-444; generate.rs:79-101) on
+    the CPU: content parts -> sources (untagged-enum rules, user messages only), a data: URI image through media_host.get_image,
+    a video through a caller-supplied loader that honours the plan (sampling + resize size), patch rows by the oracle's
+    process_images / process_videos, the text rewrite, the tokenizer, and the library's get_rope_index on the result."""
+    import base64
+    import dataclasses
+    import io
+    import json
+    tokenizers = pytest.importorskip("tokenizers")
+    PIL = pytest.importorskip("PIL.Image")
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers, trainers
+    from aha_amd import text_host as th
+    from aha_amd.configs import tiny_qwen3vl
+    from oracle.numerics import Numerics
+
+    tok = Tokenizer(models.BPE())
+    tok.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False, use_regex=False)
+    tok.decoder = decoders.ByteLevel()
+    tok.train_from_iterator(["what happens in the clip compared to the picture user assistant <0.5 seconds>"] * 4,
+                            trainers.BpeTrainer(vocab_size=330, initial_alphabet=pre_tokenizers.ByteLevel.alphabet(), special_tokens=[]))
+    tok.model.save(str(tmp_path))
+    base = tok.get_vocab_size()
+    names = ["<|im_start|>", "<|im_end|>", "<|vision_start|>", "<|vision_end|>", "<|image_pad|>", "<|video_pad|>"]
+    template = ("{%- for m in messages %}{{- '<|im_start|>' + m.role + '\\n' }}{%- if m.content is string %}{{- m.content }}{%- else %}"
+                "{%- for p in m.content %}{%- if 'image_url' in p and m.role == 'user' %}{{- '<|vision_start|><|image_pad|><|vision_end|>' }}"
+                "{%- elif 'video_url' in p and m.role == 'user' %}{{- '<|vision_start|><|video_pad|><|vision_end|>' }}{%- elif 'text' in p %}{{- p.text }}{%- endif %}"
+                "{%- endfor %}{%- endif %}{{- '<|im_end|>\\n' }}{%- endfor %}{%- if add_generation_prompt %}{{- '<|im_start|>assistant\\n' }}{%- endif %}")
+    json.dump({"added_tokens_decoder": {str(base + i): {"content": n, "special": True} for i, n in enumerate(names)},
+               "chat_template": template}, open(tmp_path / "tokenizer_config.json", "w"))
+    t = th.TokenizerModel.init(str(tmp_path))
+    ct = th.ChatTemplate.init(str(tmp_path))
+    tid = {n: t.tokenizer.token_to_id(n) for n in names}
+    cfg = dataclasses.replace(tiny_qwen3vl(), vision_start_token_id=tid["<|vision_start|>"], vision_end_token_id=tid["<|vision_end|>"],
+                              image_token_id=tid["<|image_pad|>"], video_token_id=tid["<|video_pad|>"])
+
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=(64, 96, 3), dtype=np.uint8)           # already a smart-resize size: no resize in image_fn below
+    buf = io.BytesIO()
+    PIL.fromarray(img).save(buf, format="PNG")
+    uri = "data:image/png;base64," + base64.b64encode(buf.getvalue()).decode()
+    seen = {}
+
+    def video_loader(url, plan):
+        p = plan(90, 30.0, 70, 100)                                         # a 3 s, 30 fps, 100 x 70 clip
+        seen.update(p, url=url)
+        rh, rw = p["resize_hw"]
+        return rng.integers(0, 256, size=(len(p["frame_indices"]), rh, rw, 3), dtype=np.uint8), p["frame_indices"], 30.0
+
+    nm = Numerics("bf16")
+    proc = vh.Qwen3VLProcessor(cfg, video_loader=video_loader, image_fn=lambda imgs: ov.process_images(nm, imgs),
+                               video_fn=lambda vids: ov.process_videos(nm, vids), device="cpu")
+    messages = [{"role": "system", "content": "sys"},
+                {"role": "user", "content": [{"type": "image", "image_url": {"url": uri, "detail": "auto"}},
+                                             {"type": "video", "video_url": {"url": "file:///clip.mp4"}},
+                                             {"type": "text", "text": "what happens in the clip compared to the picture"}]},
+                {"role": "assistant", "content": [{"type": "image", "image_url": {"url": "file:///ignored.png"}}]}]
+    assert vh.extract_vision_info(messages) == {"image": [uri], "video": ["file:///clip.mp4"]}
+    ids, data = vh.get_data(messages, ct, t, proc)
+    # the plan: round(90 / 30 * 2) = 6 frames, interval round(15) = 15, frames 0..75; 100 x 70 -> factor 32: (64, 96)
+    assert seen["url"] == "file:///clip.mp4" and seen["nframes"] == 6 and seen["sample_interval"] == 15
+    assert seen["frame_indices"] == [0, 15, 30, 45, 60, 75] and seen["resize_hw"] == (64, 96)
+    assert data.image_grid_thw.tolist() == [[1, 4, 6]] and data.video_grid_thw.tolist() == [[3, 4, 6]]
+    assert data.pixel_values.shape == (24, 1536) and data.pixel_values_video.shape == (72, 1536)
+    assert ids.count(cfg.image_token_id) == 6 and ids.count(cfg.video_token_id) == 18 and ids.count(cfg.vision_start_token_id) == 1 + 3
+    text = t.token_decode_with_special(ids)
+    assert text.count(" seconds>") == 3 and "<0.2 seconds>" in text      # (0 + 15/30) / 2 = 0.25 -> "0.2" (ties to even on the exact f32 0.25)
+    pos, delta = vh.get_rope_index(cfg, ids, data.image_grid_thw, data.video_grid_thw)
+    ref_pos, ref_delta = ov.get_rope_index(ids, data.image_grid_thw, cfg, data.video_grid_thw)
+    assert np.array_equal(pos, ref_pos) and delta == ref_delta and not proc.warnings
+    # a source that cannot be loaded is reported and skipped; with nothing left the text is not rewritten
+    proc2 = vh.Qwen3VLProcessor(cfg, image_fn=lambda imgs: ov.process_images(nm, imgs), device="cpu")
+    bad = [{"role": "user", "content": [{"type": "image", "image_url": {"url": "https://example.invalid/a.png"}}, {"type": "text", "text": "hi"}]}]
+    out = proc2.process_info(bad, ct.apply_chat_template(bad))
+    assert out["pixel_values"] is None and out["replace_text"].count("<|image_pad|>") == 1 and len(proc2.warnings) == 1
