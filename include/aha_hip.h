@@ -222,8 +222,8 @@ int aha_hip_sample_candidates(aha_model* m, const uint32_t* context, size_t n_co
 int aha_hip_last_logits(aha_model* m, float* logits_out);
 
 /* Extension for the image-parallel ViT (each GPU encodes its share of the images, embeddings are all-gathered over RCCL):
- * runs only the vision tower on `mm` and writes (1 + n_deepstack, n_tokens, hidden) bf16 to out_dev (device memory, may be
- * NULL to query n_tokens). */
+ * runs only the vision tower on `mm` (its images, then its videos) and writes (1 + n_deepstack, n_tokens, hidden) bf16 to out_dev
+ * (device memory, may be NULL to query n_tokens); rows = the images' tokens followed by the videos' tokens. */
 int aha_hip_vision_encode(aha_model* m, const aha_mm_input* mm, void* out_dev, int64_t* n_tokens);
 
 /* Tensor-parallel seam.  Either (a) a host callback that must leave buf = sum over ranks of buf (count f32, device memory)
