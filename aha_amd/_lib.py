@@ -113,6 +113,7 @@ SIGNATURES = {
     "aha_hip_argmax": (C.c_int, [_P, C.c_int64, _P, _P]),
     "aha_hip_logmel": (C.c_int, [_P, C.c_int64, _P, _P]),
     "aha_hip_debug_gemm_plan": (C.c_int, [C.c_int32, C.c_int32]),
+    "aha_hip_debug_plan_gemm": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_size_t, _P]),
     "aha_hip_get_rope_index": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int32, _P, _P]),
     "aha_hip_get_rope_index_mm": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int32, _P, C.c_int32, _P, _P]),
     "aha_hip_embed": (C.c_int, [_P, _P, C.c_size_t, _P]),

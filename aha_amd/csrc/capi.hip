@@ -213,6 +213,17 @@ int aha_hip_debug_gemm_plan(int32_t tile, int32_t splitk) {
   set_gemm_plan_override(tile, splitk);
   return AHA_OK;
 }
+int aha_hip_debug_plan_gemm(int32_t M, int32_t N, int32_t K, int32_t act, int32_t has_bias, int32_t has_residual, size_t workspace_bytes,
+                            int32_t* out3) {
+  if (!out3 || M <= 0 || N <= 0 || K <= 0) {
+    set_error("debug_plan_gemm: bad argument");
+    return AHA_ERR_INVALID;
+  }
+  int o[3];
+  debug_plan_gemm(M, N, K, act, has_bias != 0, has_residual != 0, workspace_bytes, o);
+  out3[0] = o[0]; out3[1] = o[1]; out3[2] = o[2];
+  return AHA_OK;
+}
 int aha_hip_debug_last_hidden(aha_model* m, float* out, size_t n) {
   API_GUARD_BEGIN
   if (!m || !out || n != (size_t)m->desc.hidden_size) {

@@ -158,6 +158,7 @@ struct GemmArgs {
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 // split-K scratch used by launch_gemm calls of this THREAD whose GemmArgs carry none (the model sets it per forward)
 void set_gemm_workspace(void* ws, size_t bytes);
+void debug_plan_gemm(int M, int N, int K, int act, bool has_bias, bool has_res, size_t ws_bytes, int* out);   // host only: {tile, splitk, n_split}
 void set_gemm_plan_override(int tile, int splitk);  // tests: force the 128 / 256 tile kernel and a split-K factor; 0 = automatic
 struct GemmWorkspaceScope {
   GemmWorkspaceScope(void* ws, size_t bytes) { set_gemm_workspace(ws, bytes); }

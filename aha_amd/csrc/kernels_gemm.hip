@@ -1088,6 +1088,27 @@ GemmPlan plan_gemm(const GemmArgs& a) {
 
 }  // namespace
 
+// The launch(es) launch_gemm would issue for a shape, without issuing them (host only): out[0..2] = {tile, splitk, 1 if the columns are
+// split into a multiple of 256 + a tail launch}.  `ws_bytes` > 0 stands for a caller workspace of that size.
+void debug_plan_gemm(int M, int N, int K, int act, bool has_bias, bool has_res, size_t ws_bytes, int* out) {
+  GemmArgs a{};
+  a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldc = act == ACT_SILU_MUL_PAIRS ? N / 2 : N; a.act = act;
+  static int dummy;
+  a.bias = has_bias ? &dummy : nullptr;
+  a.residual = has_res ? &dummy : nullptr;
+  a.workspace = ws_bytes ? &dummy : nullptr;
+  a.workspace_bytes = ws_bytes;
+  const GemmPlan plan = plan_gemm(a);
+  out[0] = plan.tile; out[1] = plan.splitk; out[2] = 0;
+  if (g_force_tile == 0 && a.act != ACT_SILU_MUL_PAIRS && a.act != ACT_PARTIAL_F32 && a.N > 512 && a.N % 256 != 0 && a.M >= 256) {   // (launch_gemm)
+    GemmArgs am = a, at = a;
+    am.N = a.N / 256 * 256;
+    at.N = a.N - am.N;
+    const GemmPlan pm = plan_gemm(am), pt = plan_gemm(at);
+    if (pm.cost + pt.cost + 3.0 < plan.cost) { out[0] = pm.tile; out[1] = pm.splitk; out[2] = 1; }
+  }
+}
+
 void set_gemm_plan_override(int tile, int splitk) {
   g_force_tile = tile;
   g_force_splitk = splitk;

@@ -267,6 +267,11 @@ int aha_hip_debug_last_hidden(aha_model* m, float* out, size_t n);
 /* Test hook: force the GEMM tile (128 or 256) and split-K factor of every following GEMM launch of the process;
  * (0, 0) restores the automatic choice (csrc/kernels_gemm.hip plan_gemm). */
 int aha_hip_debug_gemm_plan(int32_t tile, int32_t splitk);
+/* Host only (no GPU): the plan the GEMM launcher would pick for a shape -- out3 = {tile (128 | 256), split-K factor, 1 if the
+ * columns run as a multiple of 256 + a tail launch}; workspace_bytes = size of the caller's split-K scratch (0 = none).  Lets the
+ * CPU tier pin the plans of the BASELINE shapes (csrc/kernels_gemm.hip plan_gemm is a cost model fitted on MI355X). */
+int aha_hip_debug_plan_gemm(int32_t M, int32_t N, int32_t K, int32_t act, int32_t has_bias, int32_t has_residual, size_t workspace_bytes,
+                            int32_t* out3);
 int aha_hip_debug_image_embeds(aha_model* m, int which /*0=merged, 1..=deepstack k*/, float* out, size_t n);
 
 /* ---- op-level entry points (device pointers; stream = hipStream_t as void*, NULL = default stream) ---------- */

@@ -221,3 +221,32 @@ def test_rust_shim_declares_the_header_symbols():
     assert rust_fields("AhaModelDesc") == [n for n, _ in _lib.ModelDesc._fields_]
     assert rust_fields("AhaTensorView") == [n for n, _ in _lib.TensorView._fields_]
     assert rust_fields("AhaMmInput") == [n for n, _ in _lib.MmInput._fields_]
+
+
+def test_gemm_plans_of_the_baseline_shapes(hip_lib):
+    """csrc/kernels_gemm.hip plan_gemm is a cost model fitted to MI355X measurements (scripts/tune_gemm.py); the plans it yields for
+    the BASELINE shapes are the ones the profiles under profiles/r02_* were taken with.  Host-only query: a change of the model's
+    constants that moves one of them shows up here, on the CPU tier, and has to come with a new measurement."""
+    from aha_amd import _lib
+
+    def plan(M, N, K, act=_lib.ACT_NONE, bias=0, res=0, ws=1 << 30):
+        o = (ctypes.c_int32 * 3)()
+        assert hip_lib.aha_hip_debug_plan_gemm(M, N, K, act, bias, res, ws, o) == 0
+        return tuple(o)
+
+    # cfg 3 text stack at M = 1542 (8B): qkv / gate+up one round of 256^2 tiles, o_proj / down_proj two K slices
+    assert plan(1542, 6144, 4096) == (256, 1, 0)
+    assert plan(1542, 4096, 4096, res=1) == (256, 2, 0)
+    assert plan(1542, 24576, 4096, act=_lib.ACT_SILU_MUL_PAIRS) == (256, 1, 0)
+    assert plan(1542, 4096, 12288, res=1) == (256, 2, 0)
+    assert plan(1542, 4096, 4096, res=1, ws=0) == (128, 1, 0)            # no workspace: no split-K, and 112 tiles lose to the 128^2 kernel
+    # ViT at N = 4096 patches: qkv on 256^2, proj on 128^2, fc1 as 4096 columns + a 208-column tail, fc2 in three K slices
+    assert plan(4096, 3456, 1152, bias=1) == (256, 1, 0)
+    assert plan(4096, 1152, 1152, bias=1, res=1) == (128, 1, 0)
+    assert plan(4096, 4304, 1152, act=_lib.ACT_GELU_TANH, bias=1) == (256, 1, 1)
+    assert plan(4096, 1152, 4304, bias=1, res=1) == (256, 3, 0)
+    # below one 256-row tile everything stays on the 128^2 kernel; a 41 k-token prompt fills whole rounds unsplit
+    assert plan(70, 512, 512) == (128, 1, 0) and plan(255, 4096, 4096)[0] == 128
+    assert plan(40980, 6144, 4096) == (256, 1, 0) and plan(40980, 4096, 12288, res=1) == (256, 1, 0)
+    with pytest.raises(Exception):
+        assert hip_lib.aha_hip_debug_plan_gemm(0, 1, 1, 0, 0, 0, 0, (ctypes.c_int32 * 3)()) == 0
