@@ -132,6 +132,9 @@ SIGNATURES = {
     "aha_hip_debug_audio_embeds": (C.c_int, [_P, C.POINTER(C.c_float), C.c_size_t]),
     "aha_hip_image_to_patches": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float),
                                            C.POINTER(C.c_float), _P]),
+    "aha_hip_video_smart_resize": (C.c_int, [C.c_uint32] * 8 + [_P, _P]),
+    "aha_hip_video_sample_frames": (C.c_int, [C.c_uint32, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
+    "aha_hip_video_timestamps": (C.c_int64, [_P, C.c_size_t, C.c_float, C.c_uint32, _P, C.c_size_t]),
     "aha_hip_video_to_patches": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float),
                                            C.POINTER(C.c_float), _P]),
 }

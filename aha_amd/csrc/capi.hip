@@ -463,6 +463,32 @@ int aha_hip_img_smart_resize(uint32_t h, uint32_t w, uint32_t factor, uint32_t m
   API_GUARD_END
 }
 
+int aha_hip_video_smart_resize(uint32_t num_frames, uint32_t h, uint32_t w, uint32_t temporal_factor, uint32_t factor, uint32_t min_pixels,
+                               uint32_t max_pixels, uint32_t video_ratio, uint32_t* h_out, uint32_t* w_out) {
+  API_GUARD_BEGIN
+  if (!h_out || !w_out) {
+    set_error("null argument");
+    return AHA_ERR_INVALID;
+  }
+  return video_smart_resize(num_frames, h, w, temporal_factor, factor, min_pixels, max_pixels, video_ratio, h_out, w_out);
+  API_GUARD_END
+}
+int aha_hip_video_sample_frames(uint32_t total_frames, float rate, uint32_t fps, uint32_t min_frames, uint32_t max_frames,
+                                uint32_t* nframes_out, uint32_t* interval_out) {
+  API_GUARD_BEGIN
+  if (!nframes_out || !interval_out) {
+    set_error("null argument");
+    return AHA_ERR_INVALID;
+  }
+  return video_sample_frames(total_frames, rate, fps, min_frames, max_frames, nframes_out, interval_out);
+  API_GUARD_END
+}
+int64_t aha_hip_video_timestamps(const uint32_t* frame_indices, size_t n, float fps, uint32_t t_merge_size, float* out, size_t cap) {
+  API_GUARD_BEGIN
+  return video_timestamps(frame_indices, n, fps, t_merge_size, out, cap);
+  API_GUARD_END
+}
+
 int aha_hip_image_resize(const uint8_t* src_hwc, int32_t H, int32_t W, uint8_t* dst_hwc, int32_t new_h, int32_t new_w, void* stream) {
   API_GUARD_BEGIN
   if (!src_hwc || !dst_hwc || H <= 0 || W <= 0 || new_h <= 0 || new_w <= 0) {

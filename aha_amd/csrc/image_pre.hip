@@ -10,6 +10,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include "model.h"
@@ -150,6 +151,87 @@ int img_smart_resize(uint32_t h, uint32_t w, uint32_t factor, uint32_t min_pixel
   *h_out = hb;
   *w_out = wb;
   return AHA_OK;
+}
+
+// ---- the video path's host arithmetic (host only; decoding and the swscale resize are ffmpeg's and stay with the caller) --------
+// video_smart_resize (/root/reference/src/utils/video_utils.rs:9-59): the frame size get_video_data scales to.  The reference
+// multiplies in u32 (t_bar * h_bar * w_bar, num_frames * height * width: past 2^32 a debug build panics and a release build
+// wraps); the products are taken in 64 bits here.
+int video_smart_resize(uint32_t num_frames, uint32_t h, uint32_t w, uint32_t temporal_factor, uint32_t factor, uint32_t min_pixels,
+                       uint32_t max_pixels, uint32_t video_ratio, uint32_t* h_out, uint32_t* w_out) {
+  if (factor == 0 || temporal_factor == 0) {
+    set_error("video_smart_resize: zero factor");
+    return AHA_ERR_INVALID;
+  }
+  if (num_frames < temporal_factor) {
+    set_error(std::to_string(num_frames) + " must be larger than temporal_factor " + std::to_string(temporal_factor));
+    return AHA_ERR_INVALID;
+  }
+  if (h < factor || w < factor) {
+    set_error("height:" + std::to_string(h) + " or width:" + std::to_string(w) + " must be larger than factor:" + std::to_string(factor));
+    return AHA_ERR_INVALID;
+  }
+  if (std::max(h, w) / std::min(h, w) > 200) {
+    set_error("absolute aspect ratio mush be smaller than 200, got " + std::to_string(std::max(h, w) / std::min(h, w)));
+    return AHA_ERR_INVALID;
+  }
+  uint32_t f = factor;
+  if (video_ratio) {  // lcm(image_factor, ratio): swscale wants a multiple of 16 (processor.rs:492-505)
+    uint32_t a = factor, b = video_ratio;
+    while (b) { const uint32_t t = a % b; a = b; b = t; }
+    f = factor / a * video_ratio;
+  }
+  auto round_by = [](uint32_t v, uint32_t k) { return (uint32_t)roundf((float)v / (float)k) * k; };
+  uint32_t hb = round_by(h, f), wb = round_by(w, f);
+  const uint64_t tb = round_by(num_frames, temporal_factor);
+  const float vol = (float)((uint64_t)num_frames * h * w);
+  if (tb * hb * wb > max_pixels) {
+    const float beta = sqrtf(vol / (float)max_pixels);
+    hb = std::max(f, (uint32_t)floorf((float)h / beta / (float)f) * f);
+    wb = std::max(f, (uint32_t)floorf((float)w / beta / (float)f) * f);
+  } else if (tb * hb * wb < min_pixels) {
+    const float beta = sqrtf((float)min_pixels / vol);
+    hb = (uint32_t)ceilf((float)h * beta / (float)f) * f;
+    wb = (uint32_t)ceilf((float)w * beta / (float)f) * f;
+  }
+  *h_out = hb;
+  *w_out = wb;
+  return AHA_OK;
+}
+
+// Which decoded frames get_video_data keeps (/root/reference/src/models/qwen3vl/processor.rs:481-489,518-535): nframes =
+// round(frames / rate * fps) clamped to [min_frames, max_frames] and to the frame count (it only sizes the resize), and every
+// frame whose id is a multiple of round(frames / nframes).
+int video_sample_frames(uint32_t total_frames, float rate, uint32_t fps, uint32_t min_frames, uint32_t max_frames, uint32_t* nframes,
+                        uint32_t* interval) {
+  if (total_frames == 0 || !(rate > 0.f)) {
+    set_error("video_sample_frames: no frames / no frame rate");
+    return AHA_ERR_INVALID;
+  }
+  uint32_t n = (uint32_t)roundf((float)total_frames / rate * (float)fps);
+  n = std::min(std::min(std::max(n, min_frames), max_frames), total_frames);
+  if (n == 0) {
+    set_error("video_sample_frames: zero frames requested");
+    return AHA_ERR_INVALID;
+  }
+  *nframes = n;
+  *interval = (uint32_t)roundf((float)total_frames / (float)n);
+  return AHA_OK;
+}
+
+// calculate_timestamps (processor.rs:283-307): frame indices padded to a multiple of t_merge with the last one, index / fps in
+// f32, the mean of the first and last time of every group.  Returns the number of stamps (written up to cap).
+int64_t video_timestamps(const uint32_t* frame_indices, size_t n, float fps, uint32_t t_merge, float* out, size_t cap) {
+  if (!frame_indices || n == 0 || t_merge == 0 || !(fps > 0.f)) {
+    set_error("video_timestamps: bad argument");
+    return AHA_ERR_INVALID;
+  }
+  const size_t padded = (n + t_merge - 1) / t_merge * t_merge;
+  auto ts = [&](size_t i) { return (float)frame_indices[std::min(i, n - 1)] / fps; };
+  size_t k = 0;
+  for (size_t i = 0; i < padded; i += t_merge, ++k)
+    if (out && k < cap) out[k] = (ts(i) + ts(i + t_merge - 1)) / 2.0f;
+  return (int64_t)k;
 }
 
 int image_resize(const uint8_t* src, int H, int W, uint8_t* dst, int new_h, int new_w, hipStream_t st) {

@@ -204,6 +204,12 @@ void launch_vit_rope_table(const int32_t* rowcol, const float* inv_freq, int N, 
 void launch_scatter_rows(void* dst, const void* src, const int32_t* rows, int64_t n, int D, int add, hipStream_t st);
 // image_pre.hip (V0-pre): img_smart_resize (img_utils.rs:294-331) and resize_exact(.., CatmullRom) of an RGB8 image on the device
 int img_smart_resize(uint32_t h, uint32_t w, uint32_t factor, uint32_t min_pixels, uint32_t max_pixels, uint32_t* h_out, uint32_t* w_out);
+// the video path's host arithmetic (video_utils.rs:9-59, qwen3vl/processor.rs:283-307,481-535); host only
+int video_smart_resize(uint32_t num_frames, uint32_t h, uint32_t w, uint32_t temporal_factor, uint32_t factor, uint32_t min_pixels,
+                       uint32_t max_pixels, uint32_t video_ratio, uint32_t* h_out, uint32_t* w_out);
+int video_sample_frames(uint32_t total_frames, float rate, uint32_t fps, uint32_t min_frames, uint32_t max_frames, uint32_t* nframes,
+                        uint32_t* interval);
+int64_t video_timestamps(const uint32_t* frame_indices, size_t n, float fps, uint32_t t_merge, float* out, size_t cap);
 int image_resize(const uint8_t* src, int H, int W, uint8_t* dst, int new_h, int new_w, hipStream_t st);
 int debug_resize_taps(int n_in, int n_out, int32_t* left, int32_t* count, float* weights, int64_t weights_cap);
 void launch_video_to_patches(const uint8_t* frames, void* out, int T, int H, int W, int patch, int merge, const float* mean,

@@ -52,55 +52,42 @@ def process_images(imgs_u8: List[torch.Tensor], cfg: Qwen3VLConfig) -> MultiModa
 
 # ---- video path (the part of get_video_data / process_info that is the reference's own arithmetic; decoding the container and
 # the swscale BILINEAR|ACCURATE_RND resize are ffmpeg's and stay with the caller) ------------------------------------------------
-def _f32_round(q) -> int:
-    """f32::round (half away from zero) of a non-negative f32."""
-    q = np.float32(q)
-    fl = np.floor(q)
-    return int(fl) + (1 if np.float32(q - fl) >= np.float32(0.5) else 0)
-
-
 def video_smart_resize(num_frames: int, height: int, width: int, temporal_factor: int = 2, factor: int = 32, min_pixels: int = 4096,
                        max_pixels: int = 25165824, video_ratio: int | None = 16) -> Tuple[int, int]:
-    """video_smart_resize, /root/reference/src/utils/video_utils.rs:9-59: the frame size get_video_data scales to
-    (processor.rs:496-505: factor = patch_size * merge_size, min / max_pixels = the video preprocessor's shortest / longest edge,
-    video_ratio = 16 so that swscale gets a multiple of 16)."""
-    if num_frames < temporal_factor:
-        raise ValueError(f"{num_frames} must be larger than temporal_factor {temporal_factor}")
-    if height < factor or width < factor:
-        raise ValueError(f"height:{height} or width:{width} must be larger than factor:{factor}")
-    if max(height, width) // min(height, width) > 200:
-        raise ValueError(f"absolute aspect ratio mush be smaller than 200, got {max(height, width) // min(height, width)}")
-    f = factor if video_ratio is None else math.lcm(factor, video_ratio)
-    by = lambda v, k: _f32_round(np.float32(v) / np.float32(k)) * k   # round_by_factor
-    h_bar, w_bar, t_bar = by(height, f), by(width, f), by(num_frames, temporal_factor)
-    vol = np.float32(num_frames * height * width)
-    if t_bar * h_bar * w_bar > max_pixels:
-        beta = np.sqrt(vol / np.float32(max_pixels), dtype=np.float32)
-        h_bar = max(f, int(math.floor(np.float32(height) / beta / np.float32(f))) * f)
-        w_bar = max(f, int(math.floor(np.float32(width) / beta / np.float32(f))) * f)
-    elif t_bar * h_bar * w_bar < min_pixels:
-        beta = np.sqrt(np.float32(min_pixels) / vol, dtype=np.float32)
-        h_bar = int(math.ceil(np.float32(height) * beta / np.float32(f))) * f
-        w_bar = int(math.ceil(np.float32(width) * beta / np.float32(f))) * f
-    return h_bar, w_bar
+    """video_smart_resize, /root/reference/src/utils/video_utils.rs:9-59, through the library's host code (csrc/image_pre.hip): the
+    frame size get_video_data scales to (processor.rs:496-505: factor = patch_size * merge_size, min / max_pixels = the video
+    preprocessor's shortest / longest edge, video_ratio = 16 so that swscale gets a multiple of 16)."""
+    import ctypes as C
+    from ._lib import AhaHipError, check, lib
+    h, w = C.c_uint32(), C.c_uint32()
+    try:
+        check(lib().aha_hip_video_smart_resize(num_frames, height, width, temporal_factor, factor, min_pixels, max_pixels, video_ratio or 0,
+                                               C.byref(h), C.byref(w)))
+    except AhaHipError as e:   # the reference returns Err(anyhow!(..)) with these messages
+        raise ValueError(str(e)) from e
+    return int(h.value), int(w.value)
 
 
 def sample_video_frames(total_frames: int, rate: float, fps: int = 2, min_frames: int = 4, max_frames: int = 768) -> Tuple[int, int, List[int]]:
     """Which decoded frames get_video_data keeps (processor.rs:481-489,518-535): (nframes, sample_interval, frame_indices).
     nframes only sizes the resize; the kept frames are the multiples of round(frames / nframes)."""
-    fr, rt = np.float32(total_frames), np.float32(rate)
-    nframes = min(min(max(_f32_round(fr / rt * np.float32(fps)), min_frames), max_frames), total_frames)
-    interval = _f32_round(fr / np.float32(nframes))
-    return nframes, interval, list(range(0, total_frames, interval))
+    import ctypes as C
+    from ._lib import check, lib
+    n, iv = C.c_uint32(), C.c_uint32()
+    check(lib().aha_hip_video_sample_frames(total_frames, float(rate), fps, min_frames, max_frames, C.byref(n), C.byref(iv)))
+    return int(n.value), int(iv.value), list(range(0, total_frames, int(iv.value)))
 
 
 def calculate_timestamps(frame_indices: List[int], fps: float, t_merge_size: int = 2) -> List[float]:
-    """calculate_timestamps (processor.rs:283-307): seconds of every temporal patch = mean of its first and last frame time."""
-    idx = list(frame_indices)
-    if len(idx) % t_merge_size:
-        idx += [idx[-1]] * (t_merge_size - len(idx) % t_merge_size)
-    ts = [np.float32(i) / np.float32(fps) for i in idx]
-    return [float((ts[i] + ts[i + t_merge_size - 1]) / np.float32(2.0)) for i in range(0, len(ts), t_merge_size)]
+    """calculate_timestamps (processor.rs:283-307): seconds of every temporal patch = mean of its first and last frame time (f32)."""
+    import ctypes as C
+    from ._lib import check, lib
+    idx = np.ascontiguousarray(np.asarray(frame_indices, dtype=np.uint32).reshape(-1))
+    out = np.empty((idx.size + t_merge_size - 1) // t_merge_size, dtype=np.float32)
+    n = check(lib().aha_hip_video_timestamps(idx.ctypes.data_as(C.c_void_p), idx.size, float(fps), t_merge_size,
+                                             out.ctypes.data_as(C.c_void_p), out.size))
+    assert n == out.size
+    return [float(x) for x in out]
 
 
 def process_videos(videos_u8: List[torch.Tensor], cfg: Qwen3VLConfig) -> Tuple[torch.Tensor, np.ndarray]:

@@ -307,6 +307,18 @@ int aha_hip_attn_prefill(const void* q, const void* k, const void* v, void* o, i
  * exceeds 200, as the reference. */
 int aha_hip_img_smart_resize(uint32_t h, uint32_t w, uint32_t factor, uint32_t min_pixels, uint32_t max_pixels, uint32_t* h_out,
                              uint32_t* w_out);
+/* The video path's host arithmetic, host only (decoding and the swscale resize stay with the caller):
+ *  - video_smart_resize (/root/reference/src/utils/video_utils.rs:9-59): the size get_video_data scales the frames to; factor =
+ *    patch_size * merge_size, video_ratio = 16 (0 = none), min / max_pixels = the video preprocessor's shortest / longest edge
+ *    (qwen3vl/processor.rs:496-505).  Errors carry the reference's messages.
+ *  - the frame sampling of get_video_data (processor.rs:481-489,518-535): nframes (sizes the resize) and the sample interval;
+ *    the kept frames are the decoded frames whose index is a multiple of the interval.
+ *  - calculate_timestamps (processor.rs:283-307): one f32 second value per temporal patch; returns the count. */
+int aha_hip_video_smart_resize(uint32_t num_frames, uint32_t h, uint32_t w, uint32_t temporal_factor, uint32_t factor, uint32_t min_pixels,
+                               uint32_t max_pixels, uint32_t video_ratio, uint32_t* h_out, uint32_t* w_out);
+int aha_hip_video_sample_frames(uint32_t total_frames, float rate, uint32_t fps, uint32_t min_frames, uint32_t max_frames,
+                                uint32_t* nframes_out, uint32_t* interval_out);
+int64_t aha_hip_video_timestamps(const uint32_t* frame_indices, size_t n, float fps, uint32_t t_merge_size, float* out, size_t cap);
 /* V0-pre: DynamicImage::resize_exact(new_w, new_h, FilterType::CatmullRom) (qwen3vl/processor.rs:166) of an RGB8 image
  * (H, W, 3) in device memory into dst (new_h, new_w, 3), device.  Algorithm of crate image 0.25.10 imageops::resize as
  * restated in oracle/image_pre.py ([unverified] against the crate itself): vertical pass into f32, horizontal pass,
