@@ -1,0 +1,80 @@
+"""CPU tier: properties of the gfx950 code objects inside the built libaha_hip.so, read from their AMDGPU metadata notes (no GPU, no
+recompilation): register spills and scratch are silent performance killers on this path -- a spilled accumulator array turns the
+GEMM's counted vmcnt waits into full drains (scratch accesses are VMEM) -- and they show up only as numbers in a profile.  Every
+shipped kernel must be free of them, and the kernels whose occupancy the design counts on must stay inside their register budget
+(DESIGN.md section 4)."""
+import glob
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+KEYS = ("private_segment_fixed_size", "vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "group_segment_fixed_size", "max_flat_workgroup_size")
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    if not (os.path.exists(f"{LLVM}/llvm-objdump") and os.path.exists(f"{LLVM}/llvm-readelf")):
+        pytest.skip("ROCm llvm tools not found")
+    from aha_amd import build
+    build.build()
+    d = tmp_path_factory.mktemp("codeobj")
+    shutil.copy(os.path.join(ROOT, "aha_amd", "csrc", "libaha_hip.so"), d / "lib.so")
+    subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", "lib.so"], cwd=d, capture_output=True, check=True)   # writes lib.so.N.<target>
+    objs = sorted(glob.glob(str(d / "lib.so.*gfx950")))
+    assert objs, "no gfx950 code object in libaha_hip.so"
+    assert not [o for o in glob.glob(str(d / "lib.so.*amdgcn*")) if "gfx950" not in o], "a code object for another GPU target is bundled"
+    out = {}
+    for o in objs:
+        notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", o], capture_output=True, text=True, check=True).stdout
+        # one YAML list item per kernel under amdhsa.kernels ("  - .agpr_count: ..." starts it; keys are sorted, .name is in the middle)
+        body = notes[notes.index("amdhsa.kernels:"):] if "amdhsa.kernels:" in notes else ""
+        for item in re.split(r"\n  - ", body)[1:]:
+            item = item.split("\namdhsa.")[0]
+            name = re.search(r"^\s*\.name:\s+(\S+)", item, re.M)
+            if not name:
+                continue
+            cur = out.setdefault(name.group(1), {})
+            for m in re.finditer(r"^\s{0,4}\.(\w+):\s+(\d+)\s*$", item, re.M):
+                if m.group(1) in KEYS:
+                    cur[m.group(1)] = int(m.group(2))
+    assert len(out) > 200 and all(set(KEYS) <= set(k) for k in out.values()), "metadata keys missing"
+    return out
+
+
+def family(name):
+    m = re.search(r"\d+([a-z_0-9]+?_kernel)", name)
+    return m.group(1) if m else name
+
+
+def test_no_kernel_spills_or_uses_scratch(kernels):
+    # the one exception: the TRACE instantiations of the prefill attention (debug timeline, 64-bit counters; AHA_ATTN_PTRACE)
+    bad = {n: k for n, k in kernels.items()
+           if (k.get("vgpr_spill_count", 0) or k.get("sgpr_spill_count", 0) or k.get("private_segment_fixed_size", 0))
+           and not ("attn_prefill_kernel" in n and "Lb1E" in n)}
+    assert not bad, f"kernels with spills / scratch: {bad}"
+    assert any("attn_prefill_kernel" in n and "Lb0E" in n for n in kernels)
+
+
+def test_register_budgets_the_design_counts_on(kernels):
+    fam = {}
+    for n, k in kernels.items():
+        fam.setdefault(family(n), []).append((n, k))
+    # four-wave 256^2 GEMM: one wave per SIMD owns the whole 512-register file (256 accumulators in AGPRs)
+    assert fam["gemm256q_kernel"] and all(480 <= k["vgpr_count"] <= 512 and k["max_flat_workgroup_size"] == 256 for _, k in fam["gemm256q_kernel"])
+    # 128 KiB of dynamic LDS per 256^2 block is requested at launch; nothing static on top
+    assert all(k["group_segment_fixed_size"] == 0 for _, k in fam["gemm256q_kernel"])
+    # prefill attention: 128 VGPRs => two 8-wave blocks per CU (non-trace instantiations)
+    assert all(k["vgpr_count"] <= 128 for n, k in fam["attn_prefill_kernel"] if "Lb0E" in n)
+    # 8-wave 256^2 GEMM: two waves per SIMD => at most 256 registers; 128^2 kernel: four blocks of four waves per CU => at most 128 + accumulators in 168
+    assert all(k["vgpr_count"] <= 256 for _, k in fam["gemm256p_kernel"])
+    assert all(k["vgpr_count"] <= 168 for _, k in fam["gemm_glds_kernel"])
+    # fused decode attention / matvec: one to two waves per SIMD by design, but never past the register file
+    assert all(k["vgpr_count"] <= 256 for _, k in fam["attn_decode_fused_kernel"])
+    assert all(k["vgpr_count"] <= 512 for _, k in fam["gemv_kernel"]) and len(fam["gemv_kernel"]) >= 100
+    # the reduce + RMSNorm pass keeps a row slice in registers: 2 .. 10 vectors of 8 columns per lane
+    assert all(k["vgpr_count"] <= 128 for _, k in fam["gemm_splitk_reduce_norm_kernel"])
