@@ -47,8 +47,9 @@ def kernels(tmp_path_factory):
 
 
 def family(name):
+    """_ZN3aha12_GLOBAL__N_115gemm256q_kernelI... -> gemm256q_kernel; _ZN3aha19rmsnorm_rows_kernelI... -> rmsnorm_rows_kernel"""
     m = re.search(r"\d+([a-z_0-9]+?_kernel)", name)
-    return m.group(1) if m else name
+    return re.sub(r"^aha\d+", "", m.group(1)) if m else name
 
 
 def test_no_kernel_spills_or_uses_scratch(kernels):
@@ -78,3 +79,32 @@ def test_register_budgets_the_design_counts_on(kernels):
     assert all(k["vgpr_count"] <= 512 for _, k in fam["gemv_kernel"]) and len(fam["gemv_kernel"]) >= 100
     # the reduce + RMSNorm pass keeps a row slice in registers: 2 .. 10 vectors of 8 columns per lane
     assert all(k["vgpr_count"] <= 128 for _, k in fam["gemm_splitk_reduce_norm_kernel"])
+
+
+def test_hot_kernels_have_no_flat_loads(kernels, tmp_path):
+    """A load through an address the compiler cannot prove global is a flat_load: it may complete out of order with LDS traffic, so
+    every wait around it becomes vmcnt(0) lgkmcnt(0) and the counted-wait pipelines of the matvec / decode attention / GEMM loops
+    collapse (compiler facts).  Disassemble the shipped code objects and hold the hot families to zero flat
+    loads and zero scratch instructions (flat STORES into KV pages -- page addresses are integers from the page table -- are fine)."""
+    shutil.copy(os.path.join(ROOT, "aha_amd", "csrc", "libaha_hip.so"), tmp_path / "lib.so")
+    subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", "lib.so"], cwd=tmp_path, capture_output=True, check=True)
+    hot = ("gemv_kernel", "attn_decode_fused_kernel", "gemm256q_kernel", "gemm256p_kernel", "gemm_glds_kernel", "attn_prefill_kernel",
+           "gemm_splitk_reduce_kernel", "gemm_splitk_reduce_norm_kernel", "rmsnorm_rows_kernel")
+    seen, bad = set(), {}
+    for o in sorted(glob.glob(str(tmp_path / "lib.so.*gfx950"))):
+        dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", o], capture_output=True, text=True, check=True).stdout
+        cur = None
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = m.group(1)
+                continue
+            f = family(cur) if cur else None
+            if f not in hot or ("attn_prefill_kernel" in cur and "Lb1E" in cur):
+                continue
+            seen.add(f)
+            op = line.split()[0] if line.split() else ""
+            if op.startswith("flat_load") or op.startswith("scratch_"):
+                bad.setdefault(cur, []).append(op)
+    assert seen == set(hot), f"families not found in the disassembly: {set(hot) - seen}"
+    assert not bad, f"flat loads / scratch in hot kernels: { {k: v[:3] for k, v in bad.items()} }"
