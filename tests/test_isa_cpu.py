@@ -108,3 +108,37 @@ def test_hot_kernels_have_no_flat_loads(kernels, tmp_path):
                 bad.setdefault(cur, []).append(op)
     assert seen == set(hot), f"families not found in the disassembly: {set(hot) - seen}"
     assert not bad, f"flat loads / scratch in hot kernels: { {k: v[:3] for k, v in bad.items()} }"
+
+
+def test_counted_waits_in_the_mfma_loops(tmp_path):
+    """The schedules DESIGN.md describes exist only if the compiler emits them: between the first and the last MFMA of a kernel
+    (= its main loops) the four-wave GEMM must wait with COUNTED vmcnt values only (a vmcnt(0) there is a full drain of the LDS-DMA
+    queue: what a predicated load or a spilled accumulator turns every wait into), hold exactly the 2 x (2 + 1) x 64 MFMAs of its
+    full / ragged k loops, and the fused decode attention must keep its ladder of counted waits with at most one full drain."""
+    shutil.copy(os.path.join(ROOT, "aha_amd", "csrc", "libaha_hip.so"), tmp_path / "lib.so")
+    subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", "lib.so"], cwd=tmp_path, capture_output=True, check=True)
+    stats = {}
+    for o in sorted(glob.glob(str(tmp_path / "lib.so.*gfx950"))):
+        dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", o], capture_output=True, text=True, check=True).stdout
+        cur, body = None, {}
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = m.group(1)
+                continue
+            if cur and family(cur) in ("gemm256q_kernel", "gemm256p_kernel", "attn_decode_fused_kernel"):
+                body.setdefault(cur, []).append(line.strip())
+        for n, b in body.items():
+            mf = [i for i, l in enumerate(b) if l.startswith("v_mfma")]
+            span = b[mf[0]:mf[-1]] if mf else []
+            vm = [int(m.group(1)) for l in span if l.startswith("s_waitcnt") for m in [re.search(r"vmcnt\((\d+)\)", l)] if m]
+            stats[n] = (len(mf), sum(1 for v in vm if v == 0), sum(1 for v in vm if v > 0))
+    q = {n: s for n, s in stats.items() if family(n) == "gemm256q_kernel"}
+    assert len(q) >= 20
+    for n, (n_mfma, drains, counted) in q.items():
+        assert n_mfma == 384 and drains == 0 and counted >= 8, (n, n_mfma, drains, counted)
+    for n, (n_mfma, drains, counted) in stats.items():
+        if family(n) == "gemm256p_kernel" and "ELi0EEEvNS_8GemmArgs" in n:   # (the shipped MODE = 0 instantiations, not the ablations)
+            assert n_mfma in (64, 128) and drains == 0 and counted >= 1, (n, n_mfma, drains, counted)
+    fused = [s for n, s in stats.items() if family(n) == "attn_decode_fused_kernel"]
+    assert len(fused) == 1 and fused[0][0] == 64 and fused[0][1] <= 1 and fused[0][2] >= 20, fused
