@@ -812,19 +812,33 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_norm_kernel(GemmArgs a
   const int64_t slab = (int64_t)a.M * a.N;
   const float* sp = slabs + row * a.N;
   float4 s[VPL][2];
+  u32x4_t wv[VPL];   // the norm weights: requested first, consumed last (behind the stores they would otherwise be serialised, one
+#pragma unroll       // load -> wait -> store round trip per vector: the compiler cannot move a load across a store it may alias)
+  for (int i = 0; i < VPL; ++i) wv[i] = ld16((const bf16_t*)a.norm_w + (i * 64 + lane) * 8);
+  u32x4_t rv[VPL];   // likewise the residual row (it is the output row: read here, overwritten at the end by the same lane)
+  if (HAS_RES) {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) rv[i] = ld16((const bf16_t*)a.residual + row * a.ldc + (i * 64 + lane) * 8);
+  }
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int n = (i * 64 + lane) * 8;
     s[i][0] = *reinterpret_cast<const float4*>(sp + n);
     s[i][1] = *reinterpret_cast<const float4*>(sp + n + 4);
   }
-  for (int z = 1; z < nsl; ++z) {
+  for (int z = 1; z < nsl; ++z) {   // a whole slab row in flight before the first add (slice order: the reduce kernel's sums)
+    float4 t[VPL][2];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int n = (i * 64 + lane) * 8;
-      const float4 t0 = *reinterpret_cast<const float4*>(sp + z * slab + n), t1 = *reinterpret_cast<const float4*>(sp + z * slab + n + 4);
-      s[i][0].x += t0.x; s[i][0].y += t0.y; s[i][0].z += t0.z; s[i][0].w += t0.w;
-      s[i][1].x += t1.x; s[i][1].y += t1.y; s[i][1].z += t1.z; s[i][1].w += t1.w;
+      t[i][0] = *reinterpret_cast<const float4*>(sp + z * slab + n);
+      t[i][1] = *reinterpret_cast<const float4*>(sp + z * slab + n + 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      s[i][0].x += t[i][0].x; s[i][0].y += t[i][0].y; s[i][0].z += t[i][0].z; s[i][0].w += t[i][0].w;
+      s[i][1].x += t[i][1].x; s[i][1].y += t[i][1].y; s[i][1].z += t[i][1].z; s[i][1].w += t[i][1].w;
     }
   }
   u32x4_t v[VPL];
@@ -832,12 +846,10 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_norm_kernel(GemmArgs a
   bf16_t* C = (bf16_t*)a.C + row * a.ldc;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
-    const int n = (i * 64 + lane) * 8;
     float x[8] = {rbf(s[i][0].x), rbf(s[i][0].y), rbf(s[i][0].z), rbf(s[i][0].w), rbf(s[i][1].x), rbf(s[i][1].y), rbf(s[i][1].z), rbf(s[i][1].w)};
     if (HAS_RES) {
-      const u32x4_t r = ld16((const bf16_t*)a.residual + row * a.ldc + n);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { x[2 * j] += lo_bf(r[j]); x[2 * j + 1] += hi_bf(r[j]); }
+      for (int j = 0; j < 4; ++j) { x[2 * j] += lo_bf(rv[i][j]); x[2 * j + 1] += hi_bf(rv[i][j]); }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[i][j] = pack_bf(x[2 * j], x[2 * j + 1]);
@@ -857,10 +869,9 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_norm_kernel(GemmArgs a
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int n = (i * 64 + lane) * 8;
-    const u32x4_t wv = ld16((const bf16_t*)a.norm_w + n);
     u32x4_t o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = pack_bf(lo_bf(v[i][j]) * rinv * lo_bf(wv[j]), hi_bf(v[i][j]) * rinv * hi_bf(wv[j]));
+    for (int j = 0; j < 4; ++j) o[j] = pack_bf(lo_bf(v[i][j]) * rinv * lo_bf(wv[i][j]), hi_bf(v[i][j]) * rinv * hi_bf(wv[i][j]));
     *reinterpret_cast<u32x4_t*>(Y + n) = o;
   }
 }

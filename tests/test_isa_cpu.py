@@ -77,8 +77,9 @@ def test_register_budgets_the_design_counts_on(kernels):
     # fused decode attention / matvec: one to two waves per SIMD by design, but never past the register file
     assert all(k["vgpr_count"] <= 256 for _, k in fam["attn_decode_fused_kernel"])
     assert all(k["vgpr_count"] <= 512 for _, k in fam["gemv_kernel"]) and len(fam["gemv_kernel"]) >= 100
-    # the reduce + RMSNorm pass keeps a row slice in registers: 2 .. 10 vectors of 8 columns per lane
-    assert all(k["vgpr_count"] <= 128 for _, k in fam["gemm_splitk_reduce_norm_kernel"])
+    # the reduce + RMSNorm pass keeps a row slice (sums, residual, norm weights, one more slab in flight) in registers: 2 .. 10 vectors
+    # of 8 columns per lane; its occupancy is bounded by the row count, not by registers
+    assert all(k["vgpr_count"] <= 288 for _, k in fam["gemm_splitk_reduce_norm_kernel"])
 
 
 def test_hot_kernels_have_no_flat_loads(kernels, tmp_path):
