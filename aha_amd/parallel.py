@@ -48,12 +48,14 @@ def aggregate_throughput(units_this_rank: float, secs_this_rank: float, device="
     return float(u.item()) / float(t.item()), float(t.item())
 
 
-def encode_images_sharded(encode_fn, per_image_inputs: List, tokens_per_image: List[int], world: int, rank: int):
+def encode_images_sharded(encode_fn, per_image_inputs: List, tokens_per_image: List[int], world: int, rank: int, meta=None):
     """Image-parallel ViT: images are independent units (block-diagonal attention per image,
     /root/reference/src/models/qwen3vl/model.rs:258-273), so rank r encodes images shard_units(n, world, r) and ONE
     all_gather moves the embeddings.  ``encode_fn(list_of_inputs) -> (K, n_local_tokens, H)`` tensor (device for nccl,
     CPU for gloo); returns (K, total_tokens, H) in image order on every rank.  Ragged shards are padded to the largest
-    shard for the collective and trimmed afterwards."""
+    shard for the collective and trimmed afterwards.  ``meta = (K, H, dtype, device)`` of the encoder's output, known from the
+    config: a rank without images then builds its padding on ITS OWN device and the timed path has no pickle collective
+    (without it the shapes are agreed with one all_gather_object and the padding goes to this rank's current device)."""
     import torch
     import torch.distributed as dist
     n = len(per_image_inputs)
@@ -63,16 +65,18 @@ def encode_images_sharded(encode_fn, per_image_inputs: List, tokens_per_image: L
         return local
     counts = [sum(tokens_per_image[slice(*shard_units(n, world, r))]) for r in range(world)]
     mx = max(counts)
-    ref = local
-    if ref is None:  # this rank has no image: it still takes part in the collective
+    if local is not None:
+        K, H, dtype, device = local.shape[0], local.shape[2], local.dtype, local.device
+    elif meta is not None:
+        K, H, dtype, device = meta
+    if meta is None:
         shapes = [None] * world
-        dist.all_gather_object(shapes, None)
-        kh = next(s for s in shapes if s is not None)
-        buf = torch.zeros(kh[0], mx, kh[1], dtype=kh[2], device=kh[3])
-    else:
-        shapes = [None] * world
-        dist.all_gather_object(shapes, (local.shape[0], local.shape[2], local.dtype, str(local.device)))
-        buf = torch.zeros(local.shape[0], mx, local.shape[2], dtype=local.dtype, device=local.device)
+        dist.all_gather_object(shapes, None if local is None else (local.shape[0], local.shape[2], local.dtype))
+        if local is None:   # this rank has no image: it still takes part in the collective, with a buffer on its OWN device
+            K, H, dtype = next(s for s in shapes if s is not None)
+            device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    buf = torch.zeros(K, mx, H, dtype=dtype, device=device)
+    if local is not None:
         buf[:, : local.shape[1]] = local
     outs = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(outs, buf)
@@ -119,7 +123,8 @@ def sharded_prefill(cfg, weights, input_ids, data, rank: int, world: int, device
             def enc(idx_range):
                 a, b = idx_range[0], idx_range[-1] + 1
                 return model.vision_encode(MultiModalData(data.pixel_values[patches[a]:patches[b]], grid[a:b]))
-            emb = encode_images_sharded(lambda idx: enc(idx), list(range(len(grid))), toks, world, rank)
+            meta = (1 + len(cfg.vision.deepstack_visual_indexes), cfg.text.hidden_size, torch.bfloat16, torch.device("cuda", device_index))
+            emb = encode_images_sharded(lambda idx: enc(idx), list(range(len(grid))), toks, world, rank, meta=meta)
             mm = MultiModalData(image_grid_thw=grid, image_embeds=emb.contiguous())
         _, tok = model.forward_initial(input_ids, 0, mm, want_logits=False)
         return tok

@@ -91,8 +91,10 @@ class LogitsProcessor:
             if prs.sum(dtype=np.float32) < np.float32(s.p):
                 return None  # the nucleus reaches past the candidates
             w = _topp_mask(prs, s.p, None if idx is None else np.asarray(idx, dtype=np.int64))
-            if w[-1] > 0 and len(w) > 1 and prs[-1] == prs[-2]:
-                return None  # the cut falls inside a run of equal probabilities that may continue past the candidates
+            if w[-1] > 0:
+                # the cut lands ON the last candidate: a lower logit outside the list whose exp rounds to the same f32 probability
+                # (at a lower vocabulary index) would be taken first by candle's stable full-vocabulary walk -- full-vector fallback
+                return None
             return w
         raise ValueError(f"{s.kind} does not sample from candidates")
 

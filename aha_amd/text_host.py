@@ -127,7 +127,10 @@ class ChatTemplate:
 
     def __init__(self, fixed_template: str):
         import jinja2
-        env = jinja2.Environment(keep_trailing_newline=True)   # minijinja keeps the template's trailing newline by default
+        # minijinja 2.x: Environment::new() has keep_trailing_newline = false and the reference never calls
+        # set_keep_trailing_newline (chat_template/mod.rs:84-139), so ONE trailing newline of the template source is dropped --
+        # jinja2's default too
+        env = jinja2.Environment()
         env.filters["tojson"] = lambda v: json.dumps(v, ensure_ascii=False, separators=(",", ":"))   # serde_json::to_string
         env.filters["split"] = lambda s, d: str(s).split(d)
         env.filters["lstrip"] = lambda s, chars=None: str(s).lstrip() if chars is None else _trim_start_matches(str(s), chars)
@@ -135,7 +138,8 @@ class ChatTemplate:
         def _no_strip(*_a, **_k):   # fix_template rewrites `reasoning_content.strip(..)` into a `strip` FILTER that setup_environment never
             raise jinja2.TemplateRuntimeError("unknown filter: filter strip is unknown")   # registers: minijinja fails when the branch runs
         env.filters["strip"] = _no_strip
-        env.filters["string"] = lambda v: "" if v is None else (str(v).lower() if isinstance(v, bool) else str(v))
+        # the reference's filter is format!("{}", v): minijinja's Display renders none / undefined as "none"
+        env.filters["string"] = lambda v: "none" if v is None or isinstance(v, jinja2.Undefined) else (str(v).lower() if isinstance(v, bool) else str(v))
         env.tests["startingwith"] = lambda s, p: str(s).startswith(p)
         env.tests["endingwith"] = lambda s, p: str(s).endswith(p)
         self.env = env

@@ -30,6 +30,8 @@ class Numerics:
     rmsnorm_in_T: bool = False   # candle-nn CPU rms_norm: m cast to T, then x / m * w evaluated in T
     attn_probs_rounded: bool = True   # softmax output materialised in T before P.V (eager path, modules.rs:788)
     matmul_f64: bool = False     # accumulate GEMMs in f64 (ideal) instead of f32 (order-dependent)
+    attn_row_block: int = 0      # > 0: eager attention evaluated `attn_row_block` query rows at a time (same arithmetic per row --
+                                 # every row's softmax is independent -- without the (h, S, S) score tensor: 17 GB at N = 16 384)
 
     @property
     def torch_dtype(self):

@@ -91,19 +91,46 @@ def attn_scale(nm: Numerics, head_dim: int) -> float:
     return float(nm.r(torch.tensor(s, dtype=torch.float32)))
 
 
-def eager_attention_forward(nm: Numerics, q, k, v, n_rep: int, mask: Optional[torch.Tensor], scale: float):
-    """modules.rs:757-813 (non-flash branch): matmul, * scaling, + mask, softmax_last_dim, matmul, transpose(1,2)."""
+def eager_attention_forward(nm: Numerics, q, k, v, n_rep: int, mask, scale: float):
+    """modules.rs:757-813 (non-flash branch): matmul, * scaling, + mask, softmax_last_dim, matmul, transpose(1,2).
+    ``mask``: None, the (1,1,S,S) tensor of prepare_causal_attention_mask, or the string "causal" = the same mask built
+    ``nm.attn_row_block`` query rows at a time (with kv_len == q_len, as the reference's mask assumes, qwen3/model.rs:168-173)."""
     k = repeat_kv(k, n_rep)
     v = repeat_kv(v, n_rep)
-    w = nm.matmul(q, k.transpose(-2, -1))
-    w = nm.r(w * scale)
-    if mask is not None:
-        w = nm.r(w + mask)
-    p = torch.softmax(w, dim=-1)
-    if nm.attn_probs_rounded:
-        p = nm.r(p)
-    o = nm.matmul(p, v)
-    return o.transpose(1, 2).contiguous()
+    S = q.shape[2]
+    blk = nm.attn_row_block if (nm.attn_row_block > 0 and S > nm.attn_row_block) else 0
+    if not blk and isinstance(mask, str):
+        mask = prepare_causal_attention_mask(S)
+    if not blk:
+        w = nm.matmul(q, k.transpose(-2, -1))
+        w = nm.r(w * scale)
+        if mask is not None:
+            w = nm.r(w + mask)
+        p = torch.softmax(w, dim=-1)
+        if nm.attn_probs_rounded:
+            p = nm.r(p)
+        o = nm.matmul(p, v)
+        return o.transpose(1, 2).contiguous()
+    # row-blocked: rows [a, b) of the same computation.  Under the causal mask the columns >= b are -inf for every row of the
+    # block (exp -> exactly 0, products with V exactly 0), so they are left out: the sums are the full computation's sums.
+    causal = isinstance(mask, str)
+    assert mask is None or causal, "row blocking takes the causal mask by name"
+    kt = k.transpose(-2, -1)
+    outs = []
+    for a in range(0, S, blk):
+        b = min(S, a + blk)
+        kv_hi = b if causal else k.shape[2]
+        w = nm.matmul(q[:, :, a:b], kt[..., :kv_hi])
+        w = nm.r(w * scale)
+        if causal:
+            rows = torch.arange(a, b).reshape(-1, 1)
+            cols = torch.arange(0, kv_hi).reshape(1, -1)
+            w = nm.r(w + torch.where(cols > rows, float("-inf"), 0.0)[None, None])
+        p = torch.softmax(w, dim=-1)
+        if nm.attn_probs_rounded:
+            p = nm.r(p)
+        outs.append(nm.matmul(p, v[:, :, :kv_hi]))
+    return torch.cat(outs, 2).transpose(1, 2).contiguous()
 
 
 def silu(x: torch.Tensor) -> torch.Tensor:
@@ -115,14 +142,17 @@ class OracleQwen3:
     """Qwen3Model (qwen3/model.rs:94-214) with the per-layer concat KV cache of modules.rs:558-566."""
 
     def __init__(self, cfg, weights: Dict[str, torch.Tensor], nm: Optional[Numerics] = None,
-                 prefix: Optional[str] = None, lm_head_name: str = "lm_head.weight"):
+                 prefix: Optional[str] = None, lm_head_name: str = "lm_head.weight", consume: bool = False):
         self.cfg = cfg
         self.nm = nm or Numerics()
         if prefix is None:  # model.rs:105-109: optional "model." prefix
             prefix = "model." if "model.embed_tokens.weight" in weights else ""
         self.p = prefix
         # weights are stored in T already (bf16 checkpoints); hold them as f32 values of T-representable numbers
-        self.w = {k: self.nm.r(v.float()) for k, v in weights.items() if k.startswith(prefix) or k == lm_head_name}
+        # (consume: entries are popped from `weights` as they are converted -- an 8B checkpoint is 17 GB in bf16 + 35 GB as f32)
+        self.w = {}
+        for k in [k for k in weights if k.startswith(prefix) or k == lm_head_name]:
+            self.w[k] = self.nm.r((weights.pop(k) if consume else weights[k]).float())
         self.embed = self.w[prefix + "embed_tokens.weight"]
         self.lm_head = self.embed if cfg.tie_word_embeddings else self.w[lm_head_name]
         self.inv_freq = compute_default_rope_parameters(cfg.head_dim, cfg.rope_theta)
@@ -176,6 +206,37 @@ class OracleQwen3:
         h = rms_norm(nm, x, self.w[p + "post_attention_layernorm.weight"], c.rms_norm_eps)
         return nm.r(r + self._mlp(li, h))
 
+    def decoder_layer_rows(self, li: int, x, cos, sin, rows):
+        """decoder_layer (qwen3/model.rs:71-87) evaluated for the query rows ``rows`` of a prefill ONLY: K / V are computed for every
+        row (they are what the selected rows attend to), q / attention / o_proj / MLP for the selected rows.  Row r of a causal
+        prefill depends on rows <= r alone, so for a layer whose INPUT x is known for all rows these are exactly the rows
+        decoder_layer would produce (same ops, same rounding points; masked columns contribute exact zeros and are left out).
+        Makes one layer at S ~ 41k checkable on the host in seconds.  x (1,S,H); cos/sin (S,d) or (1,S,d); -> (len(rows), H)."""
+        c, nm, p = self.cfg, self.nm, f"{self.p}layers.{li}."
+        pa = p + "self_attn."
+        rows = list(rows)
+        S = x.shape[1]
+        cos2, sin2 = cos.reshape(S, -1), sin.reshape(S, -1)
+        h = rms_norm(nm, x, self.w[p + "input_layernorm.weight"], c.rms_norm_eps)
+        k = nm.linear(h, self.w[pa + "k_proj.weight"]).reshape(1, S, c.num_key_value_heads, c.head_dim)
+        k = rms_norm(nm, k, self.w[pa + "k_norm.weight"], c.rms_norm_eps).transpose(1, 2)
+        v = nm.linear(h, self.w[pa + "v_proj.weight"]).reshape(1, S, c.num_key_value_heads, c.head_dim).transpose(1, 2)
+        hq = h[:, rows]
+        q = nm.linear(hq, self.w[pa + "q_proj.weight"]).reshape(1, len(rows), c.num_attention_heads, c.head_dim)
+        q = rms_norm(nm, q, self.w[pa + "q_norm.weight"], c.rms_norm_eps).transpose(1, 2)
+        _, k = apply_rotary_pos_emb(nm, k, k, cos2, sin2)
+        q, _ = apply_rotary_pos_emb(nm, q, q, cos2[rows], sin2[rows])
+        self.kv[li] = (k, v)            # the cache a decode step continues from (modules.rs:558-566)
+        g = c.num_attention_heads // c.num_key_value_heads
+        outs = []
+        for i, r in enumerate(rows):   # one query row over its r + 1 visible keys
+            o = eager_attention_forward(nm, q[:, :, i:i + 1], k[:, :, :r + 1], v[:, :, :r + 1], g, None, self.scale)
+            outs.append(o.reshape(1, 1, c.num_attention_heads * c.head_dim))
+        o = nm.linear(torch.cat(outs, 1), self.w[pa + "o_proj.weight"])
+        xr = nm.r(x[:, rows] + o)
+        h2 = rms_norm(nm, xr, self.w[p + "post_attention_layernorm.weight"], c.rms_norm_eps)
+        return nm.r(xr + self._mlp(li, h2))[0]
+
     def embed_tokens(self, input_ids) -> torch.Tensor:
         ids = torch.as_tensor(np.asarray(input_ids, dtype=np.int64)).reshape(1, -1)
         return self.embed[ids]
@@ -186,7 +247,12 @@ class OracleQwen3:
         model (qwen3vl/model.rs:775-828: M-RoPE tables, DeepStack adds) reuse the same layer code."""
         x = inputs_embeds if inputs_embeds is not None else self.embed_tokens(input_ids)
         s = x.shape[1]
-        mask = None if s <= 1 else prepare_causal_attention_mask(s)   # offset hard-coded 0 (model.rs:168-173)
+        if s <= 1:
+            mask = None
+        elif self.nm.attn_row_block > 0 and s > self.nm.attn_row_block:
+            mask = "causal"                                           # the same mask, built per row block (eager_attention_forward)
+        else:
+            mask = prepare_causal_attention_mask(s)                   # offset hard-coded 0 (model.rs:168-173)
         cos, sin = cos_sin if cos_sin is not None else rope_cos_sin(self.inv_freq, seqlen_offset, s)
         for li in range(self.cfg.num_hidden_layers):
             x = self.decoder_layer(li, x, cos, sin, mask)

@@ -239,9 +239,11 @@ def gelu_erf(x):
 class OracleVision:
     """Qwen3VLVisionModel (qwen3vl/model.rs:372-741)."""
 
-    def __init__(self, cfg, weights: Dict[str, torch.Tensor], nm: Numerics, prefix="model.visual."):
+    def __init__(self, cfg, weights: Dict[str, torch.Tensor], nm: Numerics, prefix="model.visual.", consume: bool = False):
         self.cfg, self.v, self.nm, self.p = cfg, cfg.vision, nm, prefix
-        self.w = {k: nm.r(t.float()) for k, t in weights.items() if k.startswith(prefix)}
+        self.w = {}
+        for k in [k for k in weights if k.startswith(prefix)]:
+            self.w[k] = nm.r((weights.pop(k) if consume else weights[k]).float())
         v = self.v
         self.G = int(math.sqrt(v.num_position_embeddings))
         self.inv_freq = oq.compute_default_rope_parameters(v.head_dim // 2, 10000.0)   # rope.rs:429-433
@@ -360,12 +362,13 @@ class OracleVision:
 class OracleQwen3VL:
     """Qwen3VLModel (qwen3vl/model.rs:837-1316) with its InferenceModel impl (1279-1316)."""
 
-    def __init__(self, cfg, weights, nm: Optional[Numerics] = None):
+    def __init__(self, cfg, weights, nm: Optional[Numerics] = None, consume: bool = False):
         self.cfg, self.nm = cfg, nm or Numerics()
         tcfg = cfg.text
         tcfg.tie_word_embeddings = cfg.tie_word_embeddings
-        self.text = oq.OracleQwen3(tcfg, weights, self.nm, prefix="model.language_model.")
-        self.vision = OracleVision(cfg, weights, self.nm) if any(k.startswith("model.visual.") for k in weights) else None
+        has_vision = any(k.startswith("model.visual.") for k in weights)
+        self.text = oq.OracleQwen3(tcfg, weights, self.nm, prefix="model.language_model.", consume=consume)
+        self.vision = OracleVision(cfg, weights, self.nm, consume=consume) if has_vision else None
         self.rope_delta: Optional[int] = None
         self.last_image_embeds = None
         self.last_deepstack = None

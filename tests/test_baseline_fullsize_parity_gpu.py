@@ -1,0 +1,375 @@
+"""-m gpu: the parity holes the round-2 verdict listed, closed at BASELINE.json's sizes (HIP path through the C ABI vs oracle/).
+
+  (a) cfg 3 at FULL depth: the 27-block ViT on one 1024^2 image + all 36 layers of the Qwen3-VL-8B text tower at S = 1542
+      (M-RoPE, DeepStack): prefill logits over the 151 936-wide vocabulary + 8 teacher-forced decode steps with rope_delta positions
+      (request shape of /root/reference/tests/test_qwen3vl.rs; layers: qwen3vl/model.rs:775-828, qwen3/model.rs:71-87).
+  (b) cfg 4 at the real Qwen3-ASR-0.6B dimensions (18 encoder layers x 896, 14 heads, ffn 3584; 28-layer text tower) on 30 s
+      of 16 kHz audio = 3000 mel frames = 390 audio tokens (qwen3_asr/model.rs:171-226): audio embeddings, prefill logits, 8
+      teacher-forced decode steps, and the raw-samples entry (log-mel on the GPU).
+  (c) cfg 5 SHAPES on slices: one ViT block at N = 16 384 patches (one 2048^2 image: the block-diagonal attention segment cfg 5
+      has per image) against the oracle with row-blocked (exact) attention; one 8B text layer at S = 40 980 (641 KV pages)
+      against the oracle's sliced evaluation of the same layer (K / V for every row, q / attention / MLP for the checked rows:
+      oracle/qwen3.py decoder_layer_rows) at three prompt lengths, then 2 decode steps over the 41k-token cache.
+  (d) exact FREE-RUNNING greedy sequences on decisive-margin checkpoints (tests/decisive.py): cfg 1 (Qwen3-0.6B, 128-token
+      prompt, 64 tokens; tests/test_qwen3.rs:9-41 with temperature 0) and cfg 3 (full Qwen3-VL-8B, image + 512-token prompt, 128
+      tokens) must equal the oracle's sequence token for token -- device-resident loop and host loop -- after the oracle's own
+      top-1/top-2 margin has been checked to be >= 0.5 std at every step.
+
+Tolerances as in tests/test_baseline_parity_gpu.py (both sides round to bf16 at the same op boundaries and differ in f32
+accumulation order and the flash-style softmax): logits max <= 0.10 std, rms <= 0.02 std; tower outputs max <= 0.12 std,
+rms <= 0.02 std.  Measured values go to gpurun_out/parity_fullsize.json.
+"""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from aha_amd.configs import Qwen3VLConfig, Qwen3VLVisionConfig, qwen3_0_6b, qwen3_asr_0_6b, qwen3vl_8b, qwen3vl_8b_text
+from aha_amd.weights import qwen3_asr_weights, qwen3_text_weights, qwen3vl_weights
+from oracle.numerics import Numerics
+from oracle import qwen3 as oq
+from oracle import qwen3_asr as oa
+from oracle import qwen3vl as ov
+
+import decisive
+
+pytestmark = pytest.mark.gpu
+
+NM = Numerics("bf16", matmul_f64=False, attn_row_block=1024)
+LOGIT_MAX, LOGIT_RMS = 0.10, 0.02
+TOWER_MAX, TOWER_RMS = 0.12, 0.02
+MIN_MARGIN = 0.5
+REPORT = {}
+
+
+def _flush_report():
+    root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = os.path.join(root, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "parity_fullsize.json")
+    old = {}
+    if os.path.exists(path):
+        try:
+            old = json.load(open(path))
+        except Exception:
+            old = {}
+    old.update(REPORT)
+    json.dump(old, open(path, "w"), indent=1)
+
+
+def rel(got, ref):
+    ref = np.asarray(ref, dtype=np.float32).reshape(-1)
+    got = np.asarray(got, dtype=np.float32).reshape(-1)
+    assert np.isfinite(got).all()
+    s = float(ref.std())
+    return float(np.abs(got - ref).max()) / s, float(np.sqrt(((got - ref) ** 2).mean())) / s
+
+
+def rnd_ids(n, seed, vocab=151643):
+    return [int(x) for x in np.random.default_rng(seed).integers(0, vocab, size=n)]
+
+
+def cpu_copy(w):
+    return {k: v.cpu() for k, v in w.items()}
+
+
+def image_prompt(cfg, n_image_tokens, n_text, seed):
+    return rnd_ids(4, seed) + [cfg.vision_start_token_id] + [cfg.image_token_id] * n_image_tokens + [cfg.vision_end_token_id] + \
+        rnd_ids(n_text, seed + 1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (a) + (d): the full Qwen3-VL-8B
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def vl8b(gpu):
+    cfg = qwen3vl_8b()
+    w = qwen3vl_weights(cfg, seed=0, device=gpu)     # 17.5 GB made in HBM; the oracle converts a host copy tensor by tensor
+    t0 = time.time()
+    o = ov.OracleQwen3VL(cfg, cpu_copy(w), NM, consume=True)
+    REPORT["oracle_build_seconds_vl8b"] = time.time() - t0
+    g = np.random.default_rng(3)
+    img = g.integers(0, 256, size=(1024, 1024, 3), dtype=np.uint8)
+    pv, grid = ov.process_images(NM, [img])
+    assert pv.shape == (4096, 1536) and grid.tolist() == [[1, 64, 64]]
+    ids = image_prompt(cfg, 1024, 512, 30)
+    assert len(ids) == 1542
+    # the ViT's weights and the image are the same in (a) and (d): its oracle output is computed once
+    memo = {}
+    vis_forward = o.vision.forward
+
+    def cached_forward(pixel_values, grid_thw):
+        key = (int(pixel_values.data_ptr()), tuple(np.asarray(grid_thw).reshape(-1).tolist()))
+        if key not in memo:
+            memo[key] = vis_forward(pixel_values, grid_thw)
+        return memo[key]
+
+    o.vision.forward = cached_forward
+    yield cfg, w, o, ids, pv, grid
+    del w
+    torch.cuda.empty_cache()
+
+
+def test_cfg3_full_vit_and_all_36_layers(vl8b):
+    from aha_amd.model import HipInferenceModel, MultiModalData
+    cfg, w, o, ids, pv, grid = vl8b
+    m = HipInferenceModel(cfg, w)
+    try:
+        t0 = time.time()
+        o.clear_cache()
+        ref = o.forward_initial(ids, 0, (pv, grid)).reshape(-1).numpy()
+        t_oracle = time.time() - t0
+        got, am = m.forward_initial(ids, 0, MultiModalData(pv.to(torch.bfloat16), grid))
+        rep = dict(oracle_prefill_seconds=t_oracle)
+        rep["image_embeds"] = rel(m.debug_image_embeds(0, 1024), o.last_image_embeds.numpy())
+        rep["prefill_logits"] = rel(got, ref)
+        rep["margin_std"] = decisive.margin_std(ref)
+        rep["argmax_equal"] = bool(am == int(np.argmax(ref)))
+        assert am == int(np.argmax(got)), "device arg-max must be the first maximal index of the logits it returned"
+        assert o.rope_delta is not None and o.rope_delta < 0   # images compress positions
+        tok, off = int(np.argmax(ref)), len(ids)
+        dec = []
+        for step in range(8):
+            got_s, am_s = m.forward_step(tok, off)
+            ref_s = o.forward_step([tok], off).reshape(-1).numpy()
+            dec.append(rel(got_s, ref_s) + (decisive.margin_std(ref_s), bool(am_s == int(np.argmax(ref_s)))))
+            tok, off = int(np.argmax(ref_s)), off + 1
+        rep["decode_steps"] = dec
+        rep["oracle_total_seconds"] = time.time() - t0
+        REPORT["cfg3_vit27_N4096_text36layers_S1542"] = rep
+        _flush_report()
+        assert rep["image_embeds"][0] <= TOWER_MAX and rep["image_embeds"][1] <= TOWER_RMS, rep["image_embeds"]
+        assert rep["prefill_logits"][0] <= LOGIT_MAX and rep["prefill_logits"][1] <= LOGIT_RMS, f"36 layers, S = 1542: {rep['prefill_logits']}"
+        if rep["margin_std"] > 2 * LOGIT_MAX:
+            assert rep["argmax_equal"]
+        for step, d in enumerate(dec):
+            assert d[0] <= LOGIT_MAX and d[1] <= LOGIT_RMS, f"decode step {step}: {d}"
+            if d[2] > 2 * LOGIT_MAX:
+                assert d[3], f"decode step {step}: greedy token differs although the oracle's margin is {d[2]:.2f} std"
+    finally:
+        m.close()
+        o.clear_cache()
+
+
+def test_cfg3_decisive_checkpoint_exact_free_running_greedy_128(vl8b):
+    """(d) on the full Qwen3-VL-8B: only the embedding table and the head are restructured (tests/decisive.py); every layer and
+    the whole ViT keep the weights of test (a).  128 free-running greedy tokens, device-resident loop and host loop."""
+    from aha_amd.model import HipInferenceModel, MultiModalData, generate_generic
+    cfg, w, o, ids, pv, grid = vl8b
+    en, hn = "model.language_model.embed_tokens.weight", "lm_head.weight"
+    pi = decisive.make_untied_decisive(w, en, hn, scale=128.0, seed=7)
+    t = o.text
+    t.w[en] = NM.r(w[en].cpu().float())
+    t.w[hn] = NM.r(w[hn].cpu().float())
+    t.embed, t.lm_head = t.w[en], t.w[hn]
+    m = HipInferenceModel(cfg, w)
+    try:
+        mm = MultiModalData(pv.to(torch.bfloat16), grid)
+        t0 = time.time()
+        o.clear_cache()
+        want, logits = oq.greedy_generate(o, ids, 128, mm=(pv, grid), return_logits=True)
+        t_oracle = time.time() - t0
+        margins = [decisive.margin_std(lg) for lg in logits]
+        walk, tk = [], ids[-1]
+        for _ in range(128):
+            tk = int(pi[tk])
+            walk.append(tk)
+        m.clear_cache()
+        dev, _ = generate_generic(m, ids, 128, data=mm, device_loop=True)
+        host, _ = generate_generic(m, ids, 128, data=mm, device_loop=False)
+        # logits of the free run at a few steps (same inputs on both sides as long as the sequences agree)
+        m.clear_cache()
+        got, _ = m.forward_initial(ids, 0, mm)
+        errs = [rel(got, logits[0].numpy())]
+        off = len(ids)
+        for step in range(1, 5):
+            got, _ = m.forward_step(want[step - 1], off)
+            errs.append(rel(got, logits[step].numpy()))
+            off += 1
+        REPORT["cfg3_decisive_greedy128"] = dict(tokens=len(want), min_margin_std=min(margins), median_margin_std=float(np.median(margins)),
+                                                 device_loop_equal=bool(dev == want), host_loop_equal=bool(host == want),
+                                                 distinct_tokens=len(set(want)), follows_permutation=bool(want == walk),
+                                                 logit_errs=errs, oracle_seconds=t_oracle)
+        _flush_report()
+        assert len(want) == 128 and min(margins) >= MIN_MARGIN, f"checkpoint not decisive: min margin {min(margins):.3f} std"
+        assert dev == want, [(i, a, b) for i, (a, b) in enumerate(zip(dev, want)) if a != b][:5]
+        assert host == want
+        assert len(set(want)) == 128     # a walk through 128 different ids, not a fixed point
+        for e in errs:
+            assert e[0] <= LOGIT_MAX and e[1] <= LOGIT_RMS, errs
+    finally:
+        m.close()
+        o.clear_cache()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (d) cfg 1: Qwen3-0.6B (tied head), 128-token prompt, 64 free-running greedy tokens
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_cfg1_decisive_checkpoint_exact_free_running_greedy_64(gpu):
+    from aha_amd.model import HipInferenceModel, generate_generic
+    cfg = qwen3_0_6b()
+    w = qwen3_text_weights(cfg, seed=0, device=gpu)
+    decisive.make_tied_decisive(w, "model.embed_tokens.weight", "model.norm.weight", scale=32.0, seed=7)
+    m = HipInferenceModel(cfg, w)
+    o = oq.OracleQwen3(cfg, cpu_copy(w), NM, consume=True)
+    del w
+    try:
+        ids = rnd_ids(128, 1)
+        t0 = time.time()
+        want, logits = oq.greedy_generate(o, ids, 64, return_logits=True)
+        t_oracle = time.time() - t0
+        margins = [decisive.margin_std(lg) for lg in logits]
+        dev, _ = generate_generic(m, ids, 64, device_loop=True)
+        # host loop with the logits of every step: the free-running sequences agree, so the inputs are the same on both sides
+        m.clear_cache()
+        got, tok = m.forward_initial(ids, 0)
+        host, off, worst = [tok], len(ids), rel(got, logits[0].numpy())
+        for step in range(1, 64):
+            got, tok = m.forward_step(tok, off)
+            host.append(tok)
+            off += 1
+            if host[:step + 1] == want[:step + 1]:
+                e = rel(got, logits[step].numpy())
+                worst = (max(worst[0], e[0]), max(worst[1], e[1]))
+        REPORT["cfg1_decisive_greedy64"] = dict(tokens=len(want), min_margin_std=min(margins), median_margin_std=float(np.median(margins)),
+                                                device_loop_equal=bool(dev == want), host_loop_equal=bool(host == want),
+                                                worst_logit_err=worst, oracle_seconds=t_oracle, sequence_head=want[:6])
+        _flush_report()
+        assert len(want) == 64 and min(margins) >= MIN_MARGIN, f"checkpoint not decisive: min margin {min(margins):.3f} std"
+        assert dev == want, [(i, a, b) for i, (a, b) in enumerate(zip(dev, want)) if a != b][:5]
+        assert host == want
+        assert want[0] != ids[-1] and want[0] // 2 == ids[-1] // 2 and want[1] == ids[-1]   # the 2i <-> 2i+1 alternation the signs build
+        assert worst[0] <= LOGIT_MAX and worst[1] <= LOGIT_RMS, worst
+    finally:
+        m.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (b) cfg 4: Qwen3-ASR-0.6B at its real dimensions, 30 s of audio
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_cfg4_asr_real_dims_30s(gpu):
+    from aha_amd.model import HipInferenceModel, MultiModalData
+    cfg = qwen3_asr_0_6b()
+    assert (cfg.audio.d_model, cfg.audio.encoder_layers, cfg.audio.encoder_attention_heads, cfg.audio.encoder_ffn_dim) == (896, 18, 14, 3584)
+    w = qwen3_asr_weights(cfg, seed=0, device=gpu)
+    m = HipInferenceModel(cfg, w)
+    o = oa.OracleQwen3ASR(cfg, cpu_copy(w), NM)
+    del w
+    try:
+        wave = np.clip(np.random.default_rng(4).normal(0, 0.1, 480000), -1, 1).astype(np.float32)   # BASELINE.md section 4, cfg 4
+        feats = oa.log_mel(wave)
+        assert feats.shape == (128, 3000)
+        n_tok = oa.get_feat_extract_output_lengths(3000)
+        assert n_tok == 390
+        ids = rnd_ids(9, 40) + [cfg.audio_start_token_id] + [cfg.audio_token_id] * n_tok + [cfg.audio_end_token_id] + rnd_ids(5, 41)
+        t0 = time.time()
+        ref = o.forward_initial(ids, 0, torch.from_numpy(feats)).reshape(-1).numpy()
+        got, am = m.forward_initial(ids, 0, MultiModalData(audio_features=feats))
+        rep = dict(prompt_tokens=len(ids), audio_tokens=n_tok)
+        rep["audio_embeds"] = rel(m.debug_audio_embeds(n_tok), o.last_audio_embeds.numpy())
+        rep["prefill_logits"] = rel(got, ref)
+        rep["margin_std"] = decisive.margin_std(ref)
+        rep["argmax_equal"] = bool(am == int(np.argmax(ref)))
+        assert am == int(np.argmax(got))
+        tok, off = int(np.argmax(ref)), len(ids)
+        dec = []
+        for step in range(8):
+            got_s, am_s = m.forward_step(tok, off)
+            ref_s = o.forward_step([tok], off).reshape(-1).numpy()
+            dec.append(rel(got_s, ref_s) + (decisive.margin_std(ref_s), bool(am_s == int(np.argmax(ref_s)))))
+            tok, off = int(np.argmax(ref_s)), off + 1
+        rep["decode_steps"] = dec
+        # the raw-samples entry: log-mel on the GPU (A0), then the same path
+        m.clear_cache()
+        got_raw, _ = m.forward_initial(ids, 0, MultiModalData(audio_samples=wave))
+        rep["prefill_logits_from_raw_samples"] = rel(got_raw, ref)
+        rep["oracle_seconds"] = time.time() - t0
+        REPORT["cfg4_qwen3_asr_0.6b_30s"] = rep
+        _flush_report()
+        assert rep["audio_embeds"][0] <= TOWER_MAX and rep["audio_embeds"][1] <= TOWER_RMS, rep["audio_embeds"]
+        assert rep["prefill_logits"][0] <= LOGIT_MAX and rep["prefill_logits"][1] <= LOGIT_RMS, rep["prefill_logits"]
+        assert rep["prefill_logits_from_raw_samples"][0] <= LOGIT_MAX and rep["prefill_logits_from_raw_samples"][1] <= LOGIT_RMS
+        if rep["margin_std"] > 2 * LOGIT_MAX:
+            assert rep["argmax_equal"]
+        for step, d in enumerate(dec):
+            assert d[0] <= LOGIT_MAX and d[1] <= LOGIT_RMS, f"decode step {step}: {d}"
+            if d[2] > 2 * LOGIT_MAX:
+                assert d[3]
+    finally:
+        m.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (c) cfg 5 shapes on slices: one ViT block at N = 16 384, one 8B text layer at S = 40 980
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_cfg5_shapes_vit_block_N16384_and_text_layer_S41k(gpu):
+    from aha_amd.model import HipInferenceModel, MultiModalData
+    t = qwen3vl_8b_text()
+    t.num_hidden_layers = 1
+    cfg = Qwen3VLConfig(text=t, vision=Qwen3VLVisionConfig(depth=1, deepstack_visual_indexes=[0]), tie_word_embeddings=False)
+    w = qwen3vl_weights(cfg, seed=0, device=gpu)
+    m = HipInferenceModel(cfg, w, kv_reserve_tokens=45056)
+    o = ov.OracleQwen3VL(cfg, cpu_copy(w), NM, consume=True)
+    del w
+    try:
+        g = np.random.default_rng(5)
+        img = g.integers(0, 256, size=(2048, 2048, 3), dtype=np.uint8)
+        pv, grid = ov.process_images(NM, [img])
+        assert pv.shape == (16384, 1536) and grid.tolist() == [[1, 128, 128]]
+        ids = image_prompt(cfg, 4096, 40980 - 4 - 4096 - 2, 50)
+        S = len(ids)
+        assert S == 40980 and (S + 63) // 64 == 641
+        mm = MultiModalData(pv.to(torch.bfloat16), grid)
+        rep = {}
+        t0 = time.time()
+
+        # ---- oracle: ViT block (row-blocked exact attention), then layer 0 evaluated for the checked rows
+        nm, tx = o.nm, o.text
+        x = tx.embed_tokens(ids).clone()
+        img_emb, deep = o.vision.forward(pv, grid)
+        img_rows = [i for i, tok in enumerate(ids) if tok == cfg.image_token_id]
+        x[0, img_rows] = img_emb                                        # masked_scatter_dim0 (qwen3vl/model.rs:1150-1168)
+        pos, delta = ov.get_rope_index(ids, grid, cfg, None)
+        o.rope_delta = delta
+        cos, sin = ov.mrope_cos_sin(tx.inv_freq, pos, cfg.text.mrope_section)
+        check_n = [8193, 24577, S]                                      # prompt lengths whose last row is compared
+        rows = [n - 1 for n in check_n]                                 # text rows: no DeepStack add (model.rs:812-822 adds to the
+        xr = tx.decoder_layer_rows(0, x, cos, sin, rows)                # visual rows only; test (a) covers it at full depth)
+        hn = oq.rms_norm(nm, xr, tx.w[tx.p + "norm.weight"], cfg.text.rms_norm_eps)
+        ref_logits = nm.linear(hn, tx.lm_head).numpy()
+        rep["oracle_seconds"] = time.time() - t0
+
+        # ---- HIP: the same prompt at the three lengths (the last one is the cfg 5 shape: 641 pages, 16 384-patch ViT segment)
+        for i, n in enumerate(check_n):
+            m.clear_cache()
+            got, am = m.forward_initial(ids[:n], 0, mm)
+            rep[f"prefill_S{n}"] = rel(got, ref_logits[i]) + (decisive.margin_std(ref_logits[i]), bool(am == int(np.argmax(ref_logits[i]))))
+            if i == 0:
+                rep["vit_block_N16384_image_embeds"] = rel(m.debug_image_embeds(0, 4096), img_emb.numpy())
+                rep["vit_block_N16384_deepstack0"] = rel(m.debug_image_embeds(1, 4096), deep[0].numpy())
+        # ---- 2 decode steps over the 40 980-token cache (641 pages, decode attention splits), teacher-forced
+        tok, off = int(np.argmax(ref_logits[-1])), S
+        dec = []
+        for step in range(2):
+            got_s, am_s = m.forward_step(tok, off)
+            ref_s = o.forward_step([tok], off).reshape(-1).numpy()
+            dec.append(rel(got_s, ref_s))
+            tok, off = int(np.argmax(ref_s)), off + 1
+        rep["decode_steps_L41k"] = dec
+        rep["total_seconds"] = time.time() - t0
+        REPORT["cfg5_shapes_vit_N16384_text_layer_S40980"] = rep
+        _flush_report()
+        for k in ("vit_block_N16384_image_embeds", "vit_block_N16384_deepstack0"):
+            assert rep[k][0] <= TOWER_MAX and rep[k][1] <= TOWER_RMS, (k, rep[k])
+        for n in check_n:
+            d = rep[f"prefill_S{n}"]
+            assert d[0] <= LOGIT_MAX and d[1] <= LOGIT_RMS, (n, d)
+            if d[2] > 2 * LOGIT_MAX:
+                assert d[3], (n, d)
+        for d in dec:
+            assert d[0] <= LOGIT_MAX and d[1] <= LOGIT_RMS, dec
+    finally:
+        m.close()

@@ -48,6 +48,12 @@ def _gather_worker(rank, world, port, out):
     def encode(imgs):                                  # stand-in for HipInferenceModel.vision_encode
         return torch.cat([torch.full((2, toks[i], 4), float(i)) + torch.arange(toks[i]).float()[None, :, None] / 10 for i in imgs], 1)
     res = parallel.encode_images_sharded(encode, [0, 1, 2], toks, world, rank)
+    # fewer images than ranks: rank 1 has nothing to encode and pads on its OWN device; with `meta` (K, H, dtype, device known from
+    # the config) there is no pickle collective at all, without it the shapes are agreed first -- same result either way
+    one_a = parallel.encode_images_sharded(encode, [1], [toks[1]], world, rank, meta=(2, 4, torch.float32, torch.device("cpu")))
+    one_b = parallel.encode_images_sharded(encode, [1], [toks[1]], world, rank)
+    assert torch.equal(one_a, one_b) and tuple(one_a.shape) == (2, 5, 4) and one_a.device.type == "cpu"
+    assert abs(float(one_a[0, 3, 0]) - 1.3) < 1e-6
     out.put((rank, res.shape, res[0, :, 0].tolist()))
     dist.barrier()
     dist.destroy_process_group()

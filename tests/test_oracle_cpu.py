@@ -241,3 +241,64 @@ def test_qwen3_embedding_oracle_matches_golden_f32():
     scores = oq.rerank(o, seqs[0], seqs[1:]).numpy()
     want = g["embedding"][0] @ g["embedding"][1:].T
     assert np.abs(scores - want).max() < 5e-6
+
+
+def test_row_blocked_attention_and_sliced_layer_equal_the_full_evaluation():
+    """The two devices that make cfg 5 shapes tractable on the host (tests/test_baseline_fullsize_parity_gpu.py): attention a block
+    of query rows at a time and one layer evaluated for selected rows only.  Same arithmetic => same values."""
+    cfg = tiny_qwen3(layers=2, hidden=256, heads=4, kv_heads=2, inter=512, vocab=1024)
+    w = qwen3_text_weights(cfg, seed=0)
+    ids = [int(x) for x in np.random.default_rng(0).integers(0, 1024, size=150)]
+    for f64 in (True, False):
+        a = oq.OracleQwen3(cfg, w, Numerics("bf16", matmul_f64=f64)).forward(ids, 0)
+        b = oq.OracleQwen3(cfg, w, Numerics("bf16", matmul_f64=f64, attn_row_block=32)).forward(ids, 0)
+        assert float((a - b).abs().max()) <= (0.0 if f64 else 0.02 * float(a.std()))
+    o = oq.OracleQwen3(cfg, dict(w), Numerics("bf16", matmul_f64=True), consume=False)
+    x = o.embed_tokens(ids)
+    cos, sin = oq.rope_cos_sin(o.inv_freq, 0, len(ids))
+    full = o.decoder_layer(0, x, cos, sin, oq.prepare_causal_attention_mask(len(ids)))
+    kv_full = o.kv[0]
+    o.clear_cache()
+    rows = [0, 5, 63, 64, 149]
+    part = o.decoder_layer_rows(0, x, cos, sin, rows)
+    assert float((full[0, rows] - part).abs().max()) == 0.0
+    assert torch.equal(kv_full[0], o.kv[0][0]) and torch.equal(kv_full[1], o.kv[0][1])   # the cache a decode step continues from
+    # consume=True pops what it converts (an 8B checkpoint does not fit twice on the host)
+    w2 = dict(w)
+    o2 = oq.OracleQwen3(cfg, w2, Numerics("bf16"), consume=True)
+    assert not any(k.startswith("model.") for k in w2) and set(o2.w) == set(o.w)
+    # ViT attention (no mask) row-blocked
+    vcfg = tiny_qwen3vl()
+    vw = qwen3vl_weights(vcfg, seed=1)
+    img = np.random.default_rng(2).integers(0, 256, size=(96, 64, 3), dtype=np.uint8)
+    nm_a, nm_b = Numerics("bf16", matmul_f64=True), Numerics("bf16", matmul_f64=True, attn_row_block=8)
+    pv, grid = ov.process_images(nm_a, [img])
+    ea, da = ov.OracleVision(vcfg, vw, nm_a).forward(pv, grid)
+    eb, db = ov.OracleVision(vcfg, vw, nm_b).forward(pv, grid)
+    assert torch.equal(ea, eb) and all(torch.equal(p, q) for p, q in zip(da, db))
+
+
+def test_decisive_checkpoints_make_every_greedy_margin_decisive():
+    """tests/decisive.py on small models: the restructured embedding / head give a top-1/top-2 margin far above the fp tolerance
+    at every step, the untied walk follows the permutation, the tied one alternates 2i <-> 2i+1."""
+    import decisive
+    cfg = tiny_qwen3(layers=3, hidden=512, heads=4, kv_heads=2, inter=1024, vocab=2048, tie=False)
+    w = qwen3_text_weights(cfg, seed=0)
+    pi = decisive.make_untied_decisive(w, "model.embed_tokens.weight", "lm_head.weight", scale=32.0, seed=7, n_text=2000)
+    assert sorted(pi.tolist()) == list(range(2000)) and all(int(pi[i]) != i for i in range(2000))
+    o = oq.OracleQwen3(cfg, w, Numerics("bf16"))
+    ids = [int(x) for x in np.random.default_rng(1).integers(0, 2000, size=40)]
+    toks, lgs = oq.greedy_generate(o, ids, 24, return_logits=True)
+    walk, t = [], ids[-1]
+    for _ in range(24):
+        t = int(pi[t])
+        walk.append(t)
+    assert toks == walk and len(set(toks)) == 24
+    assert min(decisive.margin_std(l) for l in lgs) > 0.5
+    cfg = tiny_qwen3(layers=3, hidden=512, heads=4, kv_heads=2, inter=1024, vocab=2048, tie=True)
+    w = qwen3_text_weights(cfg, seed=0)
+    decisive.make_tied_decisive(w, "model.embed_tokens.weight", "model.norm.weight", scale=32.0, seed=7, n_text=2000)
+    o = oq.OracleQwen3(cfg, w, Numerics("bf16"))
+    toks, lgs = oq.greedy_generate(o, ids, 12, return_logits=True)
+    assert toks == [ids[-1] ^ 1, ids[-1]] * 6
+    assert min(decisive.margin_std(l) for l in lgs) > 0.5

@@ -109,7 +109,7 @@ def test_rewritten_template_renders_like_the_python_original(tok_dir):
             {"role": "user", "content": "thanks"}]
     tools = [{"type": "function", "function": {"name": "f", "parameters": {"a": 1}}}]
     ct = th.ChatTemplate.init(str(tok_dir))
-    env = jinja2.Environment(keep_trailing_newline=True)
+    env = jinja2.Environment()   # keep_trailing_newline = false: minijinja's default (the reference never changes it)
     env.filters["tojson"] = lambda v: json.dumps(v, ensure_ascii=False, separators=(",", ":"))
     orig = env.from_string(TEMPLATE)
     for tl in (None, tools):
@@ -117,7 +117,8 @@ def test_rewritten_template_renders_like_the_python_original(tok_dir):
             got = ct.apply_chat_template(msgs, tl, et)
             want = orig.render(messages=msgs, tools=tl, add_generation_prompt=True, enable_thinking=bool(et))
             assert got == want
-            assert got.endswith("<|im_start|>assistant\n" + ("" if et else "<think>\n\n</think>\n\n") + "\n")
+            tail = "<|im_start|>assistant\n" + ("" if et else "<think>\n\n</think>\n\n")
+            assert got.endswith(tail + ("\n" if TEMPLATE.endswith("\n\n") else ""))   # ONE trailing newline of the source is dropped
     # enable_thinking = metadata OR request flag (mod.rs:142-146); metadata parses like str::parse::<bool>
     assert ct.apply_chat_template(msgs, None, None, {"enable_thinking": "true"}) == ct.apply_chat_template(msgs, None, True)
     assert ct.apply_chat_template(msgs, None, None, {"enable_thinking": "True"}) == ct.apply_chat_template(msgs, None, False)
@@ -133,3 +134,16 @@ def test_rust_style_strip_filters():
     Python's character-set strip."""
     ct = th.ChatTemplate.str_init("{{ x | lstrip('ab') }}|{{ x | rstrip('ab') }}|{{ ' y ' | lstrip }}|{{ v | string }}")
     assert ct.template.render(x="ababbaab", v=True) == "baab|ababba|y |true"
+    # format!("{}", v) of minijinja's none / undefined is "none" (chat_template/mod.rs string filter)
+    assert th.ChatTemplate.str_init("{{ v | string }}|{{ missing | string }}").template.render(v=None) == "none|none"
+
+
+def test_trailing_newline_of_the_template_source_is_dropped():
+    """minijinja's Environment::new() keeps keep_trailing_newline = false and the reference never sets it (chat_template/mod.rs:84-139):
+    a template file ending in a newline renders WITHOUT it (one newline only).  Expected strings are hard-coded, not rendered."""
+    ct = th.ChatTemplate.str_init("{% for m in messages %}<{{ m.role }}>{{ m.content }}\n{% endfor %}A:\n")
+    assert ct.apply_chat_template([{"role": "user", "content": "hi"}]) == "<user>hi\nA:"
+    ct = th.ChatTemplate.str_init("A:\n\n")
+    assert ct.apply_chat_template([]) == "A:\n"
+    ct = th.ChatTemplate.str_init("A:")
+    assert ct.apply_chat_template([]) == "A:"
