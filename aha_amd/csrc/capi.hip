@@ -169,6 +169,7 @@ int aha_hip_last_logits(aha_model* m, float* logits_out) {
 }
 
 size_t aha_hip_cache_len(const aha_model* m) { return m ? m->cache_len : 0; }
+int64_t aha_hip_debug_steps_executed(const aha_model* m) { return m ? m->steps_executed : 0; }
 
 int aha_hip_set_profiling(aha_model* m, int enable) {
   if (!m) return AHA_ERR_INVALID;

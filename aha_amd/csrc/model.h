@@ -40,6 +40,8 @@ struct LayerWeights {
 };
 
 // device-resident scalars every decode kernel reads (so a step can be enqueued / replayed without host values)
+constexpr uint32_t RING_CAP = 256;   // token ring of the device-resident greedy loop (>> its run-ahead)
+
 struct StepState {
   uint32_t token;
   int32_t pos[3];     // rope position rows T,H,W of the current token
@@ -97,6 +99,14 @@ struct aha_model {
   aha::StepState* h_state = nullptr;  // pinned
   uint32_t* d_token_log = nullptr;
   size_t token_log_cap = 0;
+  // device-resident greedy loop (model_decode_greedy): the generated tokens and the count of finished steps, written by the last
+  // kernel of every step into PINNED host memory (system-scope stores) so the host can watch for a stop token while later steps
+  // are still queued, without a stream synchronisation
+  uint32_t* h_ring = nullptr;        // [RING_CAP] tokens, slot = step % RING_CAP   (host pointer)
+  uint32_t* h_ring_dev = nullptr;    // the same buffer as the device sees it
+  uint32_t* h_done = nullptr;        // steps finished since the loop started (host pointer; h_ring + RING_CAP)
+  uint32_t* h_done_dev = nullptr;
+  int64_t steps_executed = 0;        // decode steps that ran on the device in the last model_decode_greedy call (tests)
   bool rope_delta_valid = false;  // Qwen3VLModel::rope_deltas.is_some() (qwen3vl/model.rs:1229-1236)
   int64_t rope_delta = 0;  // Qwen3-VL: decode position = seqlen_offset + rope_delta (qwen3vl/model.rs:1235-1264)
   // decode scratch

@@ -314,6 +314,9 @@ class HipInferenceModel:
     def cache_len(self) -> int:
         return int(lib().aha_hip_cache_len(self.handle))
 
+    def debug_steps_executed(self) -> int:
+        return int(lib().aha_hip_debug_steps_executed(self.handle))
+
     def set_profiling(self, on: bool):
         check(lib().aha_hip_set_profiling(self.handle, int(on)))
 

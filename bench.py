@@ -26,6 +26,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_PEAK_TFLOPS = 2500.0  # bf16 dense
+PMC_FILE = "r03_pmc_traffic_gemv.json"      # scripts/pmc_summary.py
+STATS_FILE = "r03_cfg3_kernel_stats.md"     # scripts/stats_to_md.py of `rocprofv3 --kernel-trace --stats -- python bench.py ...`
 
 
 METRICS = {
@@ -172,6 +174,53 @@ def sharded_prefill_bench(rank, world, local_rank, n_images=8, image_px=2048, pr
             "parallelism": f"tp{world} (RCCL all-reduce of the row-parallel partial sums) + image-parallel ViT (all-gather)",
             "rccl_ranks": world, "first_token_equal_on_all_ranks": same}
 
+def self_launch(n: int) -> int:
+    """Re-executes this command under torch.distributed.run with n ranks on 127.0.0.1 (a free port) and returns its exit code."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    return subprocess.call(cmd, env=env)
+
+
+def launcher_selftest(args) -> None:
+    """`--workload launcher-selftest` (CPU tier, tests/test_bench_cpu.py): everything of a multi-rank run EXCEPT the GPU work -- the
+    rendezvous bench.py --gpus N sets up, the barrier / max-over-ranks / sum-of-units aggregation, one JSON line from rank 0 --
+    over gloo, with made-up per-rank timings.  The line says what it is; it is not a measurement."""
+    from aha_amd import parallel
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dist = parallel.init_process_group("gloo") if world > 1 else None
+    secs = 0.5 + 0.25 * rank
+    value, worst = parallel.aggregate_throughput(float(args.steps), secs)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test (no GPU work)", "value": round(value, 3), "unit": "tokens/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * worst / args.steps, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none",
+                          "config": {"workload": "launcher-selftest", "replicas": world}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def source_digest(files) -> str:
+    """sha256 over the named kernel sources: profiles taken with OTHER sources must not be attached to a fresh measurement."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, "aha_amd", "csrc", f), "rb") as fh:
+            h.update(f.encode())
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+GEMV_SOURCES = ("gemv_body.h", "kernels_gemv.hip", "common.h")
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -186,20 +235,35 @@ def main():
                     help="also run BASELINE cfg 5 through the TP + image-parallel path (always done when WORLD_SIZE > 1)")
     args = ap.parse_args()
 
+    # --gpus N without a launcher (the driver runs `python bench.py --gpus N ...`): start the N ranks ourselves, one process per
+    # GPU, exactly as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` would.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree")
+    if args.workload == "launcher-selftest":
+        return launcher_selftest(args)
+
     import numpy as np
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    ndev = torch.cuda.device_count()
+    shared_device = world > ndev          # more ranks than GPUs (tests on a 1-GPU box): ranks share devices, no RCCL (one rank per
+    if shared_device:                     # device is an RCCL requirement) -- the replicas still run, collectives go over gloo
+        local_rank = local_rank % max(ndev, 1)
     torch.cuda.set_device(local_rank)
     from aha_amd import parallel
     if world > 1:
-        dist = parallel.init_process_group("nccl", torch.device(f"cuda:{local_rank}"))
+        dist = parallel.init_process_group("gloo" if shared_device else "nccl", torch.device(f"cuda:{local_rank}"))
 
     import __graft_entry__
     __graft_entry__.build()
     if args.workload == "qwen3vl8b-cfg5-tp":   # the sharded path as the metric itself (strong scaling over --gpus)
+        if shared_device:
+            raise SystemExit("qwen3vl8b-cfg5-tp needs one GPU per rank (RCCL)")
         sp = sharded_prefill_bench(rank, world, local_rank, repeats=max(1, min(args.steps, 3)))
         if rank == 0:
             line = {"metric": sp["metric"], "value": sp["value"], "unit": "tokens/s", "n_gpus": world, "steps": max(1, min(args.steps, 3)),
@@ -285,11 +349,14 @@ def main():
 
     # ---- prefill (reported, outside the K timed steps) ----
     model.forward_initial(ids, 0, data, want_logits=False)  # warm
-    model.clear_cache()
-    barrier()
-    t0 = time.perf_counter()
-    _, tok = model.forward_initial(ids, 0, data, want_logits=False)
-    t_prefill = time.perf_counter() - t0
+    t_prefills = []
+    for _ in range(3 if len(ids) < 16384 else 1):           # median of 3 (one sample for the 41k-token workloads: seconds each)
+        model.clear_cache()
+        barrier()
+        t0 = time.perf_counter()
+        _, tok = model.forward_initial(ids, 0, data, want_logits=False)
+        t_prefills.append(time.perf_counter() - t0)
+    t_prefill = sorted(t_prefills)[len(t_prefills) // 2]
     off = len(ids)
 
     # ---- decode: W warmup steps, then exactly K timed steps ----
@@ -315,45 +382,57 @@ def main():
     # ---- roofline of the dominant kernel (weight-streaming matvec), HIP events on the model's stream ----
     model.set_profiling(True)
     tok, off = run_steps(args.steps, tok, off)
-    prof = {k: model.get_profile(k) for k in ("gemv", "attn_decode", "elem", "argmax")}
+    prof = {k: model.get_profile(k) for k in ("gemv", "attn_decode", "elem", "argmax", "null")}
     model.set_profiling(False)
     # dominant kernel class of a decode step: the weight-streaming matvec (all projections + lm_head)
     gv = prof["gemv"]
-    pmc_file = "r02_pmc_traffic_gemv.json"
-    stats_file = "r02_cfg3_kernel_stats.md"
     achieved = gv["bytes"] / (gv["ms"] * 1e-3) / 1e9 if gv["ms"] > 0 else 0.0
     roof = {"bound": "hbm",
             "kernel": "gemv_kernel (batch-1 weight streaming, all projections + lm_head)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "launches": gv["launches"], "avg_us": round(1e3 * gv["ms"] / max(gv["launches"], 1), 2),
-            "algorithmic_bytes_per_launch": round(gv["bytes"] / max(gv["launches"], 1))}
-    # HBM traffic of the same kernel class from the PMC passes (rocprofv3 cannot run inside this process): the committed
-    # summary profiles/r02_pmc_traffic_gemv.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes).
+            "algorithmic_bytes_per_launch": round(gv["bytes"] / max(gv["launches"], 1)),
+            "timing": "HIP event pairs on the model's stream around every launch of the class, collected in THIS run"}
+    # An event pair also sees the dispatch latency in front of the kernel.  Measured in the same run: an EMPTY kernel between the
+    # same kind of event pairs, once per layer inside the profiled steps ("null" class).  avg_us minus that is an estimate of the
+    # kernel-only duration (it over-corrects by the empty kernel's own ~1 us of execution) -- reported next to the raw figure.
+    nl = prof["null"]
+    if nl["launches"] > 0 and gv["launches"] > 0:
+        null_us = 1e3 * nl["ms"] / nl["launches"]
+        ko = max(roof["avg_us"] - null_us, 1e-3)
+        roof["null_launch_us"] = round(null_us, 2)
+        roof["kernel_only_est"] = {"avg_us": round(ko, 2), "achieved": round(roof["algorithmic_bytes_per_launch"] / ko / 1e3, 1),
+                                   "frac": round(roof["algorithmic_bytes_per_launch"] / ko / 1e3 / HBM_PEAK_GBS, 4)}
+    # Numbers that cannot be collected inside this process (rocprofv3 kernel durations, PMC traffic) come from committed
+    # summaries -- attached ONLY when they were taken with the same matvec sources (digest stamped by scripts/stats_to_md.py /
+    # scripts/pmc_summary.py), so a kernel change without a profile refresh leaves them out instead of quoting stale numbers.
+    dig = source_digest(GEMV_SOURCES)
+    roof["gemv_source_digest"] = dig
     try:
-        with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
+        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
             pmc = json.load(f)
-        if pmc.get("workload") == args.workload:
+        if pmc.get("workload") == args.workload and pmc.get("gemv_source_digest") == dig:
             roof["traffic"] = round(pmc["traffic_bytes_per_launch"])
-            roof["traffic_source"] = "profiles/" + pmc_file
+            roof["traffic_source"] = "profiles/" + PMC_FILE
     except (OSError, KeyError, ValueError):
         pass
-    # kernel-only duration of the same class from the committed rocprofv3 --kernel-trace --stats summary of this command: an event
-    # pair also sees the dispatch latency in front of the kernel (~2 us per launch), rocprofv3 times the kernel alone
     try:
         if args.workload == "qwen3vl8b":
-            tot_us, calls = 0.0, 0
-            with open(os.path.join(ROOT, "profiles", stats_file)) as f:
+            tot_us, calls, stamped = 0.0, 0, None
+            with open(os.path.join(ROOT, "profiles", STATS_FILE)) as f:
                 for line in f:
+                    if "gemv_source_digest:" in line:
+                        stamped = line.split("gemv_source_digest:")[1].split()[0]
                     c = [x.strip() for x in line.split("|")]
                     if len(c) >= 6 and "gemv_kernel" in c[1]:
                         calls += int(c[2])
                         tot_us += float(c[3])
-            if calls:
+            if calls and stamped == dig:
                 avg = tot_us / calls
                 roof["rocprof"] = {"avg_us": round(avg, 2), "achieved": round(roof["algorithmic_bytes_per_launch"] / avg / 1e3, 1),
                                    "frac": round(roof["algorithmic_bytes_per_launch"] / avg / 1e3 / HBM_PEAK_GBS, 4),
-                                   "source": "profiles/" + stats_file}
+                                   "source": "profiles/" + STATS_FILE}
     except (OSError, ValueError):
         pass
     ad = prof["attn_decode"]
@@ -368,9 +447,10 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": args.workload, "prompt_tokens": len(ids), "image": wl["image"],
-                       "kv_len_mid": kv_mid, "replicas": world,
+                       "kv_len_mid": kv_mid, "replicas": world, "collective_backend": ("gloo (ranks share a GPU)" if shared_device else "rccl") if world > 1 else None,
                        "loop": "host forward_step" if args.host_loop else "device-resident greedy loop"},
             "prefill_tok_s": round(len(ids) / t_prefill, 1), "prefill_ms": round(1e3 * t_prefill, 2),
+            "prefill_ms_samples": [round(1e3 * t, 2) for t in t_prefills],
             "decode_step_hbm_frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "attn_decode_GBs": round(attn_gbs, 1),
             "load_s": round(t_load, 1),
@@ -379,14 +459,15 @@ def main():
         if wl.get("video"):
             line["config"]["video_frames_hw"] = list(wl["video"])
             line["video_to_patches"] = video_patchify
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only (torchrun also pins its ranks to one OMP thread)
             line["cpu_baseline"] = cpu_baseline(cfg)
     model.close()
     torch.cuda.empty_cache()
     # The part of the path that SHARDS (north_star: long-context prefill + ViT over the node's GPUs): measured next to the
     # replica decode number whenever there is more than one rank, so a scaling run of this command covers both.
-    if (world > 1 or args.sharded_prefill) and args.workload == "qwen3vl8b":
+    if (world > 1 or args.sharded_prefill) and args.workload == "qwen3vl8b" and not shared_device:
         sp = sharded_prefill_bench(rank, world, local_rank)
+        assert sp["rccl_ranks"] == args.gpus
         if rank == 0:
             line["sharded_prefill"] = sp
     if rank == 0:

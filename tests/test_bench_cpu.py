@@ -26,3 +26,28 @@ def test_decode_bytes_per_token_formula():
     assert b0 == (t.num_hidden_layers * per_layer + t.vocab_size * t.hidden_size) * 2 + t.num_hidden_layers * 2 * t.kv_dim * 2
     assert abs(b0 / 1e9 - 15.14) < 0.02                       # 15.14 GB + 147 456 B per cached token
     assert bench.decode_bytes_per_token(cfg, 1000) - b0 == 1000 * 147456
+
+
+def test_bench_gpus_2_self_launches_two_ranks_over_gloo():
+    """`python bench.py --gpus 2 ...` with no launcher around it (how the driver calls it) must start 2 ranks itself, rendezvous on
+    127.0.0.1, aggregate (sum of units / max of seconds) and print ONE JSON line with n_gpus = 2.  The GPU work is replaced by the
+    launcher self-test workload here (no GPU in this tier); tests/test_tp_gpu.py runs `--workload tiny` through the same launcher."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "1",
+                        "--workload", "launcher-selftest"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 10 and j["config"]["replicas"] == 2
+    assert abs(j["value"] - 2 * 10 / 0.75) < 1e-3 and abs(j["ms_per_step"] - 75.0) < 1e-6   # both ranks' units / the slower rank's 0.75 s
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "launcher-selftest"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
