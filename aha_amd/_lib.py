@@ -84,6 +84,11 @@ SIGNATURES = {
                                             C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_float),
                                             C.POINTER(C.c_float)]),
     "aha_hip_last_logits": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "aha_hip_rng_create": (C.c_int, [C.c_uint64, C.POINTER(_P)]),
+    "aha_hip_rng_destroy": (None, [_P]),
+    "aha_hip_rng_next_u32": (C.c_uint32, [_P]),
+    "aha_hip_rng_weighted_index": (C.c_int, [_P, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_uint32)]),
+    "aha_hip_debug_chacha_block": (C.c_int, [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32)]),
     "aha_hip_img_smart_resize": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32),
                                            C.POINTER(C.c_uint32)]),
     "aha_hip_image_resize": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P]),

@@ -938,9 +938,6 @@ __global__ void embed_state_kernel(const bf16_t* __restrict__ table, const StepS
     rope[64 + i] = rbf(sinf(ang));
   }
 }
-// bench.py's "null" profile class: an empty launch between the same kind of HIP event pairs as every profiled kernel = the
-// dispatch latency an event pair sees in front of a kernel (only enqueued while profiling is on)
-__global__ void null_kernel() {}
 __global__ void advance_state_kernel(StepState* st, uint32_t* token_log, uint32_t* host_ring, uint32_t* host_done) {
   const uint32_t t = st->next_token;
   const int32_t step = st->step;
@@ -1017,10 +1014,6 @@ static void enqueue_decode_step(aha_model* m, size_t kv_len_after) {
   nsplit = std::max(1, std::min(std::min(nsplit, m->max_nsplit), 1024 / (nh / kvh)));  // g * nsplit <= 1024: LDS tables of the split merge
   for (int li = 0; li < c.num_hidden_layers; ++li) {
     const LayerWeights& L = m->layers[li];
-    if (m->profiling) {
-      ProfScope ps(m, "null", 0, 0);
-      hipLaunchKernelGGL(null_kernel, dim3(1), dim3(64), 0, st);
-    }
     {  // h = RMSNorm(x); qkv = h Wqkv^T                      (qwen3/model.rs:79, modules.rs:538-552)
       GemvArgs g{};
       g.W = L.wqkv; g.x = m->d_x; g.norm_w = L.in_norm; g.eps = c.rms_norm_eps; g.y = m->d_qkv; g.N = nq + 2 * nkv; g.K = H;

@@ -5,18 +5,51 @@ Reference: `GenerationContext` / `sample_and_push` (src/models/common/generate.r
 
 Split of the work: the device (aha_hip_sample_candidates) applies the repeat penalty and returns the k largest logits plus
 the full-vocabulary softmax normaliser; this module turns them into the weight vector candle would draw from (top-k,
-top-k-then-top-p, top-p) and draws.  The draw uses numpy's PCG64 -- candle's `StdRng` stream is third-party and not
-reproduced, so sampled token SEQUENCES differ from the reference's for the same seed while the DISTRIBUTION of every draw is
-the same.  Greedy requests never come here (forward_* already returns the arg-max token).
+top-k-then-top-p, top-p); the draw itself is the library's restatement of candle's RNG behind the C ABI (aha_hip_rng_*:
+rand 0.9.2 `StdRng::seed_from_u64` = PCG32-expanded ChaCha12, `WeightedIndex<f32>`; csrc/sampler_rng.hip), so a seed defines a
+token sequence.  [unverified] against the crates (not on disk): for Sampling::All / TopP the sequence is fully defined by
+that restatement; for TopK / TopKThenTopP candle draws over the k probabilities in the order `select_nth_unstable_by` leaves
+them, which Rust does not specify -- here they are ranked (probability desc, logit desc, index asc).  Greedy requests never come
+here (forward_* already returns the arg-max token).
 """
 from __future__ import annotations
 
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
+import ctypes as C
+
 import numpy as np
 
+from ._lib import check, lib
+
 MAX_CANDIDATES = 64  # aha_hip_sample_candidates limit
+
+
+class StdRng:
+    """aha_hip_rng_*: rand 0.9.2 `StdRng::seed_from_u64(seed)` (candle_transformers LogitsProcessor::from_sampling / ::new)."""
+
+    def __init__(self, seed: int):
+        self._h = C.c_void_p()
+        check(lib().aha_hip_rng_create(C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), C.byref(self._h)))
+
+    def next_u32(self) -> int:
+        return int(lib().aha_hip_rng_next_u32(self._h))
+
+    def weighted_index(self, weights: np.ndarray) -> int:
+        """WeightedIndex::<f32>::new(weights)?.sample(rng) -- one next_u32."""
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        out = C.c_uint32()
+        check(lib().aha_hip_rng_weighted_index(self._h, w.ctypes.data_as(C.POINTER(C.c_float)), w.size, C.byref(out)))
+        return int(out.value)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().aha_hip_rng_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 @dataclass
@@ -60,7 +93,7 @@ def _topp_mask(prs: np.ndarray, top_p: float, tie_key: Optional[np.ndarray] = No
 class LogitsProcessor:
     def __init__(self, seed: int, sampling: Sampling):
         self.sampling = sampling
-        self.rng = np.random.Generator(np.random.PCG64(seed))
+        self.rng = StdRng(seed)
 
     # -- deterministic part ------------------------------------------------------------------------------------------
     def candidates_needed(self, vocab_size: int) -> int:
@@ -98,42 +131,40 @@ class LogitsProcessor:
             return w
         raise ValueError(f"{s.kind} does not sample from candidates")
 
-    def weights_from_logits(self, logits: np.ndarray) -> np.ndarray:
-        """Full-vector path (Sampling::All, oversized k, TopP fallback): LogitsProcessor::sample on host logits."""
+    def weights_from_logits(self, logits: np.ndarray) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+        """Full-vector path (Sampling::All, oversized k, TopP fallback): LogitsProcessor::sample on host logits.  Returns
+        (weights, ids): the vector sample_multinomial draws from and, when that vector is NOT indexed by token id (sample_topk /
+        sample_topk_topp draw over the k selected probabilities and map the drawn position back through `indices`), the ids."""
         s = self.sampling
         logits = np.asarray(logits, dtype=np.float32)
         if s.kind == "ArgMax":
             w = np.zeros_like(logits)
             w[int(np.argmax(logits))] = 1.0
-            return w
+            return w, None
         x = logits * np.float32(1.0 / s.temperature)
         e = np.exp(x - x.max(), dtype=np.float32)
         prs = (e / e.sum(dtype=np.float32)).astype(np.float32)
         if s.kind == "All":
-            return prs
+            return prs, None
         if s.kind == "TopP":
-            return prs if (s.p <= 0.0 or s.p >= 1.0) else _topp_mask(prs, s.p)
+            return (prs if (s.p <= 0.0 or s.p >= 1.0) else _topp_mask(prs, s.p)), None
         if s.kind == "TopKThenTopP" and s.k >= logits.shape[0]:
-            return _topp_mask(prs, s.p)
+            return _topp_mask(prs, s.p), None
         if s.k >= logits.shape[0]:
-            return prs
+            return prs, None
         # candle selects the k largest PROBABILITIES (select_nth_unstable_by); equal probabilities: higher logit, then lower
-        # index (the same refinement as the device's ranking by logit)
+        # index (the same refinement as the device's ranking by logit); the draw runs over them in that order
         keep = np.lexsort((np.arange(prs.shape[0]), -logits.astype(np.float64), -prs.astype(np.float64)))[: s.k]
         sub = prs[keep]
         if s.kind == "TopKThenTopP" and not (s.p <= 0.0 or s.p >= sub.sum(dtype=np.float32)):
             sub = _topp_mask(sub, s.p)
-        w = np.zeros_like(prs)
-        w[keep] = sub
-        return w
+        return sub, keep
 
     # -- the draw ----------------------------------------------------------------------------------------------------
     def draw(self, weights: np.ndarray) -> int:
-        """WeightedIndex semantics: index of the first cumulative weight that exceeds u * total."""
-        c = np.cumsum(weights.astype(np.float64))
-        if not c[-1] > 0:
-            raise ValueError("all sampling weights are zero")
-        return int(min(np.searchsorted(c, self.rng.random() * c[-1], side="right"), len(c) - 1))
+        """sample_multinomial: WeightedIndex::new(weights)?.sample(&mut self.rng) -- running f32 sums, one u32 of the ChaCha12
+        stream, index of the first running sum greater than the uniform value (aha_hip_rng_weighted_index)."""
+        return self.rng.weighted_index(np.asarray(weights, dtype=np.float32))
 
 
 class GenerationContext:
@@ -184,7 +215,9 @@ def sample_and_push(ctx: GenerationContext, model, argmax_token: int, generated:
                     if t not in seen and 0 <= t < V:
                         logits[t] = logits[t] / np.float32(pen) if logits[t] >= 0 else logits[t] * np.float32(pen)
                     seen.add(t)
-            token = lp.draw(lp.weights_from_logits(logits))
+            w, ids = lp.weights_from_logits(logits)
+            pos = lp.draw(w)
+            token = pos if ids is None else int(ids[pos])
     generated.append(token)
     return token
 

@@ -209,7 +209,7 @@ int aha_hip_decode_greedy(aha_model* m, uint32_t first_token, size_t seqlen_offs
  *   3. max_out / sumexp_out = max_i x_i and sum_i exp((x_i - max) / temperature) over the WHOLE vocabulary, so that
  *      exp((vals_out[j] - max) / temperature) / sumexp equals the probability candle's softmax(logits / temperature)
  *      assigns to candidate j (temperature <= 0 is treated as 1).
- * The host finishes with its own RNG (top-p cut over the candidates + weighted draw): 8k + 8 bytes leave the device per
+ * The host finishes with the top-p cut over the candidates and the weighted draw (aha_hip_rng_* below): 8k + 8 bytes leave the device per
  * token instead of the V-float logits vector.  Not in the reference as a function: it replaces the body of
  * LogitsProcessor::sample up to the random draw.  If k exceeds the vocabulary the surplus entries come back as value -inf /
  * index 0xFFFFFFFF.  Under tensor parallelism (vocab-parallel lm_head) the call is collective: every rank makes it, the
@@ -220,6 +220,27 @@ int aha_hip_sample_candidates(aha_model* m, const uint32_t* context, size_t n_co
 /* The V f32 logits of the last forward call, exactly what logits_out of that call would have received (fallback of the
  * candidate path: Sampling::All, or a TopP whose nucleus is wider than 64 tokens). */
 int aha_hip_last_logits(aha_model* m, float* logits_out);
+
+/* The random draw of candle's LogitsProcessor (the `rng` field and sample_multinomial of candle-transformers 0.9.2, built by
+ * get_logit_processor, /root/reference/src/models/common/sample.rs:7-37 with seed 299792458, common/generate.rs:408,452, or
+ * 34562, qwen3_asr/generate.rs:134), host code:
+ *   aha_hip_rng_create(seed)        = rand 0.9.2 StdRng::seed_from_u64(seed)   (candle-transformers' own rand, Cargo.lock:590-606):
+ *                                     PCG32 expansion of the u64 to 32 seed bytes, ChaCha12 stream, block counter 0, stream id 0
+ *   aha_hip_rng_next_u32            = RngCore::next_u32 on it
+ *   aha_hip_rng_weighted_index      = WeightedIndex::<f32>::new(weights)?.sample(&mut rng): ONE next_u32; index of the first running
+ *                                     f32 sum greater than the uniform draw in [0, total).  AHA_ERR_INVALID for a negative / NaN
+ *                                     weight or an all-zero vector (the crate's Err(..)), with the RNG left untouched.
+ * [unverified] against the crates themselves (not on disk, no cargo): restated from their published algorithms, see
+ * csrc/sampler_rng.hip.  For Sampling::TopK / TopKThenTopP candle draws over the k probabilities in the order
+ * select_nth_unstable_by leaves them, which Rust does not specify: callers pass them ranked (probability desc, logit desc,
+ * index asc), the order aha_hip_sample_candidates returns. */
+typedef struct aha_rng aha_rng;
+int aha_hip_rng_create(uint64_t seed, aha_rng** out);
+void aha_hip_rng_destroy(aha_rng* rng);
+uint32_t aha_hip_rng_next_u32(aha_rng* rng);
+int aha_hip_rng_weighted_index(aha_rng* rng, const float* weights, size_t n, uint32_t* index_out);
+/* Test hook: the ChaCha block function (even `rounds`) on a 16-word state -- RFC 7539 section 2.3.2 pins it at 20 rounds. */
+int aha_hip_debug_chacha_block(const uint32_t* state16, int rounds, uint32_t* out16);
 
 /* Extension for the image-parallel ViT (each GPU encodes its share of the images, embeddings are all-gathered over RCCL):
  * runs only the vision tower on `mm` (its images, then its videos) and writes (1 + n_deepstack, n_tokens, hidden) bf16 to out_dev

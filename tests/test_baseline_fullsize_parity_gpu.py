@@ -17,7 +17,12 @@
 
 Tolerances as in tests/test_baseline_parity_gpu.py (both sides round to bf16 at the same op boundaries and differ in f32
 accumulation order and the flash-style softmax): logits max <= 0.10 std, rms <= 0.02 std; tower outputs max <= 0.12 std,
-rms <= 0.02 std.  Measured values go to gpurun_out/parity_fullsize.json.
+rms <= 0.02 std -- EXCEPT at the full depth of the 8B stack (36 layers x 4096), where the oracle's own rounding model is noisier
+than that: run against itself with f64 instead of f32 accumulation (same ops, same rounding points) it differs by 0.171 / 0.043
+std at 36 layers, with un-rounded softmax probabilities by 0.226 / 0.051 (scripts/oracle_noise_floor.py,
+profiles/r03_oracle_noise_floor.md: a random walk, rms ~ 0.007 sqrt(layers)).  The full-depth bound is therefore max <= 0.25 std,
+rms <= 0.05 std; greedy tokens must agree wherever the oracle's margin exceeds twice the max bound.
+Measured values go to gpurun_out/parity_fullsize.json.
 """
 import json
 import os
@@ -40,6 +45,7 @@ pytestmark = pytest.mark.gpu
 
 NM = Numerics("bf16", matmul_f64=False, attn_row_block=1024)
 LOGIT_MAX, LOGIT_RMS = 0.10, 0.02
+DEEP_MAX, DEEP_RMS = 0.25, 0.05          # 36 layers x 4096: the floor of the rounding model itself (module docstring)
 TOWER_MAX, TOWER_RMS = 0.12, 0.02
 MIN_MARGIN = 0.5
 REPORT = {}
@@ -142,12 +148,12 @@ def test_cfg3_full_vit_and_all_36_layers(vl8b):
         REPORT["cfg3_vit27_N4096_text36layers_S1542"] = rep
         _flush_report()
         assert rep["image_embeds"][0] <= TOWER_MAX and rep["image_embeds"][1] <= TOWER_RMS, rep["image_embeds"]
-        assert rep["prefill_logits"][0] <= LOGIT_MAX and rep["prefill_logits"][1] <= LOGIT_RMS, f"36 layers, S = 1542: {rep['prefill_logits']}"
-        if rep["margin_std"] > 2 * LOGIT_MAX:
+        assert rep["prefill_logits"][0] <= DEEP_MAX and rep["prefill_logits"][1] <= DEEP_RMS, f"36 layers, S = 1542: {rep['prefill_logits']}"
+        if rep["margin_std"] > 2 * DEEP_MAX:
             assert rep["argmax_equal"]
         for step, d in enumerate(dec):
-            assert d[0] <= LOGIT_MAX and d[1] <= LOGIT_RMS, f"decode step {step}: {d}"
-            if d[2] > 2 * LOGIT_MAX:
+            assert d[0] <= DEEP_MAX and d[1] <= DEEP_RMS, f"decode step {step}: {d}"
+            if d[2] > 2 * DEEP_MAX:
                 assert d[3], f"decode step {step}: greedy token differs although the oracle's margin is {d[2]:.2f} std"
     finally:
         m.close()
@@ -199,7 +205,7 @@ def test_cfg3_decisive_checkpoint_exact_free_running_greedy_128(vl8b):
         assert host == want
         assert len(set(want)) == 128     # a walk through 128 different ids, not a fixed point
         for e in errs:
-            assert e[0] <= LOGIT_MAX and e[1] <= LOGIT_RMS, errs
+            assert e[0] <= DEEP_MAX and e[1] <= DEEP_RMS, errs
     finally:
         m.close()
         o.clear_cache()

@@ -68,7 +68,12 @@ def test_host_weights_from_candidates_match_oracle(sampling, penalty):
     assert set(np.nonzero(got)[0]) == set(np.nonzero(want)[0])
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-9)
     # and the full-vector fallback is the same function of the logits
-    np.testing.assert_allclose(lp.weights_from_logits(pen), want, rtol=1e-6, atol=1e-12)
+    w_full, ids = lp.weights_from_logits(pen)
+    if ids is not None:     # the top-k samplers draw over the k selected probabilities; `ids` maps the drawn position back
+        scat = np.zeros(V, np.float32)
+        scat[ids] = w_full
+        w_full = scat
+    np.testing.assert_allclose(w_full, want, rtol=1e-6, atol=1e-12)
 
 
 def test_topp_nucleus_wider_than_candidates_falls_back():
@@ -77,28 +82,85 @@ def test_topp_nucleus_wider_than_candidates_falls_back():
     lp = hs.LogitsProcessor(0, hs.Sampling("TopP", 1.0, p=0.9))
     vals, idx, mx, se = osamp.topk_candidates(flat, 64, 1.0)
     assert lp.weights_from_candidates(vals, mx, se) is None
-    np.testing.assert_allclose(lp.weights_from_logits(flat), osamp.final_weights(flat, osamp.Sampling("TopP", 1.0, p=0.9)), rtol=1e-6)
+    w_full, ids = lp.weights_from_logits(flat)
+    assert ids is None      # TopP draws over the vocabulary in index order
+    np.testing.assert_allclose(w_full, osamp.final_weights(flat, osamp.Sampling("TopP", 1.0, p=0.9)), rtol=1e-6)
     assert hs.LogitsProcessor(0, hs.Sampling("All", 0.7)).candidates_needed(V) == 0
     assert hs.LogitsProcessor(0, hs.Sampling("TopK", 0.7, k=100)).candidates_needed(V) == 0  # above the device limit
 
 
 def test_draw_is_weighted_index():
-    lp = hs.LogitsProcessor(0, hs.Sampling("TopK", 1.0, k=4))
-
-    class _R:
-        def __init__(self, u): self.u = u
-        def random(self): return self.u
+    """LogitsProcessor.draw = candle's sample_multinomial: WeightedIndex::<f32>::new(weights)?.sample(&mut rng) on the library's
+    StdRng (aha_hip_rng_*), checked draw by draw against the independent restatement oracle/rand_stdrng.py."""
+    from oracle import rand_stdrng as R
     w = np.array([0.0, 2.0, 0.0, 6.0], np.float32)
-    for u, want in [(0.0, 1), (0.2499, 1), (0.25, 3), (0.999999, 3)]:
-        lp.rng = _R(u)
-        assert lp.draw(w) == want
-    with pytest.raises(ValueError):
-        lp.draw(np.zeros(3, np.float32))
+    lp = hs.LogitsProcessor(299792458, hs.Sampling("TopK", 1.0, k=4))     # the reference's default seed (common/generate.rs:408)
+    ref = R.StdRng.seed_from_u64(299792458)
+    got = [lp.draw(w) for _ in range(500)]
+    assert got == [R.sample_multinomial(ref, w) for _ in range(500)]
+    assert set(got) == {1, 3}
+    with pytest.raises(Exception):
+        lp.draw(np.zeros(3, np.float32))                                   # WeightedIndex::new -> Err (all weights zero)
+    with pytest.raises(Exception):
+        lp.draw(np.array([1.0, -0.5], np.float32))                         # invalid weight
+    assert lp.draw(w) == R.sample_multinomial(ref, w)                      # a refused vector consumes nothing of the stream
     # frequencies follow the weights
     lp = hs.LogitsProcessor(7, hs.Sampling("TopK", 1.0, k=4))
     n = 20000
     counts = np.bincount([lp.draw(w) for _ in range(n)], minlength=4)
     assert counts[0] == counts[2] == 0 and abs(counts[3] / n - 0.75) < 0.02
+
+
+def test_stdrng_restatement_known_answers_and_cross_check():
+    """The pieces of rand 0.9.2's StdRng that HAVE published vectors, and the C++ implementation behind the C ABI against the
+    Python restatement for everything else (seed expansion, block counter, buffer hand-out)."""
+    import ctypes as C
+    from aha_amd._lib import lib
+    from oracle import rand_stdrng as R
+    # RFC 7539 section 2.3.2: key 00..1f, block counter 1, nonce 00:00:00:09:00:00:00:4a:00:00:00:00, 20 rounds
+    key = [int.from_bytes(bytes(range(4 * i, 4 * i + 4)), "little") for i in range(8)]
+    st = list(R.CHACHA_CONSTANTS) + key + [1, 0x09000000, 0x4A000000, 0]
+    want = [0xE4E7F110, 0x15593BD1, 0x1FDD0F50, 0xC47120A3, 0xC7F4D1C7, 0x0368C033, 0x9AAA2204, 0x4E6CD4C3,
+            0x466482D2, 0x09AA9F07, 0x05D7C214, 0xA2028BD9, 0xD19C12B5, 0xB94E16DE, 0xE883D0CB, 0x4E3C50A2]
+    assert R.chacha_block(st, 20) == want
+    out = (C.c_uint32 * 16)()
+    assert lib().aha_hip_debug_chacha_block((C.c_uint32 * 16)(*st), 20, out) == 0 and list(out) == want
+    # all-zero key, counter 0, stream 0, 20 rounds: the keystream 76 b8 e0 ad a0 f1 3d 90 ... (rand_chacha's test_chacha_true_values_a)
+    z = list(R.CHACHA_CONSTANTS) + [0] * 12
+    assert R.chacha_block(z, 20)[:4] == [0xADE0B876, 0x903DF1A0, 0xE56A5D40, 0x28BD8653]
+    # the 12-round stream from a u64 seed: C ABI == restatement over several buffer refills (4 blocks = 64 words each)
+    for seed in (0, 1, 299792458, 34562, 2 ** 64 - 1):
+        a, b = hs.StdRng(seed), R.StdRng.seed_from_u64(seed)
+        assert [a.next_u32() for _ in range(200)] == [b.next_u32() for _ in range(200)]
+    assert R.pcg32_seed_bytes(0)[:4] != R.pcg32_seed_bytes(0)[4:8]
+    # UniformFloat<f32>::new(0, total): the largest sample stays below total; WeightedIndex picks the first running sum ABOVE the draw
+    g = np.random.default_rng(0)
+    for trial in range(200):
+        n = int(g.integers(1, 300))
+        w = g.random(n).astype(np.float32)
+        if trial % 3 == 0:
+            w[g.random(n) < 0.5] = 0
+        if trial % 7 == 0:
+            w *= np.float32(1e-3)
+        if w.sum() == 0:
+            w[0] = 1
+        seed = int(g.integers(0, 2 ** 63))
+        a, b = hs.StdRng(seed), R.StdRng.seed_from_u64(seed)
+        for _ in range(20):
+            i = a.weighted_index(w)
+            assert i == R.sample_multinomial(b, w) and w[i] > 0          # a zero weight is never drawn
+    u = R.UniformF32(0.0, 0.7)
+    assert np.float32(np.float32(u.scale * (np.float32(1.0) - np.float32(2.0 ** -23))) + np.float32(0.0)) < np.float32(0.7)
+
+
+def _scatter(lp, logits):
+    """weights_from_logits as a vector over the vocabulary (the top-k samplers return the k selected weights + their ids)."""
+    w, ids = lp.weights_from_logits(logits)
+    if ids is None:
+        return w
+    out = np.zeros(np.asarray(logits).shape[0], np.float32)
+    out[ids] = w
+    return out
 
 
 class _FakeModel:
@@ -206,14 +268,14 @@ def test_topk_tie_rule_equal_probabilities_seed49():
     got[idx] = lp.weights_from_candidates(vals, mx, se, idx)
     assert set(np.nonzero(got)[0]) == set(np.nonzero(want)[0])
     np.testing.assert_allclose(got, want, rtol=3e-5)
-    np.testing.assert_array_equal(lp.weights_from_logits(logits), want)
+    np.testing.assert_array_equal(_scatter(lp, logits), want)
     # the same with the nucleus cut on top (the hypothesis example that failed)
     want2 = osamp.final_weights(logits, osamp.Sampling("TopKThenTopP", t, k=k, p=p))
     lp2 = hs.LogitsProcessor(0, hs.Sampling("TopKThenTopP", t, k, p))
     got2 = np.zeros(V, np.float32)
     got2[idx] = lp2.weights_from_candidates(vals, mx, se, idx)
     assert set(np.nonzero(got2)[0]) == set(np.nonzero(want2)[0])
-    np.testing.assert_array_equal(lp2.weights_from_logits(logits), want2)
+    np.testing.assert_array_equal(_scatter(lp2, logits), want2)
 
 
 @pytest.mark.parametrize("p", [0.0, 1.0, 1.5, -0.1])
@@ -226,7 +288,7 @@ def test_topp_degenerate_p_samples_the_whole_distribution(p):
     np.testing.assert_array_equal(want, osamp.final_weights(logits, osamp.Sampling("All", 0.8)))
     lp = hs.LogitsProcessor(3, hs.Sampling("TopP", 0.8, p=p))
     assert lp.candidates_needed(V) == 0
-    w = lp.weights_from_logits(logits)
+    w = _scatter(lp, logits)
     np.testing.assert_allclose(w, want, rtol=1e-6)
     assert w.sum() > 0.999 and 0 <= lp.draw(w) < V
 
@@ -238,7 +300,7 @@ def test_topp_equal_probabilities_walk_in_position_order():
     want = osamp.final_weights(logits, osamp.Sampling("TopP", 1.0, p=0.5))
     np.testing.assert_allclose(want, [0.0, 0.3, 0.3, 0.0], atol=1e-6)
     lp = hs.LogitsProcessor(0, hs.Sampling("TopP", 1.0, p=0.5))
-    np.testing.assert_allclose(lp.weights_from_logits(logits), want, atol=1e-7)
+    np.testing.assert_allclose(_scatter(lp, logits), want, atol=1e-7)
     vals, idx = logits[[3, 2, 1, 0]], np.array([3, 2, 1, 0])       # a candidate list in a hostile order
     w = lp.weights_from_candidates(vals, float(logits.max()), float(np.exp(logits - logits.max()).sum()), idx)
     got = np.zeros(4, np.float32)
