@@ -207,8 +207,8 @@ int aha_hip_debug_scramble_pages(aha_model* m, int enable) {
   return AHA_OK;
 }
 int aha_hip_debug_gemm_plan(int32_t tile, int32_t splitk) {
-  if ((tile != 0 && tile != 128 && tile != 256) || splitk < 0 || splitk > 8) {
-    set_error("debug_gemm_plan: tile must be 0, 128 or 256; splitk 0..8");
+  if ((tile != 0 && tile != 128 && tile != 256 && tile != 192) || splitk < 0 || splitk > 8) {
+    set_error("debug_gemm_plan: tile must be 0, 128, 192 (256 x 192, where instantiated) or 256; splitk 0..8");
     return AHA_ERR_INVALID;
   }
   set_gemm_plan_override(tile, splitk);

@@ -180,7 +180,7 @@ __device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
 }
 // 32x32x16 fragments (W-fragment x A-fragment): lane l holds row m = .. + (l & 31) and, in register quad q, the columns
 // n = .. + 8 q + 4 (l >> 5) + 0..3.  acc[nf][mf]: NF x MF fragments of 32 x 32.
-template <int ACT, bool HAS_BIAS, bool HAS_RES, int NF, int MF>
+template <int ACT, bool HAS_BIAS, bool HAS_RES, int NF, int MF, int NFV = NF>
 __device__ __forceinline__ void epilogue32(const GemmArgs& a, f32x16_t (&acc)[NF][MF], int mb, int nb, int lane) {
   const int r32 = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -188,7 +188,7 @@ __device__ __forceinline__ void epilogue32(const GemmArgs& a, f32x16_t (&acc)[NF
     const int m = mb + mf * 32 + r32;
     if (m >= a.M) continue;
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
+    for (int nf = 0; nf < NFV; ++nf) {   // (NFV < NF: the 192-column tile keeps three of a wave's four fragment columns)
       const f32x16_t& v = acc[nf][mf];
       if (ACT == ACT_SILU_MUL_PAIRS) {   // a 32-row W fragment = one gate block (quads 0,1) + its up block (quads 2,3)
 #pragma unroll
@@ -215,10 +215,13 @@ __device__ __forceinline__ void epilogue32(const GemmArgs& a, f32x16_t (&acc)[NF
 // of the chain on 8 consecutive columns (16-byte bias / residual loads) and store 16 B: 4 whole 256-byte rows per instruction.
 // ACT_SILU_MUL_PAIRS: the band is the finished 64-column output (8 lanes per row).  wbuf: this wave's 32 x 264 B of LDS, free
 // once every wave of the block has left the k loop.
-template <int ACT, bool HAS_BIAS, bool HAS_RES>
+// WC: fused-weight columns of the wave's sub-tile that hold results (128, or 96 for the 192-column tile: the row pass keeps its
+// 16 / 8 lanes per row and masks the lanes past the last valid column).
+template <int ACT, bool HAS_BIAS, bool HAS_RES, int WC = 128>
 __device__ __forceinline__ void epilogue32_rows(const GemmArgs& a, f32x16_t (&acc)[4][4], int mb, int nb, int lane, char* wbuf) {
   constexpr bool PAIRS = ACT == ACT_SILU_MUL_PAIRS;
   constexpr int COLS = PAIRS ? 64 : 128, PITCH = COLS * 2 + 8, LPR = COLS / 8, RPI = 64 / LPR, NIT = 32 / RPI;
+  constexpr int NFV = WC / 32, VCOLS = PAIRS ? WC / 2 : WC;   // valid fragment columns / valid output columns of the band
   static_assert(ACT != ACT_PARTIAL_F32, "f32 partial sums keep the fragment-order epilogue");
   const int r32 = lane & 31, h = lane >> 5;
   const int rr = lane / LPR, cc = lane % LPR;
@@ -235,6 +238,7 @@ __device__ __forceinline__ void epilogue32_rows(const GemmArgs& a, f32x16_t (&ac
         for (int r = 0; r < 16; ++r) sum[j][r] = acc[nf0 + j][mf][r];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
+        if (nf0 + j >= NFV) continue;
         if (PAIRS) {   // a 32-row W fragment = one gate block (quads 0,1) + its up block (quads 2,3) -> 16 output columns
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
@@ -267,7 +271,7 @@ __device__ __forceinline__ void epilogue32_rows(const GemmArgs& a, f32x16_t (&ac
       const uint2 lo = *reinterpret_cast<const uint2*>(wbuf + row * PITCH + cc * 16);
       const uint2 hi = *reinterpret_cast<const uint2*>(wbuf + row * PITCH + cc * 16 + 8);
       uint32_t d[4] = {lo.x, lo.y, hi.x, hi.y};
-      if (m < a.M && n < ncols) {
+      if (m < a.M && n < ncols && cc * 8 < VCOLS) {
         if (!PAIRS) {
           if (HAS_BIAS) {
             const uint4 b4 = *reinterpret_cast<const uint4*>((const bf16_t*)a.bias + n);
@@ -585,15 +589,23 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs a, const void
 typedef __attribute__((address_space(3))) char* lds_cptr_t;
 
 // ABL (debug, results wrong by construction): 1 = no DMA in the steady state, 2 = no fragment reads in the steady state, 3 = no barriers
-template <int ACT, bool HAS_BIAS, bool HAS_RES, bool BAR2 = true, int ABL = 0>
+// NF3: the 256 x 192 tile (round 3).  Same program, but a wave owns 128 x 96: its W slice is three fragment columns -- W half 0 =
+// 64 rows as before, W half 1 = 32 rows -- so the phases that use W1 issue 8 MFMAs instead of 16, W1 is staged with 2 DMA pieces per
+// wave instead of 4 (8 pieces = 2 slices x 32 image rows; the region's other 64 image rows are never written or read) and read as
+// one fragment set; every counted wait drops by those 2 pieces (16 -> 14, prologue 24 -> 20).  Why: at M = 1542 the gate+up GEMM is
+// 576 full 256^2 tiles = 2.25 per CU, i.e. THREE tile times for 2.25 tiles of work; 192-column tiles make it 768 = exactly 3 per CU
+// of 3/4-size tiles, and qkv 192 full tiles instead of 144 on 256 CUs.
+template <int ACT, bool HAS_BIAS, bool HAS_RES, bool BAR2 = true, int ABL = 0, bool NF3 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256q_kernel(GemmArgs a, int kt_per_slice) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [stage][A0 | A1 | W0 | W1] x 16 KiB
   constexpr int REGION = 128 * 128, STAGE = 4 * REGION;
+  constexpr int TN = NF3 ? 192 : 256, WC = TN / 2;   // tile columns, columns per wave
+  static_assert(!NF3 || (BAR2 && ABL == 0), "the 192-column tile exists in the shipped schedule only");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   int m0, n0;
-  tile_of_block<BM2, BN2>(a, m0, n0);
+  tile_of_block<BM2, TN>(a, m0, n0);
   const int nk_all = a.K / BK;
   const int kt0 = blockIdx.y * kt_per_slice, kt1 = min(nk_all, kt0 + kt_per_slice);
   if (ACT == ACT_PARTIAL_F32) a.C = (float*)a.C + (int64_t)blockIdx.y * a.M * a.ldc;
@@ -612,14 +624,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int h = 0; h < 2; ++h) {
       const int trow = (ir >> 6) * 128 + h * 64 + (ir & 63);
       voA[h][q] = (m0 + trow < a.M) ? (int)((int64_t)trow * a.lda * 2 + slot * 16) : (int)0x80000000;
-      voW[h][q] = (n0 + trow < a.N) ? (int)((int64_t)trow * a.ldw * 2 + slot * 16) : (int)0x80000000;
+      if (!NF3) {
+        voW[h][q] = (n0 + trow < a.N) ? (int)((int64_t)trow * a.ldw * 2 + slot * 16) : (int)0x80000000;
+      } else if (h == 0) {   // W half 0: rows 0..63 of the wave's 96-row slice
+        const int wrow = (ir >> 6) * WC + (ir & 63);
+        voW[0][q] = (n0 + wrow < a.N) ? (int)((int64_t)wrow * a.ldw * 2 + slot * 16) : (int)0x80000000;
+      } else {               // W half 1: rows 64..95; pieces p = wave * 2 + q (q < 2) cover image rows (p >> 2) * 64 + (p & 3) * 8 ..
+        const int p1 = wave * 2 + (q & 1), ir1 = (p1 >> 2) * 64 + (p1 & 3) * 8 + (lane >> 3);
+        const int slot1 = (lane & 7) ^ ((ir1 >> 1) & 7);
+        const int wrow = (ir1 >> 6) * WC + 64 + (ir1 & 63);
+        voW[1][q] = (n0 + wrow < a.N) ? (int)((int64_t)wrow * a.ldw * 2 + slot1 * 16) : (int)0x80000000;
+      }
     }
   }
   const lds_cptr_t lbase = (lds_cptr_t)smem;
   // one DMA piece: region R (0..3 = A0 A1 W0 W1) of tile kt, piece q of this wave
   auto dma = [&](int kt, int R, int q) __attribute__((always_inline)) {
+    if (NF3 && R == 3 && q >= 2) return;   // W half 1 of the 192-column tile: two pieces per wave
     const int ktc = min(kt, kt1 - 1);  // past the end: the last valid tile again (into the slot the schedule assigns; never read)
-    const lds_cptr_t dst = lbase + ((kt - kt0) & 1) * STAGE + R * REGION + (wave * 4 + q) * 1024;
+    const int piece = (NF3 && R == 3) ? (((wave * 2 + q) >> 2) * 8 + ((wave * 2 + q) & 3)) : wave * 4 + q;   // 1-KiB slot in the region
+    const lds_cptr_t dst = lbase + ((kt - kt0) & 1) * STAGE + R * REGION + piece * 1024;
     const int so = ktc * (BK * 2);
     if (R < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)dst, 16, voA[R & 1][q], so, 0, 0);
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)dst, 16, voW[R & 1][q], so, 0, 0);
@@ -670,7 +694,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int q = 0; q < 4; ++q) dma(kt0 + 1, 1, q);
   }
-  AHA_WAIT(0x4F78);  // vmcnt(24): A0, W0 of kt0 have landed
+  if (NF3) AHA_WAIT(0x4F74);  // vmcnt(20): 28 pieces requested, A0 and W0 of kt0 (8) have landed
+  else AHA_WAIT(0x4F78);      // vmcnt(24): A0, W0 of kt0 have landed
   AHA_BAR();
 #pragma unroll
   for (int f = 0; f < 2; ++f)
@@ -691,13 +716,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                    int rR, int rslice, int dkt, int dR) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(full_tag)::value;
     if (decltype(bar_tag)::value) {
-      if (BAR2) AHA_WAIT(0x4070);  // vmcnt(16) lgkmcnt(0)
-      else AHA_WAIT(0x4078);       // vmcnt(24) lgkmcnt(0)
+      if (NF3) AHA_WAIT(0x007E);        // vmcnt(14) lgkmcnt(0): the four newer groups are 4 + 4 + 2 + 4 pieces
+      else if (BAR2) AHA_WAIT(0x4070);  // vmcnt(16) lgkmcnt(0)
+      else AHA_WAIT(0x4078);            // vmcnt(24) lgkmcnt(0)
       if (ABL != 3) AHA_BAR();
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       auto mm = [&](int nf, int mf) __attribute__((always_inline)) {
+        if (NF3 && nj == 1 && nf == 1) return;   // the 192-column tile has no fourth fragment column
         if (FULL || mi * 2 + mf < nmf) acc[nj * 2 + nf][mi * 2 + mf] = mfma32(Wf[nf][ks], A[mf][ks], acc[nj * 2 + nf][mi * 2 + mf]);
       };
       // k-step: MFMA | DMA piece | MFMA | fragment reads | MFMA MFMA.  The 8 fragment reads go out in the first three k-steps (3, 3, 2):
@@ -710,7 +737,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       mm(0, 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int r = ks * 3; r < min(8, ks * 3 + 3); ++r)
+      for (int r = ks * 3; r < min((NF3 && rR == 3) ? 4 : 8, ks * 3 + 3); ++r)   // (W half 1 of the 192-column tile: one fragment)
         if (ABL != 2) dst[r >> 2][r & 3] = frag(rstage, rR, rslice, r >> 2, r & 3);
       __builtin_amdgcn_sched_barrier(0);
       mm(1, 0);
@@ -751,10 +778,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef AHA_WAIT
 #undef AHA_BAR
   if (ACT == ACT_PARTIAL_F32) {
-    epilogue32<ACT, HAS_BIAS, HAS_RES, 4, 4>(a, acc, m0 + wm * 128, n0 + wn * 128, lane);
+    epilogue32<ACT, HAS_BIAS, HAS_RES, 4, 4, WC / 32>(a, acc, m0 + wm * 128, n0 + wn * WC, lane);
   } else {
     __syncthreads();   // every wave has left the k loop (and waited for its own DMAs): the stages are free
-    epilogue32_rows<ACT == ACT_PARTIAL_F32 ? ACT_NONE : ACT, HAS_BIAS, HAS_RES>(a, acc, m0 + wm * 128, n0 + wn * 128, lane, smem + wave * 8448);
+    epilogue32_rows<ACT == ACT_PARTIAL_F32 ? ACT_NONE : ACT, HAS_BIAS, HAS_RES, WC>(a, acc, m0 + wm * 128, n0 + wn * WC, lane, smem + wave * 8448);
   }
 }
 
@@ -910,12 +937,28 @@ void launch_act(const GemmArgs& a, dim3 grid, hipStream_t st) {
   else launch_one<ACT, false, false>(a, grid, st);
 }
 
+// the (ACT, bias, residual) combinations that have a 192-column instantiation (gemm256q_kernel<.., NF3 = true>): gate+up and the
+// plain projection -- the shapes whose tile count quantises badly at 256 columns (plan_gemm)
 template <int ACT, bool B, bool R>
-void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fused = nullptr) {
+constexpr bool has_n192() { return !B && !R && (ACT == ACT_SILU_MUL_PAIRS || ACT == ACT_NONE); }
+
+template <int ACT, bool B, bool R>
+void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fused = nullptr, bool n192 = false) {
   const int ntm = (a.M + BM2 - 1) / BM2, ntn = (a.N + BN2 - 1) / BN2;
   const int nk = (a.K + BK - 1) / BK;
   const size_t lds = 4 * TILE2_BYTES;
   // (> 64 KiB of dynamic LDS needs the opt-in once per kernel instance)
+  if constexpr (has_n192<ACT, B, R>()) {
+    if (n192 && splitk <= 1 && a.K % BK == 0 && 256.0 * 2.0 * (double)std::max(a.lda, a.ldw) < 1.0e9) {
+      static bool once192 = false;
+      if (!once192) {
+        hipFuncSetAttribute((const void*)gemm256q_kernel<ACT, B, R, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        once192 = true;
+      }
+      hipLaunchKernelGGL((gemm256q_kernel<ACT, B, R, true, 0, true>), dim3(ntm * ((a.N + 191) / 192)), dim3(256), lds, st, a, nk);
+      return;
+    }
+  }
   if (splitk <= 1) {
     static const bool quad = [] { const char* e = getenv("AHA_GEMM_QUAD"); return e ? atoi(e) != 0 : true; }();
     // four waves x 128 x 128 (gemm256q_kernel).  Not for short K loops (< 32 K tiles) whose epilogue reads a residual on top of a
@@ -1037,11 +1080,11 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
 }
 
 template <int ACT>
-void launch256_act(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fused) {
+void launch256_act(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fused, bool n192) {
   if (a.bias && a.residual) launch256_one<ACT, true, true>(a, splitk, st, norm_fused);
   else if (a.bias) launch256_one<ACT, true, false>(a, splitk, st, norm_fused);
   else if (a.residual) launch256_one<ACT, false, true>(a, splitk, st, norm_fused);
-  else launch256_one<ACT, false, false>(a, splitk, st, norm_fused);
+  else launch256_one<ACT, false, false>(a, splitk, st, norm_fused, n192);
 }
 
 struct GemmPlan { int tile, splitk; double cost = 0; };
@@ -1056,7 +1099,9 @@ int g_force_tile = 0, g_force_splitk = 0;  // aha_hip_debug_gemm_plan (tests): 0
 
 GemmPlan plan_gemm(const GemmArgs& a) {
   if (g_force_tile == 128) return GemmPlan{128, 1};
-  if (g_force_tile == 256 && a.M >= 1) {
+  if (g_force_tile == 192 && a.M >= 1 && !a.bias && !a.residual && (a.act == ACT_NONE || a.act == ACT_SILU_MUL_PAIRS) && a.K % BK == 0)
+    return GemmPlan{192, 1};
+  if ((g_force_tile == 256 || g_force_tile == 192) && a.M >= 1) {
     int sk = g_force_splitk > 1 ? g_force_splitk : 1;
     if (sk > 1 && (a.act == ACT_SILU_MUL_PAIRS || a.act == ACT_PARTIAL_F32 || !a.workspace || (a.N & 3) ||
                    (size_t)sk * a.M * a.N * 4 > a.workspace_bytes)) sk = 1;
@@ -1087,6 +1132,28 @@ GemmPlan plan_gemm(const GemmArgs& a) {
     if (c < best_cost || (e_tile && atoi(e_tile) == 256 && best.tile != 256)) {
       best = GemmPlan{256, sk};
       best_cost = c;
+    }
+  }
+  // 256 x 192 tiles (gemm256q_kernel NF3; unsplit, plain / gate+up epilogues): a k step of the 3/4-size tile costs ~0.8 of the 256^2
+  // one (48 of 64 MFMAs per wave, the same barrier skeleton).  Rounds are counted in FULL row tiles -- a CU that draws a ragged row
+  // tile (M = 1542: 6 valid rows, MFMAs skipped) is back at the dispatcher after ~0.35 of a tile, which only costs time when no CU
+  // has slack left in the last round.  M = 1542, gate+up: 576 full 256^2 tiles = 3 rounds of 96 us for 2.25 rounds of work against
+  // 768 full 192-column tiles = 3 rounds of 77 us + the ragged ones.
+  static const bool n192_on = [] { const char* e = getenv("AHA_GEMM_N192"); return e ? atoi(e) != 0 : true; }();
+  if (n192_on && !a.bias && !a.residual && (a.act == ACT_NONE || a.act == ACT_SILU_MUL_PAIRS) && a.K % BK == 0 && nk >= 8 && a.M >= 256 &&
+      !(e_sk && atoi(e_sk) != 1) && !(e_tile && atoi(e_tile) != 192)) {
+    auto rounds_cost = [&](int tn, double kstep_us) {
+      const int full_m = a.M / 256, rag_m = (a.M % 256) ? 1 : 0, ntn = (a.N + tn - 1) / tn;
+      const double full = (double)full_m * ntn, ragged = (double)rag_m * ntn;
+      const double rounds = ceil(full / 256.0), slack = rounds * 256.0 - full;
+      double c = rounds * nk * kstep_us;
+      if (ragged * 0.35 > slack) c += 0.35 * nk * kstep_us;
+      return c;
+    };
+    const double c192 = rounds_cost(192, 1.5 * 0.8), c256 = rounds_cost(256, 1.5);
+    if ((c192 < best_cost && c192 < c256) || (e_tile && atoi(e_tile) == 192)) {
+      best = GemmPlan{192, 1};
+      best_cost = c192;
     }
   }
   static const char* e_dbg = getenv("AHA_GEMM_PLAN_DEBUG");
@@ -1173,13 +1240,14 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t st) {
 
 static void launch_planned(const GemmArgs& a, const GemmPlan& plan, hipStream_t st, bool* norm_fused) {
   if (norm_fused != nullptr) *norm_fused = false;
-  if (plan.tile == 256) {
+  if (plan.tile == 256 || plan.tile == 192) {
+    const bool n192 = plan.tile == 192;
     switch (a.act) {
-      case ACT_NONE: launch256_act<ACT_NONE>(a, plan.splitk, st, norm_fused); break;
-      case ACT_GELU_TANH: launch256_act<ACT_GELU_TANH>(a, plan.splitk, st, norm_fused); break;
-      case ACT_GELU_ERF: launch256_act<ACT_GELU_ERF>(a, plan.splitk, st, norm_fused); break;
-      case ACT_SILU: launch256_act<ACT_SILU>(a, plan.splitk, st, norm_fused); break;
-      case ACT_SILU_MUL_PAIRS: launch256_one<ACT_SILU_MUL_PAIRS, false, false>(a, 1, st); break;
+      case ACT_NONE: launch256_act<ACT_NONE>(a, plan.splitk, st, norm_fused, n192); break;
+      case ACT_GELU_TANH: launch256_act<ACT_GELU_TANH>(a, plan.splitk, st, norm_fused, false); break;
+      case ACT_GELU_ERF: launch256_act<ACT_GELU_ERF>(a, plan.splitk, st, norm_fused, false); break;
+      case ACT_SILU: launch256_act<ACT_SILU>(a, plan.splitk, st, norm_fused, false); break;
+      case ACT_SILU_MUL_PAIRS: launch256_one<ACT_SILU_MUL_PAIRS, false, false>(a, 1, st, nullptr, n192); break;
       case ACT_PARTIAL_F32: launch256_one<ACT_PARTIAL_F32, false, false>(a, 1, st); break;
     }
     return;

@@ -6,11 +6,11 @@ import torch
 from aha_amd import ops, build
 build.build()
 dev = torch.device("cuda:0")
-shapes = [("qkv", 1542, 6144, 4096), ("o", 1542, 4096, 4096), ("down", 1542, 4096, 12288),
+shapes = [("qkv", 1542, 6144, 4096), ("o", 1542, 4096, 4096), ("down", 1542, 4096, 12288), ("gateup_plain", 1542, 24576, 4096), ("big", 8192, 8192, 8192),
           ("vit_qkv", 4096, 3456, 1152), ("vit_proj", 4096, 1152, 1152), ("vit_fc1", 4096, 4304, 1152), ("vit_fc2", 4096, 1152, 4304),
           ("qkv_2k", 2048, 4096, 1024), ("o_2k", 2048, 1024, 2048), ("down_2k", 2048, 1024, 3072),
           ("qkv_41k", 40980, 6144, 4096), ("o_41k", 40980, 4096, 4096)]
-plans = [(0, 0), (128, 1), (256, 1), (256, 2), (256, 3), (256, 4), (256, 6)]
+plans = [(0, 0), (128, 1), (256, 1), (192, 1), (256, 2), (256, 3), (256, 4), (256, 6)]
 def t(A, W, it=10):
     for _ in range(2): ops.gemm(A, W)
     torch.cuda.synchronize()

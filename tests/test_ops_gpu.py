@@ -186,6 +186,55 @@ def test_gemm_gate_up_pairs_256_tile(gpu):
     assert_close_ulps(got, ref, 2, 0.97, "gemm gate/up pairs, 256 tile")
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 192, 64), (289, 384, 192), (130, 576, 320), (700, 328, 448), (1542, 960, 4096), (513, 1000, 128)])
+def test_gemm_256x192_tile_plain(gpu, M, N, K):
+    """gemm256q_kernel<.., NF3> (256 x 192 tile, three fragment columns per wave; round 3): odd K-tile counts (1, 3, 5, 7, 64, 2), every
+    count of valid 32-row fragments in the last row tile, N a multiple of 192, ragged N (328 = 192 + 136, 1000 = 5 x 192 + 40: the last
+    column tile is partly / mostly out of range, including a wave whose whole 96-column slice is), against the oracle."""
+    from aha_amd import ops
+    A, W = rnd((M, K), 91), rnd((N, K), 92, 0.02)
+    ref = NM.linear(A.float(), W.float())
+    ops.gemm_plan(192, 1)
+    try:
+        got = ops.gemm(A.to(gpu), W.to(gpu))
+    finally:
+        ops.gemm_plan(0, 0)
+    assert_close_ulps(got, ref, 1, 0.98, "gemm 256x192 plain")
+
+
+@pytest.mark.parametrize("M,I,K", [(700, 1056, 512), (1542, 3072, 1024), (256, 96, 64), (300, 4000, 192)])
+def test_gemm_256x192_tile_gate_up_pairs(gpu, M, I, K):
+    """The gate+up epilogue on the 192-column tile: a tile holds 6 gate|up fragment pairs = 96 output columns; I = 1056 = 11 x 96,
+    3072 = 32 x 96, 96 (one tile), 4000 (ragged: 41 x 96 + 64)."""
+    from aha_amd import ops, _lib
+    A, Wg, Wu = rnd((M, K), 93), rnd((I, K), 94, 0.05), rnd((I, K), 95, 0.05)
+    lhs = NM.r(oq.silu(NM.linear(A.float(), Wg.float())))
+    ref = NM.r(lhs * NM.linear(A.float(), Wu.float()))
+    Wf = ops.interleave_gate_up(Wg, Wu)
+    ops.gemm_plan(192, 1)
+    try:
+        got = ops.gemm(A.to(gpu), Wf.to(gpu), act=_lib.ACT_SILU_MUL_PAIRS)
+    finally:
+        ops.gemm_plan(0, 0)
+    assert_close_ulps(got, ref, 2, 0.97, "gemm gate/up pairs, 256x192 tile")
+
+
+def test_gemm_256x192_tile_equals_the_256_tile_bitwise(gpu):
+    """Same MFMA order along K, same rounding chain: the 192-column tile must reproduce the 256-column tile's output bit for bit
+    (a wrong staging row / fragment column would not survive this on random data) at the cfg 3 qkv shape."""
+    from aha_amd import ops
+    M, N, K = 1542, 6144, 4096
+    A, W = rnd((M, K), 96).to(gpu), rnd((N, K), 97, 0.02).to(gpu)
+    outs = []
+    for tile in (256, 192):
+        ops.gemm_plan(tile, 1)
+        try:
+            outs.append(ops.gemm(A, W))
+        finally:
+            ops.gemm_plan(0, 0)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_gemm_transpose_detect(gpu):
     """A = I against an asymmetric W: catches swapped C rows/cols (cdna guide: always A=I-check with asymmetric B)."""
     from aha_amd import ops
