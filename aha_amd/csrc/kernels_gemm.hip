@@ -1134,26 +1134,19 @@ GemmPlan plan_gemm(const GemmArgs& a) {
       best_cost = c;
     }
   }
-  // 256 x 192 tiles (gemm256q_kernel NF3; unsplit, plain / gate+up epilogues): a k step of the 3/4-size tile costs ~0.8 of the 256^2
-  // one (48 of 64 MFMAs per wave, the same barrier skeleton).  Rounds are counted in FULL row tiles -- a CU that draws a ragged row
-  // tile (M = 1542: 6 valid rows, MFMAs skipped) is back at the dispatcher after ~0.35 of a tile, which only costs time when no CU
-  // has slack left in the last round.  M = 1542, gate+up: 576 full 256^2 tiles = 3 rounds of 96 us for 2.25 rounds of work against
-  // 768 full 192-column tiles = 3 rounds of 77 us + the ragged ones.
+  // 256 x 192 tiles (gemm256q_kernel NF3; unsplit, plain / gate+up epilogues).  Measured on MI355X (scripts/bench_gemm_ragged.py,
+  // profiles/r03_gemm_n192.md): a k step of the 3/4-size tile costs 0.73-0.78 of the 256^2 one, but whenever both tilings fill the
+  // chip the GEMM runs at the same 1.15-1.28 PF either way (gate+up at M = 1280 / 1536 / 1542 / 1792: 228 / 269 / 262 / 281 us on
+  // 256^2 against 235 / 241 / 275 / 293 us) -- whole-chip throughput at this clock, not tile rounds, sets the time, and the ragged
+  // row tiles of the finer tiling stream one more pass of W.  Where it does pay is a launch whose 256^2 tiles leave CUs idle: the
+  // cfg 3 qkv GEMM is 168 tiles of 256^2 on 256 CUs and 224 of 256 x 192 (78-80 -> 64-73 us; 81.0 -> 75.3 us inside the prefill).
   static const bool n192_on = [] { const char* e = getenv("AHA_GEMM_N192"); return e ? atoi(e) != 0 : true; }();
   if (n192_on && !a.bias && !a.residual && (a.act == ACT_NONE || a.act == ACT_SILU_MUL_PAIRS) && a.K % BK == 0 && nk >= 8 && a.M >= 256 &&
       !(e_sk && atoi(e_sk) != 1) && !(e_tile && atoi(e_tile) != 192)) {
-    auto rounds_cost = [&](int tn, double kstep_us) {
-      const int full_m = a.M / 256, rag_m = (a.M % 256) ? 1 : 0, ntn = (a.N + tn - 1) / tn;
-      const double full = (double)full_m * ntn, ragged = (double)rag_m * ntn;
-      const double rounds = ceil(full / 256.0), slack = rounds * 256.0 - full;
-      double c = rounds * nk * kstep_us;
-      if (ragged * 0.35 > slack) c += 0.35 * nk * kstep_us;
-      return c;
-    };
-    const double c192 = rounds_cost(192, 1.5 * 0.8), c256 = rounds_cost(256, 1.5);
-    if ((c192 < best_cost && c192 < c256) || (e_tile && atoi(e_tile) == 192)) {
+    const double t192 = (double)((a.M + 255) / 256) * ((a.N + 191) / 192);
+    if ((best.tile == 256 && best.splitk == 1 && t256 < 256.0 && t192 <= 256.0 && t192 > t256) || (e_tile && atoi(e_tile) == 192)) {
       best = GemmPlan{192, 1};
-      best_cost = c192;
+      best_cost = nk * 1.5 * 0.78;
     }
   }
   static const char* e_dbg = getenv("AHA_GEMM_PLAN_DEBUG");

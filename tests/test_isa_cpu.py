@@ -121,7 +121,7 @@ def test_counted_waits_in_the_mfma_loops(tmp_path):
     full / ragged k loops, and the fused decode attention must keep its ladder of counted waits with at most one full drain."""
     shutil.copy(os.path.join(ROOT, "aha_amd", "csrc", "libaha_hip.so"), tmp_path / "lib.so")
     subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", "lib.so"], cwd=tmp_path, capture_output=True, check=True)
-    stats = {}
+    stats, fused_bodies = {}, {}
     for o in sorted(glob.glob(str(tmp_path / "lib.so.*gfx950"))):
         dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", o], capture_output=True, text=True, check=True).stdout
         cur, body = None, {}
@@ -133,6 +133,8 @@ def test_counted_waits_in_the_mfma_loops(tmp_path):
             if cur and family(cur) in ("gemm256q_kernel", "gemm256p_kernel", "attn_decode_fused_kernel"):
                 body.setdefault(cur, []).append(line.strip())
         for n, b in body.items():
+            if family(n) == "attn_decode_fused_kernel":
+                fused_bodies[n] = b
             mf = [i for i, l in enumerate(b) if l.startswith("v_mfma")]
             span = b[mf[0]:mf[-1]] if mf else []
             vm = [int(m.group(1)) for l in span if l.startswith("s_waitcnt") for m in [re.search(r"vmcnt\((\d+)\)", l)] if m]
@@ -149,5 +151,18 @@ def test_counted_waits_in_the_mfma_loops(tmp_path):
     for n, (n_mfma, drains, counted) in stats.items():
         if family(n) == "gemm256p_kernel" and "ELi0EEEvNS_8GemmArgs" in n:   # (the shipped MODE = 0 instantiations, not the ablations)
             assert n_mfma in (64, 128) and drains == 0 and counted >= 1, (n, n_mfma, drains, counted)
-    fused = [s for n, s in stats.items() if family(n) == "attn_decode_fused_kernel"]
-    assert len(fused) == 1 and fused[0][0] == 64 and fused[0][1] <= 1 and fused[0][2] >= 20, fused
+    # The fused decode attention also holds the merge code and (round 3) the weight-prefetch blocks, and the compiler lays its basic
+    # blocks out in its own order, so "between the first and the last MFMA" is not the page loop any more.  The page loop is where the
+    # MFMAs are DENSE: inside every run of MFMAs less than 80 instructions apart, all waits but one must be counted (no full drain of the K/V
+    # queue), and the ladder of counted waits must be there (64 MFMAs = two page bodies of 32).
+    fused = {n: b for n, b in fused_bodies.items()}
+    assert len(fused) == 1
+    b = next(iter(fused.values()))
+    mf = [i for i, l in enumerate(b) if l.startswith("v_mfma")]
+    assert len(mf) == 64
+    dense_vm = []
+    for i, j in zip(mf[:-1], mf[1:]):
+        if j - i < 80:
+            dense_vm += [int(m.group(1)) for l in b[i:j] if l.startswith("s_waitcnt") for m in [re.search(r"vmcnt\((\d+)\)", l)] if m]
+    # (one full drain is legitimate: the last V fragment of the PEELED last page, nothing newer in flight behind it)
+    assert sum(1 for v in dense_vm if v == 0) <= 1 and sum(1 for v in dense_vm if v >= 12) >= 20, dense_vm
