@@ -170,6 +170,19 @@ int aha_hip_last_logits(aha_model* m, float* logits_out) {
 
 size_t aha_hip_cache_len(const aha_model* m) { return m ? m->cache_len : 0; }
 int64_t aha_hip_debug_steps_executed(const aha_model* m) { return m ? m->steps_executed : 0; }
+int aha_hip_kv_export(aha_model* m, void* out_dev, size_t out_bytes, size_t* bytes_needed, size_t* n_tokens, int64_t* rope_delta) {
+  if (!m) return AHA_ERR_INVALID;
+  API_GUARD_BEGIN
+  return model_kv_export(m, out_dev, out_bytes, bytes_needed, n_tokens, rope_delta);
+  API_GUARD_END
+}
+int aha_hip_kv_import(aha_model* m, const void* in_dev, int32_t src_heads, int32_t src_head0, int32_t dst_head0, int32_t n_heads,
+                      size_t n_tokens, int64_t rope_delta) {
+  if (!m) return AHA_ERR_INVALID;
+  API_GUARD_BEGIN
+  return model_kv_import(m, in_dev, src_heads, src_head0, dst_head0, n_heads, n_tokens, rope_delta);
+  API_GUARD_END
+}
 
 int aha_hip_set_profiling(aha_model* m, int enable) {
   if (!m) return AHA_ERR_INVALID;

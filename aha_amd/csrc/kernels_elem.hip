@@ -484,6 +484,26 @@ void launch_row_to_f32(const void* x_or_null, float* out, int n, hipStream_t st)
 void launch_f32_to_row(const float* x, void* out, int n, hipStream_t st) {
   hipLaunchKernelGGL(f32_to_row_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, (bf16_t*)out, n);
 }
+// the same over a column block: x[r, c] (row pitch ldx) += bf16(s[r, c]) (row pitch lds), rows x cols, cols % 4 == 0
+__global__ __launch_bounds__(256) void residual_add_f32_cols_kernel(bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ s, int64_t lds,
+                                                                    int64_t rows, int cols) {
+  const int q = cols >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * q; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / q;
+    const int c = (int)(i - r * q) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(s + r * lds + c);
+    uint2 xv = *reinterpret_cast<const uint2*>(x + r * ldx + c);
+    xv.x = pack_bf(lo_bf(xv.x) + rbf(v.x), hi_bf(xv.x) + rbf(v.y));
+    xv.y = pack_bf(lo_bf(xv.y) + rbf(v.z), hi_bf(xv.y) + rbf(v.w));
+    *reinterpret_cast<uint2*>(x + r * ldx + c) = xv;
+  }
+}
+void launch_residual_add_f32_cols(void* x, int64_t ldx, const float* sum, int64_t lds, int64_t rows, int cols, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return;
+  const int64_t blocks = (rows * (cols >> 2) + 255) / 256;
+  hipLaunchKernelGGL(residual_add_f32_cols_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, (bf16_t*)x, ldx, sum, lds,
+                     rows, cols);
+}
 void launch_residual_add_f32(void* x, const float* sum, int64_t n, hipStream_t st) {
   if (n <= 0) return;
   const int64_t blocks = (n / 4 + 255) / 256;

@@ -125,6 +125,11 @@ struct aha_model {
   aha_all_gather_fn all_gather_cb = nullptr;
   void* sp_user = nullptr;
   void* rccl_comm = nullptr;
+  // sequence-parallel prefill with the collectives of a row-parallel projection overlapped with its GEMM (model.hip
+  // gemm_row_parallel): RCCL runs on its own high-priority stream, ordered against the compute stream by events
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_gemm[8] = {};
+  hipEvent_t ev_comm = nullptr;
   int async_rc = 0;             // first error of an all-reduce issued from inside an enqueue helper
   int lm_rows = 0, lm_row0 = 0; // lm_head rows this rank streams (vocab-parallel under TP) and the first of them
   float* d_partial = nullptr;   // decode: (hidden) f32 partial projection; also the 2T-float argmax pair exchange
@@ -182,6 +187,11 @@ int model_sample_candidates(aha_model* m, const uint32_t* ctx, size_t n_ctx, flo
                             float* vals_out, uint32_t* idx_out, float* max_out, float* sumexp_out);
 int model_ensure_pages(aha_model* m, size_t tokens);
 KvLayer model_kv_layer(aha_model* m, int layer);
+int model_kv_export(aha_model* m, void* out_dev, size_t out_bytes, size_t* bytes_needed, size_t* n_tokens, int64_t* rope_delta);
+int model_kv_import(aha_model* m, const void* in_dev, int src_heads, int src_head0, int dst_head0, int n_heads, size_t n_tokens,
+                    int64_t rope_delta);
+int model_kv_export(aha_model* m, void* out_dev, size_t out_bytes, size_t* bytes_needed, size_t* n_tokens, int64_t* rope_delta);
+int model_kv_import(aha_model* m, const void* in_dev, int src_heads, int src_head0, int dst_head0, int n_heads, size_t n_tokens, int64_t rope_delta);
 int prof_collect(aha_model* m);
 int model_allreduce(aha_model* m, float* buf, size_t count);
 // loader.hip
@@ -189,7 +199,7 @@ int config_parse(const char* dir, aha_model_desc* out);
 int weights_open(const char* dir, aha_weights** out);
 int model_load(aha_ctx* ctx, const char* dir, size_t kv_reserve_tokens, aha_model** out);
 int rccl_allreduce(aha_model* m, float* buf, size_t count);  // tp_rccl.hip
-int rccl_reduce_scatter(aha_model* m, float* buf, size_t count_per_rank);   // in place: rank r keeps slice r
+int rccl_reduce_scatter(aha_model* m, float* buf, size_t count_per_rank, hipStream_t st = nullptr);   // in place: rank r keeps slice r; st: stream (default: the model's)
 int rccl_all_gather(aha_model* m, void* buf, size_t bytes_per_rank);        // in place: slice r is rank r's contribution
 int tp_unique_id(void* out128);
 int tp_init_rccl(aha_model* m, const void* id128);

@@ -352,6 +352,77 @@ KvLayer model_kv_layer(aha_model* m, int layer) {
   return kv;
 }
 
+// ---- KV hand-back (include/aha_hip.h aha_hip_kv_export / aha_hip_kv_import) ---------------------------------------------------
+// One block per (page, layer, head, K|V): 16 KB = the head's fragment-major K (or V) block of that page, copied as bytes between
+// the page (page_ptrs[page] + layer * layer_stride + block offset) and the packed buffer [layer][page][head][K | V].
+constexpr int KV_BLOCK_BYTES = KV_PAGE_TOKENS * 128 * 2;
+__global__ __launch_bounds__(256) void kv_pack_kernel(const uint64_t* __restrict__ page_ptrs, uint64_t layer_stride, int kvh_local,
+                                                      char* __restrict__ buf, int buf_heads, int buf_head0, int local_head0, int n_pages,
+                                                      int to_pages) {
+  const int page = (int)blockIdx.x, layer = (int)blockIdx.y, h = (int)blockIdx.z >> 1, kv = (int)blockIdx.z & 1;
+  char* pg = reinterpret_cast<char*>(page_ptrs[page] + (uint64_t)layer * layer_stride) +
+             ((size_t)kv * kvh_local + (size_t)(local_head0 + h)) * KV_BLOCK_BYTES;
+  char* bf = buf + ((((size_t)layer * n_pages + page) * buf_heads + (size_t)(buf_head0 + h)) * 2 + kv) * KV_BLOCK_BYTES;
+  const u32x4_t* src = reinterpret_cast<const u32x4_t*>(to_pages ? bf : pg);
+  u32x4_t* dst = reinterpret_cast<u32x4_t*>(to_pages ? pg : bf);
+  u32x4_t v[KV_BLOCK_BYTES / 16 / 256];
+#pragma unroll
+  for (int i = 0; i < KV_BLOCK_BYTES / 16 / 256; ++i) v[i] = src[threadIdx.x + i * 256];
+#pragma unroll
+  for (int i = 0; i < KV_BLOCK_BYTES / 16 / 256; ++i) dst[threadIdx.x + i * 256] = v[i];
+}
+
+int model_kv_export(aha_model* m, void* out_dev, size_t out_bytes, size_t* bytes_needed, size_t* n_tokens, int64_t* rope_delta) {
+  const aha_model_desc& c = m->desc;
+  if (c.head_dim != 128) {
+    set_error("kv_export: head_dim 128 only");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  const size_t pages = (m->cache_len + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS;
+  const size_t need_bytes = (size_t)c.num_hidden_layers * pages * c.num_key_value_heads * 2 * KV_BLOCK_BYTES;
+  if (bytes_needed) *bytes_needed = need_bytes;
+  if (n_tokens) *n_tokens = m->cache_len;
+  if (rope_delta) *rope_delta = m->rope_delta;
+  if (!out_dev || pages == 0) return AHA_OK;
+  if (out_bytes < need_bytes) {
+    set_error("kv_export: the buffer holds " + std::to_string(out_bytes) + " bytes, " + std::to_string(need_bytes) + " are needed");
+    return AHA_ERR_INVALID;
+  }
+  AHA_HIP_CHECK(hipSetDevice(m->ctx->device));
+  hipLaunchKernelGGL(kv_pack_kernel, dim3((unsigned)pages, (unsigned)c.num_hidden_layers, (unsigned)c.num_key_value_heads * 2), dim3(256), 0,
+                     m->stream, m->d_page_ptrs, m->layer_stride, c.num_key_value_heads, (char*)out_dev, c.num_key_value_heads, 0, 0, (int)pages, 0);
+  AHA_HIP_CHECK(hipGetLastError());
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));   // the caller hands the buffer to a collective on another stream
+  return AHA_OK;
+}
+
+int model_kv_import(aha_model* m, const void* in_dev, int src_heads, int src_head0, int dst_head0, int n_heads, size_t n_tokens,
+                    int64_t rope_delta) {
+  const aha_model_desc& c = m->desc;
+  if (c.head_dim != 128) {
+    set_error("kv_import: head_dim 128 only");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  if (!in_dev || n_heads <= 0 || src_head0 < 0 || dst_head0 < 0 || src_head0 + n_heads > src_heads || dst_head0 + n_heads > c.num_key_value_heads) {
+    set_error("kv_import: head ranges out of bounds (buffer holds " + std::to_string(src_heads) + " heads, the model " +
+              std::to_string(c.num_key_value_heads) + ")");
+    return AHA_ERR_INVALID;
+  }
+  if (n_tokens == 0) return AHA_OK;
+  AHA_HIP_CHECK(hipSetDevice(m->ctx->device));
+  int rc = model_ensure_pages(m, n_tokens);
+  if (rc) return rc;
+  const size_t pages = (n_tokens + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS;
+  hipLaunchKernelGGL(kv_pack_kernel, dim3((unsigned)pages, (unsigned)c.num_hidden_layers, (unsigned)n_heads * 2), dim3(256), 0, m->stream,
+                     m->d_page_ptrs, m->layer_stride, c.num_key_value_heads, (char*)in_dev, src_heads, src_head0, dst_head0, (int)pages, 1);
+  AHA_HIP_CHECK(hipGetLastError());
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));   // the caller may free / reuse the buffer
+  m->cache_len = n_tokens;
+  m->rope_delta = rope_delta;
+  m->rope_delta_valid = true;
+  return AHA_OK;
+}
+
 static int assemble_logits(aha_model* m);
 
 // D11 candidates: see kernels_sample.hip.  Works on the logits the last forward_initial / forward_step / decode_greedy left
@@ -881,12 +952,78 @@ static void gemv_row_parallel(aha_model* m, GemvArgs g) {
 }
 // rows_per_rank > 0 selects the sequence-parallel form: the partial sums are reduce-scattered over row slices and only this
 // rank's rows [tp_rank * rows_per_rank, ...) of the residual stream are updated (the caller all-gathers the NORMALISED rows).
+// Column chunks of a sequence-parallel row-parallel projection ("chunk ... to overlap with GEMMs").  The
+// projection is cut along N (output columns) -- NOT along the rows, so that rank r keeps owning the contiguous rows
+// [r * rows_per_rank, ...) -- into `nch` GEMMs whose f32 partial sums land in separate (rows_pad x N / nch) blocks; the reduce-scatter
+// of block j (count_per_rank = rows_per_rank * N / nch: rank r receives its rows of that column block) runs on the communication
+// stream while the matrix cores compute block j + 1.  Same sums in the same order as the unchunked form: every output element is one
+// K-sum and one sum over ranks either way (tests/test_tp_gpu.py compares both with the all-reduce path bit for bit).  At cfg 5
+// (S = 40 980, T = 8) a projection's reduce-scatter moves 7/8 x 671 MB per rank against ~1.2 ms of GEMM per 1024-column block.
+static int tp_overlap_chunks(const aha_model* m, const GemmArgs& g) {
+  const char* e = getenv("AHA_TP_OVERLAP_CHUNKS");
+  const char* er = getenv("AHA_TP_OVERLAP_MIN_ROWS");
+  int nch = e ? atoi(e) : 4;
+  const int min_rows = er ? atoi(er) : 2048;
+  if (nch > 8) nch = 8;
+  if (nch <= 1 || g.M < min_rows) return 1;
+  while (nch > 1 && (g.N % nch != 0 || (g.N / nch) % 256 != 0)) --nch;
+  return nch;
+}
+static int ensure_comm_stream(aha_model* m) {
+  if (m->comm_stream) return AHA_OK;
+  int lo = 0, hi = 0;
+  AHA_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // (numerically lowest = highest priority)
+  AHA_HIP_CHECK(hipStreamCreateWithPriority(&m->comm_stream, hipStreamNonBlocking, hi));
+  for (auto& ev : m->ev_gemm) AHA_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  AHA_HIP_CHECK(hipEventCreateWithFlags(&m->ev_comm, hipEventDisableTiming));
+  return AHA_OK;
+}
+
+// rows_per_rank > 0 selects the sequence-parallel form: the partial sums are reduce-scattered over row slices and only this
+// rank's rows [tp_rank * rows_per_rank, ...) of the residual stream are updated (the caller all-gathers the NORMALISED rows).
 static int gemm_row_parallel(aha_model* m, GemmArgs g, int rows_per_rank = 0) {
   if (m->tp_size <= 1) {
     launch_gemm(g, m->stream);
     return AHA_OK;
   }
   void* xres = g.C;
+  const int nch = rows_per_rank > 0 ? tp_overlap_chunks(m, g) : 1;
+  if (nch > 1) {
+    const int N = g.N, Nc = N / nch;
+    const size_t rows_pad = (size_t)rows_per_rank * m->tp_size;
+    const bool on_comm_stream = m->rccl_comm != nullptr;   // host-callback seam (tests): the callback synchronises, no overlap to set up
+    int rc;
+    if (on_comm_stream && (rc = ensure_comm_stream(m))) return rc;
+    for (int j = 0; j < nch; ++j) {
+      GemmArgs gj = g;
+      gj.W = (const bf16_t*)g.W + (int64_t)j * Nc * g.ldw;
+      gj.C = m->p_partial + (size_t)j * rows_pad * Nc;
+      gj.N = Nc;
+      gj.ldc = Nc;
+      gj.residual = nullptr;
+      gj.norm_w = nullptr;
+      gj.act = ACT_PARTIAL_F32;
+      launch_gemm(gj, m->stream);
+      float* bj = m->p_partial + (size_t)j * rows_pad * Nc;
+      if (on_comm_stream) {
+        ProfScope ps(m, "reduce_scatter", (double)rows_pad * Nc * 4, 0);
+        AHA_HIP_CHECK(hipEventRecord(m->ev_gemm[j], m->stream));
+        AHA_HIP_CHECK(hipStreamWaitEvent(m->comm_stream, m->ev_gemm[j], 0));
+        if ((rc = rccl_reduce_scatter(m, bj, (size_t)rows_per_rank * Nc, m->comm_stream))) return rc;
+      } else if ((rc = model_reduce_scatter(m, bj, (size_t)rows_per_rank * Nc))) {
+        return rc;
+      }
+    }
+    if (on_comm_stream) {
+      AHA_HIP_CHECK(hipEventRecord(m->ev_comm, m->comm_stream));
+      AHA_HIP_CHECK(hipStreamWaitEvent(m->stream, m->ev_comm, 0));
+    }
+    const int64_t r0 = (int64_t)m->tp_rank * rows_per_rank, r1 = std::min<int64_t>(g.M, r0 + rows_per_rank);
+    for (int j = 0; j < nch && r1 > r0; ++j)
+      launch_residual_add_f32_cols((char*)xres + (r0 * N + (int64_t)j * Nc) * 2, N, m->p_partial + (size_t)j * rows_pad * Nc + r0 * Nc, Nc, r1 - r0,
+                                   Nc, m->stream);
+    return AHA_OK;
+  }
   g.C = m->p_partial;
   g.residual = nullptr;
   g.act = ACT_PARTIAL_F32;

@@ -20,9 +20,9 @@ int rccl_allreduce(aha_model* m, float* buf, size_t count) {
 // Sequence-parallel prefill: the same f32 sums as the all-reduce, but each rank receives only its row slice (in place:
 // recvbuff == sendbuff + rank * recvcount), and the bf16 rows of the next GEMM's input are gathered in place
 // (sendbuff == recvbuff + rank * sendcount).
-int rccl_reduce_scatter(aha_model* m, float* buf, size_t count_per_rank) {
+int rccl_reduce_scatter(aha_model* m, float* buf, size_t count_per_rank, hipStream_t st) {
   ncclResult_t r = ncclReduceScatter(buf, buf + (size_t)m->tp_rank * count_per_rank, count_per_rank, ncclFloat, ncclSum,
-                                     (ncclComm_t)m->rccl_comm, m->stream);
+                                     (ncclComm_t)m->rccl_comm, st ? st : m->stream);
   if (r != ncclSuccess) {
     set_error(std::string("ncclReduceScatter failed: ") + ncclGetErrorString(r));
     return AHA_ERR_HIP;
@@ -70,6 +70,14 @@ int tp_init_rccl(aha_model* m, const void* id128) {
 void tp_destroy(aha_model* m) {
   if (m->rccl_comm) ncclCommDestroy((ncclComm_t)m->rccl_comm);
   m->rccl_comm = nullptr;
+  if (m->comm_stream) hipStreamDestroy(m->comm_stream);
+  m->comm_stream = nullptr;
+  for (auto& e : m->ev_gemm) {
+    if (e) hipEventDestroy(e);
+    e = nullptr;
+  }
+  if (m->ev_comm) hipEventDestroy(m->ev_comm);
+  m->ev_comm = nullptr;
 }
 
 }  // namespace aha

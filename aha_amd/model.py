@@ -314,6 +314,22 @@ class HipInferenceModel:
     def cache_len(self) -> int:
         return int(lib().aha_hip_cache_len(self.handle))
 
+    def kv_export(self):
+        """aha_hip_kv_export: -> (uint8 tensor on this model's GPU holding [layer][page][local kv head][K | V] blocks, n_tokens,
+        rope_delta).  The byte image of this rank's share of the cache -- what crosses the gather after a sharded prefill."""
+        need, ntok, delta = C.c_size_t(), C.c_size_t(), C.c_int64()
+        check(lib().aha_hip_kv_export(self.handle, None, 0, C.byref(need), C.byref(ntok), C.byref(delta)))
+        buf = torch.empty(need.value, dtype=torch.uint8, device=f"cuda:{self.ctx.device}")
+        torch.cuda.current_stream(buf.device).synchronize()
+        check(lib().aha_hip_kv_export(self.handle, buf.data_ptr(), buf.numel(), None, None, None))
+        return buf, int(ntok.value), int(delta.value)
+
+    def kv_import(self, buf: torch.Tensor, src_heads: int, src_head0: int, dst_head0: int, n_heads: int, n_tokens: int, rope_delta: int):
+        """aha_hip_kv_import: heads [src_head0, +n_heads) of a packed buffer (src_heads per page) -> this model's heads [dst_head0, ..)."""
+        assert buf.is_cuda and buf.dtype == torch.uint8 and buf.is_contiguous()
+        torch.cuda.current_stream(buf.device).synchronize()
+        check(lib().aha_hip_kv_import(self.handle, buf.data_ptr(), src_heads, src_head0, dst_head0, n_heads, n_tokens, rope_delta))
+
     def debug_steps_executed(self) -> int:
         return int(lib().aha_hip_debug_steps_executed(self.handle))
 

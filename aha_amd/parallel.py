@@ -141,3 +141,32 @@ def sharded_prefill(cfg, weights, input_ids, data, rank: int, world: int, device
         torch.cuda.synchronize()
         worst = max(worst, time.perf_counter() - t0)
     return tok, worst, model
+
+
+def gather_kv_to_rank0(tp_model, full_model, rank: int, world: int):
+    """KV hand-back after a sharded prefill (north_star: decode stays single-GPU): every rank packs the
+    K / V of its kv heads (aha_hip_kv_export: [layer][page][head][K | V] blocks, the byte image of its pages), ONE gather moves the
+    packs to rank 0 (RCCL over xGMI under the nccl backend: 738 MB per rank at 41 k tokens of the 8B model; gloo moves host copies),
+    and rank 0's un-sharded model (`full_model`: all heads, all weights -- 15 GB next to 288 GB) scatters rank r's heads into its own
+    pages at head offset r * kv_heads / world (aha_hip_kv_import), taking over the cache length and the rope_delta.  Rank 0 then
+    decodes alone, exactly as after a single-GPU prefill.  Returns the number of cached tokens (rank 0) or None."""
+    import torch
+    import torch.distributed as dist
+    buf, n_tokens, delta = tp_model.kv_export()
+    if world == 1 or not dist.is_initialized():
+        if full_model is not None and full_model is not tp_model:
+            kvh = full_model.text_cfg.num_key_value_heads
+            full_model.kv_import(buf, kvh, 0, 0, kvh, n_tokens, delta)
+        return n_tokens
+    on_host = dist.get_backend() != "nccl"
+    send = buf.cpu() if on_host else buf
+    parts = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+    dist.gather(send, parts, dst=0)
+    if rank != 0:
+        return None
+    kvh = full_model.text_cfg.num_key_value_heads
+    per = kvh // world
+    for r, part in enumerate(parts):
+        part = part.to(buf.device) if on_host else part
+        full_model.kv_import(part, per, 0, r * per, per, n_tokens, delta)
+    return n_tokens

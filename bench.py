@@ -158,6 +158,28 @@ def sharded_prefill_bench(rank, world, local_rank, n_images=8, image_px=2048, pr
     torch.cuda.synchronize()
     tok, secs, model = parallel.sharded_prefill(cfg, w, ids, data, rank, world, local_rank, kv_reserve_tokens=len(ids) + 4096,
                                                 repeats=repeats)
+    # BASELINE cfg 5 is "prefill + 16 tokens", and decode stays single-GPU (north_star): the head-sharded KV cache is gathered into an
+    # un-sharded model on rank 0 (parallel.gather_kv_to_rank0: one RCCL gather of the packed pages), which decodes the 16 tokens alone
+    from aha_amd.model import HipInferenceModel
+    handback = {}
+    full = model
+    if world > 1:
+        full = HipInferenceModel(cfg, w, device=local_rank, kv_reserve_tokens=len(ids) + 4096) if rank == 0 else None
+        import torch.distributed as dist
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        parallel.gather_kv_to_rank0(model, full, rank, world)
+        torch.cuda.synchronize()
+        dist.barrier()
+        handback["kv_handback_s"] = round(time.perf_counter() - t0, 4)
+    if rank == 0:
+        t0 = time.perf_counter()
+        out = full.decode_greedy(tok, len(ids), 16)
+        handback["decode_16_after_prefill_s"] = round(time.perf_counter() - t0, 4)
+        handback["decode_tokens"] = len(out)
+        if full is not model:
+            full.close()
     del w
     value, worst = parallel.aggregate_throughput(float(len(ids)) / world, secs, device=dev)   # sum of shares / max seconds
     toks = torch.tensor([tok], dtype=torch.int64, device=dev)
@@ -172,7 +194,7 @@ def sharded_prefill_bench(rank, world, local_rank, n_images=8, image_px=2048, pr
     return {"metric": METRICS["qwen3vl8b-cfg5-tp"], "value": round(value, 1), "unit": "tokens/s", "prefill_s": round(worst, 4),
             "prompt_tokens": len(ids), "n_images": n_images, "image": image_px, "scaling": "strong",
             "parallelism": f"tp{world} (RCCL all-reduce of the row-parallel partial sums) + image-parallel ViT (all-gather)",
-            "rccl_ranks": world, "first_token_equal_on_all_ranks": same}
+            "rccl_ranks": world, "first_token_equal_on_all_ranks": same, **handback}
 
 def self_launch(n: int) -> int:
     """Re-executes this command under torch.distributed.run with n ranks on 127.0.0.1 (a free port) and returns its exit code."""

@@ -269,6 +269,20 @@ int aha_hip_tp_init_rccl(aha_model* m, const void* unique_id128);
 typedef int (*aha_reduce_scatter_fn)(void* buf_f32_dev, size_t count_per_rank, void* user);
 typedef int (*aha_all_gather_fn)(void* buf_dev, size_t bytes_per_rank, void* user);
 int aha_hip_set_seq_parallel(aha_model* m, aha_reduce_scatter_fn reduce_scatter, aha_all_gather_fn all_gather, void* user);
+/* KV hand-back after a sharded prefill ("for single-GPU decode afterwards, all-gather KV to GPU 0";
+ * north_star: decode stays single-GPU).  A tensor-parallel prefill leaves every rank with the K / V of ITS kv heads, in its own
+ * pages.  aha_hip_kv_export packs them into a contiguous device buffer
+ *     [layer][page][this rank's kv head][K block 16 KB | V block 16 KB]      (pages = ceil(cache_len / 64), fragment-major blocks)
+ * = the byte image of the pages, so it can cross a collective (RCCL gather / all-gather, 738 MB per rank and 41 k tokens at 8B)
+ * untouched; aha_hip_kv_import copies `n_heads` heads starting at head `src_head0` of such a buffer (which holds `src_heads` heads
+ * per page) into heads [dst_head0, dst_head0 + n_heads) of THIS model's pages -- an un-sharded model on GPU 0 imports rank r's
+ * buffer at dst_head0 = r * kv_heads / T --, maps pages for n_tokens, and sets the cache length and the Qwen3-VL rope_delta so
+ * that forward_step / decode_greedy continue exactly as after a single-GPU prefill.  out_dev NULL: only the sizes are returned.
+ * No reference counterpart (the reference has no collectives): the contract is "decode after export + import == decode after
+ * the same prefill on one GPU" (tests/test_tp_gpu.py). */
+int aha_hip_kv_export(aha_model* m, void* out_dev, size_t out_bytes, size_t* bytes_needed, size_t* n_tokens, int64_t* rope_delta);
+int aha_hip_kv_import(aha_model* m, const void* in_dev, int32_t src_heads, int32_t src_head0, int32_t dst_head0, int32_t n_heads,
+                      size_t n_tokens, int64_t rope_delta);
 /* Test hook: run the installed all-reduce (RCCL communicator or callback) once on a caller-owned f32 device buffer and
  * wait for it.  Lets a 1-GPU box exercise the RCCL wiring with a communicator of size 1. */
 int aha_hip_debug_allreduce(aha_model* m, void* buf_f32_dev, size_t count);

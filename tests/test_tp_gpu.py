@@ -269,3 +269,103 @@ def test_tp2_two_processes_gloo(gpu):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "TP_WORKER_OK" in r.stdout, r.stdout[-2000:]
+
+
+def test_kv_export_import_round_trip_is_exact(gpu):
+    """aha_hip_kv_export / aha_hip_kv_import (the KV hand-back after a sharded prefill): the packed buffer is the byte image of the
+    pages, so a cache exported from one model and imported into a fresh one -- as ONE shard, and as two half-head shards the way a
+    TP = 2 gather delivers them, also under a scrambled physical page order on the importing side -- must decode bit-identically,
+    text and Qwen3-VL (rope_delta travels with the cache)."""
+    from aha_amd.model import HipInferenceModel, MultiModalData
+    from oracle.numerics import Numerics
+    from oracle import qwen3vl as ov
+    cfg = tiny_qwen3()
+    w = qwen3_text_weights(cfg, seed=0)
+    ids = [int(x) for x in np.random.default_rng(5).integers(0, cfg.vocab_size, size=150)]   # 3 pages, the last one partly filled
+    a = HipInferenceModel(cfg, w)
+    _, tok = a.forward_initial(ids, 0)
+    buf, ntok, delta = a.kv_export()
+    kvh = cfg.num_key_value_heads
+    assert ntok == 150 and buf.numel() == cfg.num_hidden_layers * 3 * kvh * 2 * 16384
+    ref = [a.forward_step(tok, 150)[0].copy()]
+    ref.append(a.forward_step(7, 151)[0].copy())
+    for halves, scramble in ((False, False), (True, False), (True, True)):
+        c = HipInferenceModel(cfg, w)
+        c.debug_scramble_pages(scramble)
+        if halves:
+            h = kvh // 2
+            c.kv_import(buf, kvh, 0, 0, h, ntok, delta)          # heads [0, h) of the buffer -> heads [0, h)
+            c.kv_import(buf, kvh, h, h, kvh - h, ntok, delta)    # heads [h, kvh)
+        else:
+            c.kv_import(buf, kvh, 0, 0, kvh, ntok, delta)
+        assert c.cache_len() == 150
+        np.testing.assert_array_equal(c.forward_step(tok, 150)[0], ref[0])
+        np.testing.assert_array_equal(c.forward_step(7, 151)[0], ref[1])
+        c.close()
+    a.close()
+    # a shard buffer that holds only h heads (what a TP rank exports): built by slicing the full buffer's head axis
+    full = buf.view(cfg.num_hidden_layers, 3, kvh, 2 * 16384)
+    c = HipInferenceModel(cfg, w)
+    for r in range(2):
+        h = kvh // 2
+        shard = full[:, :, r * h:(r + 1) * h].contiguous().view(-1)
+        c.kv_import(shard, h, 0, r * h, h, ntok, delta)
+    np.testing.assert_array_equal(c.forward_step(tok, 150)[0], ref[0])
+    c.close()
+    # Qwen3-VL: the decode position is seqlen_offset + rope_delta
+    vcfg = tiny_qwen3vl()
+    vw = qwen3vl_weights(vcfg, seed=0)
+    g = np.random.default_rng(7)
+    img = g.integers(0, 256, size=(96, 160, 3), dtype=np.uint8)
+    pv, grid = ov.process_images(Numerics("bf16"), [img])
+    vids = [3, 4] + [vcfg.vision_start_token_id] + [vcfg.image_token_id] * (int(grid[0, 1] * grid[0, 2]) // 4) + [vcfg.vision_end_token_id] + [9, 10, 11]
+    va = HipInferenceModel(vcfg, vw)
+    _, vt = va.forward_initial(vids, 0, MultiModalData(pv.to(torch.bfloat16), grid))
+    vbuf, vn, vdelta = va.kv_export()
+    assert vdelta < 0
+    vref = va.forward_step(vt, len(vids))[0].copy()
+    vc = HipInferenceModel(vcfg, vw)
+    vc.kv_import(vbuf, vcfg.text.num_key_value_heads, 0, 0, vcfg.text.num_key_value_heads, vn, vdelta)
+    np.testing.assert_array_equal(vc.forward_step(vt, len(vids))[0], vref)
+    va.close(); vc.close()
+    # bounds are checked
+    from aha_amd._lib import AhaHipError
+    c = HipInferenceModel(cfg, w)
+    with pytest.raises(AhaHipError):
+        c.kv_import(buf, kvh, 0, 1, kvh, ntok, delta)
+    c.close()
+
+
+@pytest.mark.parametrize("S", [300, 513])
+def test_tp2_column_chunked_reduce_scatter_equals_the_unchunked_paths(gpu, S, monkeypatch):
+    """The overlap form of the sequence-parallel prefill (model.hip gemm_row_parallel: the row-parallel projection cut into column
+    blocks, one reduce-scatter per block -- on the RCCL communication stream while the next block's GEMM runs; through the host
+    callbacks here, which serialise it but move the same data): every output element is still one K-sum and one sum over ranks, so
+    the logits must equal the unchunked sequence-parallel path AND the all-reduce path bit for bit.  hidden 512 -> two 256-column
+    blocks; ragged row slices at S = 513."""
+    from aha_amd.model import HipInferenceModel
+    cfg = tiny_qwen3(layers=2, hidden=512, heads=4, kv_heads=2, inter=1024, vocab=1024)
+    w = qwen3_text_weights(cfg, seed=0)
+    ids = [int(x) for x in np.random.default_rng(S).integers(0, cfg.vocab_size, size=S)]
+    outs = {}
+    for mode in ("allreduce", "sp", "sp_chunked"):
+        monkeypatch.setenv("AHA_TP_OVERLAP_MIN_ROWS", "64" if mode == "sp_chunked" else "1000000")
+        red = TwoRankSum()
+        sp = mode != "allreduce"
+        ranks = [HipInferenceModel(cfg, w, tp_rank=r, tp_size=2, allreduce=lambda p, n, r=r: red.allreduce(r, p, n),
+                                   reduce_scatter=(lambda p, n, r=r: red.reduce_scatter(r, p, n)) if sp else None,
+                                   all_gather=(lambda p, n, r=r: red.all_gather(r, p, n)) if sp else None) for r in range(2)]
+        got = run_ranks([lambda m=m: m.forward_initial(ids, 0)[0].copy() for m in ranks])
+        np.testing.assert_array_equal(got[0], got[1])
+        if mode == "sp":
+            assert red.rs_calls == 2 * cfg.num_hidden_layers
+        if mode == "sp_chunked":
+            assert red.rs_calls == 2 * 2 * cfg.num_hidden_layers      # two column blocks per projection
+        tok = int(np.argmax(got[0]))
+        step = run_ranks([lambda m=m: m.forward_step(tok, S)[0].copy() for m in ranks])
+        outs[mode] = (got[0], step[0])
+        for m in ranks:
+            m.close()
+    for mode in ("sp", "sp_chunked"):
+        np.testing.assert_array_equal(outs[mode][0], outs["allreduce"][0])
+        np.testing.assert_array_equal(outs[mode][1], outs["allreduce"][1])

@@ -82,6 +82,11 @@ def main():
 
     emb = parallel.encode_images_sharded(enc, list(range(len(imgs))), toks, world, rank).cuda().contiguous()
     got, tok = m.forward_initial(ids, 0, MultiModalData(image_grid_thw=grid, image_embeds=emb))
+    # KV hand-back: the head-sharded cache of the TP prefill gathered into an UN-sharded model on rank 0,
+    # which then decodes alone (north_star: decode stays single-GPU); checked below against a model prefilled on one GPU
+    handback = HipInferenceModel(cfg, w) if rank == 0 else None
+    n_cached = parallel.gather_kv_to_rank0(m, handback, rank, world)
+    assert (n_cached == len(ids)) if rank == 0 else (n_cached is None)
     dec = [tok]
     off = len(ids)
     for _ in range(6):
@@ -108,8 +113,17 @@ def main():
         s2 = float(rl.std())
         assert float(np.abs(lg - rl).max()) <= 0.03 * s2 or dec != rdec, "TP decode logits drifted"
         margin_ok = dec == rdec
-        print(f"TP_WORKER_OK tokens_equal={margin_ok} allreduce_calls={calls[0]} reduce_scatter_calls={sp_calls[0]} "
-              f"all_gather_calls={sp_calls[1]}", flush=True)
+        # single-GPU decode on the gathered cache: position / rope_delta / cache length taken over by aha_hip_kv_import
+        assert handback.cache_len() == len(ids)
+        hdec, o3 = [rtok], len(ids)
+        for i in range(6):                     # teacher-forced with the single-GPU run's tokens: same inputs on both sides
+            hl, t = handback.forward_step(rdec[i], o3)
+            hdec.append(t)
+            o3 += 1
+        assert float(np.abs(hl - rl).max()) <= 0.03 * s2, "decode on the gathered KV cache drifted from the single-GPU run"
+        print(f"TP_WORKER_OK tokens_equal={margin_ok} handback_tokens_equal={hdec == rdec} allreduce_calls={calls[0]} "
+              f"reduce_scatter_calls={sp_calls[0]} all_gather_calls={sp_calls[1]}", flush=True)
+        handback.close()
         single.close()
     m.close()
     dist.barrier()
