@@ -170,6 +170,12 @@ int aha_hip_last_logits(aha_model* m, float* logits_out) {
 
 size_t aha_hip_cache_len(const aha_model* m) { return m ? m->cache_len : 0; }
 int64_t aha_hip_debug_steps_executed(const aha_model* m) { return m ? m->steps_executed : 0; }
+int aha_hip_debug_graph_step(aha_model* m, int32_t replays, double* us_launches, double* us_graph) {
+  if (!m) return AHA_ERR_INVALID;
+  API_GUARD_BEGIN
+  return model_debug_graph_step(m, replays, us_launches, us_graph);
+  API_GUARD_END
+}
 int aha_hip_kv_export(aha_model* m, void* out_dev, size_t out_bytes, size_t* bytes_needed, size_t* n_tokens, int64_t* rope_delta) {
   if (!m) return AHA_ERR_INVALID;
   API_GUARD_BEGIN

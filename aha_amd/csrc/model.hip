@@ -1255,6 +1255,61 @@ int model_forward_step(aha_model* m, uint32_t token, size_t offset, float* logit
   return fetch_outputs(m, logits_out, argmax_out);
 }
 
+// Diagnostic (include/aha_hip.h aha_hip_debug_graph_step): what a hipGraph replay of ONE decode step would cost against enqueueing
+// its launches, at the current cache length.  Both variants run `replays` times with the SAME kernel arguments (lengths travel as
+// kernel arguments here, so a captured step can only be replayed for the length it was captured at): the attention's split-arrival
+// target is stale after the first repetition in BOTH, the step's results are not meaningful, and the cache is cleared afterwards --
+// the comparison isolates the launch path (stream launches vs one graph launch), nothing else.
+int model_debug_graph_step(aha_model* m, int replays, double* us_launches, double* us_graph) {
+  if (replays <= 0 || m->cache_len == 0 || m->tp_size > 1 || m->profiling) {
+    set_error("debug_graph_step: needs a non-empty cache, tp_size 1, profiling off, replays > 0");
+    return AHA_ERR_STATE;
+  }
+  AHA_HIP_CHECK(hipSetDevice(m->ctx->device));
+  int rc = model_ensure_pages(m, m->cache_len + 1);
+  if (rc) return rc;
+  const int64_t pos[3] = {(int64_t)m->cache_len, (int64_t)m->cache_len, (int64_t)m->cache_len};
+  if ((rc = push_state(m, 0, pos, m->cache_len, m->cache_len + 1))) return rc;
+  hipEvent_t e0, e1;
+  AHA_HIP_CHECK(hipEventCreate(&e0));
+  AHA_HIP_CHECK(hipEventCreate(&e1));
+  const unsigned base = m->head_ctr_base;
+  auto step_with_fixed_args = [&] {
+    m->head_ctr_base = base;   // the same arguments every repetition (see above)
+    enqueue_decode_step(m, m->cache_len + 1);
+  };
+  for (int i = 0; i < 3; ++i) step_with_fixed_args();
+  AHA_HIP_CHECK(hipEventRecord(e0, m->stream));
+  for (int i = 0; i < replays; ++i) step_with_fixed_args();
+  AHA_HIP_CHECK(hipEventRecord(e1, m->stream));
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  float ms = 0.f;
+  AHA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  if (us_launches) *us_launches = 1e3 * ms / replays;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  AHA_HIP_CHECK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+  step_with_fixed_args();
+  AHA_HIP_CHECK(hipStreamEndCapture(m->stream, &graph));
+  AHA_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  for (int i = 0; i < 3; ++i) AHA_HIP_CHECK(hipGraphLaunch(exec, m->stream));
+  AHA_HIP_CHECK(hipEventRecord(e0, m->stream));
+  for (int i = 0; i < replays; ++i) AHA_HIP_CHECK(hipGraphLaunch(exec, m->stream));
+  AHA_HIP_CHECK(hipEventRecord(e1, m->stream));
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  AHA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  if (us_graph) *us_graph = 1e3 * ms / replays;
+  hipGraphExecDestroy(exec);
+  hipGraphDestroy(graph);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  // leave a consistent model behind: arrival counters back to zero, cache cleared
+  AHA_HIP_CHECK(hipMemsetAsync(m->d_bar, 0, DECODE_SYNC_BYTES, m->stream));
+  m->head_ctr_base = 0;
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  return model_clear_cache(m);
+}
+
 int model_decode_greedy(aha_model* m, uint32_t first_token, size_t offset, size_t max_new, uint32_t* out) {
   const aha_model_desc& c = m->desc;
   if (max_new == 0) return 0;

@@ -330,6 +330,12 @@ class HipInferenceModel:
         torch.cuda.current_stream(buf.device).synchronize()
         check(lib().aha_hip_kv_import(self.handle, buf.data_ptr(), src_heads, src_head0, dst_head0, n_heads, n_tokens, rope_delta))
 
+    def debug_graph_step(self, replays: int = 50):
+        """(us per decode step enqueued launch by launch, us per step replayed as one hipGraph) at the current cache length; clears the cache."""
+        a, b = C.c_double(), C.c_double()
+        check(lib().aha_hip_debug_graph_step(self.handle, replays, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def debug_steps_executed(self) -> int:
         return int(lib().aha_hip_debug_steps_executed(self.handle))
 

@@ -193,7 +193,8 @@ def sharded_prefill_bench(rank, world, local_rank, n_images=8, image_px=2048, pr
     torch.cuda.empty_cache()
     return {"metric": METRICS["qwen3vl8b-cfg5-tp"], "value": round(value, 1), "unit": "tokens/s", "prefill_s": round(worst, 4),
             "prompt_tokens": len(ids), "n_images": n_images, "image": image_px, "scaling": "strong",
-            "parallelism": f"tp{world} (RCCL all-reduce of the row-parallel partial sums) + image-parallel ViT (all-gather)",
+            "parallelism": f"tp{world} (sequence-parallel: RCCL reduce-scatter of the row-parallel partial sums in column blocks overlapped with "
+                           "the GEMMs + all-gather of the normalised rows) + image-parallel ViT (all-gather) + KV gather to rank 0 for decode",
             "rccl_ranks": world, "first_token_equal_on_all_ranks": same, **handback}
 
 def self_launch(n: int) -> int:
@@ -294,6 +295,9 @@ def main():
                     "config": {"workload": args.workload, "prompt_tokens": sp["prompt_tokens"], "image": sp["image"],
                                "n_images": sp["n_images"], "parallelism": sp["parallelism"], "rccl_ranks": world},
                     "first_token_equal_on_all_ranks": sp["first_token_equal_on_all_ranks"]}
+            for k in ("kv_handback_s", "decode_16_after_prefill_s", "decode_tokens"):
+                if k in sp:
+                    line[k] = sp[k]
             print(json.dumps(line), flush=True)
         if world > 1:
             dist.barrier()

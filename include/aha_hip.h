@@ -292,6 +292,9 @@ size_t aha_hip_cache_len(const aha_model* m);
 /* Decode steps the device ran in the last aha_hip_decode_greedy call, including the ones queued past a stop token (at most
  * AHA_DECODE_RUNAHEAD - 1 = 3 by default: the host watches the tokens in pinned memory while later steps are queued). */
 int64_t aha_hip_debug_steps_executed(const aha_model* m);
+/* Diagnostic: microseconds per decode step at the current cache length, (a) enqueued launch by launch, (b) replayed as one captured
+ * hipGraph -- identical kernel arguments in both, results discarded, the cache is cleared afterwards (scripts/bench_graph_step.py). */
+int aha_hip_debug_graph_step(aha_model* m, int32_t replays, double* us_launches, double* us_graph);
 /* Per-kernel-class HIP-event timing of subsequent forward calls (adds one event pair per launch).  0 = off. */
 int aha_hip_set_profiling(aha_model* m, int enable);
 /* name: e.g. "gemv", "gemm", "attn_decode", "attn_prefill".  Returns accumulated ms and launch count since enable. */
