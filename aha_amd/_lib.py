@@ -127,6 +127,7 @@ SIGNATURES = {
     "aha_hip_get_rope_index_mm": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int32, _P, C.c_int32, _P, _P]),
     "aha_hip_embed": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "aha_hip_config_parse": (C.c_int, [C.c_char_p, _P]),
+    "aha_hip_config_torch_dtype": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
     "aha_hip_weights_open": (C.c_int, [C.c_char_p, _P]),
     "aha_hip_weights_count": (C.c_size_t, [_P]),
     "aha_hip_weights_get": (C.c_int, [_P, C.c_size_t, _P]),

@@ -578,6 +578,23 @@ int aha_hip_config_parse(const char* model_dir, aha_model_desc* out) {
   return config_parse(model_dir, out);
   API_GUARD_END
 }
+int aha_hip_config_torch_dtype(const char* model_dir, char* out, size_t cap) {
+  API_GUARD_BEGIN
+  if (!model_dir || !out || cap == 0) {
+    set_error("aha_hip_config_torch_dtype: null argument");
+    return AHA_ERR_INVALID;
+  }
+  std::string s;
+  const int rc = config_torch_dtype(model_dir, &s);
+  if (rc) return rc;
+  if (s.size() + 1 > cap) {
+    set_error("aha_hip_config_torch_dtype: the buffer is too small");
+    return AHA_ERR_INVALID;
+  }
+  memcpy(out, s.c_str(), s.size() + 1);
+  return AHA_OK;
+  API_GUARD_END
+}
 int aha_hip_weights_open(const char* model_dir, aha_weights** out) {
   API_GUARD_BEGIN
   if (!model_dir || !out) {

@@ -105,6 +105,38 @@ int parse_text_tower(const JsonValue& t, const std::string& where, aha_model_des
 
 }  // namespace
 
+// The string get_dtype's cfg_dtype argument receives in the reference's XxxGenerateModel::init: Qwen3 `cfg.torch_dtype`
+// (qwen3/config.rs:23, generate.rs:28), Qwen3-VL `text_config.dtype` (qwen3vl/config.rs:100), Qwen3-ASR the constant "bfloat16"
+// (qwen3_asr/config.rs:186).  A missing field is an error (serde: no default on it).
+int config_torch_dtype(const char* dir, std::string* out) {
+  const std::string where = std::string(dir) + "/config.json";
+  JsonValue cfg;
+  NEED(parse_json_file(where, &cfg, true));
+  if (cfg.kind != JsonValue::OBJ) {
+    set_error(where + ": top level is not an object");
+    return AHA_ERR_INVALID;
+  }
+  if (cfg.get("thinker_config")) {
+    *out = "bfloat16";
+    return AHA_OK;
+  }
+  const JsonValue* v = nullptr;
+  std::string field = "torch_dtype";
+  if (cfg.get("vision_config")) {
+    const JsonValue* t = cfg.get("text_config");
+    v = t ? t->get("dtype") : nullptr;
+    field = "text_config.dtype";
+  } else {
+    v = cfg.get("torch_dtype");
+  }
+  if (!v || v->kind != JsonValue::STR) {
+    set_error(where + ": missing string field \"" + field + "\"");
+    return AHA_ERR_INVALID;
+  }
+  *out = v->str;
+  return AHA_OK;
+}
+
 int config_parse(const char* dir, aha_model_desc* d) {
   memset(d, 0, sizeof(*d));
   const std::string base = std::string(dir) + "/";

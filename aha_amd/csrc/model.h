@@ -197,6 +197,7 @@ int prof_collect(aha_model* m);
 int model_allreduce(aha_model* m, float* buf, size_t count);
 // loader.hip
 int config_parse(const char* dir, aha_model_desc* out);
+int config_torch_dtype(const char* dir, std::string* out);
 int weights_open(const char* dir, aha_weights** out);
 int model_load(aha_ctx* ctx, const char* dir, size_t kv_reserve_tokens, aha_model** out);
 int rccl_allreduce(aha_model* m, float* buf, size_t count);  // tp_rccl.hip

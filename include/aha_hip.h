@@ -174,6 +174,12 @@ int aha_hip_embed(aha_model* m, const uint32_t* input_ids, size_t n_ids, float* 
  * aha_hip_model_load = config_parse + weights_open + aha_hip_model_create + weights_close. */
 typedef struct aha_weights aha_weights;
 int aha_hip_config_parse(const char* model_dir, aha_model_desc* out);
+/* The dtype string the reference's init passes to get_dtype for this checkpoint: Qwen3 config.json "torch_dtype"
+ * (qwen3/config.rs:23, qwen3/generate.rs:28), Qwen3-VL "text_config.dtype" (qwen3vl/config.rs:100), Qwen3-ASR the constant
+ * "bfloat16" (qwen3_asr/config.rs:186).  NUL-terminated into out (cap bytes).  A host calls
+ * aha_hip_get_dtype(requested, <this>, &d) and aha_hip_check_dtype(d) before aha_hip_model_load, so that an f16 / f32
+ * checkpoint without an explicit dtype is refused the way the header promises instead of silently computing in bf16. */
+int aha_hip_config_torch_dtype(const char* model_dir, char* out, size_t cap);
 int aha_hip_weights_open(const char* model_dir, aha_weights** out);
 size_t aha_hip_weights_count(const aha_weights* w);
 int aha_hip_weights_get(const aha_weights* w, size_t index, aha_tensor_view* out);

@@ -18,6 +18,10 @@ pub mod sys {
         _p: [u8; 0],
     }
     #[repr(C)]
+    pub struct AhaRng {
+        _private: [u8; 0],
+    }
+    #[repr(C)]
     pub struct AhaModel {
         _p: [u8; 0],
     }
@@ -147,6 +151,7 @@ pub mod sys {
         ) -> i32;
         /// config.json + generation_config.json + every *.safetensors of `dir`, parsed / mmapped by the library itself
         pub fn aha_hip_config_parse(dir: *const c_char, out: *mut AhaModelDesc) -> i32;
+        pub fn aha_hip_config_torch_dtype(dir: *const c_char, out: *mut c_char, cap: usize) -> i32;
         pub fn aha_hip_model_load(ctx: *mut AhaCtx, dir: *const c_char, kv_reserve_tokens: usize, out: *mut *mut AhaModel) -> i32;
         pub fn aha_hip_model_destroy(m: *mut AhaModel);
         pub fn aha_hip_forward_initial(
@@ -175,6 +180,12 @@ pub mod sys {
             sumexp_out: *mut f32,
         ) -> i32;
         pub fn aha_hip_last_logits(m: *mut AhaModel, logits_out: *mut f32) -> i32;
+        pub fn aha_hip_rng_create(seed: u64, out: *mut *mut AhaRng) -> i32;
+        pub fn aha_hip_rng_destroy(rng: *mut AhaRng);
+        pub fn aha_hip_rng_next_u32(rng: *mut AhaRng) -> u32;
+        pub fn aha_hip_rng_weighted_index(rng: *mut AhaRng, weights: *const f32, n: usize, index_out: *mut u32) -> i32;
+        pub fn aha_hip_kv_export(m: *mut AhaModel, out_dev: *mut c_void, out_bytes: usize, bytes_needed: *mut usize, n_tokens: *mut usize, rope_delta: *mut i64) -> i32;
+        pub fn aha_hip_kv_import(m: *mut AhaModel, in_dev: *const c_void, src_heads: i32, src_head0: i32, dst_head0: i32, n_heads: i32, n_tokens: usize, rope_delta: i64) -> i32;
         pub fn aha_hip_embed(m: *mut AhaModel, ids: *const u32, n_ids: usize, out: *mut f32) -> i32;
         pub fn aha_hip_cache_len(m: *const AhaModel) -> usize;
         pub fn aha_hip_audio_resample(
@@ -190,7 +201,7 @@ pub mod sys {
     }
 }
 
-use std::ffi::{CStr, CString};
+use std::ffi::{c_char, CStr, CString};
 use std::fmt;
 
 /// Non-zero status of the library + its thread-local message (`aha_hip_last_error`)
@@ -254,9 +265,14 @@ impl Model {
         let c = CString::new(dir).map_err(|_| Error { code: -1, message: "path contains NUL".into() })?;
         let mut desc = sys::AhaModelDesc::default();
         check(unsafe { sys::aha_hip_config_parse(c.as_ptr(), &mut desc) })?;
-        if let Some(d) = dtype {
-            check(unsafe { sys::aha_hip_check_dtype(d) })?;
-        }
+        // get_dtype(dtype, cfg_dtype) exactly as XxxGenerateModel::init resolves it (utils/mod.rs:77-115): an explicit request wins,
+        // otherwise the checkpoint's own dtype string decides -- and whatever comes out must be a dtype the kernels compute in, so
+        // a float16 / float32 checkpoint with `dtype == None` is REFUSED here instead of silently running in bf16
+        let mut buf = [0 as c_char; 64];
+        check(unsafe { sys::aha_hip_config_torch_dtype(c.as_ptr(), buf.as_mut_ptr(), buf.len()) })?;
+        let cfg_dtype = unsafe { CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned();
+        let resolved = get_dtype(dtype, &cfg_dtype)?;
+        check(unsafe { sys::aha_hip_check_dtype(resolved) })?;
         let mut ctx = std::ptr::null_mut();
         check(unsafe { sys::aha_hip_init(device, &mut ctx) })?;
         let mut model = std::ptr::null_mut();
@@ -433,6 +449,34 @@ impl Drop for Model {
             sys::aha_hip_model_destroy(self.model);
             sys::aha_hip_shutdown(self.ctx);
         }
+    }
+}
+
+/// candle's `LogitsProcessor::rng` + `sample_multinomial` behind the C ABI (`aha_hip_rng_*`): rand 0.9.2 `StdRng::seed_from_u64`
+/// (candle-transformers' own rand, Cargo.lock:590-606) and `WeightedIndex::<f32>::new(prs)?.sample(&mut rng)`.  A host that keeps
+/// candle's `LogitsProcessor` does not need this; a host that takes `aha_hip_sample_candidates`' candidates instead of the
+/// V-float logits draws with it so that a seed still defines the token sequence.
+pub struct StdRng(*mut sys::AhaRng);
+unsafe impl Send for StdRng {}
+impl StdRng {
+    pub fn seed_from_u64(seed: u64) -> Result<Self, Error> {
+        let mut h = std::ptr::null_mut();
+        check(unsafe { sys::aha_hip_rng_create(seed, &mut h) })?;
+        Ok(Self(h))
+    }
+    pub fn next_u32(&mut self) -> u32 {
+        unsafe { sys::aha_hip_rng_next_u32(self.0) }
+    }
+    /// `WeightedIndex::new(weights)?.sample(self)`: Err for a negative / NaN weight or an all-zero vector, the stream untouched.
+    pub fn weighted_index(&mut self, weights: &[f32]) -> Result<usize, Error> {
+        let mut idx = 0u32;
+        check(unsafe { sys::aha_hip_rng_weighted_index(self.0, weights.as_ptr(), weights.len(), &mut idx) })?;
+        Ok(idx as usize)
+    }
+}
+impl Drop for StdRng {
+    fn drop(&mut self) {
+        unsafe { sys::aha_hip_rng_destroy(self.0) }
     }
 }
 

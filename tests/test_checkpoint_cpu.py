@@ -136,3 +136,33 @@ def test_safetensors_reader_survives_odd_names_and_metadata(tmp_path):
         dt, shape, raw = got[n]
         assert dt == _lib.AHA_BF16 and shape == tuple(t.shape)
         assert raw == t.contiguous().reshape(-1).view(torch.uint8).numpy().tobytes()
+
+
+def test_config_torch_dtype_is_the_string_the_reference_resolves(tmp_path, hip_lib):
+    """aha_hip_config_torch_dtype: Qwen3 reads config.json "torch_dtype" (qwen3/config.rs:23), Qwen3-VL "text_config.dtype"
+    (qwen3vl/config.rs:100), Qwen3-ASR is the constant "bfloat16" (qwen3_asr/config.rs:186); a host feeds it to aha_hip_get_dtype and
+    aha_hip_check_dtype, so an f16 checkpoint without an explicit dtype is refused instead of silently computing in bf16."""
+    import ctypes as C
+    import json
+    from aha_amd import _lib
+    buf = C.create_string_buffer(64)
+
+    def write(d, sub):
+        p = tmp_path / sub
+        p.mkdir()
+        (p / "config.json").write_text(json.dumps(d))
+        return str(p).encode()
+
+    d = write({"torch_dtype": "float16", "hidden_size": 8}, "q3")
+    assert hip_lib.aha_hip_config_torch_dtype(d, buf, 64) == 0 and buf.value == b"float16"
+    out = C.c_int32()
+    assert hip_lib.aha_hip_get_dtype(-1, buf.value, C.byref(out)) == 0 and out.value == _lib.AHA_F16
+    assert hip_lib.aha_hip_check_dtype(out.value) == -6        # AHA_ERR_UNSUPPORTED: refused, not silently bf16
+    d = write({"vision_config": {}, "text_config": {"dtype": "bfloat16"}, "torch_dtype": "float32"}, "vl")
+    assert hip_lib.aha_hip_config_torch_dtype(d, buf, 64) == 0 and buf.value == b"bfloat16"
+    d = write({"thinker_config": {"dtype": "float16"}}, "asr")
+    assert hip_lib.aha_hip_config_torch_dtype(d, buf, 64) == 0 and buf.value == b"bfloat16"
+    d = write({"hidden_size": 8}, "missing")
+    assert hip_lib.aha_hip_config_torch_dtype(d, buf, 64) < 0 and b"torch_dtype" in hip_lib.aha_hip_last_error()
+    d = write({"torch_dtype": "bfloat16"}, "small")
+    assert hip_lib.aha_hip_config_torch_dtype(d, buf, 4) < 0
