@@ -244,6 +244,43 @@ def source_digest(files) -> str:
 
 GEMV_SOURCES = ("gemv_body.h", "kernels_gemv.hip", "common.h")
 
+def attach_committed_profiles(roof: dict, workload: str, profiles_dir: str = None) -> dict:
+    """Numbers that cannot be collected inside the bench process (rocprofv3 kernel-only durations, PMC traffic) come from the committed
+    summaries under profiles/ -- attached ONLY when they were taken with the same matvec sources (the digest scripts/stats_to_md.py /
+    scripts/pmc_summary.py stamp into them), so a kernel change without a profile refresh leaves them out instead of quoting stale
+    numbers next to a fresh ms_per_step (round-2 verdict, weak #7)."""
+    pdir = profiles_dir or os.path.join(ROOT, "profiles")
+    dig = source_digest(GEMV_SOURCES)
+    roof["gemv_source_digest"] = dig
+    try:
+        with open(os.path.join(pdir, PMC_FILE)) as f:
+            pmc = json.load(f)
+        if pmc.get("workload") == workload and pmc.get("gemv_source_digest") == dig:
+            roof["traffic"] = round(pmc["traffic_bytes_per_launch"])
+            roof["traffic_source"] = "profiles/" + PMC_FILE
+    except (OSError, KeyError, ValueError):
+        pass
+    try:
+        if workload == "qwen3vl8b":
+            tot_us, calls, stamped = 0.0, 0, None
+            with open(os.path.join(pdir, STATS_FILE)) as f:
+                for line in f:
+                    if "gemv_source_digest:" in line:
+                        stamped = line.split("gemv_source_digest:")[1].split()[0]
+                    c = [x.strip() for x in line.split("|")]
+                    if len(c) >= 6 and "gemv_kernel" in c[1]:
+                        calls += int(c[2])
+                        tot_us += float(c[3])
+            if calls and stamped == dig:
+                avg = tot_us / calls
+                roof["rocprof"] = {"avg_us": round(avg, 2), "achieved": round(roof["algorithmic_bytes_per_launch"] / avg / 1e3, 1),
+                                   "frac": round(roof["algorithmic_bytes_per_launch"] / avg / 1e3 / HBM_PEAK_GBS, 4),
+                                   "source": "profiles/" + STATS_FILE}
+    except (OSError, ValueError):
+        pass
+    return roof
+
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -421,37 +458,7 @@ def main():
             "algorithmic_bytes_per_launch": round(gv["bytes"] / max(gv["launches"], 1)),
             "timing": "HIP event pairs on the model's stream around every launch of the class, collected in THIS run (a pair also sees "
                       "the ~2.5 us of dispatch latency in front of a kernel: the rocprofv3 kernel-only figure, when attached, is the higher one)"}
-    # Numbers that cannot be collected inside this process (rocprofv3 kernel durations, PMC traffic) come from committed
-    # summaries -- attached ONLY when they were taken with the same matvec sources (digest stamped by scripts/stats_to_md.py /
-    # scripts/pmc_summary.py), so a kernel change without a profile refresh leaves them out instead of quoting stale numbers.
-    dig = source_digest(GEMV_SOURCES)
-    roof["gemv_source_digest"] = dig
-    try:
-        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
-            pmc = json.load(f)
-        if pmc.get("workload") == args.workload and pmc.get("gemv_source_digest") == dig:
-            roof["traffic"] = round(pmc["traffic_bytes_per_launch"])
-            roof["traffic_source"] = "profiles/" + PMC_FILE
-    except (OSError, KeyError, ValueError):
-        pass
-    try:
-        if args.workload == "qwen3vl8b":
-            tot_us, calls, stamped = 0.0, 0, None
-            with open(os.path.join(ROOT, "profiles", STATS_FILE)) as f:
-                for line in f:
-                    if "gemv_source_digest:" in line:
-                        stamped = line.split("gemv_source_digest:")[1].split()[0]
-                    c = [x.strip() for x in line.split("|")]
-                    if len(c) >= 6 and "gemv_kernel" in c[1]:
-                        calls += int(c[2])
-                        tot_us += float(c[3])
-            if calls and stamped == dig:
-                avg = tot_us / calls
-                roof["rocprof"] = {"avg_us": round(avg, 2), "achieved": round(roof["algorithmic_bytes_per_launch"] / avg / 1e3, 1),
-                                   "frac": round(roof["algorithmic_bytes_per_launch"] / avg / 1e3 / HBM_PEAK_GBS, 4),
-                                   "source": "profiles/" + STATS_FILE}
-    except (OSError, ValueError):
-        pass
+    attach_committed_profiles(roof, args.workload)
     ad = prof["attn_decode"]
     attn_gbs = ad["bytes"] / (ad["ms"] * 1e-3) / 1e9 if ad["ms"] > 0 else 0.0
 

@@ -11,8 +11,8 @@
       against the oracle's sliced evaluation of the same layer (K / V for every row, q / attention / MLP for the checked rows:
       oracle/qwen3.py decoder_layer_rows) at three prompt lengths, then 2 decode steps over the 41k-token cache.
   (d) exact FREE-RUNNING greedy sequences on decisive-margin checkpoints (tests/decisive.py): cfg 1 (Qwen3-0.6B, 128-token
-      prompt, 64 tokens; tests/test_qwen3.rs:9-41 with temperature 0) and cfg 3 (full Qwen3-VL-8B, image + 512-token prompt, 128
-      tokens) must equal the oracle's sequence token for token -- device-resident loop and host loop -- after the oracle's own
+      prompt, 64 tokens; tests/test_qwen3.rs:9-41 with temperature 0), cfg 2 (Qwen3-0.6B, 2048-token prefill + 256 tokens) and cfg 3
+      (full Qwen3-VL-8B, image + 512-token prompt, 128 tokens) must equal the oracle's sequence token for token -- device-resident loop and host loop -- after the oracle's own
       top-1/top-2 margin has been checked to be >= 0.5 std at every step.
 
 Tolerances as in tests/test_baseline_parity_gpu.py (both sides round to bf16 at the same op boundaries and differ in f32
@@ -214,7 +214,10 @@ def test_cfg3_decisive_checkpoint_exact_free_running_greedy_128(vl8b):
 # ---------------------------------------------------------------------------------------------------------------------------
 # (d) cfg 1: Qwen3-0.6B (tied head), 128-token prompt, 64 free-running greedy tokens
 # ---------------------------------------------------------------------------------------------------------------------------
-def test_cfg1_decisive_checkpoint_exact_free_running_greedy_64(gpu):
+@pytest.mark.parametrize("name,prompt,steps", [("cfg1", 128, 64), ("cfg2", 2048, 256)])
+def test_cfg1_cfg2_decisive_checkpoint_exact_free_running_greedy(gpu, name, prompt, steps):
+    """cfg 1 (128-token prompt, 64 tokens; /root/reference/tests/test_qwen3.rs:9-41 with temperature 0) and cfg 2 (2048-token prefill +
+    256 decode steps: the MFMA prefill path, 36 KV pages, the decode attention's split merge on every step) on the full Qwen3-0.6B."""
     from aha_amd.model import HipInferenceModel, generate_generic
     cfg = qwen3_0_6b()
     w = qwen3_text_weights(cfg, seed=0, device=gpu)
@@ -223,28 +226,28 @@ def test_cfg1_decisive_checkpoint_exact_free_running_greedy_64(gpu):
     o = oq.OracleQwen3(cfg, cpu_copy(w), NM, consume=True)
     del w
     try:
-        ids = rnd_ids(128, 1)
+        ids = rnd_ids(prompt, 1 if name == "cfg1" else 2)
         t0 = time.time()
-        want, logits = oq.greedy_generate(o, ids, 64, return_logits=True)
+        want, logits = oq.greedy_generate(o, ids, steps, return_logits=True)
         t_oracle = time.time() - t0
         margins = [decisive.margin_std(lg) for lg in logits]
-        dev, _ = generate_generic(m, ids, 64, device_loop=True)
+        dev, _ = generate_generic(m, ids, steps, device_loop=True)
         # host loop with the logits of every step: the free-running sequences agree, so the inputs are the same on both sides
         m.clear_cache()
         got, tok = m.forward_initial(ids, 0)
         host, off, worst = [tok], len(ids), rel(got, logits[0].numpy())
-        for step in range(1, 64):
+        for step in range(1, steps):
             got, tok = m.forward_step(tok, off)
             host.append(tok)
             off += 1
             if host[:step + 1] == want[:step + 1]:
                 e = rel(got, logits[step].numpy())
                 worst = (max(worst[0], e[0]), max(worst[1], e[1]))
-        REPORT["cfg1_decisive_greedy64"] = dict(tokens=len(want), min_margin_std=min(margins), median_margin_std=float(np.median(margins)),
-                                                device_loop_equal=bool(dev == want), host_loop_equal=bool(host == want),
-                                                worst_logit_err=worst, oracle_seconds=t_oracle, sequence_head=want[:6])
+        REPORT[f"{name}_decisive_greedy{steps}"] = dict(tokens=len(want), min_margin_std=min(margins), median_margin_std=float(np.median(margins)),
+                                                         device_loop_equal=bool(dev == want), host_loop_equal=bool(host == want),
+                                                         worst_logit_err=worst, oracle_seconds=t_oracle, sequence_head=want[:6])
         _flush_report()
-        assert len(want) == 64 and min(margins) >= MIN_MARGIN, f"checkpoint not decisive: min margin {min(margins):.3f} std"
+        assert len(want) == steps and min(margins) >= MIN_MARGIN, f"checkpoint not decisive: min margin {min(margins):.3f} std"
         assert dev == want, [(i, a, b) for i, (a, b) in enumerate(zip(dev, want)) if a != b][:5]
         assert host == want
         assert want[0] != ids[-1] and want[0] // 2 == ids[-1] // 2 and want[1] == ids[-1]   # the 2i <-> 2i+1 alternation the signs build

@@ -51,3 +51,30 @@ def test_bench_rejects_a_world_size_that_contradicts_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "launcher-selftest"],
                        capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
+
+
+def test_committed_profiles_are_attached_only_under_a_matching_source_digest(tmp_path):
+    """bench.py's roofline.traffic / roofline.rocprof come from committed rocprofv3 summaries: they must be attached when the summaries
+    were taken with the CURRENT matvec sources and left out otherwise (a stale number next to a fresh ms_per_step is worse than none)."""
+    import json
+    import shutil
+    import bench
+    roof = {"algorithmic_bytes_per_launch": 104425355, "traffic": None}
+    out = bench.attach_committed_profiles(dict(roof), "qwen3vl8b")
+    dig = bench.source_digest(bench.GEMV_SOURCES)
+    stats = open(os.path.join(ROOT, "profiles", bench.STATS_FILE)).read()
+    stamped = stats.split("gemv_source_digest:")[1].split()[0]
+    pmc = json.load(open(os.path.join(ROOT, "profiles", bench.PMC_FILE)))
+    assert ("rocprof" in out) == (stamped == dig)
+    assert (out["traffic"] is not None) == (pmc["gemv_source_digest"] == dig)
+    if "rocprof" in out:
+        assert 0.5 < out["rocprof"]["frac"] < 1.0 and abs(out["traffic"] / roof["algorithmic_bytes_per_launch"] - 1.0) < 0.1
+    # a copy stamped with another digest is refused; another workload never gets the cfg 3 numbers
+    shutil.copy(os.path.join(ROOT, "profiles", bench.PMC_FILE), tmp_path / bench.PMC_FILE)
+    (tmp_path / bench.STATS_FILE).write_text(stats.replace(stamped, "0" * 16))
+    pmc["gemv_source_digest"] = "0" * 16
+    (tmp_path / bench.PMC_FILE).write_text(json.dumps(pmc))
+    stale = bench.attach_committed_profiles(dict(roof), "qwen3vl8b", profiles_dir=str(tmp_path))
+    assert "rocprof" not in stale and stale["traffic"] is None
+    other = bench.attach_committed_profiles(dict(roof), "qwen3-0.6b")
+    assert "rocprof" not in other and other["traffic"] is None
