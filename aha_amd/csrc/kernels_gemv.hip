@@ -63,6 +63,17 @@ GemvPlan plan_gemv(int N, int K, GemvEpi epi) {
   }
   const int ntiles = (N + 4 * R - 1) / (4 * R);
   int grid = ntiles < gmax ? ntiles : gmax;
+  // Whole rounds: with 1024 tiles (N = 4096: o_proj, down_proj) 768 blocks leave a third of them a second tile and the rest idle
+  // behind it; the largest grid in [gmax / 2, gmax] that divides the tile count (512 there: two tiles each) measured +1.9 % on the
+  // 8B decode step (316.9 -> 323.0 tok/s, same box; 1024 and 1536 blocks: 313.9 / 304.6).  Multiples of 8 only (one share per XCD).
+  static const bool even_on = [] { const char* e = getenv("AHA_GEMV_EVEN_GRID"); return e ? atoi(e) != 0 : true; }();
+  if (even_on && !e_grid && !(e_grid1 && R == 1) && ntiles > gmax) {
+    for (int g = gmax; g >= gmax / 2; g -= 8)
+      if (ntiles % g == 0) {
+        grid = g;
+        break;
+      }
+  }
   return {R, Up, grid};
 }
 
