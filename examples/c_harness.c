@@ -9,6 +9,7 @@
  * 44.1 kHz stereo second brought to 16 kHz mono by aha_hip_audio_resample); exit code 0.
  * No torch, no HIP headers: only the C ABI. */
 #include <stdint.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -102,6 +103,24 @@ int main(int argc, char** argv) {
   if (!(cand_val[0] >= cand_val[1] && cand_val[1] >= cand_val[2] && cand_val[2] >= cand_val[3] && cmax == cand_val[0] && csum >= 1.0f)) {
     fprintf(stderr, "candidate ordering / normaliser inconsistent\n");
     return 1;
+  }
+
+  /* (3b) ... and the draw: candle's softmax values of the four candidates, then eight draws of the reference's default-seed stream
+   * (LogitsProcessor::from_sampling(299792458, ..), common/generate.rs:408; rand 0.9.2 StdRng + WeightedIndex<f32> behind the ABI) */
+  {
+    float prs[4];
+    const float inv_t = (float)(1.0 / 0.6);
+    for (int j = 0; j < 4; ++j) prs[j] = expf((cand_val[j] - cmax) * inv_t) / csum;
+    aha_rng* rng = NULL;
+    CHECK(aha_hip_rng_create(299792458ull, &rng));
+    printf("weights: %a %a %a %a\ndraws:", prs[0], prs[1], prs[2], prs[3]);
+    for (int i = 0; i < 8; ++i) {
+      uint32_t pos = 0;
+      CHECK(aha_hip_rng_weighted_index(rng, prs, 4, &pos));
+      printf(" %u", cand_idx[pos]);
+    }
+    printf("\n");
+    aha_hip_rng_destroy(rng);
   }
 
   /* (4) audio pre-processing: one second of 44.1 kHz stereo -> 16 kHz mono */

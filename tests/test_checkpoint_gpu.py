@@ -106,4 +106,14 @@ def test_plain_c_host_over_the_abi(gpu, tmp_path):
     _, idx, _, _ = m.sample_candidates(want, 1.1, 0.6, 4)
     m.close()
     assert out[2].split() == ["candidates:"] + [str(int(i)) for i in idx]
-    assert out[3].split() == ["resampled:", "16000"]
+    # the draw from C: the weights it used (printed as hex floats) through the Python mirror's StdRng and through the independent
+    # restatement oracle/rand_stdrng.py give the same eight tokens of the reference's default-seed stream
+    from aha_amd import sampling as hs
+    from oracle import rand_stdrng as R
+    wts = np.array([float.fromhex(x) for x in out[3].split()[1:]], dtype=np.float32)
+    assert out[3].startswith("weights:") and wts.shape == (4,) and abs(float(wts.sum()) - 1.0) < 0.5
+    rng, ref = hs.StdRng(299792458), R.StdRng.seed_from_u64(299792458)
+    want_draws = [int(idx[rng.weighted_index(wts)]) for _ in range(8)]
+    assert want_draws == [int(idx[R.sample_multinomial(ref, wts)]) for _ in range(8)]
+    assert out[4].split() == ["draws:"] + [str(t) for t in want_draws]
+    assert out[5].split() == ["resampled:", "16000"]
