@@ -111,7 +111,7 @@ def test_plain_c_host_over_the_abi(gpu, tmp_path):
     from aha_amd import sampling as hs
     from oracle import rand_stdrng as R
     wts = np.array([float.fromhex(x) for x in out[3].split()[1:]], dtype=np.float32)
-    assert out[3].startswith("weights:") and wts.shape == (4,) and abs(float(wts.sum()) - 1.0) < 0.5
+    assert out[3].startswith("weights:") and wts.shape == (4,) and (wts > 0).all() and (np.diff(wts) <= 0).all()   # softmax values of the ranked candidates
     rng, ref = hs.StdRng(299792458), R.StdRng.seed_from_u64(299792458)
     want_draws = [int(idx[rng.weighted_index(wts)]) for _ in range(8)]
     assert want_draws == [int(idx[R.sample_multinomial(ref, wts)]) for _ in range(8)]
