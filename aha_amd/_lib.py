@@ -121,6 +121,7 @@ SIGNATURES = {
                                        C.c_int32, C.c_int32, C.c_float, _P]),
     "aha_hip_argmax": (C.c_int, [_P, C.c_int64, _P, _P]),
     "aha_hip_logmel": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "aha_hip_debug_poison_lds": (C.c_int, [C.c_uint32, _P]),
     "aha_hip_debug_gemm_plan": (C.c_int, [C.c_int32, C.c_int32]),
     "aha_hip_debug_plan_gemm": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_size_t, _P]),
     "aha_hip_get_rope_index": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int32, _P, _P]),

@@ -225,6 +225,13 @@ int aha_hip_debug_scramble_pages(aha_model* m, int enable) {
   }
   return AHA_OK;
 }
+int aha_hip_debug_poison_lds(uint32_t seed, void* stream) {
+  API_GUARD_BEGIN
+  launch_poison_lds(seed, (hipStream_t)stream);
+  AHA_HIP_CHECK(hipGetLastError());
+  return AHA_OK;
+  API_GUARD_END
+}
 int aha_hip_debug_gemm_plan(int32_t tile, int32_t splitk) {
   if ((tile != 0 && tile != 128 && tile != 256 && tile != 192) || splitk < 0 || splitk > 8) {
     set_error("debug_gemm_plan: tile must be 0, 128, 192 (256 x 192, where instantiated) or 256; splitk 0..8");

@@ -166,6 +166,7 @@ struct GemmWorkspaceScope {
 };
 // x[i] = bf16(x[i] + bf16(sum[i])): Linear output tensor (all-reduced f32 partials) -> bf16, then the residual add -> bf16
 void launch_residual_add_f32(void* x, const float* sum, int64_t n, hipStream_t st);
+void launch_poison_lds(uint32_t seed, hipStream_t st);
 void launch_residual_add_f32_cols(void* x, int64_t ldx, const float* sum, int64_t lds, int64_t rows, int cols, hipStream_t st);
 void launch_row_to_f32(const void* x_bf16_or_null, float* out, int n, hipStream_t st);   // nullptr: zeros
 void launch_f32_to_row(const float* x, void* out_bf16, int n, hipStream_t st);

@@ -43,7 +43,13 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const bf16_t* __restr
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float a = lo_bf(v[i][j]), b = hi_bf(v[i][j]);
-        ss += a * a + b * b;
+        float t = fmaf(a, a, b * b);   // == a * a + b * b as the compiler contracts it
+        // The four terms are added by four scalar v_add_f32 in order.  Left to itself clang packs the running sum into v_pk_add_f32
+        // pairs and finishes with `v_pk_add_f32 vD, vA, vB op_sel:[0,1] op_sel_hi:[1,0]` (lo = A.lo + B.hi): on gfx950 that form
+        // was measured to add B.lo instead in lanes 16-31 / 48-63 whenever the wave shares a SIMD with a wave of another kernel
+        // running on a concurrent stream (profiles/r03_simd_coresidency.md; tests/test_isa_cpu.py keeps it out of every kernel).
+        asm volatile("" : "+v"(t));
+        ss += t;
       }
     }
   }
@@ -508,5 +514,23 @@ void launch_residual_add_f32(void* x, const float* sum, int64_t n, hipStream_t s
   if (n <= 0) return;
   const int64_t blocks = (n / 4 + 255) / 256;
   hipLaunchKernelGGL(residual_add_f32_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, (bf16_t*)x, sum, n);
+}
+// Test tool (aha_hip_debug_poison_lds): fills the LDS of every CU with seeded garbage.  A kernel that consumes LDS it did not stage
+// in the same launch computes from whatever the previous kernel on that CU left there -- identical, hence invisible, when the same
+// launch is repeated; with a different poison in front of each launch it shows up as
+// run-to-run differences.  1024 blocks x 64 KiB: several blocks per CU, every byte of the 160 KiB written by one of them.
+__global__ __launch_bounds__(256) void poison_lds_kernel(uint32_t seed, uint32_t* sink) {
+  extern __shared__ uint32_t lds_words[];
+  const int n = 64 * 1024 / 4;
+  uint32_t x = seed * 2654435761u + blockIdx.x * 40503u + threadIdx.x;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    x = x * 1664525u + 1013904223u;
+    lds_words[i] = (x & 0x7f7f7f7fu) | 0x3f003f00u;   // finite bf16 / f32 patterns of order 1
+  }
+  __syncthreads();
+  if (sink != nullptr && lds_words[(seed + threadIdx.x) % n] == 0xdeadbeefu) *sink = x;   // keep the stores alive
+}
+void launch_poison_lds(uint32_t seed, hipStream_t st) {
+  hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(256), 64 * 1024, st, seed, (uint32_t*)nullptr);
 }
 }  // namespace aha

@@ -68,6 +68,11 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
     return Cm
 
 
+def poison_lds(seed: int) -> None:
+    """Test tool: seeded garbage into the LDS of every CU, on the current stream (aha_hip_debug_poison_lds)."""
+    check(lib().aha_hip_debug_poison_lds(int(seed) & 0xFFFFFFFF, _stream()))
+
+
 def gemm_plan(tile: int = 0, splitk: int = 0) -> None:
     """Test hook: force the 128 / 256 tile kernel and a split-K factor for the following GEMMs; (0, 0) = automatic."""
     check(lib().aha_hip_debug_gemm_plan(tile, splitk))

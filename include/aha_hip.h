@@ -311,6 +311,10 @@ int aha_hip_debug_scramble_pages(aha_model* m, int enable);
 /* Copies the last hidden state before lm_head (hidden_size floats) / the image embeddings of the last
  * forward_initial (rows x out_hidden floats) to the host, for parity tests of intermediate tensors. */
 int aha_hip_debug_last_hidden(aha_model* m, float* out, size_t n);
+/* Test tool: fill the LDS of every CU with seeded garbage (on `stream`).  A kernel that consumes LDS it did not stage itself gives
+ * run-to-run identical results when its launch is simply repeated and different ones behind different poisons
+ * (tests/test_ops_gpu.py::test_kernels_do_not_consume_unstaged_lds). */
+int aha_hip_debug_poison_lds(uint32_t seed, void* stream);
 /* Test hook: force the GEMM tile (128 or 256) and split-K factor of every following GEMM launch of the process;
  * (0, 0) restores the automatic choice (csrc/kernels_gemm.hip plan_gemm). */
 int aha_hip_debug_gemm_plan(int32_t tile, int32_t splitk);

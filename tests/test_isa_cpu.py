@@ -65,11 +65,11 @@ def test_register_budgets_the_design_counts_on(kernels):
     fam = {}
     for n, k in kernels.items():
         fam.setdefault(family(n), []).append((n, k))
-    # four-wave 256^2 GEMM: one wave per SIMD owns the whole 512-register file (256 accumulators in AGPRs)
-    # (the 256 x 192 tile -- last template argument true -- keeps three of the four accumulator columns: 192 + operands)
-    is192 = lambda n: n.endswith("Lb1EEEvNS_8GemmArgsEi")
-    assert fam["gemm256q_kernel"] and all((400 if is192(n) else 480) <= k["vgpr_count"] <= 512 and k["max_flat_workgroup_size"] == 256
-                                          for n, k in fam["gemm256q_kernel"])
+    # four-wave 256^2 GEMM: one wave per SIMD owns the whole 512-register file (256 accumulators in AGPRs).  EXACTLY 512 in every
+    # variant (the 256 x 192 tile needs only 424): a smaller claim lets a wave of another stream's kernel onto the SIMD, and such
+    # co-residents were measured to compute wrong packed-f32 sums (profiles/r03_simd_coresidency.md; kernels_gemm.hip gemm256q_kernel)
+    assert fam["gemm256q_kernel"] and all(k["vgpr_count"] == 512 and k["max_flat_workgroup_size"] == 256 for n, k in fam["gemm256q_kernel"])
+    assert sum(n.endswith("Lb1EEEvNS_8GemmArgsEi") for n, _ in fam["gemm256q_kernel"]) == 2   # the two 192-column instantiations
     # 128 KiB of dynamic LDS per 256^2 block is requested at launch; nothing static on top
     assert all(k["group_segment_fixed_size"] == 0 for _, k in fam["gemm256q_kernel"])
     # prefill attention: 128 VGPRs => two 8-wave blocks per CU (non-trace instantiations)
@@ -112,6 +112,36 @@ def test_hot_kernels_have_no_flat_loads(kernels, tmp_path):
                 bad.setdefault(cur, []).append(op)
     assert seen == set(hot), f"families not found in the disassembly: {set(hot) - seen}"
     assert not bad, f"flat loads / scratch in hot kernels: { {k: v[:3] for k, v in bad.items()} }"
+
+
+def test_no_packed_f32_op_with_swapped_second_source(tmp_path):
+    """`v_pk_{add,mul,fma}_f32 vD, vA, vB op_sel:[0,1] op_sel_hi:[1,0]` with vA != vB (low result = A.lo op B.hi, what clang emits for
+    the tail of a horizontal sum it has packed) was measured on MI355X to use B.lo in lanes 16-31 and 48-63 when the wave shares a
+    SIMD with a wave of a kernel running on another stream: profiles/r03_simd_coresidency.md (probe: scripts/simd_coresidency_probe.hip).
+    The form with vA == vB, the mirrored form (op_sel:[1,0] op_sel_hi:[0,1]) and the broadcast forms (op_sel_hi only) were not
+    affected.  No shipped kernel may contain the affected form (kernels_elem.hip rmsnorm_rows_kernel is written around it)."""
+    shutil.copy(os.path.join(ROOT, "aha_amd", "csrc", "libaha_hip.so"), tmp_path / "lib.so")
+    subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", "lib.so"], cwd=tmp_path, capture_output=True, check=True)
+    bad, n_pk = [], 0
+    for o in sorted(glob.glob(str(tmp_path / "lib.so.*gfx950"))):
+        dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", o], capture_output=True, text=True, check=True).stdout
+        cur = None
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = m.group(1)
+                continue
+            t = line.strip()
+            if not re.match(r"v_pk_(add|mul|fma)_f32 ", t):
+                continue
+            n_pk += 1
+            if "op_sel:[0,1] op_sel_hi:[1,0]" not in t:
+                continue
+            ops = re.findall(r"v\[\d+:\d+\]", t)
+            if len(ops) >= 3 and ops[1] != ops[2]:
+                bad.append((cur, t.split("//")[0].strip()))
+    assert n_pk > 1000, "no packed f32 instructions found: is the disassembly being parsed?"
+    assert not bad, f"packed f32 ops with a swapped second source: {bad[:5]}"
 
 
 def test_counted_waits_in_the_mfma_loops(tmp_path):

@@ -235,6 +235,73 @@ def test_gemm_256x192_tile_equals_the_256_tile_bitwise(gpu):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("tile", [128, 192, 256])
+def test_kernels_do_not_consume_unstaged_lds(gpu, tile):
+    """aha_hip_debug_poison_lds fills the LDS of every CU with seeded garbage.  A GEMM tile that read a staging slot it had not
+    (yet) written in this launch would see the previous kernel's leftovers: invisible when a launch is simply repeated (the
+    leftovers are its own, identical, data), visible as run-to-run differences behind different poisons.  Ragged M and N so that
+    the masked rows / columns and the 192-column tile's half-used W region are exercised."""
+    from aha_amd import ops, _lib
+    A, W = rnd((513, 512), 211).to(gpu), rnd((1000, 512), 212, 0.05).to(gpu)
+    Wp = rnd((1024, 512), 213, 0.05).to(gpu)
+    ops.gemm_plan(tile, 1)
+    try:
+        outs = []
+        for seed in (None, 1, 2, 3):
+            if seed is not None:
+                ops.poison_lds(seed)
+            outs.append((ops.gemm(A, W).clone(), ops.gemm(A, Wp, act=_lib.ACT_SILU_MUL_PAIRS).clone()))
+    finally:
+        ops.gemm_plan(0, 0)
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+
+
+@pytest.mark.parametrize("tile", [192, 128])
+def test_rmsnorm_beside_a_gemm_on_another_stream(gpu, tile):
+    """Two streams, one GPU (what two tensor-parallel rank threads of tests/test_tp_gpu.py, or two models of one process, produce):
+    the RMSNorm rows must come out the same whatever GEMM waves share their CUs.  Round 3 found that they did not: beside the
+    192-column GEMM tile (424 VGPRs: room for a foreign wave on the SIMD) ~20% of the launches returned rows scaled by
+    sqrt(16/15) -- clang's `v_pk_add_f32 .. op_sel:[0,1] op_sel_hi:[1,0]` at the end of the sum of squares picked the wrong
+    half of its second source in lanes 16-31 / 48-63 (profiles/r03_simd_coresidency.md).  Both sides are closed: the kernel no
+    longer contains that instruction form (tests/test_isa_cpu.py) and the four-wave GEMM claims the whole register file."""
+    import threading
+    from aha_amd import ops, _lib
+    x = rnd((513, 512), 201).to(gpu)
+    w = bf(1 + 0.1 * torch.randn(512, generator=torch.Generator().manual_seed(202))).to(gpu)
+    A, W = rnd((513, 512), 203).to(gpu), rnd((1024, 512), 204, 0.05).to(gpu)
+    ref = ops.rmsnorm(x, w, 1e-6).clone()
+    torch.cuda.synchronize()
+    stop, started = [False], threading.Event()
+
+    def other_stream():
+        s2 = torch.cuda.Stream()
+        with torch.cuda.stream(s2):
+            while not stop[0]:
+                for _ in range(20):
+                    ops.gemm(A, W, act=_lib.ACT_SILU_MUL_PAIRS)
+                s2.synchronize()
+                started.set()
+
+    ops.gemm_plan(tile, 1)
+    t = threading.Thread(target=other_stream)
+    t.start()
+    try:
+        assert started.wait(60)
+        s = torch.cuda.Stream()
+        bad = 0
+        with torch.cuda.stream(s):
+            for _ in range(1500):
+                y = ops.rmsnorm(x, w, 1e-6)
+                s.synchronize()
+                bad += not torch.equal(y, ref)
+    finally:
+        stop[0] = True
+        t.join()
+        ops.gemm_plan(0, 0)
+    assert bad == 0, f"{bad} of 1500 RMSNorm launches differ beside the {tile}-column GEMM on another stream"
+
+
 def test_gemm_transpose_detect(gpu):
     """A = I against an asymmetric W: catches swapped C rows/cols (cdna guide: always A=I-check with asymmetric B)."""
     from aha_amd import ops
