@@ -199,10 +199,15 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, float* xs, const in
           for (int r = 0; r < R; ++r) {
             const u32x4_t w = buf[u][m][r];
             float s = acc[m][r];
-            s = fmaf(lo_bf(w[0]), xlo.x, s); s = fmaf(hi_bf(w[0]), xlo.y, s);
-            s = fmaf(lo_bf(w[1]), xlo.z, s); s = fmaf(hi_bf(w[1]), xlo.w, s);
-            s = fmaf(lo_bf(w[2]), xhi.x, s); s = fmaf(hi_bf(w[2]), xhi.y, s);
-            s = fmaf(lo_bf(w[3]), xhi.z, s); s = fmaf(hi_bf(w[3]), xhi.w, s);
+            // ACTIVATION FIRST, weight second -- on purpose.  clang packs two rows' fmas into v_pk_fma_f32 and broadcasts the shared
+            // activation element with op_sel; as the SECOND source that is `op_sel:[0,1,0]` for the odd elements, the form that was
+            // measured to read the wrong element in lanes 16-31 / 48-63 when another stream's kernel shares the SIMD; as the FIRST
+            // source (`op_sel:[1,0,0]` / `op_sel_hi:[0,1,1]`) it measured clean (profiles/r03_simd_coresidency.md; a * b == b * a, so
+            // the bits do not change; tests/test_isa_cpu.py keeps the affected forms out of every kernel).
+            s = fmaf(xlo.x, lo_bf(w[0]), s); s = fmaf(xlo.y, hi_bf(w[0]), s);
+            s = fmaf(xlo.z, lo_bf(w[1]), s); s = fmaf(xlo.w, hi_bf(w[1]), s);
+            s = fmaf(xhi.x, lo_bf(w[2]), s); s = fmaf(xhi.y, hi_bf(w[2]), s);
+            s = fmaf(xhi.z, lo_bf(w[3]), s); s = fmaf(xhi.w, hi_bf(w[3]), s);
             acc[m][r] = s;
           }
       }

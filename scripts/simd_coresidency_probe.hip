@@ -18,7 +18,7 @@
 #include "../include/aha_hip.h"
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-// result = a0 + a1 + b0 + b1 per lane, the packed step under test in the middle
+// one packed step under test per victim, then the two halves are added (the result only has to be reproducible)
 #define VICTIM_ASM(STEP)                                                                                                              \
   asm volatile("v_mov_b32 v40, %[a0]\n v_mov_b32 v41, %[a1]\n v_mov_b32 v42, %[b0]\n v_mov_b32 v43, %[b1]\n s_nop 7\n" STEP          \
                "s_nop 7\n v_mov_b32 %[r], v40\n"                                                                                      \
@@ -40,11 +40,24 @@ __global__ __launch_bounds__(256) void victim(const float* __restrict__ x, float
     VICTIM_ASM("v_pk_add_f32 v[40:41], v[40:41], v[42:43]\n s_nop 7\n v_add_f32 v40, v40, v41\n");
   else if (FORM == 4)   // broadcast of the low half of the second source (the matvec kernels' form)
     VICTIM_ASM("v_pk_mul_f32 v[40:41], v[40:41], v[42:43] op_sel_hi:[1,0]\n s_nop 7\n v_add_f32 v40, v40, v41\n");
-  else                  // scalar adds only
+  else if (FORM == 5)   // scalar adds only
     VICTIM_ASM("v_add_f32 v40, v40, v41\n s_nop 1\n v_add_f32 v40, v40, v42\n s_nop 1\n v_add_f32 v40, v40, v43\n");
+  else if (FORM == 6)   // the swapped second source on a multiply
+    VICTIM_ASM("v_pk_mul_f32 v[40:41], v[40:41], v[42:43] op_sel:[0,1] op_sel_hi:[1,0]\n s_nop 7\n v_add_f32 v40, v40, v41\n");
+  else if (FORM == 7)   // ... on the second source of an fma
+    VICTIM_ASM("v_pk_fma_f32 v[40:41], v[40:41], v[42:43], v[40:41] op_sel:[0,1,0] op_sel_hi:[1,0,1]\n s_nop 7\n v_add_f32 v40, v40, v41\n");
+  else if (FORM == 8)   // the swap on the THIRD source of an fma
+    VICTIM_ASM("v_pk_fma_f32 v[40:41], v[40:41], v[40:41], v[42:43] op_sel:[0,0,1] op_sel_hi:[1,1,0]\n s_nop 7\n v_add_f32 v40, v40, v41\n");
+  else if (FORM == 9)   // high element of the second source in BOTH halves
+    VICTIM_ASM("v_pk_add_f32 v[40:41], v[40:41], v[42:43] op_sel:[0,1] op_sel_hi:[1,1]\n s_nop 7\n v_add_f32 v40, v40, v41\n");
+  else if (FORM == 10)  // high element of the FIRST source in both halves (the matvec kernels' form since round 3)
+    VICTIM_ASM("v_pk_fma_f32 v[40:41], v[42:43], v[40:41], v[40:41] op_sel:[1,0,0]\n s_nop 7\n v_add_f32 v40, v40, v41\n");
+  else                  // low element of the first source in both halves (the matvec kernels' other form)
+    VICTIM_ASM("v_pk_fma_f32 v[40:41], v[42:43], v[40:41], v[40:41] op_sel_hi:[0,1,1]\n s_nop 7\n v_add_f32 v40, v40, v41\n");
   out[(size_t)row * 64 + lane] = r;
 }
 
+constexpr int NV = 13;   // victims: 12 instruction forms + the library kernel
 int main() {
   const int rows = 513, M = 513, N = 1024, K = 512;
   std::vector<float> hx((size_t)rows * 256);
@@ -66,10 +79,13 @@ int main() {
   hipStream_t sv, sa;
   CK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking));
   CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
-  const char* vn[7] = {"pk_add, second source swapped, vA != vB", "pk_add, first source swapped", "pk_add, second source swapped, vA == vB",
-                       "pk_add, no op_sel", "pk_mul, op_sel_hi:[1,0] broadcast", "scalar adds", "library RMSNorm rows (aha_hip_rmsnorm)"};
+  const char* vn[NV] = {"pk_add, second source swapped, vA != vB", "pk_add, first source swapped", "pk_add, second source swapped, vA == vB",
+                        "pk_add, no op_sel", "pk_mul, op_sel_hi:[1,0] broadcast", "scalar adds", "pk_mul, second source swapped",
+                        "pk_fma, second source swapped", "pk_fma, third source swapped", "pk_add, op_sel:[0,1] op_sel_hi:[1,1]",
+                        "pk_fma, op_sel:[1,0,0] (first source high)", "pk_fma, op_sel_hi:[0,1,1] (first source low)",
+                        "library RMSNorm rows (aha_hip_rmsnorm)"};
   const int tiles[3] = {0, 128, 192};
-  std::vector<std::vector<uint8_t>> idle(7);
+  std::vector<std::vector<uint8_t>> idle(NV);
   for (int ai = 0; ai < 3; ++ai) {
     std::atomic<bool> stop{false};
     std::thread th;
@@ -82,8 +98,8 @@ int main() {
         }
       });
     }
-    for (int v = 0; v < 7; ++v) {
-      const size_t bytes = v == 6 ? (size_t)rows * 512 * 2 : (size_t)rows * 64 * 4;
+    for (int v = 0; v < NV; ++v) {
+      const size_t bytes = v == NV - 1 ? (size_t)rows * 512 * 2 : (size_t)rows * 64 * 4;
       std::vector<uint8_t> got(bytes);
       int bad = 0, bad_lanes_odd = 0, bad_lanes_even = 0;
       for (int it = 0; it < 3000; ++it) {
@@ -94,14 +110,20 @@ int main() {
           case 3: hipLaunchKernelGGL(victim<3>, dim3((rows + 3) / 4), dim3(256), 0, sv, dx, dout, rows); break;
           case 4: hipLaunchKernelGGL(victim<4>, dim3((rows + 3) / 4), dim3(256), 0, sv, dx, dout, rows); break;
           case 5: hipLaunchKernelGGL(victim<5>, dim3((rows + 3) / 4), dim3(256), 0, sv, dx, dout, rows); break;
+          case 6: hipLaunchKernelGGL(victim<6>, dim3((rows + 3) / 4), dim3(256), 0, sv, dx, dout, rows); break;
+          case 7: hipLaunchKernelGGL(victim<7>, dim3((rows + 3) / 4), dim3(256), 0, sv, dx, dout, rows); break;
+          case 8: hipLaunchKernelGGL(victim<8>, dim3((rows + 3) / 4), dim3(256), 0, sv, dx, dout, rows); break;
+          case 9: hipLaunchKernelGGL(victim<9>, dim3((rows + 3) / 4), dim3(256), 0, sv, dx, dout, rows); break;
+          case 10: hipLaunchKernelGGL(victim<10>, dim3((rows + 3) / 4), dim3(256), 0, sv, dx, dout, rows); break;
+          case 11: hipLaunchKernelGGL(victim<11>, dim3((rows + 3) / 4), dim3(256), 0, sv, dx, dout, rows); break;
           default: aha_hip_rmsnorm(A, nw, ny, rows, 512, 1e-6f, sv); break;
         }
-        CK(hipMemcpyAsync(got.data(), v == 6 ? ny : (void*)dout, bytes, hipMemcpyDeviceToHost, sv));
+        CK(hipMemcpyAsync(got.data(), v == NV - 1 ? ny : (void*)dout, bytes, hipMemcpyDeviceToHost, sv));
         CK(hipStreamSynchronize(sv));
         if (ai == 0 && it == 0) idle[v] = got;
         if (memcmp(idle[v].data(), got.data(), bytes) != 0) {
           ++bad;
-          if (v < 6) {
+          if (v < NV - 1) {
             const float* g = (const float*)got.data(); const float* r = (const float*)idle[v].data();
             for (size_t i = 0; i < (size_t)rows * 64; ++i)
               if (g[i] != r[i]) { if (((i & 63) >> 4) & 1) ++bad_lanes_odd; else ++bad_lanes_even; }
@@ -109,7 +131,7 @@ int main() {
         }
       }
       printf("aggressor %-22s | victim %-42s: %4d of 3000 launches differ", tiles[ai] == 0 ? "none (idle GPU)" : tiles[ai] == 128 ? "128^2 GEMM tile" : "256x192 GEMM tile", vn[v], bad);
-      if (bad && v < 6) printf("  (wrong values in lanes 16-31/48-63: %d, in lanes 0-15/32-47: %d)", bad_lanes_odd, bad_lanes_even);
+      if (bad && v < NV - 1) printf("  (wrong values in lanes 16-31/48-63: %d, in lanes 0-15/32-47: %d)", bad_lanes_odd, bad_lanes_even);
       printf("\n");
       fflush(stdout);
     }

@@ -258,7 +258,7 @@ def test_kernels_do_not_consume_unstaged_lds(gpu, tile):
 
 
 @pytest.mark.parametrize("tile", [192, 128])
-def test_rmsnorm_beside_a_gemm_on_another_stream(gpu, tile):
+def test_small_kernels_beside_a_gemm_on_another_stream(gpu, tile):
     """Two streams, one GPU (what two tensor-parallel rank threads of tests/test_tp_gpu.py, or two models of one process, produce):
     the RMSNorm rows must come out the same whatever GEMM waves share their CUs.  Round 3 found that they did not: beside the
     192-column GEMM tile (424 VGPRs: room for a foreign wave on the SIMD) ~20% of the launches returned rows scaled by
@@ -270,7 +270,18 @@ def test_rmsnorm_beside_a_gemm_on_another_stream(gpu, tile):
     x = rnd((513, 512), 201).to(gpu)
     w = bf(1 + 0.1 * torch.randn(512, generator=torch.Generator().manual_seed(202))).to(gpu)
     A, W = rnd((513, 512), 203).to(gpu), rnd((1024, 512), 204, 0.05).to(gpu)
-    ref = ops.rmsnorm(x, w, 1e-6).clone()
+    # ... and the batch-1 matvecs (their packed fmas broadcast one activation element per pair of rows: second-source selects until
+    # round 3, first-source selects -- measured safe -- since): qkv-like (1 row per wave), gate+up (2 rows per wave), wide N (4 rows)
+    xv = rnd((4096,), 205).to(gpu)
+    Wq, Wg, Wu, Wl = (rnd((n, 4096), 206 + i, 0.02).to(gpu) for i, n in enumerate((6144, 12288, 12288, 32768)))
+    victims = {
+        "rmsnorm rows": lambda: ops.rmsnorm(x, w, 1e-6),
+        "matvec 6144 x 4096": lambda: ops.gemv(Wq, xv),
+        "gate+up matvec 12288 x 4096": lambda: ops.gemv_gate_up(Wg, Wu, xv),
+        "matvec 32768 x 4096": lambda: ops.gemv(Wl, xv),
+    }
+    refs = {k: f().clone() for k, f in victims.items()}
+    ref = refs["rmsnorm rows"]
     torch.cuda.synchronize()
     stop, started = [False], threading.Event()
 
@@ -289,17 +300,18 @@ def test_rmsnorm_beside_a_gemm_on_another_stream(gpu, tile):
     try:
         assert started.wait(60)
         s = torch.cuda.Stream()
-        bad = 0
+        bad = {k: 0 for k in victims}
         with torch.cuda.stream(s):
-            for _ in range(1500):
-                y = ops.rmsnorm(x, w, 1e-6)
-                s.synchronize()
-                bad += not torch.equal(y, ref)
+            for k, f in victims.items():
+                for _ in range(1500 if k == "rmsnorm rows" else 500):
+                    y = f()
+                    s.synchronize()
+                    bad[k] += not torch.equal(y, refs[k])
     finally:
         stop[0] = True
         t.join()
         ops.gemm_plan(0, 0)
-    assert bad == 0, f"{bad} of 1500 RMSNorm launches differ beside the {tile}-column GEMM on another stream"
+    assert not any(bad.values()), f"launches that differ beside the {tile}-column GEMM on another stream: {bad}"
 
 
 def test_gemm_transpose_detect(gpu):
