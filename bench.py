@@ -197,6 +197,33 @@ def sharded_prefill_bench(rank, world, local_rank, n_images=8, image_px=2048, pr
                            "the GEMMs + all-gather of the normalised rows) + image-parallel ViT (all-gather) + KV gather to rank 0 for decode",
             "rccl_ranks": world, "first_token_equal_on_all_ranks": same, **handback}
 
+SHARDED_LEG_TIMEOUT_S = int(os.environ.get("AHA_BENCH_SHARDED_TIMEOUT_S", "420"))
+
+
+def guarded(fn, seconds, on_timeout):
+    """fn() on the calling thread -> (result, None), or (None, "<exception text>") if it raised.  If it has not returned after `seconds`,
+    a timer thread calls on_timeout() and ends the PROCESS with os._exit(0): a hung collective cannot be interrupted any other way, and
+    the launcher only returns when every rank has exited."""
+    import threading
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(seconds):
+            try:
+                on_timeout()
+            finally:
+                sys.stdout.flush()
+                os._exit(0)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        return fn(), None
+    except BaseException as e:   # noqa: BLE001 -- including SystemExit from an assert inside a library call
+        return None, f"{type(e).__name__}: {e}"[:400]
+    finally:
+        done.set()
+
+
 def self_launch(n: int) -> int:
     """Re-executes this command under torch.distributed.run with n ranks on 127.0.0.1 (a free port) and returns its exit code."""
     import socket
@@ -489,16 +516,30 @@ def main():
     torch.cuda.empty_cache()
     # The part of the path that SHARDS (north_star: long-context prefill + ViT over the node's GPUs): measured next to the
     # replica decode number whenever there is more than one rank, so a scaling run of this command covers both.
+    clean = True
     if (world > 1 or args.sharded_prefill) and args.workload == "qwen3vl8b" and not shared_device:
-        sp = sharded_prefill_bench(rank, world, local_rank)
-        assert sp["rccl_ranks"] == args.gpus
+        # This leg has never run on more than one GPU (no multi-GPU box in the build loop): the replica decode numbers above must reach the
+        # driver whatever happens in it.  An exception becomes an "error" entry; a hang (a collective that never completes) is ended by a
+        # watchdog on EVERY rank -- rank 0 prints the line it has, all ranks leave with os._exit so that the launcher returns.
+        def on_timeout():
+            if rank == 0:
+                line["sharded_prefill"] = {"error": f"did not finish within {SHARDED_LEG_TIMEOUT_S} s (watchdog); replica decode numbers above are complete"}
+                print(json.dumps(line), flush=True)
+        sp, err = guarded(lambda: sharded_prefill_bench(rank, world, local_rank), SHARDED_LEG_TIMEOUT_S, on_timeout)
+        if err is None and sp["rccl_ranks"] != args.gpus:
+            err = f"rccl_ranks {sp['rccl_ranks']} != --gpus {args.gpus}"
+        clean = err is None
         if rank == 0:
-            line["sharded_prefill"] = sp
+            line["sharded_prefill"] = sp if err is None else {"error": err}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        if clean:
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            sys.stdout.flush()
+            os._exit(0)    # the other ranks may be inside a collective this rank left: no barrier, no teardown
 
 
 if __name__ == "__main__":

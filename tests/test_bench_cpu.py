@@ -78,3 +78,22 @@ def test_committed_profiles_are_attached_only_under_a_matching_source_digest(tmp
     assert "rocprof" not in stale and stale["traffic"] is None
     other = bench.attach_committed_profiles(dict(roof), "qwen3-0.6b")
     assert "rocprof" not in other and other["traffic"] is None
+
+
+def test_guarded_leg_result_exception_and_watchdog():
+    """bench.guarded: the multi-rank extra leg (sharded prefill) must not be able to take the replica decode line down with it -- a
+    result passes through, an exception becomes text, and a call that never returns ends the process from a watchdog thread after
+    on_timeout() has run (exit code 0, so that the launcher returns once every rank has left)."""
+    import subprocess
+    import sys
+    import time
+    import bench
+    assert bench.guarded(lambda: 41 + 1, 5, lambda: None) == (42, None)
+    res, err = bench.guarded(lambda: [][1], 5, lambda: None)
+    assert res is None and err.startswith("IndexError")
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; "
+            "bench.guarded(lambda: time.sleep(30), 0.5, lambda: print('line printed by the watchdog')); print('not reached')" % ROOT)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and "line printed by the watchdog" in p.stdout and "not reached" not in p.stdout
+    assert time.time() - t0 < 25
