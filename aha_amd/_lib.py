@@ -102,7 +102,7 @@ SIGNATURES = {
     "aha_hip_debug_steps_executed": (C.c_int64, [_P]),
     "aha_hip_debug_graph_step": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "aha_hip_kv_export": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
-    "aha_hip_kv_import": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_size_t, C.c_int64]),
+    "aha_hip_kv_import": (C.c_int, [_P, _P, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_size_t, C.c_int64]),
     "aha_hip_set_profiling": (C.c_int, [_P, C.c_int]),
     "aha_hip_get_profile": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]),

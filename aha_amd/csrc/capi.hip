@@ -182,11 +182,11 @@ int aha_hip_kv_export(aha_model* m, void* out_dev, size_t out_bytes, size_t* byt
   return model_kv_export(m, out_dev, out_bytes, bytes_needed, n_tokens, rope_delta);
   API_GUARD_END
 }
-int aha_hip_kv_import(aha_model* m, const void* in_dev, int32_t src_heads, int32_t src_head0, int32_t dst_head0, int32_t n_heads,
+int aha_hip_kv_import(aha_model* m, const void* in_dev, size_t in_bytes, int32_t src_heads, int32_t src_head0, int32_t dst_head0, int32_t n_heads,
                       size_t n_tokens, int64_t rope_delta) {
   if (!m) return AHA_ERR_INVALID;
   API_GUARD_BEGIN
-  return model_kv_import(m, in_dev, src_heads, src_head0, dst_head0, n_heads, n_tokens, rope_delta);
+  return model_kv_import(m, in_dev, in_bytes, src_heads, src_head0, dst_head0, n_heads, n_tokens, rope_delta);
   API_GUARD_END
 }
 

@@ -189,10 +189,8 @@ int model_ensure_pages(aha_model* m, size_t tokens);
 KvLayer model_kv_layer(aha_model* m, int layer);
 int model_debug_graph_step(aha_model* m, int replays, double* us_launches, double* us_graph);
 int model_kv_export(aha_model* m, void* out_dev, size_t out_bytes, size_t* bytes_needed, size_t* n_tokens, int64_t* rope_delta);
-int model_kv_import(aha_model* m, const void* in_dev, int src_heads, int src_head0, int dst_head0, int n_heads, size_t n_tokens,
+int model_kv_import(aha_model* m, const void* in_dev, size_t in_bytes, int src_heads, int src_head0, int dst_head0, int n_heads, size_t n_tokens,
                     int64_t rope_delta);
-int model_kv_export(aha_model* m, void* out_dev, size_t out_bytes, size_t* bytes_needed, size_t* n_tokens, int64_t* rope_delta);
-int model_kv_import(aha_model* m, const void* in_dev, int src_heads, int src_head0, int dst_head0, int n_heads, size_t n_tokens, int64_t rope_delta);
 int prof_collect(aha_model* m);
 int model_allreduce(aha_model* m, float* buf, size_t count);
 // loader.hip

@@ -396,11 +396,15 @@ int model_kv_export(aha_model* m, void* out_dev, size_t out_bytes, size_t* bytes
   return AHA_OK;
 }
 
-int model_kv_import(aha_model* m, const void* in_dev, int src_heads, int src_head0, int dst_head0, int n_heads, size_t n_tokens,
+int model_kv_import(aha_model* m, const void* in_dev, size_t in_bytes, int src_heads, int src_head0, int dst_head0, int n_heads, size_t n_tokens,
                     int64_t rope_delta) {
   const aha_model_desc& c = m->desc;
   if (c.head_dim != 128) {
     set_error("kv_import: head_dim 128 only");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  if (m->tp_size > 1) {   // the hand-back ends in an UN-sharded model (decode stays single-GPU); a sharded destination would need a head map
+    set_error("kv_import: the destination model is tensor-parallel (tp_size " + std::to_string(m->tp_size) + "); import into an un-sharded model");
     return AHA_ERR_UNSUPPORTED;
   }
   if (!in_dev || n_heads <= 0 || src_head0 < 0 || dst_head0 < 0 || src_head0 + n_heads > src_heads || dst_head0 + n_heads > c.num_key_value_heads) {
@@ -409,10 +413,17 @@ int model_kv_import(aha_model* m, const void* in_dev, int src_heads, int src_hea
     return AHA_ERR_INVALID;
   }
   if (n_tokens == 0) return AHA_OK;
+  const size_t pages = (n_tokens + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS;
+  // the kernel reads layers x pages x src_heads x (K | V) blocks of 16 KB from in_dev: the caller states what the buffer holds
+  const size_t need_bytes = (size_t)c.num_hidden_layers * pages * (size_t)src_heads * 2 * KV_BLOCK_BYTES;
+  if (in_bytes < need_bytes) {
+    set_error("kv_import: the buffer holds " + std::to_string(in_bytes) + " bytes, " + std::to_string(need_bytes) + " are needed for " +
+              std::to_string(n_tokens) + " tokens of " + std::to_string(src_heads) + " heads");
+    return AHA_ERR_INVALID;
+  }
   AHA_HIP_CHECK(hipSetDevice(m->ctx->device));
   int rc = model_ensure_pages(m, n_tokens);
   if (rc) return rc;
-  const size_t pages = (n_tokens + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS;
   hipLaunchKernelGGL(kv_pack_kernel, dim3((unsigned)pages, (unsigned)c.num_hidden_layers, (unsigned)n_heads * 2), dim3(256), 0, m->stream,
                      m->d_page_ptrs, m->layer_stride, c.num_key_value_heads, (char*)in_dev, src_heads, src_head0, dst_head0, (int)pages, 1);
   AHA_HIP_CHECK(hipGetLastError());
@@ -420,6 +431,8 @@ int model_kv_import(aha_model* m, const void* in_dev, int src_heads, int src_hea
   m->cache_len = n_tokens;
   m->rope_delta = rope_delta;
   m->rope_delta_valid = true;
+  m->have_logits = false;        // whatever logits an earlier forward left on the device belong to another cache
+  m->logits_assembled = false;
   return AHA_OK;
 }
 
@@ -994,6 +1007,12 @@ static int gemm_row_parallel(aha_model* m, GemmArgs g, int rows_per_rank = 0) {
     const bool on_comm_stream = m->rccl_comm != nullptr;   // host-callback seam (tests): the callback synchronises, no overlap to set up
     int rc;
     if (on_comm_stream && (rc = ensure_comm_stream(m))) return rc;
+    // an error inside the loop must not leave the compute stream free to overwrite p_partial while the communication stream still
+    // reads it: join the streams before returning
+    auto fail = [&](int code) {
+      if (on_comm_stream && hipEventRecord(m->ev_comm, m->comm_stream) == hipSuccess) (void)hipStreamWaitEvent(m->stream, m->ev_comm, 0);
+      return code;
+    };
     for (int j = 0; j < nch; ++j) {
       GemmArgs gj = g;
       gj.W = (const bf16_t*)g.W + (int64_t)j * Nc * g.ldw;
@@ -1006,15 +1025,19 @@ static int gemm_row_parallel(aha_model* m, GemmArgs g, int rows_per_rank = 0) {
       launch_gemm(gj, m->stream);
       float* bj = m->p_partial + (size_t)j * rows_pad * Nc;
       if (on_comm_stream) {
-        ProfScope ps(m, "reduce_scatter", (double)rows_pad * Nc * 4, 0);
-        AHA_HIP_CHECK(hipEventRecord(m->ev_gemm[j], m->stream));
-        AHA_HIP_CHECK(hipStreamWaitEvent(m->comm_stream, m->ev_gemm[j], 0));
-        if ((rc = rccl_reduce_scatter(m, bj, (size_t)rows_per_rank * Nc, m->comm_stream))) return rc;
+        // (no ProfScope here: it would time m->stream, and this collective runs on the communication stream; the wait for it is
+        // what the compute stream sees -- the "rs_wait" scope below)
+        if (hipEventRecord(m->ev_gemm[j], m->stream) != hipSuccess || hipStreamWaitEvent(m->comm_stream, m->ev_gemm[j], 0) != hipSuccess) {
+          set_error("gemm_row_parallel: event hand-off to the communication stream failed");
+          return fail(AHA_ERR_HIP);
+        }
+        if ((rc = rccl_reduce_scatter(m, bj, (size_t)rows_per_rank * Nc, m->comm_stream))) return fail(rc);
       } else if ((rc = model_reduce_scatter(m, bj, (size_t)rows_per_rank * Nc))) {
         return rc;
       }
     }
     if (on_comm_stream) {
+      ProfScope ps(m, "rs_wait", (double)rows_pad * N * 4, 0);   // what the compute stream waits for the overlapped reduce-scatters
       AHA_HIP_CHECK(hipEventRecord(m->ev_comm, m->comm_stream));
       AHA_HIP_CHECK(hipStreamWaitEvent(m->stream, m->ev_comm, 0));
     }
@@ -1334,8 +1357,16 @@ int model_decode_greedy(aha_model* m, uint32_t first_token, size_t offset, size_
   size_t produced = 0, enq = 0, seen = 0;
   bool stop = false;
   const size_t base_len = m->cache_len;
+  // Tensor parallelism: every step holds collectives, so all ranks must enqueue the SAME number of steps.  The run-ahead rule above
+  // depends on when this host thread happens to read h_done (one rank may have seen the stop token and queue nothing while another
+  // queues `ahead` more steps and then waits for ever in their all-reduces).  Under TP the schedule is therefore a function of the
+  // token sequence alone: whole groups of `ahead` steps, the next group only after every token of the last one has been read.
+  const bool lockstep = m->tp_size > 1;
   while (seen < max_new && !stop) {
-    while (enq < max_new && enq - seen < ahead) {
+    size_t want = 0;
+    if (!lockstep) want = enq < max_new && enq - seen < ahead ? std::min(max_new - enq, ahead - (enq - seen)) : 0;
+    else if (seen == enq) want = std::min(max_new - enq, ahead);
+    for (size_t i = 0; i < want; ++i) {
       enqueue_decode_step(m, base_len + enq + 1);
       hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(1), 0, m->stream, m->d_state, m->d_token_log, m->h_ring_dev, m->h_done_dev);
       ++enq;

@@ -328,7 +328,7 @@ class HipInferenceModel:
         """aha_hip_kv_import: heads [src_head0, +n_heads) of a packed buffer (src_heads per page) -> this model's heads [dst_head0, ..)."""
         assert buf.is_cuda and buf.dtype == torch.uint8 and buf.is_contiguous()
         torch.cuda.current_stream(buf.device).synchronize()
-        check(lib().aha_hip_kv_import(self.handle, buf.data_ptr(), src_heads, src_head0, dst_head0, n_heads, n_tokens, rope_delta))
+        check(lib().aha_hip_kv_import(self.handle, buf.data_ptr(), buf.numel(), src_heads, src_head0, dst_head0, n_heads, n_tokens, rope_delta))
 
     def debug_graph_step(self, replays: int = 50):
         """(us per decode step enqueued launch by launch, us per step replayed as one hipGraph) at the current cache length; clears the cache."""

@@ -10,7 +10,7 @@ One process per GPU; `torch.distributed` backend "nccl" (= RCCL over xGMI) on GP
 from __future__ import annotations
 
 import os
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 
 def shard_units(n_units: int, world: int, rank: int) -> Tuple[int, int]:
@@ -48,19 +48,36 @@ def aggregate_throughput(units_this_rank: float, secs_this_rank: float, device="
     return float(u.item()) / float(t.item()), float(t.item())
 
 
-def encode_images_sharded(encode_fn, per_image_inputs: List, tokens_per_image: List[int], world: int, rank: int, meta=None):
+def _sync_clock(device=None) -> float:
+    """perf_counter after the device's queues have drained (phase boundaries of the diagnostic pass; never inside a timed region)."""
+    import time
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize(device)
+    return time.perf_counter()
+
+
+def encode_images_sharded(encode_fn, per_image_inputs: List, tokens_per_image: List[int], world: int, rank: int, meta=None,
+                          timings: Optional[dict] = None):
     """Image-parallel ViT: images are independent units (block-diagonal attention per image,
     /root/reference/src/models/qwen3vl/model.rs:258-273), so rank r encodes images shard_units(n, world, r) and ONE
     all_gather moves the embeddings.  ``encode_fn(list_of_inputs) -> (K, n_local_tokens, H)`` tensor (device for nccl,
     CPU for gloo); returns (K, total_tokens, H) in image order on every rank.  Ragged shards are padded to the largest
     shard for the collective and trimmed afterwards.  ``meta = (K, H, dtype, device)`` of the encoder's output, known from the
     config: a rank without images then builds its padding on ITS OWN device and the timed path has no pickle collective
-    (without it the shapes are agreed with one all_gather_object and the padding goes to this rank's current device)."""
+    (without it the shapes are agreed with one all_gather_object and the padding goes to this rank's current device).
+    ``timings`` (diagnostic pass only: it synchronises the device at the phase boundaries) receives ``vit_s`` = this rank's encoder
+    time and ``embeds_all_gather_s`` = padding + collective + trim."""
     import torch
     import torch.distributed as dist
     n = len(per_image_inputs)
     a, b = shard_units(n, world, rank)
+    t0 = _sync_clock() if timings is not None else 0.0
     local = encode_fn(per_image_inputs[a:b]) if b > a else None
+    if timings is not None:
+        t1 = _sync_clock()
+        timings["vit_s"] = timings.get("vit_s", 0.0) + (t1 - t0)
+        timings["vit_images_this_rank"] = b - a
     if world == 1 or not dist.is_initialized():
         return local
     counts = [sum(tokens_per_image[slice(*shard_units(n, world, r))]) for r in range(world)]
@@ -80,7 +97,11 @@ def encode_images_sharded(encode_fn, per_image_inputs: List, tokens_per_image: L
         buf[:, : local.shape[1]] = local
     outs = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(outs, buf)
-    return torch.cat([o[:, :c] for o, c in zip(outs, counts) if c > 0], dim=1)
+    res = torch.cat([o[:, :c] for o, c in zip(outs, counts) if c > 0], dim=1)
+    if timings is not None:
+        timings["embeds_all_gather_s"] = timings.get("embeds_all_gather_s", 0.0) + (_sync_clock() - t1)
+        timings["embeds_all_gather_bytes"] = int(buf.numel() * buf.element_size() * world)
+    return res
 
 
 def broadcast_bytes(payload, src: int = 0):
@@ -91,8 +112,24 @@ def broadcast_bytes(payload, src: int = 0):
     return box[0]
 
 
+# library profiler classes (csrc/model.hip ProfScope: HIP events on the model's stream around each launch group) -> phase names
+PREFILL_PHASE_CLASSES = (("gemm", "gemm_s"), ("attn_prefill", "attn_s"), ("attn_vit", "vit_attn_s"), ("elem", "rowwise_s"),
+                         ("reduce_scatter", "reduce_scatter_s"), ("rs_wait", "reduce_scatter_wait_s"), ("all_gather", "all_gather_s"),
+                         ("allreduce", "allreduce_s"), ("gemv", "lm_head_s"))
+
+
+def read_prefill_phases(model, ph: dict) -> dict:
+    """Seconds per profiler class of the forward calls since model.set_profiling(True), under the phase names of the bench line."""
+    for cls, name in PREFILL_PHASE_CLASSES:
+        pr = model.get_profile(cls)
+        if pr["launches"]:
+            ph[name] = round(pr["ms"] * 1e-3, 5)
+            ph[name[:-2] + "_launches"] = int(pr["launches"])
+    return ph
+
+
 def sharded_prefill(cfg, weights, input_ids, data, rank: int, world: int, device_index: int, kv_reserve_tokens: int = 0,
-                    repeats: int = 1):
+                    repeats: int = 1, phases_out: Optional[dict] = None):
     """BASELINE cfg 5's sharded path on `world` GPUs of one node, one process per GPU:
       * the ranks form ONE tensor-parallel group: every rank passes the full checkpoint, the library keeps its q/k/v heads,
         gate/up rows and o/down columns, and all-reduces the row-parallel partial sums over RCCL (aha_hip_tp_init_rccl);
@@ -100,7 +137,13 @@ def sharded_prefill(cfg, weights, input_ids, data, rank: int, world: int, device
         DeepStack embeddings (encode_images_sharded), and every rank scatters all of them into its prompt;
       * lm_head is vocabulary-parallel inside the library (arg-max pair exchange).
     Returns (first greedy token, seconds of the slowest of `repeats` timed prefills on this rank, model).  world == 1 is the
-    plain single-GPU call, so the N = 1 value of a scaling curve is the single-GPU cfg 5 prefill."""
+    plain single-GPU call, so the N = 1 value of a scaling curve is the single-GPU cfg 5 prefill.
+    ``phases_out`` (a dict): ONE more, untimed prefill runs with the library profiler on and the device synchronised at the host-side
+    phase boundaries, and the dict receives this rank's seconds per phase -- ViT encode, embeddings all-gather, and inside the decoder
+    stack (HIP events on the model's stream): GEMMs, attention, row-wise kernels, blocking reduce-scatters, the wait for the
+    reduce-scatters overlapped on the communication stream, all-gathers of the normalised rows, all-reduces, lm_head -- plus
+    ``stack_s`` (wall clock of forward_initial) so that what the events do not cover (host gaps, page mapping) shows as the
+    difference.  A first multi-GPU run then says WHERE the time went, not only how long it took."""
     import time
     import numpy as np
     import torch
@@ -112,7 +155,7 @@ def sharded_prefill(cfg, weights, input_ids, data, rank: int, world: int, device
                               tp_rank=rank if world > 1 else 0, tp_size=world, rccl_unique_id=uid)
     grid = None if data is None else np.asarray(data.image_grid_thw, dtype=np.uint32).reshape(-1, 3)
 
-    def one_prefill():
+    def one_prefill(ph=None):
         model.clear_cache()
         mm = data
         if data is not None and world > 1:
@@ -124,9 +167,20 @@ def sharded_prefill(cfg, weights, input_ids, data, rank: int, world: int, device
                 a, b = idx_range[0], idx_range[-1] + 1
                 return model.vision_encode(MultiModalData(data.pixel_values[patches[a]:patches[b]], grid[a:b]))
             meta = (1 + len(cfg.vision.deepstack_visual_indexes), cfg.text.hidden_size, torch.bfloat16, torch.device("cuda", device_index))
-            emb = encode_images_sharded(lambda idx: enc(idx), list(range(len(grid))), toks, world, rank, meta=meta)
+            emb = encode_images_sharded(lambda idx: enc(idx), list(range(len(grid))), toks, world, rank, meta=meta, timings=ph)
             mm = MultiModalData(image_grid_thw=grid, image_embeds=emb.contiguous())
+        if ph is None:
+            _, tok = model.forward_initial(input_ids, 0, mm, want_logits=False)
+            return tok
+        t0 = _sync_clock()
+        model.set_profiling(True)
         _, tok = model.forward_initial(input_ids, 0, mm, want_logits=False)
+        read_prefill_phases(model, ph)
+        model.set_profiling(False)
+        ph["stack_s"] = round(_sync_clock() - t0, 5)
+        for k in ("vit_s", "embeds_all_gather_s"):
+            if k in ph:
+                ph[k] = round(ph[k], 5)
         return tok
 
     tok = one_prefill()   # warm (page allocation, RCCL channels)
@@ -140,6 +194,12 @@ def sharded_prefill(cfg, weights, input_ids, data, rank: int, world: int, device
         tok = one_prefill()
         torch.cuda.synchronize()
         worst = max(worst, time.perf_counter() - t0)
+    if phases_out is not None:
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        tok_d = one_prefill(phases_out)
+        phases_out["first_token_equal_to_timed_run"] = bool(tok_d == tok)
     return tok, worst, model
 
 

@@ -189,6 +189,19 @@ def penalty_context(repeat_penalty: float, repeat_last_n: Optional[int], generat
     return (float(repeat_penalty), ids) if len(ids) else (1.0, [])
 
 
+def draw_from_candidates(lp: "LogitsProcessor", w: np.ndarray, idx: np.ndarray) -> int:
+    """The weighted draw over a candidate list, in the order candle draws in.  sample_topk / sample_topk_topp draw over the k
+    selected probabilities in selection order and map the position back through `indices` -- the candidate order.  sample_topp
+    zeroes the tail INSIDE the full-vocabulary vector and calls sample_multinomial(prs): WeightedIndex takes its running sums in
+    TOKEN-ID order, so the surviving candidates are put in vocabulary order first (zeros in between add nothing to an f32 running
+    sum): the same u32 of the stream then picks the token the full-vector path (weights_from_logits) picks."""
+    idx = np.asarray(idx)
+    if lp.sampling.kind == "TopP":
+        order = np.argsort(idx, kind="stable")
+        return int(idx[order][lp.draw(np.asarray(w)[order])])
+    return int(idx[lp.draw(w)])
+
+
 def sample_and_push(ctx: GenerationContext, model, argmax_token: int, generated: List[int]) -> int:
     """common/generate.rs:70-86 on the logits of the model's last forward call."""
     lp = ctx.logit_processor
@@ -206,7 +219,7 @@ def sample_and_push(ctx: GenerationContext, model, argmax_token: int, generated:
             else:
                 w = lp.weights_from_candidates(vals, mx, se, idx)
                 if w is not None:
-                    token = int(idx[lp.draw(w)])
+                    token = draw_from_candidates(lp, w, idx)
         if token is None:  # full-vector fallback
             logits = model.last_logits()
             if pen != 1.0:

@@ -138,8 +138,9 @@ class ChatTemplate:
         def _no_strip(*_a, **_k):   # fix_template rewrites `reasoning_content.strip(..)` into a `strip` FILTER that setup_environment never
             raise jinja2.TemplateRuntimeError("unknown filter: filter strip is unknown")   # registers: minijinja fails when the branch runs
         env.filters["strip"] = _no_strip
-        # the reference's filter is format!("{}", v): minijinja's Display renders none / undefined as "none"
-        env.filters["string"] = lambda v: "none" if v is None or isinstance(v, jinja2.Undefined) else (str(v).lower() if isinstance(v, bool) else str(v))
+        # the reference's filter is format!("{}", v): minijinja 2.x's Display for Value writes "none" for None and NOTHING for Undefined
+        # ([unverified]: the crate is not on disk; from its published source, ValueRepr::Undefined => Ok(()))
+        env.filters["string"] = lambda v: "" if isinstance(v, jinja2.Undefined) else ("none" if v is None else (str(v).lower() if isinstance(v, bool) else str(v)))
         env.tests["startingwith"] = lambda s, p: str(s).startswith(p)
         env.tests["endingwith"] = lambda s, p: str(s).endswith(p)
         self.env = env

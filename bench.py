@@ -156,8 +156,9 @@ def sharded_prefill_bench(rank, world, local_rank, n_images=8, image_px=2048, pr
     g = torch.Generator().manual_seed(5)
     ids, data = synthetic_image_request(cfg, image_px, prompt, g, device=dev, n_images=n_images)
     torch.cuda.synchronize()
+    phases = {}
     tok, secs, model = parallel.sharded_prefill(cfg, w, ids, data, rank, world, local_rank, kv_reserve_tokens=len(ids) + 4096,
-                                                repeats=repeats)
+                                                repeats=repeats, phases_out=phases)
     # BASELINE cfg 5 is "prefill + 16 tokens", and decode stays single-GPU (north_star): the head-sharded KV cache is gathered into an
     # un-sharded model on rank 0 (parallel.gather_kv_to_rank0: one RCCL gather of the packed pages), which decodes the 16 tokens alone
     from aha_amd.model import HipInferenceModel
@@ -173,6 +174,7 @@ def sharded_prefill_bench(rank, world, local_rank, n_images=8, image_px=2048, pr
         torch.cuda.synchronize()
         dist.barrier()
         handback["kv_handback_s"] = round(time.perf_counter() - t0, 4)
+        phases["kv_gather_s"] = handback["kv_handback_s"]
     if rank == 0:
         t0 = time.perf_counter()
         out = full.decode_greedy(tok, len(ids), 16)
@@ -191,11 +193,26 @@ def sharded_prefill_bench(rank, world, local_rank, n_images=8, image_px=2048, pr
         same = all(int(t.item()) == int(lst[0].item()) for t in lst)
     model.close()
     torch.cuda.empty_cache()
+    # per-phase seconds: rank 0's own diagnosis + the slowest rank's figure for every phase (one MAX all-reduce over the value vector)
+    keys = sorted(k for k, v in phases.items() if isinstance(v, float))
+    phases_max = {}
+    if world > 1 and keys:
+        import torch.distributed as dist
+        allk = [None] * world
+        dist.all_gather_object(allk, keys)
+        keys = sorted(set().union(*[set(k) for k in allk]))
+        vec = torch.tensor([float(phases.get(k, 0.0)) for k in keys], dtype=torch.float64, device=dev)
+        dist.all_reduce(vec, op=dist.ReduceOp.MAX)
+        phases_max = {k: round(float(v), 5) for k, v in zip(keys, vec.tolist())}
     return {"metric": METRICS["qwen3vl8b-cfg5-tp"], "value": round(value, 1), "unit": "tokens/s", "prefill_s": round(worst, 4),
             "prompt_tokens": len(ids), "n_images": n_images, "image": image_px, "scaling": "strong",
             "parallelism": f"tp{world} (sequence-parallel: RCCL reduce-scatter of the row-parallel partial sums in column blocks overlapped with "
                            "the GEMMs + all-gather of the normalised rows) + image-parallel ViT (all-gather) + KV gather to rank 0 for decode",
-            "rccl_ranks": world, "first_token_equal_on_all_ranks": same, **handback}
+            "rccl_ranks": world, "first_token_equal_on_all_ranks": same, **handback,
+            "phases_rank0": phases, "phases_max_over_ranks": phases_max,
+            "phases_note": "one extra UNTIMED prefill with the library profiler on (HIP events per launch group on the model's stream; host-side phases "
+                           "bracketed by device synchronisation): vit_s / embeds_all_gather_s / stack_s are wall clock, the rest event time inside stack_s; "
+                           "reduce_scatter_wait_s = what the compute stream waited for the collectives overlapped on the communication stream"}
 
 SHARDED_LEG_TIMEOUT_S = int(os.environ.get("AHA_BENCH_SHARDED_TIMEOUT_S", "420"))
 
@@ -359,9 +376,10 @@ def main():
                     "config": {"workload": args.workload, "prompt_tokens": sp["prompt_tokens"], "image": sp["image"],
                                "n_images": sp["n_images"], "parallelism": sp["parallelism"], "rccl_ranks": world},
                     "first_token_equal_on_all_ranks": sp["first_token_equal_on_all_ranks"]}
-            for k in ("kv_handback_s", "decode_16_after_prefill_s", "decode_tokens"):
+            for k in ("kv_handback_s", "decode_16_after_prefill_s", "decode_tokens", "phases_rank0", "phases_max_over_ranks", "phases_note"):
                 if k in sp:
                     line[k] = sp[k]
+            line["sharded_ok"] = bool(sp["first_token_equal_on_all_ranks"])
             print(json.dumps(line), flush=True)
         if world > 1:
             dist.barrier()
@@ -524,6 +542,7 @@ def main():
         def on_timeout():
             if rank == 0:
                 line["sharded_prefill"] = {"error": f"did not finish within {SHARDED_LEG_TIMEOUT_S} s (watchdog); replica decode numbers above are complete"}
+                line["sharded_ok"] = False
                 print(json.dumps(line), flush=True)
         sp, err = guarded(lambda: sharded_prefill_bench(rank, world, local_rank), SHARDED_LEG_TIMEOUT_S, on_timeout)
         if err is None and sp["rccl_ranks"] != args.gpus:
@@ -531,6 +550,9 @@ def main():
         clean = err is None
         if rank == 0:
             line["sharded_prefill"] = sp if err is None else {"error": err}
+            # top level, next to the replica numbers: the process exits 0 either way (the replica line must reach the driver), so a
+            # consumer that reads only the exit code would otherwise see success after a failed or hung sharded leg
+            line["sharded_ok"] = bool(clean and sp["first_token_equal_on_all_ranks"])
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -284,11 +284,14 @@ int aha_hip_set_seq_parallel(aha_model* m, aha_reduce_scatter_fn reduce_scatter,
  * per page) into heads [dst_head0, dst_head0 + n_heads) of THIS model's pages -- an un-sharded model on GPU 0 imports rank r's
  * buffer at dst_head0 = r * kv_heads / T --, maps pages for n_tokens, and sets the cache length and the Qwen3-VL rope_delta so
  * that forward_step / decode_greedy continue exactly as after a single-GPU prefill.  out_dev NULL: only the sizes are returned.
+ * `in_bytes` is the size of the buffer behind in_dev: it must hold layers x ceil(n_tokens / 64) x src_heads x 32 KB, else
+ * AHA_ERR_INVALID (nothing is read).  The destination must be un-sharded (tp_size 1); an import invalidates the logits an earlier
+ * forward call left behind.
  * No reference counterpart (the reference has no collectives): the contract is "decode after export + import == decode after
  * the same prefill on one GPU" (tests/test_tp_gpu.py). */
 int aha_hip_kv_export(aha_model* m, void* out_dev, size_t out_bytes, size_t* bytes_needed, size_t* n_tokens, int64_t* rope_delta);
-int aha_hip_kv_import(aha_model* m, const void* in_dev, int32_t src_heads, int32_t src_head0, int32_t dst_head0, int32_t n_heads,
-                      size_t n_tokens, int64_t rope_delta);
+int aha_hip_kv_import(aha_model* m, const void* in_dev, size_t in_bytes, int32_t src_heads, int32_t src_head0, int32_t dst_head0,
+                      int32_t n_heads, size_t n_tokens, int64_t rope_delta);
 /* Test hook: run the installed all-reduce (RCCL communicator or callback) once on a caller-owned f32 device buffer and
  * wait for it.  Lets a 1-GPU box exercise the RCCL wiring with a communicator of size 1. */
 int aha_hip_debug_allreduce(aha_model* m, void* buf_f32_dev, size_t count);

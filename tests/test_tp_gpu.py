@@ -192,6 +192,38 @@ def test_tp2_greedy_tokens_and_vl(gpu):
         m.close()
 
 
+def test_tp2_greedy_loop_with_a_stop_token_mid_sequence(gpu):
+    """A stop token in the middle of a TP greedy run (round-3 advisor, high): every decode step holds all-reduces, so both ranks must
+    enqueue the same number of steps whatever the moment their host threads read the published tokens.  Under TP the loop enqueues
+    whole groups of AHA_DECODE_RUNAHEAD steps as a function of the token sequence alone: no rank may be left waiting in a collective
+    (the barrier of TwoRankSum times out after 60 s), both ranks return the tokens up to and including the stop token, executed the
+    same number of steps, and a second call on the same handles (leftover collectives would pair with it) still agrees."""
+    from aha_amd.model import HipContext, HipInferenceModel
+    cfg = tiny_qwen3()
+    w = qwen3_text_weights(cfg, seed=0)
+    ids = [int(x) for x in np.random.default_rng(3).integers(0, cfg.vocab_size, size=21)]
+    single = HipInferenceModel(cfg, w, ctx=HipContext(0))
+    _, am = single.forward_initial(ids, 0)
+    base = single.decode_greedy(am, len(ids), 24)
+    single.close()
+    for stop_at in (2, 5, 6):      # inside the first group of 4, first / second step of the second group
+        if base[stop_at] in base[:stop_at]:
+            continue
+        cfg.eos_token_ids = [base[stop_at]]
+        red = TwoRankSum()
+        ranks = [HipInferenceModel(cfg, w, tp_rank=r, tp_size=2, allreduce=lambda p, n, r=r: red.allreduce(r, p, n)) for r in range(2)]
+        run_ranks([lambda m=m: m.forward_initial(ids, 0, want_logits=False) for m in ranks])
+        toks = run_ranks([lambda m=m: m.decode_greedy(am, len(ids), 24) for m in ranks])
+        assert list(toks[0]) == list(toks[1]) == list(base[: stop_at + 1])
+        steps = [m.debug_steps_executed() for m in ranks]
+        assert steps[0] == steps[1] and stop_at + 1 <= steps[0] <= stop_at + 4, steps
+        more = run_ranks([lambda m=m: m.decode_greedy(int(toks[0][-1]), len(ids) + stop_at + 1, 4) for m in ranks])
+        assert list(more[0]) == list(more[1]) and len(more[0]) >= 1
+        for m in ranks:
+            m.close()
+    cfg.eos_token_ids = []
+
+
 def test_tp2_vocab_parallel_lm_head_is_exact_given_the_hidden_state(gpu):
     """With ONE decoder layer whose row-parallel partial sums are exact in f32 (weights and activations are small integers /
     powers of two in bf16), the TP stack's hidden state equals the single-GPU one bit for bit, so the vocab-sharded lm_head
@@ -269,6 +301,7 @@ def test_tp2_two_processes_gloo(gpu):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "TP_WORKER_OK" in r.stdout, r.stdout[-2000:]
+    assert "phases=[" in r.stdout and "reduce_scatter_s" in r.stdout and "vit_s" in r.stdout   # the per-phase diagnosis of the sharded prefill
 
 
 def test_kv_export_import_round_trip_is_exact(gpu):
@@ -333,7 +366,22 @@ def test_kv_export_import_round_trip_is_exact(gpu):
     c = HipInferenceModel(cfg, w)
     with pytest.raises(AhaHipError):
         c.kv_import(buf, kvh, 0, 1, kvh, ntok, delta)
+    # the buffer's size is part of the call: a token count (or head count) the buffer cannot hold is refused before anything is read
+    with pytest.raises(AhaHipError, match="bytes"):
+        c.kv_import(buf, kvh, 0, 0, kvh, ntok + 64, delta)
+    with pytest.raises(AhaHipError, match="bytes"):
+        c.kv_import(buf[: buf.numel() // 2].contiguous(), kvh, 0, 0, kvh, ntok, delta)
+    # a logits query after an import must not return the previous cache's logits
+    c.forward_initial(ids[:5], 0)
+    c.clear_cache()
+    c.kv_import(buf, kvh, 0, 0, kvh, ntok, delta)
+    with pytest.raises(AhaHipError):
+        c.sample_candidates([], 1.0, 1.0, 4)
     c.close()
+    t = HipInferenceModel(cfg, w, tp_rank=0, tp_size=2, allreduce=lambda p, n: 0)
+    with pytest.raises(AhaHipError, match="tensor-parallel"):
+        t.kv_import(buf, kvh, 0, 0, kvh // 2, ntok, delta)
+    t.close()
 
 
 @pytest.mark.parametrize("S", [300, 513])

@@ -96,6 +96,24 @@ def main():
     assert calls[0] > 0, "the all-reduce seam was never used"
     if sp:
         assert sp_calls[0] > 0 and sp_calls[1] > 0, "the sequence-parallel seam was never used"
+    # the per-phase diagnosis bench.py attaches to its sharded-prefill object (parallel.sharded_prefill phases_out): one more prefill
+    # with the library profiler on; every phase of THIS path must show up with a time and a launch count, and the token must not move
+    ph = {}
+    emb2 = parallel.encode_images_sharded(enc, list(range(len(imgs))), toks, world, rank, timings=ph).cuda().contiguous()
+    assert torch.equal(emb2, emb)
+    m.clear_cache()
+    m.set_profiling(True)
+    _, tok2 = m.forward_initial(ids, 0, MultiModalData(image_grid_thw=grid, image_embeds=emb2), want_logits=False)
+    parallel.read_prefill_phases(m, ph)
+    m.set_profiling(False)
+    assert tok2 == tok
+    want_ph = ["vit_s", "embeds_all_gather_s", "gemm_s", "attn_s", "rowwise_s", "lm_head_s"] + (["reduce_scatter_s", "all_gather_s"] if sp else ["allreduce_s"])
+    assert all(k in ph and ph[k] >= 0.0 for k in want_ph), (want_ph, ph)
+    L = cfg.text.num_hidden_layers
+    if sp:
+        assert ph["reduce_scatter_launches"] == 2 * L and ph["all_gather_launches"] >= 2 * L, ph
+    m.clear_cache()
+    m.forward_initial(ids, 0, MultiModalData(image_grid_thw=grid, image_embeds=emb), want_logits=False)   # the cache the checks below continue from
     all_dec = [None] * world
     dist.all_gather_object(all_dec, dec)
     assert all(d == all_dec[0] for d in all_dec), f"ranks disagree on the greedy tokens: {all_dec}"
@@ -122,7 +140,7 @@ def main():
             o3 += 1
         assert float(np.abs(hl - rl).max()) <= 0.03 * s2, "decode on the gathered KV cache drifted from the single-GPU run"
         print(f"TP_WORKER_OK tokens_equal={margin_ok} handback_tokens_equal={hdec == rdec} allreduce_calls={calls[0]} "
-              f"reduce_scatter_calls={sp_calls[0]} all_gather_calls={sp_calls[1]}", flush=True)
+              f"reduce_scatter_calls={sp_calls[0]} all_gather_calls={sp_calls[1]} phases={sorted(k for k in ph if k.endswith('_s'))}", flush=True)
         handback.close()
         single.close()
     m.close()
