@@ -251,6 +251,23 @@ int aha_hip_debug_plan_gemm(int32_t M, int32_t N, int32_t K, int32_t act, int32_
   out3[0] = o[0]; out3[1] = o[1]; out3[2] = o[2];
   return AHA_OK;
 }
+int aha_hip_debug_streamk_plan(int32_t M, int32_t N, int32_t K, int32_t tile_n, int32_t workers, size_t workspace_bytes, int32_t* out,
+                               int32_t cap, int32_t* off_out, int32_t* info7) {
+  if (!out || cap < 0 || M <= 0 || N <= 0 || K <= 0) {
+    set_error("debug_streamk_plan: bad argument");
+    return AHA_ERR_INVALID;
+  }
+  const int n = debug_streamk_plan(M, N, K, tile_n, workers, 8, workspace_bytes, out, cap, off_out, info7);
+  if (n < 0) {
+    set_error("debug_streamk_plan: K must be a multiple of 64, workers a multiple of 8, tile_n 256 or 192, and the workspace must hold the chunks");
+    return AHA_ERR_INVALID;
+  }
+  return n;
+}
+int aha_hip_set_gemm_reserved_cus(int32_t n) {
+  set_gemm_reserved_cus(n);
+  return AHA_OK;
+}
 int aha_hip_debug_last_hidden(aha_model* m, float* out, size_t n) {
   API_GUARD_BEGIN
   if (!m || !out || n != (size_t)m->desc.hidden_size) {
@@ -319,15 +336,18 @@ int aha_hip_gemm(const void* A, const void* W, void* C, int32_t M, int32_t N, in
   // op-level entry (tests, scripts): one process-wide split-K scratch, grown on demand; not for concurrent callers
   static void* ws = nullptr;
   static size_t ws_bytes = 0;
-  const size_t want = (size_t)4 * M * N * 4;
+  const size_t want = std::max((size_t)4 * M * N * 4, (size_t)96 << 20);   // split-K slabs / >= 384 chunks of the persistent kernel
   if (want > ws_bytes && want <= ((size_t)1 << 30)) {
     if (ws) hipFree(ws);
     ws = nullptr;
     ws_bytes = 0;
     if (hipMalloc(&ws, want) == hipSuccess) ws_bytes = want;
   }
+  static void* ctrs = nullptr;   // the persistent kernel's per-tile counters (zero between launches)
+  if (!ctrs && (hipMalloc(&ctrs, SK_MAX_COUNTERS * 4) != hipSuccess || hipMemset(ctrs, 0, SK_MAX_COUNTERS * 4) != hipSuccess)) ctrs = nullptr;
   g.workspace = ws;
   g.workspace_bytes = ws_bytes;
+  g.sk_counters = ws ? ctrs : nullptr;
   launch_gemm(g, (hipStream_t)stream);
   AHA_HIP_CHECK(hipGetLastError());
   return AHA_OK;

@@ -333,7 +333,7 @@ typedef __attribute__((address_space(3))) char* lds_cptr_t;
 // loops -- cdna guide, "three .s-level traps".)
 template <int ACT, bool HAS_BIAS, bool HAS_RES, bool BAR2 = true, int ABL = 0, bool NF3 = false>
 __device__ __forceinline__ void gemm256q_mainloop(const GemmArgs& a, int m0, int n0, int kt0, int kt1, int lane, int wave,
-                                                  f32x16_t (&acc)[4][4]) {
+                                                  f32x16_t (&acc)[4][4], float zero = 0.f) {   // zero: see gemm256s_kernel
   char* const smem = gemm_smem;
   constexpr int REGION = 128 * 128, STAGE = 4 * REGION;
   constexpr int TN = NF3 ? 192 : 256, WC = TN / 2;   // tile columns, columns per wave
@@ -404,7 +404,7 @@ __device__ __forceinline__ void gemm256q_mainloop(const GemmArgs& a, int m0, int
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = zero;
   bf16x8_t fa[2][2][4], fw[2][2][4];  // [register set][fragment][k-step]; A half i lives in fa[i], W half j of tile t in fw[j ^ parity(t)]
 
   const int nmf = __builtin_amdgcn_readfirstlane(max(0, min(4, (a.M - (m0 + wm * 128) + 31) / 32)));  // valid 32-row fragments

@@ -151,18 +151,29 @@ struct GemmArgs {
   const void* norm_w = nullptr;
   void* norm_out = nullptr;
   float norm_eps = 0.f;
-  void* workspace = nullptr;     // optional f32 scratch for split-K slabs (splitk * M * N * 4 bytes)
+  void* workspace = nullptr;     // optional f32 scratch for split-K slabs (splitk * M * N * 4 bytes) / the persistent kernel's chunks
   size_t workspace_bytes = 0;
+  void* sk_counters = nullptr;   // optional SK_MAX_COUNTERS zeroed u32 words that belong to `workspace` (one per tile cut along K by the
+                                 // persistent kernel, kernels_gemm_sk.hip; every launch leaves them zero again)
   int tile_group = 8;            // band width of the grouped tile order inside an XCD's run (kernels_gemm.hip tile_of_block); 0 = plain
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 // split-K scratch used by launch_gemm calls of this THREAD whose GemmArgs carry none (the model sets it per forward)
-void set_gemm_workspace(void* ws, size_t bytes);
+void set_gemm_workspace(void* ws, size_t bytes, void* sk_counters = nullptr);
+// ---- the persistent, segment-table-driven kernel (kernels_gemm_sk.hip) ----
+constexpr int SK_MAX_COUNTERS = 4096;   // u32 words of GemmArgs::sk_counters
+bool streamk_has_kernel(int act, bool has_bias, bool has_res, bool n192);
+double streamk_estimate(const GemmArgs& a, int tile_n, int* n_chunks, int* n_split);   // k steps on the slowest worker; < 0: cannot plan
+bool launch_gemm_streamk(const GemmArgs& a, int tile_n, hipStream_t st);               // false: nothing was launched
+void set_streamk_forced_cut(int code);  // tests: style * 10 + cuts of the last round's tiles (style 0 = equal pieces, 1 = big + remainder); 0 = automatic
+int gemm_streamk_workers();            // workgroups of the persistent kernel = CUs - reserved, a multiple of 8
+void set_gemm_reserved_cus(int n);     // CUs the persistent GEMM leaves free (RCCL beside the GEMMs under TP); < 0: AHA_GEMM_RESERVE_CUS
+int debug_streamk_plan(int M, int N, int K, int tile_n, int workers, int group, size_t ws_bytes, int* out, int cap, int* off_out, int* info);
 void debug_plan_gemm(int M, int N, int K, int act, bool has_bias, bool has_res, size_t ws_bytes, int* out);   // host only: {tile, splitk, n_split}
 void set_gemm_plan_override(int tile, int splitk);  // tests: force the 128 / 256 tile kernel and a split-K factor; 0 = automatic
 struct GemmWorkspaceScope {
-  GemmWorkspaceScope(void* ws, size_t bytes) { set_gemm_workspace(ws, bytes); }
-  ~GemmWorkspaceScope() { set_gemm_workspace(nullptr, 0); }
+  GemmWorkspaceScope(void* ws, size_t bytes, void* sk_counters = nullptr) { set_gemm_workspace(ws, bytes, sk_counters); }
+  ~GemmWorkspaceScope() { set_gemm_workspace(nullptr, 0, nullptr); }
 };
 // x[i] = bf16(x[i] + bf16(sum[i])): Linear output tensor (all-reduced f32 partials) -> bf16, then the residual add -> bf16
 void launch_residual_add_f32(void* x, const float* sum, int64_t n, hipStream_t st);

@@ -620,7 +620,7 @@ void launch256_act(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
   else launch256_one<ACT, false, false>(a, splitk, st, norm_fused, n192);
 }
 
-struct GemmPlan { int tile, splitk; double cost = 0; };
+struct GemmPlan { int tile, splitk; double cost = 0; bool streamk = false; };   // streamk: the persistent kernel of kernels_gemm_sk.hip on `tile`-column tiles
 
 // Tile choice by a two-parameter cost model fitted to scripts/bench_gemm.py on MI355X (256 CUs): a CU retires one
 // (128^2 tile, 64-deep k step) in ~0.68 us when it has two or more 128^2 blocks resident, and one (256^2 tile, k step) in
@@ -632,6 +632,13 @@ int g_force_tile = 0, g_force_splitk = 0;  // aha_hip_debug_gemm_plan (tests): 0
 
 GemmPlan plan_gemm(const GemmArgs& a) {
   if (g_force_tile == 128) return GemmPlan{128, 1};
+  if (g_force_tile == 1256 || g_force_tile == 1192) {   // tests: the persistent kernel wherever it has an instantiation and a workspace
+    const int tn = g_force_tile - 1000;
+    if (a.M >= 1 && a.K % BK == 0 && a.act != ACT_PARTIAL_F32 && streamk_has_kernel(a.act, a.bias != nullptr, a.residual != nullptr, tn == 192) &&
+        streamk_estimate(a, tn, nullptr, nullptr) >= 0.0)
+      return GemmPlan{tn, 1, 0.0, true};
+    return GemmPlan{128, 1};
+  }
   if (g_force_tile == 192 && a.M >= 1 && !a.bias && !a.residual && (a.act == ACT_NONE || a.act == ACT_SILU_MUL_PAIRS) && a.K % BK == 0)
     return GemmPlan{192, 1};
   if ((g_force_tile == 256 || g_force_tile == 192) && a.M >= 1) {
@@ -682,8 +689,31 @@ GemmPlan plan_gemm(const GemmArgs& a) {
       best_cost = nk * 1.5 * 0.78;
     }
   }
+  // The persistent kernel (kernels_gemm_sk.hip): whole tiles round by round, the last round cut along K and finished in the launch.
+  // Its plan gives the k steps of a full 256^2 tile the slowest worker runs (segment / publish / fix-up overheads included); priced with
+  // the same 1.5 us per k step as the rounds above (x 0.78 for the 192-column tile).  A split-K plan above ends in a reduce pass that also
+  // does the RMSNorm riding on the call (GemmArgs::norm_w); every other plan pays ~9 us for the separate launch_rmsnorm_rows.
+  // AHA_GEMM_STREAMK: 0 = never, 1 (default) = where the model says it wins, 2 = wherever it can run.
+  static const int sk_mode = [] { const char* e = getenv("AHA_GEMM_STREAMK"); return e ? atoi(e) : 1; }();
+  const double norm_pen = a.norm_w ? 9.0 : 0.0;
+  if (sk_mode > 0 && a.M >= 256 && a.K % BK == 0 && nk >= 8 && a.act != ACT_PARTIAL_F32 && a.workspace && a.sk_counters && !e_tile && !e_sk &&
+      256.0 * 2.0 * (double)std::max(a.lda, a.ldw) < 1.0e9) {
+    double ref = best_cost + (best.splitk > 1 ? 0.0 : norm_pen);
+    if (sk_mode >= 2) ref = 1.0e30;
+    for (int tn : {256, 192}) {
+      if (!streamk_has_kernel(a.act, a.bias != nullptr, a.residual != nullptr, tn == 192)) continue;
+      const double steps = streamk_estimate(a, tn, nullptr, nullptr);
+      if (steps < 0.0) continue;
+      const double c = steps * 1.5 * (tn == 192 ? 0.78 : 1.0) + 2.0;
+      if (c + norm_pen < 0.97 * ref) {
+        best = GemmPlan{tn, 1, c, true};
+        best_cost = c;
+        ref = (c + norm_pen) / 0.97;
+      }
+    }
+  }
   static const char* e_dbg = getenv("AHA_GEMM_PLAN_DEBUG");
-  if (e_dbg && atoi(e_dbg)) fprintf(stderr, "[gemm plan] M=%d N=%d K=%d act=%d -> tile %d splitk %d (cost %.1f us, 128^2 %.1f us)\n", a.M, a.N, a.K, a.act, best.tile, best.splitk, best_cost, cost128);
+  if (e_dbg && atoi(e_dbg)) fprintf(stderr, "[gemm plan] M=%d N=%d K=%d act=%d -> tile %d splitk %d%s (cost %.1f us, 128^2 %.1f us)\n", a.M, a.N, a.K, a.act, best.tile, best.splitk, best.streamk ? " persistent" : "", best_cost, cost128);
   best.cost = best_cost;
   if (a.M < 256) best = GemmPlan{128, 1, cost128};
   if (e_tile && atoi(e_tile) == 128) best = GemmPlan{128, 1, cost128};
@@ -702,8 +732,9 @@ void debug_plan_gemm(int M, int N, int K, int act, bool has_bias, bool has_res, 
   a.residual = has_res ? &dummy : nullptr;
   a.workspace = ws_bytes ? &dummy : nullptr;
   a.workspace_bytes = ws_bytes;
+  a.sk_counters = ws_bytes ? &dummy : nullptr;
   const GemmPlan plan = plan_gemm(a);
-  out[0] = plan.tile; out[1] = plan.splitk; out[2] = 0;
+  out[0] = plan.tile + (plan.streamk ? 1000 : 0); out[1] = plan.splitk; out[2] = 0;   // (1256 / 1192: the persistent kernel)
   if (g_force_tile == 0 && a.act != ACT_SILU_MUL_PAIRS && a.act != ACT_PARTIAL_F32 && a.N > 512 && a.N % 256 != 0 && a.M >= 256) {   // (launch_gemm)
     GemmArgs am = a, at = a;
     am.N = a.N / 256 * 256;
@@ -716,13 +747,16 @@ void debug_plan_gemm(int M, int N, int K, int act, bool has_bias, bool has_res, 
 void set_gemm_plan_override(int tile, int splitk) {
   g_force_tile = tile;
   g_force_splitk = splitk;
+  set_streamk_forced_cut((tile == 1256 || tile == 1192) ? splitk : 0);   // persistent kernel: splitk = style * 10 + cuts of the last round
 }
 
 static thread_local void* tl_ws = nullptr;
 static thread_local size_t tl_ws_bytes = 0;
-void set_gemm_workspace(void* ws, size_t bytes) {
+static thread_local void* tl_sk_counters = nullptr;
+void set_gemm_workspace(void* ws, size_t bytes, void* sk_counters) {
   tl_ws = ws;
   tl_ws_bytes = bytes;
+  tl_sk_counters = sk_counters;
 }
 
 static void launch_planned(const GemmArgs& a, const GemmPlan& plan, hipStream_t st, bool* norm_fused = nullptr);
@@ -733,6 +767,7 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t st) {
   if (a.workspace == nullptr) {
     a.workspace = tl_ws;
     a.workspace_bytes = tl_ws_bytes;
+    a.sk_counters = tl_sk_counters;
   }
   static const int e_grp = [] { const char* e = getenv("AHA_GEMM_GROUP"); return e ? atoi(e) : 8; }();
   a.tile_group = e_grp;
@@ -766,6 +801,7 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t st) {
 
 static void launch_planned(const GemmArgs& a, const GemmPlan& plan, hipStream_t st, bool* norm_fused) {
   if (norm_fused != nullptr) *norm_fused = false;
+  if (plan.streamk && launch_gemm_streamk(a, plan.tile, st)) return;
   if (plan.tile == 256 || plan.tile == 192) {
     const bool n192 = plan.tile == 192;
     switch (a.act) {

@@ -157,6 +157,7 @@ struct aha_model {
   void* p_rope = nullptr;       // (S, 128) bf16 cos | sin table of the prefill's positions (kernels.h launch_rope_table)
   void* p_gemm_ws = nullptr;    // f32 split-K slabs (kernels_gemm.hip)
   size_t gemm_ws_bytes = 0;
+  void* d_sk_ctrs = nullptr;    // SK_MAX_COUNTERS zeroed u32: per-tile arrival counters of the persistent GEMM kernel (kernels_gemm_sk.hip)
   std::vector<void*> pf_owned;
   // vision tower (Qwen3-VL)
   aha::VisionModel* vision = nullptr;

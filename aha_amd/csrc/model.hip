@@ -739,6 +739,8 @@ int model_create(aha_ctx* ctx, const aha_model_desc* desc, const aha_tensor_view
   // accesses are agent-scope atomics
   if ((rc = dev_alloc(m, DECODE_SYNC_BYTES, &p, true))) return fail(rc);
   m->d_bar = (unsigned*)p;
+  // per-tile arrival counters of the persistent prefill GEMM (kernels_gemm_sk.hip): zeroed once, every launch leaves them zero
+  if ((rc = dev_alloc(m, SK_MAX_COUNTERS * 4, &m->d_sk_ctrs, true))) return fail(rc);
 
   if (c.arch == AHA_ARCH_QWEN3VL) {
     if ((rc = vision_create(m, w, nw))) return fail(rc);
@@ -1462,7 +1464,7 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
   hipStream_t st = m->stream;
   int rc;
   if ((rc = ensure_prefill_scratch(m, n))) return rc;
-  GemmWorkspaceScope ws_scope(m->p_gemm_ws, m->gemm_ws_bytes);  // split-K slabs for this thread's GEMM launches
+  GemmWorkspaceScope ws_scope(m->p_gemm_ws, m->gemm_ws_bytes, m->d_sk_ctrs);  // split-K slabs / persistent-kernel chunks of this thread's GEMM launches
   if ((rc = model_ensure_pages(m, m->cache_len + n))) return rc;
 
   // positions: 1-D arange(offset, offset+S) on all three rows (rope.rs:599-604), or get_rope_index for Qwen3-VL

@@ -319,13 +319,27 @@ int aha_hip_debug_last_hidden(aha_model* m, float* out, size_t n);
  * (tests/test_ops_gpu.py::test_kernels_do_not_consume_unstaged_lds). */
 int aha_hip_debug_poison_lds(uint32_t seed, void* stream);
 /* Test hook: force the GEMM tile (128 or 256) and split-K factor of every following GEMM launch of the process;
- * (0, 0) restores the automatic choice (csrc/kernels_gemm.hip plan_gemm). */
+ * (0, 0) restores the automatic choice (csrc/kernels_gemm.hip plan_gemm).  tile 1256 / 1192: the persistent kernel on 256- /
+ * 192-column tiles wherever it has an instantiation and a workspace (128^2 kernel elsewhere). */
 int aha_hip_debug_gemm_plan(int32_t tile, int32_t splitk);
 /* Host only (no GPU): the plan the GEMM launcher would pick for a shape -- out3 = {tile (128 | 256), split-K factor, 1 if the
  * columns run as a multiple of 256 + a tail launch}; workspace_bytes = size of the caller's split-K scratch (0 = none).  Lets the
  * CPU tier pin the plans of the BASELINE shapes (csrc/kernels_gemm.hip plan_gemm is a cost model fitted on MI355X). */
 int aha_hip_debug_plan_gemm(int32_t M, int32_t N, int32_t K, int32_t act, int32_t has_bias, int32_t has_residual, size_t workspace_bytes,
                             int32_t* out3);
+/* Host only (no GPU): the segment lists the persistent GEMM kernel (csrc/kernels_gemm_sk.hip) would walk for a shape on `workers`
+ * workgroups (a multiple of 8) with `tile_n` (256 | 192) column tiles: out = 8 ints per segment {m0, n0, first K tile, end K tile,
+ * pieces the tile is cut into, this piece's index in K order, first chunk of the tile, counter of the tile}, grouped by worker;
+ * off_out[workers + 1] = where each worker's list starts; info7 = {workers, chunks, counters, tiles cut, cut style, cuts, k steps on
+ * the slowest worker x 1000}.  Returns the number of segments (at most `cap` are written) or a negative error.  The CPU tier checks
+ * that every (tile, K tile) is covered exactly once for the BASELINE shapes. */
+int aha_hip_debug_streamk_plan(int32_t M, int32_t N, int32_t K, int32_t tile_n, int32_t workers, size_t workspace_bytes, int32_t* out,
+                               int32_t cap, int32_t* off_out, int32_t* info7);
+/* CUs the persistent GEMM kernel leaves free (rounded so that its workgroup count stays a multiple of 8; 0 = use every CU; < 0 = take
+ * AHA_GEMM_RESERVE_CUS from the environment).  Process-wide.  For tensor-parallel prefill: RCCL's kernels on the communication stream
+ * need CUs next to a GEMM whose workgroups each fill one (csrc/model.hip gemm_row_parallel).  Must be the same on every rank only
+ * for speed, not for correctness (no collective depends on it). */
+int aha_hip_set_gemm_reserved_cus(int32_t n);
 int aha_hip_debug_image_embeds(aha_model* m, int which /*0=merged, 1..=deepstack k*/, float* out, size_t n);
 
 /* ---- op-level entry points (device pointers; stream = hipStream_t as void*, NULL = default stream) ---------- */

@@ -54,9 +54,17 @@ def family(name):
 
 def test_no_kernel_spills_or_uses_scratch(kernels):
     # the one exception: the TRACE instantiations of the prefill attention (debug timeline, 64-bit counters; AHA_ATTN_PTRACE)
+    # The persistent GEMM (gemm256s_kernel) keeps ~25 more scalars live across its segment loop than the SGPR file holds next to the
+    # main loop's descriptors: they sit in lanes of a VGPR (v_writelane / v_readlane outside the k loop), which is not memory traffic.
+    # No vector register may spill and nothing may touch scratch.
+    def tolerated(n, k):
+        if "attn_prefill_kernel" in n and "Lb1E" in n:
+            return True
+        if "gemm256s_kernel" in n:
+            return k.get("vgpr_spill_count", 0) == 0 and k.get("sgpr_spill_count", 0) <= 32 and k.get("private_segment_fixed_size", 0) == 0
+        return False
     bad = {n: k for n, k in kernels.items()
-           if (k.get("vgpr_spill_count", 0) or k.get("sgpr_spill_count", 0) or k.get("private_segment_fixed_size", 0))
-           and not ("attn_prefill_kernel" in n and "Lb1E" in n)}
+           if (k.get("vgpr_spill_count", 0) or k.get("sgpr_spill_count", 0) or k.get("private_segment_fixed_size", 0)) and not tolerated(n, k)}
     assert not bad, f"kernels with spills / scratch: {bad}"
     assert any("attn_prefill_kernel" in n and "Lb0E" in n for n in kernels)
 
@@ -72,6 +80,9 @@ def test_register_budgets_the_design_counts_on(kernels):
     assert sum(n.endswith("Lb1EEEvNS_8GemmArgsEi") for n, _ in fam["gemm256q_kernel"]) == 2   # the two 192-column instantiations
     # 128 KiB of dynamic LDS per 256^2 block is requested at launch; nothing static on top
     assert all(k["group_segment_fixed_size"] == 0 for _, k in fam["gemm256q_kernel"])
+    # the persistent form of the same tile: the same claim (one workgroup per CU is what its planner counts on)
+    assert len(fam["gemm256s_kernel"]) >= 8 and all(k["vgpr_count"] == 512 and k["max_flat_workgroup_size"] == 256 and k["group_segment_fixed_size"] == 0
+                                                    for _, k in fam["gemm256s_kernel"])
     # prefill attention: 128 VGPRs => two 8-wave blocks per CU (non-trace instantiations)
     assert all(k["vgpr_count"] <= 128 for n, k in fam["attn_prefill_kernel"] if "Lb0E" in n)
     # 8-wave 256^2 GEMM: two waves per SIMD => at most 256 registers; 128^2 kernel: four blocks of four waves per CU => at most 128 + accumulators in 168
@@ -92,7 +103,7 @@ def test_hot_kernels_have_no_flat_loads(kernels, tmp_path):
     loads and zero scratch instructions (flat STORES into KV pages -- page addresses are integers from the page table -- are fine)."""
     shutil.copy(os.path.join(ROOT, "aha_amd", "csrc", "libaha_hip.so"), tmp_path / "lib.so")
     subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", "lib.so"], cwd=tmp_path, capture_output=True, check=True)
-    hot = ("gemv_kernel", "attn_decode_fused_kernel", "gemm256q_kernel", "gemm256p_kernel", "gemm_glds_kernel", "attn_prefill_kernel",
+    hot = ("gemv_kernel", "attn_decode_fused_kernel", "gemm256q_kernel", "gemm256s_kernel", "gemm256p_kernel", "gemm_glds_kernel", "attn_prefill_kernel",
            "gemm_splitk_reduce_kernel", "gemm_splitk_reduce_norm_kernel", "rmsnorm_rows_kernel")
     seen, bad = set(), {}
     for o in sorted(glob.glob(str(tmp_path / "lib.so.*gfx950"))):
@@ -156,7 +167,7 @@ def test_counted_waits_in_the_mfma_loops(tmp_path):
     full / ragged k loops, and the fused decode attention must keep its ladder of counted waits with at most one full drain."""
     shutil.copy(os.path.join(ROOT, "aha_amd", "csrc", "libaha_hip.so"), tmp_path / "lib.so")
     subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", "lib.so"], cwd=tmp_path, capture_output=True, check=True)
-    stats, fused_bodies = {}, {}
+    stats, fused_bodies, sk_scratch = {}, {}, {}
     for o in sorted(glob.glob(str(tmp_path / "lib.so.*gfx950"))):
         dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", o], capture_output=True, text=True, check=True).stdout
         cur, body = None, {}
@@ -165,13 +176,15 @@ def test_counted_waits_in_the_mfma_loops(tmp_path):
             if m:
                 cur = m.group(1)
                 continue
-            if cur and family(cur) in ("gemm256q_kernel", "gemm256p_kernel", "attn_decode_fused_kernel"):
+            if cur and family(cur) in ("gemm256q_kernel", "gemm256s_kernel", "gemm256p_kernel", "attn_decode_fused_kernel"):
                 body.setdefault(cur, []).append(line.strip())
         for n, b in body.items():
             if family(n) == "attn_decode_fused_kernel":
                 fused_bodies[n] = b
             mf = [i for i, l in enumerate(b) if l.startswith("v_mfma")]
             span = b[mf[0]:mf[-1]] if mf else []
+            if family(n) == "gemm256s_kernel":
+                sk_scratch[n] = sum(1 for l in span if l.startswith("scratch_"))
             vm = [int(m.group(1)) for l in span if l.startswith("s_waitcnt") for m in [re.search(r"vmcnt\((\d+)\)", l)] if m]
             stats[n] = (len(mf), sum(1 for v in vm if v == 0), sum(1 for v in vm if v > 0))
     q = {n: s for n, s in stats.items() if family(n) == "gemm256q_kernel"}
@@ -183,6 +196,14 @@ def test_counted_waits_in_the_mfma_loops(tmp_path):
         n192 += int(is192)
         assert n_mfma == (288 if is192 else 384) and drains == 0 and counted >= 8, (n, n_mfma, drains, counted)
     assert n192 >= 2, "the 256 x 192 instantiations (gate+up, plain) are missing"
+    # the persistent kernel inlines the same main loop: the same MFMA counts, counted waits only, and no scratch access between its
+    # first and last MFMA
+    sk = {n: s for n, s in stats.items() if family(n) == "gemm256s_kernel"}
+    assert len(sk) >= 8
+    for n, (n_mfma, drains, counted) in sk.items():
+        is192 = "Lb1EEEvNS_8GemmArgsEPKiiPfPj" in n
+        assert n_mfma == (288 if is192 else 384) and drains == 0 and counted >= 8, (n, n_mfma, drains, counted)
+        assert not sk_scratch[n], (n, sk_scratch[n])
     for n, (n_mfma, drains, counted) in stats.items():
         if family(n) == "gemm256p_kernel" and "ELi0EEEvNS_8GemmArgs" in n:   # (the shipped MODE = 0 instantiations, not the ablations)
             assert n_mfma in (64, 128) and drains == 0 and counted >= 1, (n, n_mfma, drains, counted)
