@@ -634,7 +634,7 @@ GemmPlan plan_gemm(const GemmArgs& a) {
   if (g_force_tile == 128) return GemmPlan{128, 1};
   if (g_force_tile == 1256 || g_force_tile == 1192) {   // tests: the persistent kernel wherever it has an instantiation and a workspace
     const int tn = g_force_tile - 1000;
-    if (a.M >= 1 && a.K % BK == 0 && a.act != ACT_PARTIAL_F32 && streamk_has_kernel(a.act, a.bias != nullptr, a.residual != nullptr, tn == 192) &&
+    if (a.M >= 1 && a.K % BK == 0 && streamk_has_kernel(a.act, a.bias != nullptr, a.residual != nullptr, tn == 192) &&
         streamk_estimate(a, tn, nullptr, nullptr) >= 0.0)
       return GemmPlan{tn, 1, 0.0, true};
     return GemmPlan{128, 1};
@@ -690,13 +690,21 @@ GemmPlan plan_gemm(const GemmArgs& a) {
     }
   }
   // The persistent kernel (kernels_gemm_sk.hip): whole tiles round by round, the last round cut along K and finished in the launch.
-  // Its plan gives the k steps of a full 256^2 tile the slowest worker runs (segment / publish / fix-up overheads included); priced with
-  // the same 1.5 us per k step as the rounds above (x 0.78 for the 192-column tile).  A split-K plan above ends in a reduce pass that also
-  // does the RMSNorm riding on the call (GemmArgs::norm_w); every other plan pays ~9 us for the separate launch_rmsnorm_rows.
-  // AHA_GEMM_STREAMK: 0 = never, 1 (default) = where the model says it wins, 2 = wherever it can run.
-  static const int sk_mode = [] { const char* e = getenv("AHA_GEMM_STREAMK"); return e ? atoi(e) : 1; }();
+  // Its plan gives the k steps of a full 256^2 tile the slowest worker runs (segment overheads and the chip-wide cost of publishing and
+  // re-reading the chunks included); priced with the same 1.5 us per k step as the rounds above (x 0.78 for the 192-column tile).  A
+  // split-K plan above ends in a reduce pass that also does the RMSNorm riding on the call (GemmArgs::norm_w); every other plan pays
+  // ~9 us for the separate launch_rmsnorm_rows.
+  // What MI355X said (profiles/r04_gemm_sk.md): with whole tiles the persistent kernel runs exactly as fast as one tile per block
+  // (gate+up 271.6 vs 271.7 us, 8192^3 730 vs 734 us), and every cut LOSES at the cfg 3 shapes -- the chunks are 256 KiB per piece
+  // through the fabric, all pieces at once (o_proj in two pieces 80 + 8.5 us of RMSNorm against 73 us for the f32-slab plan whose
+  // reduce pass holds the norm; gate+up 335 against 272 us) -- so there is no shape yet where it is picked for speed.
+  // AHA_GEMM_STREAMK: 0 = never, 1 (default) = only when CUs are reserved for a concurrent stream (tensor-parallel prefill: a grid of
+  // one-tile blocks cannot leave CUs free, a worker count can), 2 = wherever the model says it wins, 3 = wherever it can run.
+  static const int sk_env = [] { const char* e = getenv("AHA_GEMM_STREAMK"); return e ? atoi(e) : 1; }();
+  const bool reserving = gemm_streamk_workers() < gemm_streamk_cus();
+  const int sk_mode = sk_env == 1 ? (reserving ? 2 : 0) : (sk_env >= 2 ? sk_env - 1 : 0);   // 0 off, 1 by the model, 2 wherever it can run
   const double norm_pen = a.norm_w ? 9.0 : 0.0;
-  if (sk_mode > 0 && a.M >= 256 && a.K % BK == 0 && nk >= 8 && a.act != ACT_PARTIAL_F32 && a.workspace && a.sk_counters && !e_tile && !e_sk &&
+  if (sk_mode > 0 && a.M >= 256 && a.K % BK == 0 && nk >= 8 && a.workspace && a.sk_counters && !e_tile && !e_sk &&
       256.0 * 2.0 * (double)std::max(a.lda, a.ldw) < 1.0e9) {
     double ref = best_cost + (best.splitk > 1 ? 0.0 : norm_pen);
     if (sk_mode >= 2) ref = 1.0e30;

@@ -171,13 +171,18 @@ struct SkPlan {
 struct SkCost {
   double ragged_floor = 0.23;   // cost of a k step of a tile whose MFMAs are all skipped (staging + barrier skeleton), in full k steps
   double seg = 3.0;             // per segment: pipeline fill + epilogue, in k steps
-  double publish = 2.0;         // writing a 256-KiB chunk
-  double fixup = 2.5;           // reading one chunk back in the last arriver
+  double publish = 1.0;         // issuing a chunk's stores / the counter round trip, per piece
+  double fixup = 1.0;           // issuing a chunk's loads in the last arriver, per chunk
+  // What a cut really costs is chip-wide: every piece of the last round publishes at the same time and every finisher reads back at the
+  // same time, 256 KiB each through the fabric (write-through).  Measured on MI355X (scripts/bench_gemm_sk.py, profiles/r04_gemm_sk.md):
+  // o_proj cut in two = 50 MB published + read back = +25 us; gate+up's last round = 71 MB = +35 us: ~0.5 us per MB published, i.e. 0.34 k
+  // steps (of 1.45 us) per MB, added to the slowest worker.
+  double steps_per_mb = 0.34;
 };
 SkCost sk_cost() {
   static const SkCost c = [] {
     SkCost k;
-    if (const char* e = getenv("AHA_GEMM_SK_COST")) sscanf(e, "%lf,%lf,%lf,%lf", &k.ragged_floor, &k.seg, &k.publish, &k.fixup);
+    if (const char* e = getenv("AHA_GEMM_SK_COST")) sscanf(e, "%lf,%lf,%lf,%lf,%lf", &k.ragged_floor, &k.seg, &k.publish, &k.fixup, &k.steps_per_mb);
     return k;
   }();
   return c;
@@ -235,6 +240,11 @@ SkPlan sk_plan_one(int M, int N, int K, int tile_n, int G, int group, int style,
     t.w = sk_tile_weight(M, t.m0, c);
     per_xcd[v & 7].push_back(t);
   }
+  // (Measured and NOT done: moving the tiles of a ragged last row -- M = 1542: six rows -- to the end of their XCD's list so that the
+  // whole rounds hold full tiles only.  A ragged tile is cheap only while the full tiles of its column panel run beside it and pull its
+  // W rows into the L2; sixteen of them alone in a last round each stream their panel from HBM at the latency-bound pace of the
+  // staging skeleton, ~76 us against 79 us for a FULL 256 x 192 tile: gate+up 313 us against 289 us in the interleaved order,
+  // profiles/r04_gemm_sk.md.)
   std::vector<std::vector<SkSeg>> wsegs(G);
   std::vector<double> load(G, 0.0);
   const std::vector<int> cutp = sk_cut_points(nk, style, cuts);
@@ -282,7 +292,7 @@ SkPlan sk_plan_one(int M, int N, int K, int tile_n, int G, int group, int style,
     pl.off[b + 1] = pl.off[b] + (int)wsegs[b].size();
     pl.segs.insert(pl.segs.end(), wsegs[b].begin(), wsegs[b].end());
   }
-  pl.makespan = *std::max_element(load.begin(), load.end());
+  pl.makespan = *std::max_element(load.begin(), load.end()) + c.steps_per_mb * pl.n_chunks * (SK_CHUNK_BYTES / 1048576.0);
   pl.ok = true;
   return pl;
 }
@@ -421,6 +431,8 @@ void set_streamk_forced_cut(int code) {
   g_sk_force_cut = code;
 }
 
+int gemm_streamk_cus() { return sk_num_cus() / 8 * 8; }
+
 int gemm_streamk_workers() {
   int res = g_reserved_cus;
   if (res < 0) {
@@ -438,6 +450,7 @@ bool streamk_has_kernel(int act, bool has_bias, bool has_res, bool n192) {
     case ACT_NONE: return true;
     case ACT_SILU_MUL_PAIRS: return !has_bias && !has_res;
     case ACT_GELU_TANH: return has_bias && !has_res;
+    case ACT_PARTIAL_F32: return !has_bias && !has_res;   // tensor-parallel row-split projections: the kernel the CU reservation is for
     default: return false;
   }
 }
@@ -473,6 +486,7 @@ bool launch_gemm_streamk(const GemmArgs& a, int tile_n, hipStream_t st) {
       break;
     case ACT_SILU_MUL_PAIRS: sk_launch_one<ACT_SILU_MUL_PAIRS, false, false, false>(a, e, st); break;
     case ACT_GELU_TANH: sk_launch_one<ACT_GELU_TANH, true, false, false>(a, e, st); break;
+    case ACT_PARTIAL_F32: sk_launch_one<ACT_PARTIAL_F32, false, false, false>(a, e, st); break;
     default: return false;
   }
   return true;

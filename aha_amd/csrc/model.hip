@@ -986,6 +986,11 @@ static int tp_overlap_chunks(const aha_model* m, const GemmArgs& g) {
 }
 static int ensure_comm_stream(aha_model* m) {
   if (m->comm_stream) return AHA_OK;
+  // RCCL's kernels run on the communication stream BESIDE the next column block's GEMM.  A grid of one-tile blocks fills every CU with
+  // a 512-register wave per SIMD + 128 KiB of LDS, so nothing else can be placed until a block retires; the persistent GEMM kernel takes
+  // a worker count instead (kernels_gemm_sk.hip).  Leave 16 CUs (two per XCD) to the collective unless the caller chose a number
+  // (aha_hip_set_gemm_reserved_cus / AHA_GEMM_RESERVE_CUS); process-wide, so it also applies to this rank's other GEMMs from here on.
+  if (!getenv("AHA_GEMM_RESERVE_CUS") && gemm_streamk_workers() == gemm_streamk_cus()) set_gemm_reserved_cus(16);
   int lo = 0, hi = 0;
   AHA_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // (numerically lowest = highest priority)
   AHA_HIP_CHECK(hipStreamCreateWithPriority(&m->comm_stream, hipStreamNonBlocking, hi));

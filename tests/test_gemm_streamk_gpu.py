@@ -40,7 +40,8 @@ def test_whole_tiles_equal_the_one_tile_per_block_kernel_bitwise(gpu, M, N, K):
         ref = run((256, 1), lambda: ops.gemm(Ag, Wg, *args))
         got = run((1256, 1), lambda: ops.gemm(Ag, Wg, *args))          # persistent kernel, last round NOT cut
         assert torch.equal(got, ref), f"persistent kernel (whole tiles) != gemm256q_kernel for epilogue {len(args)}"
-    assert_close_ulps(got, NM.r(torch.nn.functional.gelu(NM.linear(A.float(), W.float(), b.float()), approximate="tanh")), 2, 0.97, "bias+gelu")
+    # (sanity against the oracle; 3 ulps: one or two elements in a million of these large products land 3 bf16 ulps away in BOTH kernels)
+    assert_close_ulps(got, NM.r(torch.nn.functional.gelu(NM.linear(A.float(), W.float(), b.float()), approximate="tanh")), 3, 0.97, "bias+gelu")
 
 
 @pytest.mark.parametrize("M,N,K", [(1542, 1024, 4096), (600, 768, 2048), (300, 520, 1024)])
@@ -105,7 +106,9 @@ def test_automatic_plans_of_the_cfg3_shapes(gpu):
     ref = NM.r(NM.r(oq.silu(NM.linear(A.float(), Wg_.float()))) * NM.linear(A.float(), Wu.float()))
     Wf = ops.interleave_gate_up(Wg_, Wu).to(gpu)
     got = run((1256, 0), lambda: ops.gemm(A.to(gpu), Wf, act=_lib.ACT_SILU_MUL_PAIRS))
-    assert_close_ulps(got, ref, 2, 0.97, "cfg 3 gate+up on the persistent kernel")
+    base = run((256, 1), lambda: ops.gemm(A.to(gpu), Wf, act=_lib.ACT_SILU_MUL_PAIRS))
+    assert_close_ulps(got, ref, 3, 0.97, "cfg 3 gate+up on the persistent kernel")      # 19 M products: a handful land 3 ulps away ...
+    assert_close_ulps(base, ref, 3, 0.97, "cfg 3 gate+up on gemm256q_kernel")            # ... in the one-tile-per-block kernel as well
 
 
 @pytest.mark.parametrize("reserve", [8, 32, 100])
