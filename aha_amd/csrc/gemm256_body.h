@@ -206,8 +206,10 @@ __device__ __forceinline__ void epilogue32(const GemmArgs& a, f32x16_t (&acc)[NF
 // once every wave of the block has left the k loop.
 // WC: fused-weight columns of the wave's sub-tile that hold results (128, or 96 for the 192-column tile: the row pass keeps its
 // 16 / 8 lanes per row and masks the lanes past the last valid column).
+// One 32-row band of a wave's sub-tile: `f` = its four (three) fragments [n fragment of 32], rows mband + 0..31.
 template <int ACT, bool HAS_BIAS, bool HAS_RES, int WC = 128>
-__device__ __forceinline__ void epilogue32_rows(const GemmArgs& a, f32x16_t (&acc)[4][4], int mb, int nb, int lane, char* wbuf) {
+__device__ __forceinline__ void epilogue32_band(const GemmArgs& a, const f32x16_t& f0, const f32x16_t& f1, const f32x16_t& f2, const f32x16_t& f3,
+                                                int mband, int nb, int lane, char* wbuf) {
   constexpr bool PAIRS = ACT == ACT_SILU_MUL_PAIRS;
   constexpr int COLS = PAIRS ? 64 : 128, PITCH = COLS * 2 + 8, LPR = COLS / 8, RPI = 64 / LPR, NIT = 32 / RPI;
   constexpr int NFV = WC / 32, VCOLS = PAIRS ? WC / 2 : WC;   // valid fragment columns / valid output columns of the band
@@ -216,15 +218,14 @@ __device__ __forceinline__ void epilogue32_rows(const GemmArgs& a, f32x16_t (&ac
   const int rr = lane / LPR, cc = lane % LPR;
   const int n = (PAIRS ? nb / 2 : nb) + cc * 8;   // this lane's 8 output columns in the row pass
   const int ncols = PAIRS ? a.N / 2 : a.N;
-#pragma unroll
-  for (int mf = 0; mf < 4; ++mf) {
+  {
 #pragma unroll
     for (int nf0 = 0; nf0 < 4; nf0 += 2) {
       f32x16_t sum[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sum[j][r] = acc[nf0 + j][mf][r];
+        for (int r = 0; r < 16; ++r) sum[j][r] = (nf0 + j == 0 ? f0 : nf0 + j == 1 ? f1 : nf0 + j == 2 ? f2 : f3)[r];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (nf0 + j >= NFV) continue;
@@ -256,7 +257,7 @@ __device__ __forceinline__ void epilogue32_rows(const GemmArgs& a, f32x16_t (&ac
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int row = it * RPI + rr, m = mb + mf * 32 + row;
+      const int row = it * RPI + rr, m = mband + row;
       const uint2 lo = *reinterpret_cast<const uint2*>(wbuf + row * PITCH + cc * 16);
       const uint2 hi = *reinterpret_cast<const uint2*>(wbuf + row * PITCH + cc * 16 + 8);
       uint32_t d[4] = {lo.x, lo.y, hi.x, hi.y};
@@ -289,6 +290,12 @@ __device__ __forceinline__ void epilogue32_rows(const GemmArgs& a, f32x16_t (&ac
       }
     }
   }
+}
+template <int ACT, bool HAS_BIAS, bool HAS_RES, int WC = 128>
+__device__ __forceinline__ void epilogue32_rows(const GemmArgs& a, f32x16_t (&acc)[4][4], int mb, int nb, int lane, char* wbuf) {
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf)
+    epilogue32_band<ACT, HAS_BIAS, HAS_RES, WC>(a, acc[0][mf], acc[1][mf], acc[2][mf], acc[3][mf], mb + mf * 32, nb, lane, wbuf);
 }
 
 constexpr int BM2 = 256, BN2 = 256;
@@ -331,13 +338,22 @@ typedef __attribute__((address_space(3))) char* lds_cptr_t;
 // (The dynamic LDS is ONE object at namespace scope, named by every kernel of the translation unit: a `char*` parameter made the
 // fragment-read addresses 64 run-time VGPR sums instead of instruction offsets, and a second __shared__ object de-pipelines LDS-DMA
 // loops -- cdna guide, "three .s-level traps".)
-template <int ACT, bool HAS_BIAS, bool HAS_RES, bool BAR2 = true, int ABL = 0, bool NF3 = false>
+// ROW5 (round 4; 192-column tile only): the LAST row tile also carries the up to 32 rows past its 256 (M = 1542 = 6 x 256 + 6: six row
+// tiles instead of seven -- a tile of six rows costs as much as a full one, profiles/r04_gemm_sk.md section 3).  The wave row wm = 1
+// of that tile owns a FIFTH 32-row fragment row: 3 more accumulator fragments (acc5; the 192-column tile leaves 64 accumulator
+// registers free), its A rows staged as ONE more LDS-DMA piece per wave and K tile into the half of the W1 region the 192-column tile
+// never uses (image rows 32..63), issued with the A1 group (so every counted wait grows by one: 15 / prologue 22), read into four
+// registers next to A1 in phase 2 and multiplied in phases 3 (x W1) and 4 (x W0): 12 more MFMAs per K tile for two of the block's
+// waves.  Every block of a ROW5 launch issues the extra piece (out of range => zeros, no fetch) so that the counts are uniform; only
+// the last row tile's wm = 1 waves run the k loop copy that reads and multiplies it (rows5 > 0).
+template <int ACT, bool HAS_BIAS, bool HAS_RES, bool BAR2 = true, int ABL = 0, bool NF3 = false, bool ROW5 = false>
 __device__ __forceinline__ void gemm256q_mainloop(const GemmArgs& a, int m0, int n0, int kt0, int kt1, int lane, int wave,
-                                                  f32x16_t (&acc)[4][4], float zero = 0.f) {   // zero: see gemm256s_kernel
+                                                  f32x16_t (&acc)[4][4], float zero = 0.f, int rows5 = 0, f32x16_t* acc5 = nullptr) {   // zero: see gemm256s_kernel
   char* const smem = gemm_smem;
   constexpr int REGION = 128 * 128, STAGE = 4 * REGION;
   constexpr int TN = NF3 ? 192 : 256, WC = TN / 2;   // tile columns, columns per wave
   static_assert(!NF3 || (BAR2 && ABL == 0), "the 192-column tile exists in the shipped schedule only");
+  static_assert(!ROW5 || NF3, "the fifth fragment row needs the 192-column tile's free accumulator registers and LDS rows");
   const int wm = wave >> 1, wn = wave & 1;
 
   // buffer resources: base = first row of this block's panel, offsets below are relative to it (< 2^31: 256 rows)
@@ -367,6 +383,13 @@ __device__ __forceinline__ void gemm256q_mainloop(const GemmArgs& a, int m0, int
       }
     }
   }
+  // ROW5: tile rows 256 .. 287 -> image rows 32 .. 63 of the W1 region; wave w stages image rows 32 + 8 w ..
+  int voA5 = (int)0x80000000;
+  if (ROW5) {
+    const int ir = 32 + wave * 8 + (lane >> 3), trow = 256 + wave * 8 + (lane >> 3);
+    const int slot = (lane & 7) ^ ((ir >> 1) & 7);
+    if (rows5 > 0 && m0 + trow < a.M) voA5 = (int)((int64_t)trow * a.lda * 2 + slot * 16);
+  }
   const lds_cptr_t lbase = (lds_cptr_t)smem;
   // one DMA piece: region R (0..3 = A0 A1 W0 W1) of tile kt, piece q of this wave
   auto dma = [&](int kt, int R, int q) __attribute__((always_inline)) {
@@ -377,6 +400,11 @@ __device__ __forceinline__ void gemm256q_mainloop(const GemmArgs& a, int m0, int
     const int so = ktc * (BK * 2);
     if (R < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)dst, 16, voA[R & 1][q], so, 0, 0);
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)dst, 16, voW[R & 1][q], so, 0, 0);
+  };
+  auto dma5 = [&](int kt) __attribute__((always_inline)) {   // the fifth fragment row's piece of this wave (rides with the A1 group)
+    const int ktc = min(kt, kt1 - 1);
+    const lds_cptr_t dst = lbase + ((kt - kt0) & 1) * STAGE + 3 * REGION + (4 + wave) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)dst, 16, voA5, ktc * (BK * 2), 0, 0);
   };
   // fragment reads: set of 8 = [32-row fragment f][k-step ks]; lane (r32, hk) reads image row slice*64 + f*32 + r32, slot ks*2 + hk
   const int r32 = lane & 31, hk = lane >> 5;
@@ -398,6 +426,11 @@ __device__ __forceinline__ void gemm256q_mainloop(const GemmArgs& a, int m0, int
     (void)slice;
     return as_frag(*reinterpret_cast<const u32x4_t*>(smem + lb[stage][R >> 1][ks] + (R * REGION + f * 32 * 128)));
   };
+  // the fifth fragment row (read by wm = 1 waves only: their A base carries + 8192): image rows 32 .. 63 of region 3
+  auto frag5 = [&](int stage, int ks) __attribute__((always_inline)) {
+    return as_frag(*reinterpret_cast<const u32x4_t*>(smem + lb[stage][0][ks] + (3 * REGION + 32 * 128 - 8192)));
+  };
+  bf16x8_t fa5[4];
 
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -426,6 +459,7 @@ __device__ __forceinline__ void gemm256q_mainloop(const GemmArgs& a, int m0, int
     for (int q = 0; q < 4; ++q) dma(kt0, 3, q);
 #pragma unroll
     for (int q = 0; q < 4; ++q) dma(kt0, 1, q);
+    if (ROW5) dma5(kt0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) dma(kt0 + 1, 0, q);
 #pragma unroll
@@ -434,9 +468,11 @@ __device__ __forceinline__ void gemm256q_mainloop(const GemmArgs& a, int m0, int
     for (int q = 0; q < 4; ++q) dma(kt0 + 1, 3, q);
 #pragma unroll
     for (int q = 0; q < 4; ++q) dma(kt0 + 1, 1, q);
+    if (ROW5) dma5(kt0 + 1);
   }
-  if (NF3) AHA_WAIT(0x4F74);  // vmcnt(20): 28 pieces requested, A0 and W0 of kt0 (8) have landed
-  else AHA_WAIT(0x4F78);      // vmcnt(24): A0, W0 of kt0 have landed
+  if (ROW5) AHA_WAIT(0x4F76);      // vmcnt(22): 30 pieces requested, A0 and W0 of kt0 (8) have landed
+  else if (NF3) AHA_WAIT(0x4F74);  // vmcnt(20): 28 pieces requested, A0 and W0 of kt0 (8) have landed
+  else AHA_WAIT(0x4F78);           // vmcnt(24): A0, W0 of kt0 have landed
   AHA_BAR();
 #pragma unroll
   for (int f = 0; f < 2; ++f)
@@ -453,11 +489,13 @@ __device__ __forceinline__ void gemm256q_mainloop(const GemmArgs& a, int m0, int
   }
 
   // one phase: [barrier,] then 4 k-steps of { 4 MFMAs, fragment reads for a later phase, 1 DMA piece }
-  auto phase = [&](auto full_tag, auto bar_tag, int mi, bf16x8_t (&A)[2][4], int nj, bf16x8_t (&Wf)[2][4], bf16x8_t (&dst)[2][4], int rstage,
+  auto phase = [&](auto full_tag, auto r5_tag, auto bar_tag, int mi, bf16x8_t (&A)[2][4], int nj, bf16x8_t (&Wf)[2][4], bf16x8_t (&dst)[2][4], int rstage,
                    int rR, int rslice, int dkt, int dR) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(full_tag)::value;
+    constexpr bool R5 = decltype(r5_tag)::value;   // this wave owns a fifth fragment row (wm = 1 of the last row tile of a ROW5 launch)
     if (decltype(bar_tag)::value) {
-      if (NF3) AHA_WAIT(0x007E);        // vmcnt(14) lgkmcnt(0): the four newer groups are 4 + 4 + 2 + 4 pieces
+      if (ROW5) AHA_WAIT(0x007F);       // vmcnt(15) lgkmcnt(0): 4 + 4 + 2 + 5
+      else if (NF3) AHA_WAIT(0x007E);   // vmcnt(14) lgkmcnt(0): the four newer groups are 4 + 4 + 2 + 4 pieces
       else if (BAR2) AHA_WAIT(0x4070);  // vmcnt(16) lgkmcnt(0)
       else AHA_WAIT(0x4078);            // vmcnt(24) lgkmcnt(0)
       if (ABL != 3) AHA_BAR();
@@ -474,47 +512,60 @@ __device__ __forceinline__ void gemm256q_mainloop(const GemmArgs& a, int m0, int
       mm(0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (ABL != 1) dma(dkt, dR, ks);
+      if (ROW5 && dR == 1 && ks == 3) dma5(dkt);   // the fifth row's piece closes the A1 group
       __builtin_amdgcn_sched_barrier(0);
       mm(0, 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = ks * 3; r < min((NF3 && rR == 3) ? 4 : 8, ks * 3 + 3); ++r)   // (W half 1 of the 192-column tile: one fragment)
         if (ABL != 2) dst[r >> 2][r & 3] = frag(rstage, rR, rslice, r >> 2, r & 3);
+      if (R5 && rR == 1) fa5[ks] = frag5(rstage, ks);   // beside A1(t), phase 2: one read per k-step
       __builtin_amdgcn_sched_barrier(0);
       mm(1, 0);
       mm(1, 1);
+      if (R5 && mi == 1) {   // phases 3 (W1: one fragment column) and 4 (W0: two)
+        acc5[nj * 2] = mfma32(Wf[0][ks], fa5[ks], acc5[nj * 2]);
+        if (nj == 0) acc5[1] = mfma32(Wf[1][ks], fa5[ks], acc5[1]);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  auto tile = [&](auto full_tag, auto par_tag, int kt) __attribute__((always_inline)) {
+  auto tile = [&](auto full_tag, auto r5_tag, auto par_tag, int kt) __attribute__((always_inline)) {
     constexpr int P = decltype(par_tag)::value;  // parity of (kt - kt0): stage of this tile, and which W register set holds W0
     constexpr std::true_type bar{};
     if (!BAR2) {
-      phase(full_tag, bar, 0, fa[0], 0, fw[P], fw[P ^ 1], P, 3, wn, kt + 2, 2);      // A0 W0 | read W1(t)   | stage W0(t+2)
-      phase(full_tag, bar, 0, fa[0], 1, fw[P ^ 1], fa[1], P, 1, wm, kt + 2, 3);      // A0 W1 | read A1(t)   | stage W1(t+2)
-      phase(full_tag, bar, 1, fa[1], 1, fw[P ^ 1], fa[0], P ^ 1, 0, wm, kt + 2, 1);  // A1 W1 | read A0(t+1) | stage A1(t+2)
-      phase(full_tag, bar, 1, fa[1], 0, fw[P], fw[P ^ 1], P ^ 1, 2, wn, kt + 3, 0);  // A1 W0 | read W0(t+1) | stage A0(t+3)
+      phase(full_tag, r5_tag, bar, 0, fa[0], 0, fw[P], fw[P ^ 1], P, 3, wn, kt + 2, 2);      // A0 W0 | read W1(t)   | stage W0(t+2)
+      phase(full_tag, r5_tag, bar, 0, fa[0], 1, fw[P ^ 1], fa[1], P, 1, wm, kt + 2, 3);      // A0 W1 | read A1(t)   | stage W1(t+2)
+      phase(full_tag, r5_tag, bar, 1, fa[1], 1, fw[P ^ 1], fa[0], P ^ 1, 0, wm, kt + 2, 1);  // A1 W1 | read A0(t+1) | stage A1(t+2)
+      phase(full_tag, r5_tag, bar, 1, fa[1], 0, fw[P], fw[P ^ 1], P ^ 1, 2, wn, kt + 3, 0);  // A1 W0 | read W0(t+1) | stage A0(t+3)
     } else {
       // BAR2: a barrier every SECOND phase.  A region is restaged two phases after it was read (the barrier in between covers
       // both), its data is read six phases after the request; at a barrier the groups of the two coming reads have landed and
       // the four newer ones may still be in flight: vmcnt(16).
       constexpr std::false_type nobar{};
-      phase(full_tag, bar, 0, fa[0], 0, fw[P], fw[P ^ 1], P, 3, wn, kt + 2, 0);        // A0 W0 | read W1(t)   | stage A0(t+2)
-      phase(full_tag, nobar, 0, fa[0], 1, fw[P ^ 1], fa[1], P, 1, wm, kt + 2, 2);      // A0 W1 | read A1(t)   | stage W0(t+2)
-      phase(full_tag, bar, 1, fa[1], 1, fw[P ^ 1], fa[0], P ^ 1, 0, wm, kt + 2, 3);    // A1 W1 | read A0(t+1) | stage W1(t+2)
-      phase(full_tag, nobar, 1, fa[1], 0, fw[P], fw[P ^ 1], P ^ 1, 2, wn, kt + 2, 1);  // A1 W0 | read W0(t+1) | stage A1(t+2)
+      phase(full_tag, r5_tag, bar, 0, fa[0], 0, fw[P], fw[P ^ 1], P, 3, wn, kt + 2, 0);        // A0 W0 | read W1(t)   | stage A0(t+2)
+      phase(full_tag, r5_tag, nobar, 0, fa[0], 1, fw[P ^ 1], fa[1], P, 1, wm, kt + 2, 2);      // A0 W1 | read A1(t)   | stage W0(t+2)
+      phase(full_tag, r5_tag, bar, 1, fa[1], 1, fw[P ^ 1], fa[0], P ^ 1, 0, wm, kt + 2, 3);    // A1 W1 | read A0(t+1) | stage W1(t+2)
+      phase(full_tag, r5_tag, nobar, 1, fa[1], 0, fw[P], fw[P ^ 1], P ^ 1, 2, wn, kt + 2, 1);  // A1 W0 | read W0(t+1) | stage A1(t+2)
     }
   };
-  auto k_loop = [&](auto full_tag) __attribute__((always_inline)) {
+  auto k_loop = [&](auto full_tag, auto r5_tag) __attribute__((always_inline)) {
     int kt = kt0;
     for (; kt + 1 < kt1; kt += 2) {
-      tile(full_tag, std::integral_constant<int, 0>{}, kt);
-      tile(full_tag, std::integral_constant<int, 1>{}, kt + 1);
+      tile(full_tag, r5_tag, std::integral_constant<int, 0>{}, kt);
+      tile(full_tag, r5_tag, std::integral_constant<int, 1>{}, kt + 1);
     }
-    if (kt < kt1) tile(full_tag, std::integral_constant<int, 0>{}, kt);
+    if (kt < kt1) tile(full_tag, r5_tag, std::integral_constant<int, 0>{}, kt);
   };
-  if (nmf == 4) k_loop(std::true_type{});
-  else k_loop(std::false_type{});
+  if (ROW5) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc5[i][e] = zero;
+  }
+  if (ROW5 && rows5 > 0 && wm == 1) k_loop(std::true_type{}, std::true_type{});   // (the tile that carries a fifth row is full)
+  else if (nmf == 4) k_loop(std::true_type{}, std::false_type{});
+  else k_loop(std::false_type{}, std::false_type{});
   AHA_WAIT(0x0F70);  // vmcnt(0): nothing may still be writing this block's LDS when it retires (or reuses it below)
 #undef AHA_WAIT
 #undef AHA_BAR

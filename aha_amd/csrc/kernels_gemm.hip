@@ -288,15 +288,23 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs a, const void
 }
 
 // ---- variant 5: the 256 x 256 x 64 tile on FOUR waves (gemm256_body.h gemm256q_mainloop: schedule, LDS plan, counted waits) ---------
-template <int ACT, bool HAS_BIAS, bool HAS_RES, bool BAR2 = true, int ABL = 0, bool NF3 = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256q_kernel(GemmArgs a, int kt_per_slice) {
+// ROW5 (gemm256_body.h): rows5 = M mod 256 (1..32) rows ride as a fifth fragment row of the last row tile; the grid has M / 256 row tiles.
+template <int ACT, bool HAS_BIAS, bool HAS_RES, bool BAR2 = true, int ABL = 0, bool NF3 = false, bool ROW5 = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256q_kernel(GemmArgs a, int kt_per_slice, int rows5) {
   char* const smem = gemm_smem;  // [stage][A0 | A1 | W0 | W1] x 16 KiB
   constexpr int TN = NF3 ? 192 : 256, WC = TN / 2;   // tile columns, columns per wave
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   int m0, n0;
-  tile_of_block<BM2, TN>(a, m0, n0);
+  if (ROW5) {
+    GemmArgs at = a;
+    at.M = a.M - rows5;   // the tiling covers the multiple of 256; the last row tile owns the rest
+    tile_of_block<BM2, TN>(at, m0, n0);
+  } else {
+    tile_of_block<BM2, TN>(a, m0, n0);
+  }
+  const int rows5_here = ROW5 && m0 + 256 + rows5 == a.M ? rows5 : 0;
   // Claim the SIMD's whole register file (512 VGPRs: v255 and a255 count as used).  The kernel runs one wave per SIMD by design, so
   // the claim costs nothing -- but the 192-column variant needs only 424 registers, which left room for a wave of ANOTHER kernel
   // (one running on a concurrent stream) on the same SIMD, and on gfx950 such co-residents were measured to compute
@@ -309,12 +317,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int kt0 = blockIdx.y * kt_per_slice, kt1 = min(nk_all, kt0 + kt_per_slice);
   if (ACT == ACT_PARTIAL_F32) a.C = (float*)a.C + (int64_t)blockIdx.y * a.M * a.ldc;
   f32x16_t acc[4][4];  // [n fragment of 32][m fragment of 32]
-  gemm256q_mainloop<ACT, HAS_BIAS, HAS_RES, BAR2, ABL, NF3>(a, m0, n0, kt0, kt1, lane, wave, acc);
+  f32x16_t acc5[3];    // ROW5: the fifth fragment row of the wm = 1 waves of the last row tile
+  gemm256q_mainloop<ACT, HAS_BIAS, HAS_RES, BAR2, ABL, NF3, ROW5>(a, m0, n0, kt0, kt1, lane, wave, acc, 0.f, rows5_here, acc5);
   if (ACT == ACT_PARTIAL_F32) {
     epilogue32<ACT, HAS_BIAS, HAS_RES, 4, 4, WC / 32>(a, acc, m0 + wm * 128, n0 + wn * WC, lane);
   } else {
     __syncthreads();   // every wave has left the k loop (and waited for its own DMAs): the stages are free
     epilogue32_rows<ACT == ACT_PARTIAL_F32 ? ACT_NONE : ACT, HAS_BIAS, HAS_RES, WC>(a, acc, m0 + wm * 128, n0 + wn * WC, lane, smem + wave * 8448);
+    if (ROW5 && rows5_here > 0 && wm == 1)
+      epilogue32_band<ACT == ACT_PARTIAL_F32 ? ACT_NONE : ACT, HAS_BIAS, HAS_RES, WC>(a, acc5[0], acc5[1], acc5[2], acc5[2], m0 + 256, n0 + wn * WC, lane,
+                                                                                      smem + wave * 8448);
   }
 }
 
@@ -486,9 +498,17 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
       static bool once192 = false;
       if (!once192) {
         hipFuncSetAttribute((const void*)gemm256q_kernel<ACT, B, R, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)gemm256q_kernel<ACT, B, R, true, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         once192 = true;
       }
-      hipLaunchKernelGGL((gemm256q_kernel<ACT, B, R, true, 0, true>), dim3(ntm * ((a.N + 191) / 192)), dim3(256), lds, st, a, nk);
+      // M = 256 q + r with 1 <= r <= 32: the r rows ride as a fifth fragment row of the last row tile (one row of tiles less)
+      static const bool row5_on = [] { const char* e = getenv("AHA_GEMM_ROW5"); return e ? atoi(e) != 0 : true; }();
+      const int r5 = a.M % 256;
+      if (row5_on && a.M > 256 && r5 >= 1 && r5 <= 32) {
+        hipLaunchKernelGGL((gemm256q_kernel<ACT, B, R, true, 0, true, true>), dim3((a.M / 256) * ((a.N + 191) / 192)), dim3(256), lds, st, a, nk, r5);
+        return;
+      }
+      hipLaunchKernelGGL((gemm256q_kernel<ACT, B, R, true, 0, true>), dim3(ntm * ((a.N + 191) / 192)), dim3(256), lds, st, a, nk, 0);
       return;
     }
   }
@@ -513,7 +533,7 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
           hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_NONE, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
           once1 = true;
         }
-        hipLaunchKernelGGL((gemm256q_kernel<ACT_NONE, false, false, false>), dim3(ntm * ntn), dim3(256), lds, st, a, nk);
+        hipLaunchKernelGGL((gemm256q_kernel<ACT_NONE, false, false, false>), dim3(ntm * ntn), dim3(256), lds, st, a, nk, 0);
         return;
       }
       static const int abl = [] { const char* e = getenv("AHA_GEMM_ABL"); return e ? atoi(e) : 0; }();
@@ -525,12 +545,12 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
           hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_NONE, false, false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
           once2 = true;
         }
-        if (abl == 1) hipLaunchKernelGGL((gemm256q_kernel<ACT_NONE, false, false, true, 1>), dim3(ntm * ntn), dim3(256), lds, st, a, nk);
-        if (abl == 2) hipLaunchKernelGGL((gemm256q_kernel<ACT_NONE, false, false, true, 2>), dim3(ntm * ntn), dim3(256), lds, st, a, nk);
-        if (abl == 3) hipLaunchKernelGGL((gemm256q_kernel<ACT_NONE, false, false, true, 3>), dim3(ntm * ntn), dim3(256), lds, st, a, nk);
+        if (abl == 1) hipLaunchKernelGGL((gemm256q_kernel<ACT_NONE, false, false, true, 1>), dim3(ntm * ntn), dim3(256), lds, st, a, nk, 0);
+        if (abl == 2) hipLaunchKernelGGL((gemm256q_kernel<ACT_NONE, false, false, true, 2>), dim3(ntm * ntn), dim3(256), lds, st, a, nk, 0);
+        if (abl == 3) hipLaunchKernelGGL((gemm256q_kernel<ACT_NONE, false, false, true, 3>), dim3(ntm * ntn), dim3(256), lds, st, a, nk, 0);
         return;
       }
-      hipLaunchKernelGGL((gemm256q_kernel<ACT, B, R>), dim3(ntm * ntn), dim3(256), lds, st, a, nk);
+      hipLaunchKernelGGL((gemm256q_kernel<ACT, B, R>), dim3(ntm * ntn), dim3(256), lds, st, a, nk, 0);
       return;
     }
     {
@@ -597,7 +617,7 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
       hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_PARTIAL_F32, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       onceq = true;
     }
-    hipLaunchKernelGGL((gemm256q_kernel<ACT_PARTIAL_F32, false, false>), dim3(ntm * ntn, splitk), dim3(256), lds, st, p, kps);
+    hipLaunchKernelGGL((gemm256q_kernel<ACT_PARTIAL_F32, false, false>), dim3(ntm * ntn, splitk), dim3(256), lds, st, p, kps, 0);
   } else {
     hipLaunchKernelGGL((gemm256p_kernel<ACT_PARTIAL_F32, false, false>), dim3(ntm * ntn, splitk), dim3(512), lds, st, p, zero_block(), kps, nullptr);
   }
@@ -687,6 +707,23 @@ GemmPlan plan_gemm(const GemmArgs& a) {
     if ((best.tile == 256 && best.splitk == 1 && t256 < 256.0 && t192 <= 256.0 && t192 > t256) || (e_tile && atoi(e_tile) == 192)) {
       best = GemmPlan{192, 1};
       best_cost = nk * 1.5 * 0.78;
+    }
+    // ROW5 (round 4): M = 256 q + r with r <= 32 runs as q row tiles on the 192-column kernel, the r rows as a fifth fragment row of the
+    // last one.  cfg 3 gate+up: 6 x 128 = 768 tiles = exactly three rounds of 3/4-size tiles where 256^2 tiles need three rounds of
+    // full-size ones (672 tiles, 96 of them six rows high and as slow as a full one).
+    // By rounds (round 4; measured at M = 1280 / 1536 / 1542 / 1792, profiles/r03_gemm_n192.md, r04_gemm_row5.md): a round of 192-column
+    // tiles costs ~0.80 of a round of 256^2 ones, so the finer tiling wins where it needs fewer than 1.25 x the rounds (M = 1536: 3 vs 3;
+    // not M = 1280: 3 vs 2, nor M = 1792: 4 vs 3).
+    static const bool row5_on = [] { const char* e = getenv("AHA_GEMM_ROW5"); return e ? atoi(e) != 0 : true; }();
+    const int r5 = a.M % 256;
+    const bool row5 = row5_on && a.M > 256 && r5 >= 1 && r5 <= 32;
+    if (!e_tile) {
+      const double t5 = (double)(row5 ? a.M / 256 : (a.M + 255) / 256) * ((a.N + 191) / 192);
+      const double c5 = ceil(t5 / 256.0) * nk * 1.5 * 0.80;
+      if (c5 < best_cost) {
+        best = GemmPlan{192, 1};
+        best_cost = c5;
+      }
     }
   }
   // The persistent kernel (kernels_gemm_sk.hip): whole tiles round by round, the last round cut along K and finished in the launch.

@@ -448,7 +448,7 @@ bool streamk_has_kernel(int act, bool has_bias, bool has_res, bool n192) {
   if (n192) return !has_bias && !has_res && (act == ACT_NONE || act == ACT_SILU_MUL_PAIRS);
   switch (act) {
     case ACT_NONE: return true;
-    case ACT_SILU_MUL_PAIRS: return !has_bias && !has_res;
+    case ACT_SILU_MUL_PAIRS: return false;   // gate * up: 192-column tiles only (on 256 columns the chunk sum + this epilogue spill a fragment)
     case ACT_GELU_TANH: return has_bias && !has_res;
     case ACT_PARTIAL_F32: return !has_bias && !has_res;   // tensor-parallel row-split projections: the kernel the CU reservation is for
     default: return false;
@@ -484,7 +484,6 @@ bool launch_gemm_streamk(const GemmArgs& a, int tile_n, hipStream_t st) {
       else if (R) sk_launch_one<ACT_NONE, false, true, false>(a, e, st);
       else sk_launch_one<ACT_NONE, false, false, false>(a, e, st);
       break;
-    case ACT_SILU_MUL_PAIRS: sk_launch_one<ACT_SILU_MUL_PAIRS, false, false, false>(a, e, st); break;
     case ACT_GELU_TANH: sk_launch_one<ACT_GELU_TANH, true, false, false>(a, e, st); break;
     case ACT_PARTIAL_F32: sk_launch_one<ACT_PARTIAL_F32, false, false, false>(a, e, st); break;
     default: return false;

@@ -235,6 +235,35 @@ def test_gemm_256x192_tile_equals_the_256_tile_bitwise(gpu):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("M", [257, 262, 288, 513, 1542, 1568, 2049])
+@pytest.mark.parametrize("N,K", [(192, 64), (328, 192), (1152, 1024), (6144, 4096)])
+def test_gemm_fifth_fragment_row_equals_the_256_tile_bitwise(gpu, M, N, K):
+    """ROW5 (round 4): M = 256 q + r, 1 <= r <= 32, runs on the 192-column kernel with q row tiles, the r rows as a fifth fragment row
+    of the wm = 1 waves of the last one.  Every element is still the same K-ordered MFMA sum and goes through the same epilogue band
+    code, so the output -- plain and gate * up -- must equal the 256-column kernel's bit for bit: r = 1, 6, 32, the q = 1 / 2 / 6 / 8
+    cases, one / three / 16 / 64 K tiles, ragged N (328), the poisoned-LDS repeat (the fifth row's pieces live in the half of the W1
+    region the 192-column tile otherwise never writes)."""
+    from aha_amd import ops, _lib
+    if M == 2049 and K == 4096:
+        pytest.skip("size")
+    A, W = rnd((M, K), 221).to(gpu), rnd((N, K), 222, 0.02).to(gpu)
+    outs, pairs = [], []
+    for tile in (256, 192):
+        ops.gemm_plan(tile, 1)
+        try:
+            if tile == 192:
+                ops.poison_lds(M + N)
+            outs.append(ops.gemm(A, W))
+            if N % 32 == 0:
+                pairs.append(ops.gemm(A, W, act=_lib.ACT_SILU_MUL_PAIRS))
+        finally:
+            ops.gemm_plan(0, 0)
+    assert torch.equal(outs[0], outs[1]), f"rows differ: {(outs[0] != outs[1]).any(-1).nonzero().flatten()[:8].tolist()}"
+    if pairs:
+        assert torch.equal(pairs[0], pairs[1])
+    assert_close_ulps(outs[1], NM.linear(A.float().cpu(), W.float().cpu()), 1, 0.98, "gemm 256x192 + fifth fragment row")
+
+
 @pytest.mark.parametrize("tile", [128, 192, 256])
 def test_kernels_do_not_consume_unstaged_lds(gpu, tile):
     """aha_hip_debug_poison_lds fills the LDS of every CU with seeded garbage.  A GEMM tile that read a staging slot it had not
