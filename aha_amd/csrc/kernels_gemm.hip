@@ -501,10 +501,14 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
         hipFuncSetAttribute((const void*)gemm256q_kernel<ACT, B, R, true, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         once192 = true;
       }
-      // M = 256 q + r with 1 <= r <= 32: the r rows ride as a fifth fragment row of the last row tile (one row of tiles less)
+      // M = 256 q + r with 1 <= r <= 32: the r rows ride as a fifth fragment row of the last row tile (one row of tiles less) -- where
+      // that saves a ROUND.  A tile with a fifth row costs 1.28 x a plain one (its wm = 1 waves issue 60 MFMAs per K tile instead of 48),
+      // so below one round it is slower than the ragged tiles it replaces, which run on otherwise idle CUs (qkv at M = 1542: 78.3 us
+      // against 74.5 us; gate+up, 768 tiles instead of 896: 273.0 against 286.7 us -- profiles/r04_gemm_row5.md).
       static const bool row5_on = [] { const char* e = getenv("AHA_GEMM_ROW5"); return e ? atoi(e) != 0 : true; }();
       const int r5 = a.M % 256;
-      if (row5_on && a.M > 256 && r5 >= 1 && r5 <= 32) {
+      const int ntn192 = (a.N + 191) / 192, cus = gemm_streamk_cus();
+      if (row5_on && a.M > 256 && r5 >= 1 && r5 <= 32 && ((a.M / 256) * ntn192 + cus - 1) / cus < (ntm * ntn192 + cus - 1) / cus) {
         hipLaunchKernelGGL((gemm256q_kernel<ACT, B, R, true, 0, true, true>), dim3((a.M / 256) * ((a.N + 191) / 192)), dim3(256), lds, st, a, nk, r5);
         return;
       }
@@ -719,7 +723,8 @@ GemmPlan plan_gemm(const GemmArgs& a) {
     const bool row5 = row5_on && a.M > 256 && r5 >= 1 && r5 <= 32;
     if (!e_tile) {
       const double t5 = (double)(row5 ? a.M / 256 : (a.M + 255) / 256) * ((a.N + 191) / 192);
-      const double c5 = ceil(t5 / 256.0) * nk * 1.5 * 0.80;
+      // (a tile that carries a fifth row costs 1.28 x: the round that holds them is that much longer)
+      const double c5 = (ceil(t5 / 256.0) + (row5 ? 0.28 : 0.0)) * nk * 1.5 * 0.80;
       if (c5 < best_cost) {
         best = GemmPlan{192, 1};
         best_cost = c5;

@@ -234,11 +234,17 @@ def test_gemm_plans_of_the_baseline_shapes(hip_lib):
         assert hip_lib.aha_hip_debug_plan_gemm(M, N, K, act, bias, res, ws, o) == 0
         return tuple(o)
 
-    # cfg 3 text stack at M = 1542 (8B): qkv on 256 x 192 tiles (224 tiles instead of 168 on 256 CUs, round 3), gate+up one round of
-    # 256^2 tiles (the finer tiling measured slower there), o_proj / down_proj two K slices of 256^2 tiles
+    # cfg 3 text stack at M = 1542 (8B): qkv on 256 x 192 tiles (224 tiles instead of 168 on 256 CUs, round 3), gate+up on 256 x 192
+    # tiles with the six extra rows as a fifth fragment row of the last row tile (768 tiles = three rounds; round 4: the same 272 us as
+    # the 256^2 tiling, profiles/r04_gemm_row5.md), o_proj / down_proj two K slices of 256^2 tiles -- and NOT the persistent kernel:
+    # every cut of its last round measured slower (profiles/r04_gemm_sk.md)
     assert plan(1542, 6144, 4096) == (192, 1, 0)
     assert plan(1542, 4096, 4096, res=1) == (256, 2, 0)
-    assert plan(1542, 24576, 4096, act=_lib.ACT_SILU_MUL_PAIRS) == (256, 1, 0)
+    assert plan(1542, 24576, 4096, act=_lib.ACT_SILU_MUL_PAIRS) == (192, 1, 0)
+    # by rounds: three exact rounds of 3/4-size tiles at M = 1536, two rounds of 256^2 tiles at M = 1280, three at M = 1792
+    assert plan(1536, 24576, 4096, act=_lib.ACT_SILU_MUL_PAIRS) == (192, 1, 0)
+    assert plan(1280, 24576, 4096, act=_lib.ACT_SILU_MUL_PAIRS) == (256, 1, 0)
+    assert plan(1792, 24576, 4096, act=_lib.ACT_SILU_MUL_PAIRS) == (256, 1, 0)
     assert plan(1542, 4096, 12288, res=1) == (256, 2, 0)
     assert plan(1542, 4096, 4096, res=1, ws=0) == (128, 1, 0)            # no workspace: no split-K, and 112 tiles lose to the 128^2 kernel
     # ViT at N = 4096 patches: qkv on 256^2, proj on 128^2, fc1 as 4096 columns + a 208-column tail, fc2 in three K slices
