@@ -70,6 +70,34 @@ def decode_bytes_per_token(cfg, L):
     return w + kv * L + kv
 
 
+MFMA_PEAK_BF16_TFLOPS = 2500.0   # dense bf16 (MI355X_MICROARCH.md; AMD's headline 5 PF includes 2:1 sparsity)
+
+
+def prefill_flops(cfg, S, kv_offset=0, vit_segments=()):
+    """Algorithmic FLOPs of one prefill of S prompt tokens (2 per multiply-add), the decoder stack + the vision tower:
+      * text GEMMs: 2 S K N for qkv, o_proj, gate+up, down_proj of every layer; lm_head for ONE row (qwen3/model.rs:187: last position only);
+      * text attention, CAUSAL-counted: row i sees kv_offset + i + 1 keys, QK^T + P.V = 4 d per (query, key, head);
+      * ViT (one entry of `vit_segments` per image / video frame group = its patch count n): the four GEMMs of each block over all
+        patches, FULL attention inside a segment (4 n^2 D per block), the patch-embed GEMM and the mergers' two GEMMs each.
+    Element-wise work (norms, rope, softmax, activations) is not counted."""
+    t = cfg.text if hasattr(cfg, "text") else cfg
+    H, I, L = t.hidden_size, t.intermediate_size, t.num_hidden_layers
+    gemm = 2.0 * S * H * (t.q_dim + 2 * t.kv_dim) + 2.0 * S * t.q_dim * H + 2.0 * S * H * 2 * I + 2.0 * S * I * H
+    attn = 4.0 * t.q_dim * (S * kv_offset + S * (S + 1) / 2.0)
+    out = {"text_gemm": L * gemm + 2.0 * t.vocab_size * H, "text_attention_causal": L * attn, "vit_gemm": 0.0, "vit_attention": 0.0}
+    v = getattr(cfg, "vision", None)
+    if v is not None and vit_segments:
+        n = float(sum(vit_segments))
+        D, VI = v.hidden_size, v.intermediate_size
+        out["vit_gemm"] = v.depth * (2.0 * n * D * 3 * D + 2.0 * n * D * D + 4.0 * n * D * VI) + 2.0 * n * v.patch_dim * D
+        m2 = v.spatial_merge_size ** 2
+        n_mergers = 1 + len(v.deepstack_visual_indexes)
+        out["vit_gemm"] += n_mergers * (2.0 * (n / m2) * (D * m2) * (D * m2) + 2.0 * (n / m2) * (D * m2) * v.out_hidden_size)
+        out["vit_attention"] = v.depth * 4.0 * D * sum(float(s) * s for s in vit_segments)
+    out["total"] = sum(out.values())
+    return out
+
+
 def cpu_baseline(cfg, sample_secs=20.0):
     """Oracle restatement timed end to end on the host cores ("port"; the Candle reference cannot be built here -- BASELINE.md
     section 2): the FULL-depth text stack (every layer its own weights in memory: layer i is layer 0's tensors rotated by a
@@ -508,6 +536,20 @@ def main():
     attn_gbs = ad["bytes"] / (ad["ms"] * 1e-3) / 1e9 if ad["ms"] > 0 else 0.0
 
     if rank == 0:
+        # the other half of BASELINE's metric: the prefill against the dense bf16 MFMA peak (attention counted causally; stated)
+        segs = []
+        if data is not None and getattr(data, "image_grid_thw", None) is not None:
+            segs += [int(g[1]) * int(g[2]) for g in np.asarray(data.image_grid_thw).reshape(-1, 3) for _ in range(int(g[0]))]
+        if data is not None and getattr(data, "video_grid_thw", None) is not None:
+            segs += [int(g[1]) * int(g[2]) for g in np.asarray(data.video_grid_thw).reshape(-1, 3) for _ in range(int(g[0]))]
+        pf = prefill_flops(cfg, len(ids), 0, segs if is_vl else ())
+        ach = pf["total"] / t_prefill / 1e12
+        roof_prefill = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / MFMA_PEAK_BF16_TFLOPS, 4), "flops": {k: round(v / 1e12, 3) for k, v in pf.items()},
+                        "flops_unit": "TFLOP per prefill", "seconds": round(t_prefill, 5),
+                        "counting": "2 FLOP per multiply-add; text attention causal (row i: i + 1 keys), ViT attention full within an image; "
+                                    "lm_head for the last position only; element-wise work not counted; whole prefill wall clock (ViT + "
+                                    "36 layers + lm_head + host-side position / page bookkeeping) in the denominator"}
         step_bytes = decode_bytes_per_token(cfg, kv_mid)
         line = {
             "metric": METRICS.get(args.workload, "decode tokens/s (greedy, batch 1) -- " + args.workload),
@@ -519,6 +561,7 @@ def main():
                        "kv_len_mid": kv_mid, "replicas": world, "collective_backend": ("gloo (ranks share a GPU)" if shared_device else "rccl") if world > 1 else None,
                        "loop": "host forward_step" if args.host_loop else "device-resident greedy loop"},
             "prefill_tok_s": round(len(ids) / t_prefill, 1), "prefill_ms": round(1e3 * t_prefill, 2),
+            "roofline_prefill": roof_prefill,
             "prefill_ms_samples": [round(1e3 * t, 2) for t in t_prefills],
             "decode_step_hbm_frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "attn_decode_GBs": round(attn_gbs, 1),

@@ -28,6 +28,27 @@ def test_decode_bytes_per_token_formula():
     assert bench.decode_bytes_per_token(cfg, 1000) - b0 == 1000 * 147456
 
 
+def test_prefill_flops_formula():
+    """bench.py's roofline_prefill object: the FLOP count of BASELINE cfg 3's prefill (1542 prompt tokens, one 1024^2 image = 4096
+    patches), by hand: text GEMMs 2 S H (q + 2 kv + q + 3 I) per layer, causal attention 4 q_dim S (S + 1) / 2 per layer, the ViT's
+    four GEMMs per block over its patches, full attention inside the image."""
+    import bench
+    from aha_amd import configs
+    cfg = configs.qwen3vl_8b()
+    t, v = cfg.text, cfg.vision
+    S, n = 1542, 4096
+    pf = bench.prefill_flops(cfg, S, 0, [n])
+    gemm = 2.0 * S * t.hidden_size * (2 * t.q_dim + 2 * t.kv_dim + 3 * t.intermediate_size)
+    assert abs(pf["text_gemm"] - (36 * gemm + 2.0 * t.vocab_size * t.hidden_size)) < 1e6
+    assert abs(pf["text_attention_causal"] - 36 * 4.0 * t.q_dim * S * (S + 1) / 2) < 1e6
+    assert abs(pf["vit_attention"] - 27 * 4.0 * v.hidden_size * n * n) < 1e6
+    assert 21.0e12 < pf["text_gemm"] < 21.8e12 and 3.5e12 < pf["vit_gemm"] < 3.9e12 and 27.5e12 < pf["total"] < 28.3e12
+    # text only: no ViT terms; a cache offset adds S * offset (query, key) pairs
+    tx = bench.prefill_flops(cfg.text, 128)
+    assert tx["vit_gemm"] == 0.0 and tx["vit_attention"] == 0.0
+    assert bench.prefill_flops(cfg.text, 128, 100)["text_attention_causal"] - tx["text_attention_causal"] == 36 * 4.0 * t.q_dim * 128 * 100
+
+
 def test_bench_gpus_2_self_launches_two_ranks_over_gloo():
     """`python bench.py --gpus 2 ...` with no launcher around it (how the driver calls it) must start 2 ranks itself, rendezvous on
     127.0.0.1, aggregate (sum of units / max of seconds) and print ONE JSON line with n_gpus = 2.  The GPU work is replaced by the
