@@ -226,3 +226,25 @@ def test_counted_waits_in_the_mfma_loops(tmp_path):
             dense_vm += [int(m.group(1)) for l in b[i:j] if l.startswith("s_waitcnt") for m in [re.search(r"vmcnt\((\d+)\)", l)] if m]
     # (one full drain is legitimate: the last V fragment of the PEELED last page, nothing newer in flight behind it)
     assert sum(1 for v in dense_vm if v == 0) <= 1 and sum(1 for v in dense_vm if v >= 12) >= 20, dense_vm
+
+
+def test_rccl_has_no_affected_packed_f32_form():
+    """Round-3 verdict, next-round item 3(a): RCCL's reduce / reduce-scatter kernels run on the communication stream BESIDE this library's
+    kernels under tensor parallelism, i.e. they are potential victims of the co-residency misread of `v_pk_*_f32 .. op_sel:[0,1..]`
+    (profiles/r03_simd_coresidency.md).  Disassemble the gfx950 code object of the RCCL this library links (scripts/scan_rccl_isa.py:
+    zstd-compressed fat binary -> llvm-objdump) and require that none of its packed f32 instructions has the affected form -- if a
+    future RCCL build has one, the comm stream must not share CUs with kernels of another stream (profiles/r04_rccl_isa_scan.md)."""
+    import sys
+    lib = "/opt/rocm/lib/librccl.so"
+    if not (os.path.exists(lib) and os.path.exists(f"{LLVM}/llvm-objdump") and os.path.exists(f"{LLVM}/llvm-objcopy")):
+        pytest.skip("ROCm RCCL / llvm tools not found")
+    try:
+        import ctypes
+        ctypes.CDLL("libzstd.so.1")
+    except OSError:
+        pytest.skip("libzstd not found")
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import scan_rccl_isa
+    r = scan_rccl_isa.scan(lib)
+    assert r["gfx950_objects"] >= 1 and r["packed_f32"] > 100, r      # the scan saw RCCL's f32 reduction code
+    assert not r["affected"], r["affected"][:5]
