@@ -128,6 +128,39 @@ __global__ __launch_bounds__(256) void agg_mfma_kind(float* out, int iters) {
   }
   if (res == 12345.678f) out[threadIdx.x] = res;
 }
+// the thinned-out loop (one MFMA, then ~130 idle cycles) for the other instructions: KIND 0 = 32x32x16 bf16, 1 = 16x16x32 f16, 2 = 16x16x16 bf16
+template <int KIND>
+__global__ __launch_bounds__(256) void agg_mfma_sparse(float* out, int iters) {
+  float res = 0.f;
+  if (KIND == 0) {
+    bf16x8_t a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (threadIdx.x + i)); b[i] = (__bf16)(0.002f * (i + 1)); }
+    f32x16_t c0 = {};
+    for (int i = 0; i < iters; ++i) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+      asm volatile("s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7" ::: "memory");
+    }
+    res = c0[0];
+  } else if (KIND == 1) {
+    f16x8_t a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.001f * (threadIdx.x + i)); b[i] = (_Float16)(0.002f * (i + 1)); }
+    f32x4_t c0 = {};
+    for (int i = 0; i < iters; ++i) {
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+      asm volatile("s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7" ::: "memory");
+    }
+    res = c0[0];
+  } else {
+    s16x4_t a = {1, 2, 3, (short)threadIdx.x}, b = {4, 5, 6, 7};
+    f32x4_t c0 = {};
+    for (int i = 0; i < iters; ++i) {
+      c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c0, 0, 0, 0);
+      asm volatile("s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7" ::: "memory");
+    }
+    res = c0[0];
+  }
+  if (res == 12345.678f) out[threadIdx.x] = res;
+}
 __global__ __launch_bounds__(256) void agg_valu(float* out, int iters) {
   float x[16];
   for (int i = 0; i < 16; ++i) x[i] = 0.001f * (threadIdx.x + i);
@@ -191,10 +224,11 @@ int main() {
   CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
   hipblasHandle_t hb;
   const bool have_blas = hipblasCreate(&hb) == HIPBLAS_STATUS_SUCCESS && hipblasSetStream(hb, sa) == HIPBLAS_STATUS_SUCCESS;
-  constexpr int NA = 14;
+  constexpr int NA = 17;
   const char* an[NA] = {"none (idle GPU)", "mfma 32x32x16 bf16 only", "mfma 16x16x32 bf16 only", "VALU fma only", "LDS-DMA + barrier only", "ds_read only",
                         "vendor GEMM (hipblasGemmEx bf16)", "own 128^2 GEMM tile", "mfma 16x16x16 bf16 (_1k) only", "mfma 32x32x8 bf16 (_1k) only",
-                        "mfma 16x16x32 f16 only", "mfma 32x32x16 bf16, AGPR acc", "mfma 16x16x32 bf16, 1 per ~130 cycles", "mfma 16x16x32 bf16, AGPR acc"};
+                        "mfma 16x16x32 f16 only", "mfma 32x32x16 bf16, asm in place", "mfma 16x16x32 bf16, 1 per ~130 cycles", "mfma 16x16x32 bf16, asm in place x4",
+                        "mfma 32x32x16 bf16, 1 per ~130 cycles", "mfma 16x16x32 f16, 1 per ~130 cycles", "mfma 16x16x16 bf16, 1 per ~130 cycles"};
   const char* vn[2] = {"pk_add, second source swapped (affected form)", "pk_add, no op_sel (control)"};
   std::vector<std::vector<uint8_t>> idle(2);
   for (int ai = 0; ai < NA; ++ai) {
@@ -219,6 +253,9 @@ int main() {
               case 11: hipLaunchKernelGGL(agg_mfma_kind<3>, dim3(2048), dim3(256), 0, sa, dsink, 2000); break;
               case 12: hipLaunchKernelGGL(agg_mfma_kind<4>, dim3(2048), dim3(256), 0, sa, dsink, 2000); break;
               case 13: hipLaunchKernelGGL(agg_mfma_kind<5>, dim3(2048), dim3(256), 0, sa, dsink, 4000); break;
+              case 14: hipLaunchKernelGGL(agg_mfma_sparse<0>, dim3(2048), dim3(256), 0, sa, dsink, 2000); break;
+              case 15: hipLaunchKernelGGL(agg_mfma_sparse<1>, dim3(2048), dim3(256), 0, sa, dsink, 2000); break;
+              case 16: hipLaunchKernelGGL(agg_mfma_sparse<2>, dim3(2048), dim3(256), 0, sa, dsink, 2000); break;
               case 6: hipblasGemmEx(hb, HIPBLAS_OP_T, HIPBLAS_OP_N, BN, BN, BN, &alpha, bigA, HIP_R_16BF, BN, bigB, HIP_R_16BF, BN, &beta, bigC,
                                     HIP_R_16BF, BN, HIPBLAS_COMPUTE_32F, HIPBLAS_GEMM_DEFAULT); break;
               default: aha_hip_gemm(A, W, Cb, M, N, K, K, K, N / 2, nullptr, nullptr, 4 /* gate+up pairs */, sa); break;
