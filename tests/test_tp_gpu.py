@@ -417,3 +417,41 @@ def test_tp2_column_chunked_reduce_scatter_equals_the_unchunked_paths(gpu, S, mo
     for mode in ("sp", "sp_chunked"):
         np.testing.assert_array_equal(outs[mode][0], outs["allreduce"][0])
         np.testing.assert_array_equal(outs[mode][1], outs["allreduce"][1])
+
+
+def test_tp2_prefill_with_reserved_cus_runs_the_persistent_gemm_and_keeps_the_bits(gpu, monkeypatch):
+    """Round 4: when the RCCL communication stream is set up the library reserves 16 CUs for it (aha_hip_set_gemm_reserved_cus) and
+    every eligible GEMM of the rank -- the f32-partial row-parallel projections included -- then runs as the persistent kernel on
+    CUs - 16 workgroups (whole tiles: the planner cuts nothing that costs more than it saves).  Same K-ordered sums per element, so a
+    sequence-parallel prefill + a decode step under the reservation must agree with the unreserved run within the sharded-vs-unsharded
+    bound, and two different reservations with each other bit for bit (host-callback seam)."""
+    from aha_amd import _lib
+    from aha_amd.model import HipInferenceModel
+    cfg = tiny_qwen3(layers=2, hidden=512, heads=4, kv_heads=2, inter=1024, vocab=1024)
+    w = qwen3_text_weights(cfg, seed=0)
+    S = 600
+    ids = [int(x) for x in np.random.default_rng(S).integers(0, cfg.vocab_size, size=S)]
+    monkeypatch.setenv("AHA_TP_OVERLAP_MIN_ROWS", "64")
+    outs = []
+    for reserve in (0, 16, 96):
+        assert _lib.lib().aha_hip_set_gemm_reserved_cus(reserve) == 0
+        try:
+            red = TwoRankSum()
+            ranks = [HipInferenceModel(cfg, w, tp_rank=r, tp_size=2, allreduce=lambda p, n, r=r: red.allreduce(r, p, n),
+                                       reduce_scatter=lambda p, n, r=r: red.reduce_scatter(r, p, n),
+                                       all_gather=lambda p, n, r=r: red.all_gather(r, p, n)) for r in range(2)]
+            got = run_ranks([lambda m=m: m.forward_initial(ids, 0)[0].copy() for m in ranks])
+            tok = int(np.argmax(got[0]))
+            step = run_ranks([lambda m=m: m.forward_step(tok, S)[0].copy() for m in ranks])
+            outs.append((got[0], step[0]))
+            for m in ranks:
+                m.close()
+        finally:
+            _lib.lib().aha_hip_set_gemm_reserved_cus(-1)
+    # (not bit-equal to the unreserved run: that one takes f32-slab split-K plans for some projections, the persistent kernel sums
+    # every element's K range in one piece -- another f32 summation order, the same bound as sharded vs unsharded)
+    for o in outs[1:]:
+        for got, ref, what in ((o[0], outs[0][0], "prefill"), (o[1], outs[0][1], "decode step")):
+            s = float(ref.std())
+            assert float(np.abs(got - ref).max()) <= 0.04 * s and float(np.sqrt(((got - ref) ** 2).mean())) <= 0.01 * s, what
+    np.testing.assert_array_equal(outs[1][0], outs[2][0])    # 240 and 160 workers: whole tiles either way -> the same bits
