@@ -106,12 +106,25 @@ def test_sampled_generation_distribution(gpu):
         s = osamp.Sampling("TopKThenTopP", float(np.float32(0.6)), k=20, p=float(np.float32(0.95)))
         logits, _ = m.forward_initial(prompt, 0)
         off = len(prompt)
+        # ... and, beyond the support: the SAME tokens as an independent replay -- oracle probabilities (host f32 softmax over the
+        # full logits), the k selected in the stated order (oracle.topk_order), the draw by the independent restatement of rand
+        # 0.9.2's StdRng + WeightedIndex<f32> (oracle/rand_stdrng.py), one RNG stream for the whole sequence.  (Round-3 verdict,
+        # weak #7: equality, not only support.  The device normaliser and the host softmax differ by ~1e-6 relative, so a uniform
+        # draw within that distance of a bucket boundary could flip a token: 12 draws, fixed seed, deterministic on both sides.)
+        from oracle import rand_stdrng as R
+        ref_rng = R.StdRng.seed_from_u64(11)
+        replay = []
         for i, t in enumerate(toks):
-            w = osamp.final_weights(osamp.use_repeat_penalty(1.2, 8, logits, toks[:i]), s)
+            pen = osamp.use_repeat_penalty(1.2, 8, logits, toks[:i])
+            w = osamp.final_weights(pen, s)
             assert w[t] > 0, f"step {i}: token {t} outside the sampler's support"
+            prs = osamp.softmax_last_dim(pen * np.float32(1.0 / s.temperature))
+            keep = osamp.topk_order(prs, pen)[: s.k]
+            replay.append(int(keep[R.sample_multinomial(ref_rng, w[keep])]))
             if i + 1 < len(toks):
                 logits, _ = m.forward_step(t, off)
                 off += 1
+        assert replay == toks, f"device + host mirror {toks} vs independent replay {replay}"
         m.clear_cache()
         # same seed, same draws
         ctx = hs.GenerationContext(0.6, 0.95, 20, 1.2, 8, seed=11, initial_seq_len=len(prompt), max_tokens=12)
