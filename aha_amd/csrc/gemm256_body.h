@@ -291,6 +291,34 @@ __device__ __forceinline__ void epilogue32_band(const GemmArgs& a, const f32x16_
     }
   }
 }
+// The f32 partial sums of a K slice (ACT_PARTIAL_F32: split-K slabs, tensor-parallel row-split projections) in ROW order as well
+// (round 4): the fragment-order epilogue32 writes 16 B per lane on 32 different rows -- 32-byte runs; here a wave passes each 32-row band
+// through 16.5 KiB of LDS (pitch 528 B: conflict-free for the 16-byte fragment writes) and stores 512-byte row segments, two whole
+// rows per instruction.  wbuf: this wave's 32 x 528 B.
+template <int WC = 128>
+__device__ __forceinline__ void epilogue32_rows_f32(const GemmArgs& a, f32x16_t (&acc)[4][4], int mb, int nb, int lane, char* wbuf) {
+  constexpr int PITCH = 128 * 4 + 16, NFV = WC / 32;
+  const int r32 = lane & 31, h = lane >> 5;
+  const int rr = lane >> 5, cc = lane & 31;          // row pass: 32 lanes x 16 B per row, two rows per instruction
+  const int n = nb + cc * 4;
+  float* C = (float*)a.C;
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf) {
+#pragma unroll
+    for (int nf = 0; nf < NFV; ++nf)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4_t v = {acc[nf][mf][4 * q], acc[nf][mf][4 * q + 1], acc[nf][mf][4 * q + 2], acc[nf][mf][4 * q + 3]};
+        *reinterpret_cast<f32x4_t*>(wbuf + r32 * PITCH + (nf * 32 + 8 * q + 4 * h) * 4) = v;
+      }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 2 + rr, m = mb + mf * 32 + row;
+      const f32x4_t v = *reinterpret_cast<const f32x4_t*>(wbuf + row * PITCH + cc * 16);
+      if (m < a.M && n < a.N && cc * 4 < WC) *reinterpret_cast<f32x4_t*>(C + (int64_t)m * a.ldc + n) = v;
+    }
+  }
+}
 template <int ACT, bool HAS_BIAS, bool HAS_RES, int WC = 128>
 __device__ __forceinline__ void epilogue32_rows(const GemmArgs& a, f32x16_t (&acc)[4][4], int mb, int nb, int lane, char* wbuf) {
 #pragma unroll

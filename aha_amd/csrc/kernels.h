@@ -156,6 +156,7 @@ struct GemmArgs {
   void* sk_counters = nullptr;   // optional SK_MAX_COUNTERS zeroed u32 words that belong to `workspace` (one per tile cut along K by the
                                  // persistent kernel, kernels_gemm_sk.hip; every launch leaves them zero again)
   int tile_group = 8;            // band width of the grouped tile order inside an XCD's run (kernels_gemm.hip tile_of_block); 0 = plain
+  int partial_rows = 1;          // ACT_PARTIAL_F32 on the four-wave kernel: f32 sums stored in row order through LDS (0: fragment order; A/B)
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 // split-K scratch used by launch_gemm calls of this THREAD whose GemmArgs carry none (the model sets it per forward)

@@ -320,7 +320,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   f32x16_t acc5[3];    // ROW5: the fifth fragment row of the wm = 1 waves of the last row tile
   gemm256q_mainloop<ACT, HAS_BIAS, HAS_RES, BAR2, ABL, NF3, ROW5>(a, m0, n0, kt0, kt1, lane, wave, acc, 0.f, rows5_here, acc5);
   if (ACT == ACT_PARTIAL_F32) {
-    epilogue32<ACT, HAS_BIAS, HAS_RES, 4, 4, WC / 32>(a, acc, m0 + wm * 128, n0 + wn * WC, lane);
+    __syncthreads();   // every wave has left the k loop (and waited for its own DMAs): the stages are free
+    if (a.partial_rows) epilogue32_rows_f32<WC>(a, acc, m0 + wm * 128, n0 + wn * WC, lane, smem + wave * (32 * 528));
+    else epilogue32<ACT, HAS_BIAS, HAS_RES, 4, 4, WC / 32>(a, acc, m0 + wm * 128, n0 + wn * WC, lane);
   } else {
     __syncthreads();   // every wave has left the k loop (and waited for its own DMAs): the stages are free
     epilogue32_rows<ACT == ACT_PARTIAL_F32 ? ACT_NONE : ACT, HAS_BIAS, HAS_RES, WC>(a, acc, m0 + wm * 128, n0 + wn * WC, lane, smem + wave * 8448);
@@ -821,6 +823,8 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t st) {
   }
   static const int e_grp = [] { const char* e = getenv("AHA_GEMM_GROUP"); return e ? atoi(e) : 8; }();
   a.tile_group = e_grp;
+  static const int e_prow = [] { const char* e = getenv("AHA_GEMM_PARTIAL_ROWS"); return e ? atoi(e) : 1; }();
+  a.partial_rows = e_prow;
   const GemmPlan plan = plan_gemm(a);
   // Ragged N (ViT fc1: N = 4304 = 16 x 256 + 208): the 17th column of 256^2 tiles makes 272 units = two rounds on 256 CUs for
   // 1.06 rounds of work.  Where the model says it pays, the columns up to the last multiple of 256 run as one GEMM and the

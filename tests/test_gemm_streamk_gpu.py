@@ -40,8 +40,9 @@ def test_whole_tiles_equal_the_one_tile_per_block_kernel_bitwise(gpu, M, N, K):
         ref = run((256, 1), lambda: ops.gemm(Ag, Wg, *args))
         got = run((1256, 1), lambda: ops.gemm(Ag, Wg, *args))          # persistent kernel, last round NOT cut
         assert torch.equal(got, ref), f"persistent kernel (whole tiles) != gemm256q_kernel for epilogue {len(args)}"
-    # (sanity against the oracle; 3 ulps: one or two elements in a million of these large products land 3 bf16 ulps away in BOTH kernels)
-    assert_close_ulps(got, NM.r(torch.nn.functional.gelu(NM.linear(A.float(), W.float(), b.float()), approximate="tanh")), 3, 0.97, "bias+gelu")
+    # (the oracle bounds of these epilogues are tests/test_ops_gpu.py's, on the one-tile-per-block kernels this one equals bit for bit)
+    plain = run((1256, 1), lambda: ops.gemm(Ag, Wg))
+    assert_close_ulps(plain, NM.linear(A.float(), W.float()), 1, 0.98, "persistent kernel, plain")
 
 
 @pytest.mark.parametrize("M,N,K", [(1542, 1024, 4096), (600, 768, 2048), (300, 520, 1024)])
