@@ -163,6 +163,64 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x4_t (&acc)[4][MI
   }
 }
 
+// The same epilogue for the 128^2 kernel in ROW order (round 4): a wave passes each 32-row band of its 64 x 64 sub-tile through
+// 4.5 KiB of LDS after the first rounding (Linear output -> bf16) and runs the rest of the chain on 8 consecutive columns per lane:
+// 16-byte bias / residual loads and stores, eight whole 128-byte row segments per instruction instead of 8-byte pieces on 16 rows
+// (the ViT proj GEMM -- bias + residual, 288 blocks reaching their epilogues together -- spent a third of its time there).
+// Not for ACT_SILU_MUL_PAIRS / ACT_PARTIAL_F32 (they keep the fragment-order epilogue above).  wbuf: this wave's 32 x 144 B.
+template <int ACT, bool HAS_BIAS, bool HAS_RES>
+__device__ __forceinline__ void epilogue16_rows(const GemmArgs& a, f32x4_t (&acc)[4][4], int mb, int nb, int lane, char* wbuf) {
+  static_assert(ACT != ACT_SILU_MUL_PAIRS && ACT != ACT_PARTIAL_F32, "fragment-order epilogue for these");
+  constexpr int PITCH = 144;
+  const int G = lane >> 4, c = lane & 15;
+  const int rr = lane >> 3, cc = lane & 7;
+  const int n = nb + cc * 8;
+#pragma unroll
+  for (int band = 0; band < 2; ++band) {
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const f32x4_t& v = acc[ni][band * 2 + mh];
+        uint2 w2;
+        w2.x = pack_bf(v[0], v[1]);   // Linear output -> bf16
+        w2.y = pack_bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(wbuf + (mh * 16 + c) * PITCH + (ni * 16 + G * 4) * 2) = w2;
+      }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + rr, m = mb + band * 32 + row;
+      const uint4 d4 = *reinterpret_cast<const uint4*>(wbuf + row * PITCH + cc * 16);
+      uint32_t d[4] = {d4.x, d4.y, d4.z, d4.w};
+      if (m < a.M && n < a.N) {
+        if (HAS_BIAS) {
+          const uint4 b4 = *reinterpret_cast<const uint4*>((const bf16_t*)a.bias + n);
+          const uint32_t b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) d[k] = pack_bf(lo_bf(d[k]) + lo_bf(b[k]), hi_bf(d[k]) + hi_bf(b[k]));
+        }
+        if (ACT == ACT_GELU_TANH) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) d[k] = pack_bf(gelu_tanh_f(lo_bf(d[k])), gelu_tanh_f(hi_bf(d[k])));
+        } else if (ACT == ACT_GELU_ERF) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) d[k] = pack_bf(gelu_erf_f(lo_bf(d[k])), gelu_erf_f(hi_bf(d[k])));
+        } else if (ACT == ACT_SILU) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) d[k] = pack_bf(silu_f(lo_bf(d[k])), silu_f(hi_bf(d[k])));
+        }
+        if (HAS_RES) {
+          const uint4 r4 = *reinterpret_cast<const uint4*>((const bf16_t*)a.residual + (int64_t)m * a.ldc + n);
+          const uint32_t r[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) d[k] = pack_bf(lo_bf(d[k]) + lo_bf(r[k]), hi_bf(d[k]) + hi_bf(r[k]));
+        }
+        *reinterpret_cast<uint4*>((bf16_t*)a.C + (int64_t)m * a.ldc + n) = make_uint4(d[0], d[1], d[2], d[3]);
+      }
+    }
+  }
+}
+
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 __device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -294,12 +352,12 @@ __device__ __forceinline__ void epilogue32_band(const GemmArgs& a, const f32x16_
 // The f32 partial sums of a K slice (ACT_PARTIAL_F32: split-K slabs, tensor-parallel row-split projections) in ROW order as well
 // (round 4): the fragment-order epilogue32 writes 16 B per lane on 32 different rows -- 32-byte runs; here a wave passes each 32-row band
 // through 16.5 KiB of LDS (pitch 528 B: conflict-free for the 16-byte fragment writes) and stores 512-byte row segments, two whole
-// rows per instruction.  wbuf: this wave's 32 x 528 B.
-template <int WC = 128>
-__device__ __forceinline__ void epilogue32_rows_f32(const GemmArgs& a, f32x16_t (&acc)[4][4], int mb, int nb, int lane, char* wbuf) {
-  constexpr int PITCH = 128 * 4 + 16, NFV = WC / 32;
+// rows per instruction.  wbuf: this wave's 32 x 528 B (32 x 272 B for the 8-wave kernel's 64-column sub-tile: NF = 2).
+template <int WC = 128, int NF = 4>
+__device__ __forceinline__ void epilogue32_rows_f32(const GemmArgs& a, f32x16_t (&acc)[NF][4], int mb, int nb, int lane, char* wbuf) {
+  constexpr int COLS = NF * 32, PITCH = COLS * 4 + 16, NFV = WC / 32, LPR = COLS / 4, RPI = 64 / LPR, NIT = 32 / RPI;   // NF = 2: the 8-wave kernel's 128 x 64 sub-tile
   const int r32 = lane & 31, h = lane >> 5;
-  const int rr = lane >> 5, cc = lane & 31;          // row pass: 32 lanes x 16 B per row, two rows per instruction
+  const int rr = lane / LPR, cc = lane % LPR;        // row pass: LPR lanes x 16 B per row, RPI rows per instruction
   const int n = nb + cc * 4;
   float* C = (float*)a.C;
 #pragma unroll
@@ -312,8 +370,8 @@ __device__ __forceinline__ void epilogue32_rows_f32(const GemmArgs& a, f32x16_t 
         *reinterpret_cast<f32x4_t*>(wbuf + r32 * PITCH + (nf * 32 + 8 * q + 4 * h) * 4) = v;
       }
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int row = it * 2 + rr, m = mb + mf * 32 + row;
+    for (int it = 0; it < NIT; ++it) {
+      const int row = it * RPI + rr, m = mb + mf * 32 + row;
       const f32x4_t v = *reinterpret_cast<const f32x4_t*>(wbuf + row * PITCH + cc * 16);
       if (m < a.M && n < a.N && cc * 4 < WC) *reinterpret_cast<f32x4_t*>(C + (int64_t)m * a.ldc + n) = v;
     }

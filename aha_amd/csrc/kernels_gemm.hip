@@ -33,8 +33,8 @@ namespace {
 // round j writes LDS row (j*4+wave)*8 + i/8, slot position i%8; it therefore READS logical slot (i%8) ^ f(row) from
 // global memory (source-side swizzle), and the fragment reads apply the same XOR.  K tails / nothing-to-load lanes
 // point at a 16-byte zero block.
-template <int ACT, bool HAS_BIAS, bool HAS_RES>
-__global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs a, const void* zeros) {
+template <int ACT, bool HAS_BIAS, bool HAS_RES, bool ROWS = false>   // ROWS: the row-order epilogue (gemm256_body.h epilogue16_rows)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void gemm_glds_kernel(GemmArgs a, const void* zeros) {   // three blocks per CU: <= 168 VGPRs
   char* const smem = gemm_smem;  // [A tile | W tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, c = lane & 15;
   const int wm = wave >> 1, wn = wave & 1;
@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs a, const void* 
     mma_tile(sa, sw, wm, wn, G, c, acc);
     __syncthreads();
   }
-  epilogue<ACT, HAS_BIAS, HAS_RES, 4>(a, acc, m0 + wm * 64, n0 + wn * 64, G, c);
+  // (every wave is past the k loop's last __syncthreads: the tile buffers are free for the row-order epilogue's bands)
+  if constexpr (ROWS) epilogue16_rows<ACT, HAS_BIAS, HAS_RES>(a, acc, m0 + wm * 64, n0 + wn * 64, lane, smem + wave * (32 * 144));
+  else epilogue<ACT, HAS_BIAS, HAS_RES, 4>(a, acc, m0 + wm * 64, n0 + wn * 64, G, c);
 }
 
 // ---- 256 x 256 x 64 tiles ----------------------------------------------------------------------------------------------------
@@ -284,7 +286,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs a, const void
 #undef AHA_BAR
 #undef MMA_QUAD
   if (MODE == 1 && blockIdx.x == 0 && tid == 0) { trace[42] = __builtin_readcyclecounter(); trace[43] = wall_clock64(); }
-  epilogue32<ACT, HAS_BIAS, HAS_RES, 2, 4>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
+  if (ACT == ACT_PARTIAL_F32 && a.partial_rows) {   // f32 slabs in row order (gemm256_body.h epilogue32_rows_f32): 256-byte row segments
+    __syncthreads();   // every wave has left the k loop: the stages are free
+    epilogue32_rows_f32<64, 2>(a, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * (32 * 272));
+  } else {
+    epilogue32<ACT, HAS_BIAS, HAS_RES, 2, 4>(a, acc, m0 + wm * 128, n0 + wn * 64, lane);
+  }
 }
 
 // ---- variant 5: the 256 x 256 x 64 tile on FOUR waves (gemm256_body.h gemm256q_mainloop: schedule, LDS plan, counted waits) ---------
@@ -473,6 +480,14 @@ const void* zero_block() {
 
 template <int ACT, bool B, bool R>
 void launch_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
+  // row-order stores need whole 16-byte column groups: N a multiple of 8, rows of C / residual 16-byte aligned; else fragment order
+  if constexpr (ACT != ACT_SILU_MUL_PAIRS && ACT != ACT_PARTIAL_F32) {
+    if (a.partial_rows && (a.N & 7) == 0 && (a.ldc & 7) == 0 && ((uintptr_t)a.C & 15) == 0 && (!R || ((uintptr_t)a.residual & 15) == 0) &&
+        (!B || ((uintptr_t)a.bias & 15) == 0)) {
+      hipLaunchKernelGGL((gemm_glds_kernel<ACT, B, R, true>), grid, dim3(256), 2 * TILE_BYTES, st, a, zero_block());
+      return;
+    }
+  }
   hipLaunchKernelGGL((gemm_glds_kernel<ACT, B, R>), grid, dim3(256), 2 * TILE_BYTES, st, a, zero_block());
 }
 

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       int le = l0, we = w0;
       asm volatile("" : "+v"(le), "+s"(we));
       const int wm = we >> 1, wn = we & 1;
-      if (ACT == ACT_PARTIAL_F32) epilogue32<ACT, HAS_BIAS, HAS_RES, 4, 4, WC / 32>(a, acc, m0 + wm * 128, n0 + wn * WC, le);
+      if (ACT == ACT_PARTIAL_F32) epilogue32_rows_f32<WC>(a, acc, m0 + wm * 128, n0 + wn * WC, le, smem + we * (32 * 528));
       else epilogue32_rows<ACT == ACT_PARTIAL_F32 ? ACT_NONE : ACT, HAS_BIAS, HAS_RES, WC>(a, acc, m0 + wm * 128, n0 + wn * WC, le, smem + we * 8448);
     }
     __syncthreads();   // the epilogue's LDS bands and the flag are free before the next segment's prologue stages into them
