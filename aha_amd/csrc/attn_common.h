@@ -15,6 +15,27 @@ __device__ __forceinline__ bf16x8_t as_frag(u32x4_t v) {
   x.u = v;
   return x.b;
 }
+// v_mfma_f32_16x16x16_bf16 with A = diag(v): lane (G, c) holds A[row c][k = 4G .. 4G+3] and B[k = 4G .. 4G+3][col c], and receives
+// D[row 4G + reg][col c] -- so D = diag(v) . B hands every lane back its OWN four B values times v.  Exact: each output is ONE
+// bf16 x bf16 product (exact in f32) plus zeros.  What it is for: the reference's `bf16(scores) * bf16(scale)` (modules.rs:782-783)
+// costs the VALU-bound prefill softmax an unpack (shift / and) and a multiply per score when done in the vector ALU; here the packed
+// bf16 pair of the first rounding goes straight into the matrix pipe (which has slack) and comes back as the f32 product.
+typedef short __attribute__((ext_vector_type(4))) s16x4_t;
+__device__ __forceinline__ s16x4_t diag_frag(float v, int G, int c) {
+  const short b = (short)(__float_as_uint(v) >> 16);   // v is bf16-exact (checked on the host)
+  const int j = c - 4 * G;
+  s16x4_t a;
+  a[0] = j == 0 ? b : (short)0;
+  a[1] = j == 1 ? b : (short)0;
+  a[2] = j == 2 ? b : (short)0;
+  a[3] = j == 3 ? b : (short)0;
+  return a;
+}
+__device__ __forceinline__ f32x4_t mfma_diag(s16x4_t dg, uint32_t lo, uint32_t hi) {
+  union { uint32_t u[2]; s16x4_t s; } x;
+  x.u[0] = lo; x.u[1] = hi;
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dg, x.s, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+}
 __device__ __forceinline__ float group_max(float v) {  // across the 4 lane groups (same column c)
   // v_permlane32_swap / v_permlane16_swap instead of __shfl_xor (ds_bpermute: an LDS round trip in the middle of the softmax's
   // dependency chain, once per tile); max is exact in any order
@@ -38,14 +59,24 @@ __device__ __forceinline__ float group_sum(float v) {
 //   softmax_scores: the reference's rounding chain on the scores, the mask, the tile maximum, the new running maximum and the
 //                   rescale factor alpha of everything accumulated so far; st is left holding the rounded, masked scores;
 //   softmax_probs:  p = e^(s - m) (one fma + one v_exp_f32 per score), the row sum, the bf16 P^T fragments.
-template <typename ValidFn>
-__device__ __forceinline__ void softmax_scores(f32x4_t (&st)[4], float scale, ValidFn valid, int G, float& m, float& alpha, float& m2) {
+// SMX (prefill kernel): 0 = the whole rounding chain in the vector ALU; 1 = `* scaling` through the matrix pipe (mfma_diag with
+// dg = diag(scale)): 24 of the ~120 vector instructions per 64-token tile become 4 MFMAs -- cfg 3 ViT kernel 152 -> 140 us, text
+// 8192 causal 0.685 -> 0.65 ms (profiles/r04_attn_prefill.md; widening the SECOND rounding through diag(1) as well: ViT 144 us)
+template <int SMX = 0, typename ValidFn>
+__device__ __forceinline__ void softmax_scores(f32x4_t (&st)[4], float scale, ValidFn valid, int G, float& m, float& alpha, float& m2,
+                                               s16x4_t dg = s16x4_t{0, 0, 0, 0}) {
   float tmax = -INFINITY;
+  if constexpr (SMX >= 1) {
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)   // matmul output -> bf16 (v_cvt_pk), x bf16(scaling) exactly in f32
+      st[sub] = mfma_diag(dg, pack_bf(st[sub][0], st[sub][1]), pack_bf(st[sub][2], st[sub][3]));
+  }
 #pragma unroll
   for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float s = rbf(rbf(st[sub][r]) * scale);  // matmul output -> bf16, then `* scaling` -> bf16 (modules.rs:782-783)
+      // matmul output -> bf16, then `* scaling` -> bf16 (modules.rs:782-783)
+      float s = SMX == 1 ? rbf(st[sub][r]) : rbf(rbf(st[sub][r]) * scale);
       if (!valid(sub * 16 + G * 4 + r)) s = -INFINITY;
       st[sub][r] = s;
       tmax = fmaxf(tmax, s);

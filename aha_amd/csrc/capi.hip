@@ -232,6 +232,14 @@ int aha_hip_debug_poison_lds(uint32_t seed, void* stream) {
   return AHA_OK;
   API_GUARD_END
 }
+int aha_hip_debug_attn_variant(int32_t smx) {
+  if (smx < -1 || smx > 1) {
+    set_error("debug_attn_variant: smx -1..1");
+    return AHA_ERR_INVALID;
+  }
+  set_attn_variant_override(smx);
+  return AHA_OK;
+}
 int aha_hip_debug_gemm_plan(int32_t tile, int32_t splitk) {
   const bool sk = tile == 1256 || tile == 1192;   // the persistent kernel; splitk = style * 10 + cuts of the last round (0 = the planner's)
   if ((tile != 0 && tile != 128 && tile != 256 && tile != 192 && !sk) || splitk < 0 || (!sk && splitk > 8) ||

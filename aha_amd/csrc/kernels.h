@@ -133,6 +133,7 @@ struct AttnPrefillArgs {
   int nqb;                 // set by the launcher: > 0 selects the XCD-aware 1-D block order over nqb q blocks x nh heads
 };
 void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st);
+void set_attn_variant_override(int smx);   // test hook: -1 = the environment's / default choice
 
 // ACT_PARTIAL_F32: tensor-parallel row-split projection -- C is (M,N) f32, the un-rounded partial sums over this rank's K slice
 enum GemmAct { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_SILU_MUL_PAIRS = 4, ACT_PARTIAL_F32 = 5 };

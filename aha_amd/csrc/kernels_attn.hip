@@ -32,7 +32,8 @@ namespace {
 // blocks: the kernel is held to 128 VGPRs (amdgpu_waves_per_eu 4) so that two 8-wave blocks are resident per CU.
 // TRACE (debug, AHA_ATTN_PTRACE=1): waves 0 and 4 of the middle block add up the shader cycles they spend in each part of the loop body
 // ABL (debug, AHA_ATTN_ABL, results wrong by construction): 2 = no softmax arithmetic, 3 = no staging of the next tile, 4 = no MFMAs
-template <int DQK, int DV, int QT, int NWV, bool TRACE = false, int ABL = 0>
+// SMX: which parts of the score rounding chain run on the matrix pipe (attn_common.h softmax_scores)
+template <int DQK, int DV, int QT, int NWV, bool TRACE = false, int ABL = 0, int SMX = 0>
 __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV == 8 || DQK < 128) ? 4 : 3, 4))) void attn_prefill_kernel(AttnPrefillArgs a, unsigned long long* trace = nullptr) {
   constexpr int KS = DQK / 32, DS = DV / 16;
   constexpr int RING = (DQK >= 128) ? 6 : 4;  // LDS fragment reads in flight ahead of the MFMA that consumes them
@@ -56,6 +57,9 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
     qblk = blockIdx.x;
   }
   const int kvhd = head / (a.nh / a.kvh);
+  const s16x4_t dg = diag_frag(a.scale, G, c);
+  // (a static `s_setprio 1` for the second-dispatched half of an 8-wave block -- the age-arbitration loser -- measured as noise:
+  // profiles/r04_attn_prefill.md)
   const int qb = qblk * (16 * QT * NWV);  // first q row of the block
   const int q0 = qb + wave * (16 * QT);        // first q row of the wave
   bf16x8_t qf[QT][KS];
@@ -192,9 +196,9 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
       const int lim_min = a.causal ? min(a.kv_offset + q0 + t * 16, a.kv_total - 1) : a.kv_total - 1;
       if (ABL == 2) { alpha[t] = 1.f; m2[t] = 0.f; continue; }
       if (t0 + KV_PAGE_TOKENS - 1 <= lim_min)
-        softmax_scores(st[t], a.scale, [](int) { return true; }, G, m[t], alpha[t], m2[t]);
+        softmax_scores<SMX>(st[t], a.scale, [](int) { return true; }, G, m[t], alpha[t], m2[t], dg);
       else
-        softmax_scores(st[t], a.scale, [&](int tk) { return t0 + tk <= lim; }, G, m[t], alpha[t], m2[t]);
+        softmax_scores<SMX>(st[t], a.scale, [&](int tk) { return t0 + tk <= lim; }, G, m[t], alpha[t], m2[t], dg);
     }
     stamp(2);   // scores
   };
@@ -426,6 +430,9 @@ void launch_attn_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(a.kvh, a.nsplit), dim3(256), 0, st, a);
 }
 
+static int g_attn_smx_override = -1;
+void set_attn_variant_override(int smx) { g_attn_smx_override = smx; }
+
 void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
   if (a_in.S <= 0) return;
   AttnPrefillArgs a = a_in;
@@ -445,6 +452,23 @@ void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
   const int nqb = (a.S + 16 * qt * nwv - 1) / (16 * qt * nwv);
   a.nqb = (sched_env && a.kvh % 8 == 0 && a.nh % a.kvh == 0) ? nqb : 0;
   dim3 grid = a.nqb ? dim3(nqb * a.nh) : dim3(nqb, a.nh), block(nwv * 64);
+  // AHA_ATTN_SMX: parts of the score rounding chain on the matrix pipe (0 none, 1 the scale multiply);
+  // needs a bf16-exact scale (every model path has one; an op-level caller with another scale gets the vector-ALU chain)
+  static const int smx_env = [] { const char* e = getenv("AHA_ATTN_SMX"); return e ? atoi(e) : 1; }();
+  union { float f; uint32_t u; } sb;
+  sb.f = a.scale;
+  const uint32_t scale_bits = sb.u;
+  const int smx = (scale_bits & 0xffffu) == 0 ? (g_attn_smx_override >= 0 ? g_attn_smx_override : smx_env) : 0;
+#define ATTN_LAUNCH(DQK_, DV_)                                                                                                   \
+  do {                                                                                                                           \
+    if (nwv == 8) {                                                                                                              \
+      if (smx == 1) hipLaunchKernelGGL((attn_prefill_kernel<DQK_, DV_, 1, 8, false, 0, 1>), grid, block, lds, st, a, nullptr); \
+      else hipLaunchKernelGGL((attn_prefill_kernel<DQK_, DV_, 1, 8>), grid, block, lds, st, a, nullptr);                         \
+    } else {                                                                                                                     \
+      if (smx == 1) hipLaunchKernelGGL((attn_prefill_kernel<DQK_, DV_, 1, 4, false, 0, 1>), grid, block, lds, st, a, nullptr); \
+      else hipLaunchKernelGGL((attn_prefill_kernel<DQK_, DV_, 1, 4>), grid, block, lds, st, a, nullptr);                         \
+    }                                                                                                                            \
+  } while (0)
   if (a.d == 128) {
     const size_t lds = 2 * KV_PAGE_TOKENS * 2 * (128 + 128);
     static const bool ptrace = [] { const char* e = getenv("AHA_ATTN_PTRACE"); return e && atoi(e) != 0; }();
@@ -471,16 +495,16 @@ void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
       if (abl == 4) hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 1, 8, false, 4>), grid, block, lds, st, a, nullptr);
       return;
     }
-    if (nwv == 8) hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 1, 8>), grid, block, lds, st, a, nullptr);
-    else hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 1, 4>), grid, block, lds, st, a, nullptr);
+    ATTN_LAUNCH(128, 128);
   } else if (a.d == 64) {  // Qwen3-ASR audio encoder
     const size_t lds = 2 * KV_PAGE_TOKENS * 2 * (64 + 64);
-    hipLaunchKernelGGL((attn_prefill_kernel<64, 64, 1, 4>), grid, block, lds, st, a, nullptr);
+    if (smx == 1) hipLaunchKernelGGL((attn_prefill_kernel<64, 64, 1, 4, false, 0, 1>), grid, block, lds, st, a, nullptr);
+    else hipLaunchKernelGGL((attn_prefill_kernel<64, 64, 1, 4>), grid, block, lds, st, a, nullptr);
   } else {  // head_dim 72 (Qwen3-VL ViT): Q/K rows padded to 96, V block to 80
     const size_t lds = 2 * KV_PAGE_TOKENS * 2 * (96 + 80);
-    if (nwv == 8) hipLaunchKernelGGL((attn_prefill_kernel<96, 80, 1, 8>), grid, block, lds, st, a, nullptr);
-    else hipLaunchKernelGGL((attn_prefill_kernel<96, 80, 1, 4>), grid, block, lds, st, a, nullptr);
+    ATTN_LAUNCH(96, 80);
   }
+#undef ATTN_LAUNCH
 }
 
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {

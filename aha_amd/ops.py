@@ -78,6 +78,11 @@ def gemm_plan(tile: int = 0, splitk: int = 0) -> None:
     check(lib().aha_hip_debug_gemm_plan(tile, splitk))
 
 
+def attn_variant(smx: int = -1) -> None:
+    """Test hook: the prefill attention's score-chain variant (aha_hip_debug_attn_variant); -1 = default."""
+    check(lib().aha_hip_debug_attn_variant(smx))
+
+
 def interleave_gate_up(Wg: torch.Tensor, Wu: torch.Tensor) -> torch.Tensor:
     """The model loader's fused layout: 16-row blocks alternating gate / up (csrc/model.hip upload_gate_up)."""
     I, K = Wg.shape

@@ -318,6 +318,10 @@ int aha_hip_debug_last_hidden(aha_model* m, float* out, size_t n);
  * run-to-run identical results when its launch is simply repeated and different ones behind different poisons
  * (tests/test_ops_gpu.py::test_kernels_do_not_consume_unstaged_lds). */
 int aha_hip_debug_poison_lds(uint32_t seed, void* stream);
+/* Test hook: whether the `* scaling` multiply of the prefill attention's score rounding chain (modules.rs:782-783) runs on the matrix
+ * pipe (1: csrc/attn_common.h mfma_diag, the default) or in the vector ALU (0); both give the same bits.  -1 = the default
+ * (AHA_ATTN_SMX). */
+int aha_hip_debug_attn_variant(int32_t smx);
 /* Test hook: force the GEMM tile (128 or 256) and split-K factor of every following GEMM launch of the process;
  * (0, 0) restores the automatic choice (csrc/kernels_gemm.hip plan_gemm).  tile 1256 / 1192: the persistent kernel on 256- /
  * 192-column tiles wherever it has an instantiation and a workspace (128^2 kernel elsewhere). */

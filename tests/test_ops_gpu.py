@@ -482,6 +482,28 @@ def test_attn_prefill_full(gpu):
     assert_close_ulps(got, ref, 3, None, "attn_prefill full", row_scale=True)
 
 
+@pytest.mark.parametrize("S,off,nh,kvh,causal", [(300, 0, 8, 2, True), (100, 333, 4, 2, True), (2048, 0, 32, 8, True), (1542, 0, 32, 8, True),
+                                                 (150, 0, 4, 4, False)])
+def test_attn_prefill_score_chain_on_the_matrix_pipe_gives_the_same_bits(gpu, S, off, nh, kvh, causal):
+    """`bf16(q.k) * bf16(scale)` (modules.rs:782-783) as diag(scale) x packed-bf16 on the matrix pipe (csrc/attn_common.h
+    mfma_diag) is ONE exact bf16 x bf16 product per score, like the vector-ALU multiply: the two variants must agree bit for bit
+    (4-wave and 8-wave blocks, diagonal and interior tiles, offsets)."""
+    from aha_amd import ops
+    d, L = 128, S + off
+    q, k, v = rnd((S, nh * d), 46), rnd((L, kvh * d), 47), rnd((L, kvh * d), 48)
+    qg, kg, vg = q.to(gpu), k.to(gpu), v.to(gpu)
+    outs = {}
+    try:
+        for smx in (0, 1):
+            ops.attn_variant(smx)
+            outs[smx] = ops.attn_prefill(qg, kg, vg, nh, kvh, d, off, causal)
+    finally:
+        ops.attn_variant(-1)
+    assert torch.equal(outs[1], outs[0]), "the matrix-pipe scale multiply differs from the vector-ALU chain"
+    if S <= 300:
+        assert_close_ulps(outs[1], _attn_ref(q, k, v, nh, kvh, d, causal, off), 3, None, "attn_prefill smx 1", row_scale=True)
+
+
 def test_argmax_first_max(gpu):
     from aha_amd import ops
     x = torch.randn(151936, generator=torch.Generator().manual_seed(50))

@@ -238,3 +238,20 @@ def test_vision_encode_then_precomputed_embeds(vl, gpu):
     b, _ = m.forward_initial(ids, 0, MultiModalData(image_grid_thw=grid, image_embeds=emb))
     assert np.array_equal(a, b)
     m.clear_cache()
+
+
+def test_vit_attention_score_chain_variants_give_the_same_bits(vl, gpu):
+    """head_dim 72 (96 / 80 padded) instantiations of the prefill attention: the matrix-pipe score chain (csrc/attn_common.h
+    mfma_diag) against the vector-ALU one through the whole tower -- bit-identical merged embeddings and DeepStack taps."""
+    from aha_amd import ops
+    from aha_amd.model import MultiModalData
+    cfg, m, o = vl
+    imgs, pv, grid, ids = make_request(cfg, [(160, 96), (64, 128)], 6, 29)
+    embs = {}
+    try:
+        for smx in (0, 1):
+            ops.attn_variant(smx)
+            embs[smx] = m.vision_encode(MultiModalData(pv.to(torch.bfloat16), grid))
+    finally:
+        ops.attn_variant(-1)
+    assert torch.equal(embs[1], embs[0])
