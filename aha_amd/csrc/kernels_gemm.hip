@@ -636,9 +636,11 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
     static bool onceq = false;
     if (!onceq) {
       hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_PARTIAL_F32, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_PARTIAL_F32, false, false, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       onceq = true;
     }
-    hipLaunchKernelGGL((gemm256q_kernel<ACT_PARTIAL_F32, false, false>), dim3(ntm * ntn, splitk), dim3(256), lds, st, p, kps, 0);
+    if (n192) hipLaunchKernelGGL((gemm256q_kernel<ACT_PARTIAL_F32, false, false, true, 0, true>), dim3(ntm * ((a.N + 191) / 192), splitk), dim3(256), lds, st, p, kps, 0);
+    else hipLaunchKernelGGL((gemm256q_kernel<ACT_PARTIAL_F32, false, false>), dim3(ntm * ntn, splitk), dim3(256), lds, st, p, kps, 0);
   } else {
     hipLaunchKernelGGL((gemm256p_kernel<ACT_PARTIAL_F32, false, false>), dim3(ntm * ntn, splitk), dim3(512), lds, st, p, zero_block(), kps, nullptr);
   }
@@ -655,9 +657,10 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
 
 template <int ACT>
 void launch256_act(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fused, bool n192) {
-  if (a.bias && a.residual) launch256_one<ACT, true, true>(a, splitk, st, norm_fused);
-  else if (a.bias) launch256_one<ACT, true, false>(a, splitk, st, norm_fused);
-  else if (a.residual) launch256_one<ACT, false, true>(a, splitk, st, norm_fused);
+  // (n192 with bias / residual only matters under split-K: the slabs are plain f32 sums whatever the epilogue of the reduce pass)
+  if (a.bias && a.residual) launch256_one<ACT, true, true>(a, splitk, st, norm_fused, n192);
+  else if (a.bias) launch256_one<ACT, true, false>(a, splitk, st, norm_fused, n192);
+  else if (a.residual) launch256_one<ACT, false, true>(a, splitk, st, norm_fused, n192);
   else launch256_one<ACT, false, false>(a, splitk, st, norm_fused, n192);
 }
 
@@ -680,12 +683,13 @@ GemmPlan plan_gemm(const GemmArgs& a) {
       return GemmPlan{tn, 1, 0.0, true};
     return GemmPlan{128, 1};
   }
-  if (g_force_tile == 192 && a.M >= 1 && !a.bias && !a.residual && (a.act == ACT_NONE || a.act == ACT_SILU_MUL_PAIRS) && a.K % BK == 0)
-    return GemmPlan{192, 1};
   if ((g_force_tile == 256 || g_force_tile == 192) && a.M >= 1) {
     int sk = g_force_splitk > 1 ? g_force_splitk : 1;
     if (sk > 1 && (a.act == ACT_SILU_MUL_PAIRS || a.act == ACT_PARTIAL_F32 || !a.workspace || (a.N & 3) ||
                    (size_t)sk * a.M * a.N * 4 > a.workspace_bytes)) sk = 1;
+    // 192-column tiles: unsplit for the plain / gate+up epilogues, f32 slabs (any epilogue in the reduce pass) under split-K
+    if (g_force_tile == 192 && a.K % BK == 0 && (sk > 1 || (!a.bias && !a.residual && (a.act == ACT_NONE || a.act == ACT_SILU_MUL_PAIRS))))
+      return GemmPlan{192, sk};
     return GemmPlan{256, sk};
   }
   static const char* e_tile = getenv("AHA_GEMM_TILE");
@@ -745,6 +749,23 @@ GemmPlan plan_gemm(const GemmArgs& a) {
       if (c5 < best_cost) {
         best = GemmPlan{192, 1};
         best_cost = c5;
+      }
+    }
+  }
+  // 192-column tiles under split-K (round 4: gemm256q_kernel<ACT_PARTIAL_F32, .., NF3>; any epilogue -- it runs in the reduce pass):
+  // where tiles x slices make ONE round that fills at least half the chip.  ViT fc2 (4096 x 1152 x 4352, bias + residual): 96 tiles x 2
+  // = 192 blocks of 34 K tiles, 50.8 us, against 80 x 3 = 240 blocks of 23 on 256^2 tiles, 54.9 us (one f32 slab less through the
+  // reduce pass; 0.99 us per K tile at that fill) -- scripts/bench_gemm_fc2.py.  Also 0.6B down_proj at 2 k / 4 k tokens: 29.9 / 41.6 us
+  // against 34.0 / 47.7 us.  The cfg 3 text projections never qualify (o / down: 154 tiles x 2 = two rounds, measured 82.7 / 196.7 us
+  // against 61.8 / 138.3 us).
+  if (n192_on && can_split && a.K % BK == 0 && a.M >= 256 && !e_tile && !e_sk && 256.0 * 2.0 * (double)std::max(a.lda, a.ldw) < 1.0e9) {
+    const double t192 = (double)((a.M + 255) / 256) * ((a.N + 191) / 192);
+    for (int sk : {2, 3, 4}) {
+      if ((size_t)sk * a.M * a.N * 4 > a.workspace_bytes || nk / sk < 16 || t192 * sk > 256.0 || t192 * sk < 128.0) continue;   // (short K loops: ViT proj, K = 1152, 28.5 us against 26.3 us on the 128^2 kernel)
+      const double c = ceil(nk / sk) * 1.5 * 0.72 + (double)(sk + 1) * a.M * a.N * 4.0 / 4.0e6 + 3.0;
+      if (c < best_cost) {
+        best = GemmPlan{192, sk};
+        best_cost = c;
       }
     }
   }
@@ -875,9 +896,9 @@ static void launch_planned(const GemmArgs& a, const GemmPlan& plan, hipStream_t 
     const bool n192 = plan.tile == 192;
     switch (a.act) {
       case ACT_NONE: launch256_act<ACT_NONE>(a, plan.splitk, st, norm_fused, n192); break;
-      case ACT_GELU_TANH: launch256_act<ACT_GELU_TANH>(a, plan.splitk, st, norm_fused, false); break;
-      case ACT_GELU_ERF: launch256_act<ACT_GELU_ERF>(a, plan.splitk, st, norm_fused, false); break;
-      case ACT_SILU: launch256_act<ACT_SILU>(a, plan.splitk, st, norm_fused, false); break;
+      case ACT_GELU_TANH: launch256_act<ACT_GELU_TANH>(a, plan.splitk, st, norm_fused, n192 && plan.splitk > 1); break;
+      case ACT_GELU_ERF: launch256_act<ACT_GELU_ERF>(a, plan.splitk, st, norm_fused, n192 && plan.splitk > 1); break;
+      case ACT_SILU: launch256_act<ACT_SILU>(a, plan.splitk, st, norm_fused, n192 && plan.splitk > 1); break;
       case ACT_SILU_MUL_PAIRS: launch256_one<ACT_SILU_MUL_PAIRS, false, false>(a, 1, st, nullptr, n192); break;
       case ACT_PARTIAL_F32: launch256_one<ACT_PARTIAL_F32, false, false>(a, 1, st); break;
     }

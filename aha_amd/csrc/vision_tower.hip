@@ -24,6 +24,10 @@ struct MergerW {
 
 struct VisionModel {
   int D = 0, nh = 0, hd = 0, I = 0, depth = 0, merge = 0, out = 0, G = 0, patch_dim = 0, M4 = 0;
+  // fc2 contracts over I padded to whole 64-deep K tiles (Qwen3-VL: 4304 -> 4352): the MLP buffer rows and fc2's weight rows are Ipad
+  // wide with zeros in the pad (fc1 writes I columns of the zeroed buffer), so fc2 runs on the four-wave kernels (which stage whole K
+  // tiles) instead of the 8-wave one -- exact: the pad adds 0 x 0 products
+  int Ipad = 0;
   void *patch_w = nullptr, *patch_b = nullptr, *pos_table = nullptr;
   float* d_inv_freq = nullptr;
   std::vector<VisBlockW> blocks;
@@ -69,7 +73,7 @@ int vision_create(aha_model* m, const aha_tensor_view* w, size_t nw) {
   }
   VisionModel* v = new VisionModel();
   m->vision = v;
-  v->D = c.vis_hidden_size; v->nh = c.vis_num_heads; v->hd = v->D / v->nh; v->I = c.vis_intermediate_size;
+  v->D = c.vis_hidden_size; v->nh = c.vis_num_heads; v->hd = v->D / v->nh; v->I = c.vis_intermediate_size; v->Ipad = (v->I + 63) / 64 * 64;
   v->depth = c.vis_depth; v->merge = c.vis_spatial_merge_size; v->out = c.vis_out_hidden_size;
   v->G = (int)sqrtf((float)c.vis_num_position_embeddings);
   v->patch_dim = c.vis_in_channels * c.vis_temporal_patch_size * c.vis_patch_size * c.vis_patch_size;
@@ -102,7 +106,8 @@ int vision_create(aha_model* m, const aha_tensor_view* w, size_t nw) {
     LOAD(p + "attn.proj.bias", (S{v->D}), b.proj_b);
     LOAD(p + "mlp.linear_fc1.weight", (S{v->I, v->D}), b.fc1_w);
     LOAD(p + "mlp.linear_fc1.bias", (S{v->I}), b.fc1_b);
-    LOAD(p + "mlp.linear_fc2.weight", (S{v->D, v->I}), b.fc2_w);
+    if ((rc = vneed(w, nw, p + "mlp.linear_fc2.weight", &t))) return rc;
+    if ((rc = upload_tensor(m, t, S{v->D, v->I}, &b.fc2_w, 0, v->Ipad))) return rc;
     LOAD(p + "mlp.linear_fc2.bias", (S{v->D}), b.fc2_b);
   }
   auto load_merger = [&](const std::string& p, bool post, MergerW& mw) -> int {
@@ -179,7 +184,7 @@ static int vision_ensure_scratch(aha_model* m, size_t N, size_t npages) {
   if ((rc = al(cap * 3 * D * 2, &v->qkv))) return rc;
   if ((rc = al(cap * v->nh * VIT_DQK * 2, &v->q))) return rc;
   if ((rc = al(cap * D * 2, &v->attn))) return rc;
-  if ((rc = al(cap * (size_t)v->I * 2, &v->mlp))) return rc;
+  if ((rc = al(cap * (size_t)v->Ipad * 2, &v->mlp, true))) return rc;   // zero: the pad columns are never written
   if ((rc = al(n4 * v->M4 * 2, &v->mh))) return rc;
   if ((rc = al(cap * 4 * 4, (void**)&v->d_idx))) return rc;
   if ((rc = al(cap * 4 * 4, (void**)&v->d_wt))) return rc;
@@ -214,9 +219,9 @@ static inline uint16_t f2bf_host(float f) {
 }
 
 static void vgemm(aha_model* m, const void* A, const void* W, void* C, int M, int N, int K, const void* bias,
-                  const void* residual, int act) {
+                  const void* residual, int act, int ldc = 0) {
   GemmArgs g{};
-  g.A = A; g.W = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N; g.bias = bias; g.residual = residual; g.act = act;
+  g.A = A; g.W = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = ldc ? ldc : N; g.bias = bias; g.residual = residual; g.act = act;
   ProfScope ps(m, "gemm", ((double)M * K + (double)N * K + (double)M * N * (residual ? 2 : 1)) * 2, 2.0 * M * N * K);
   launch_gemm(g, m->stream);
 }
@@ -448,8 +453,8 @@ int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, cons
       ProfScope ps(m, "elem", (double)N * v->D * 4, 0);
       launch_layernorm_rows(v->x, b.n2w, b.n2b, v->h, N, v->D, 1e-6f, st);
     }
-    vgemm(m, v->h, b.fc1_w, v->mlp, (int)N, v->I, v->D, b.fc1_b, nullptr, ACT_GELU_TANH);
-    vgemm(m, v->mlp, b.fc2_w, v->x, (int)N, v->D, v->I, b.fc2_b, v->x, ACT_NONE);
+    vgemm(m, v->h, b.fc1_w, v->mlp, (int)N, v->I, v->D, b.fc1_b, nullptr, ACT_GELU_TANH, v->Ipad);
+    vgemm(m, v->mlp, b.fc2_w, v->x, (int)N, v->D, v->Ipad, b.fc2_b, v->x, ACT_NONE);
     for (size_t k = 0; k < v->ds_idx.size(); ++k)
       if (v->ds_idx[k] == li) run_merger(m, v->ds_mergers[k], true, v->x, N, v->deep[k]);
   }

@@ -247,7 +247,10 @@ def test_gemm_plans_of_the_baseline_shapes(hip_lib):
     assert plan(1792, 24576, 4096, act=_lib.ACT_SILU_MUL_PAIRS) == (256, 1, 0)
     assert plan(1542, 4096, 12288, res=1) == (256, 2, 0)
     assert plan(1542, 4096, 4096, res=1, ws=0) == (128, 1, 0)            # no workspace: no split-K, and 112 tiles lose to the 128^2 kernel
-    # ViT at N = 4096 patches: qkv on 256^2, proj on 128^2, fc1 as 4096 columns + a 208-column tail, fc2 in three K slices
+    # ViT at N = 4096 patches: qkv on 256^2, proj on 128^2, fc1 as 4096 columns + a 208-column tail; fc2 contracts over the MLP width padded
+    # to whole K tiles (4352; csrc/vision_tower.hip Ipad) as two K slices of 192-column tiles = 192 blocks (scripts/bench_gemm_fc2.py:
+    # 50.8 us against 54.9 us for three slices of 256^2 tiles and 61.6-64.9 us for the unpadded K = 4304 on the 8-wave kernel)
+    assert plan(4096, 1152, 4352, bias=1, res=1) == (192, 2, 0)
     assert plan(4096, 3456, 1152, bias=1) == (256, 1, 0)
     assert plan(4096, 1152, 1152, bias=1, res=1) == (128, 1, 0)
     assert plan(4096, 4304, 1152, act=_lib.ACT_GELU_TANH, bias=1) == (256, 1, 1)

@@ -235,6 +235,31 @@ def test_gemm_256x192_tile_equals_the_256_tile_bitwise(gpu):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("M,N,K,sk", [(4096, 1152, 4352, 2), (1542, 1000, 2048, 3), (300, 328, 1024, 4), (600, 576, 1280, 2)])
+def test_gemm_256x192_tile_split_k_equals_the_256_tile_split_bitwise(gpu, M, N, K, sk):
+    """Split-K on the 192-column tile (gemm256q_kernel<ACT_PARTIAL_F32, .., NF3>; round 4, the ViT fc2 plan): the same K slices, the
+    same K order inside a slice, the same reduce pass -> bit-identical to the 256-column slabs, with every epilogue the reduce pass runs
+    (bias + residual, bias + GELU, plain); ragged N (1000 = 5 x 192 + 40, 328), ragged M, a K-tile count the slices do not divide (20 / 3)."""
+    from aha_amd import ops, _lib
+    A, W, b, res = rnd((M, K), 101).to(gpu), rnd((N, K), 102, 0.02).to(gpu), rnd((N,), 103, 0.5).to(gpu), rnd((M, N), 104).to(gpu)
+    for args in [(b, res), (b, None, _lib.ACT_GELU_TANH), ()]:
+        outs = []
+        for tile in (256, 192):
+            ops.gemm_plan(tile, sk)
+            try:
+                outs.append(ops.gemm(A, W, *args))
+            finally:
+                ops.gemm_plan(0, 0)
+        assert torch.equal(outs[0], outs[1]), f"epilogue {len(args)}"
+    ref = NM.r(NM.r(NM.linear(A.float().cpu(), W.float().cpu()) + b.float().cpu()) + res.float().cpu())
+    ops.gemm_plan(192, sk)
+    try:
+        got = ops.gemm(A, W, b, res)
+    finally:
+        ops.gemm_plan(0, 0)
+    assert_close_ulps(got, ref, 2, 0.97, "192-column split-K, bias + residual")
+
+
 @pytest.mark.parametrize("M", [257, 262, 288, 513, 1542, 1568, 2049])
 @pytest.mark.parametrize("N,K", [(192, 64), (328, 192), (1152, 1024), (6144, 4096)])
 def test_gemm_fifth_fragment_row_equals_the_256_tile_bitwise(gpu, M, N, K):
