@@ -175,18 +175,21 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(RopeArgs a) {
 // V rows take a second block role: 128 lanes per (page, kv head) load 8 tokens x 8 dims each, transpose 8 x 8 in registers
 // and store eight 16-byte pieces of the fragment-major V page (a piece = one dim x 8 token slots); pieces that
 // are only partly covered by this call's tokens fall back to 2-byte stores.
-constexpr int ROPE_ROWS_CHUNK = 10;  // head slots per wave in the q / k role
 template <int CTRL>
 __device__ __forceinline__ float dpp_rot(float v) {
   return __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), CTRL, 0xf, 0xf, false));
 }
+// ROPE_ROWS_CHUNK = head slots per wave in the q / k role: 8 (40 q + k heads of the 8B model = 5 waves per 4 tokens, 24 of the 0.6B = 3)
+// against 10: 15.2 vs 17.0 us at cfg 3 (more waves in flight; 5: 15.6 us).  Leading the grid with the V blocks: no difference.
+template <int ROPE_ROWS_CHUNK>
 __global__ __launch_bounds__(256) void qknorm_rope_rows_kernel(RopeArgs a, int n_qk_blocks) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nqk = a.nh + a.kvh;
-  if ((int)blockIdx.x < n_qk_blocks) {
+  const int bid = (int)blockIdx.x;
+  if (bid < n_qk_blocks) {
     // ---- role A: q / k heads ----
     const int nchunk = (nqk + ROPE_ROWS_CHUNK - 1) / ROPE_ROWS_CHUNK;
-    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t wid = (int64_t)bid * 4 + wave;
     const int tg = (int)(wid / nchunk), chunk = (int)(wid % nchunk);
     const int tq = lane >> 4, sub = lane & 15, sp = sub & 7;
     const int tok = tg * 4 + tq;
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_rows_kernel(RopeArgs a, int n
     return;
   }
   // ---- role B: V rows, 128 lanes per (page of this call, kv head) ----
-  const int64_t u = ((int64_t)(blockIdx.x - n_qk_blocks) * 256 + threadIdx.x);
+  const int64_t u = ((int64_t)(bid - n_qk_blocks) * 256 + threadIdx.x);
   const int unit = (int)(u >> 7), lu = (int)(u & 127);
   const int p0 = a.kv_start_host / KV_PAGE_TOKENS, p1 = (a.kv_start_host + a.S - 1) / KV_PAGE_TOKENS;
   const int page = p0 + unit / a.kvh, h = unit % a.kvh;
@@ -333,12 +336,16 @@ void launch_rope_table(const int32_t* pos, int64_t pos_ld, const float* inv_freq
 void launch_qknorm_rope(const RopeArgs& a, hipStream_t st) {
   static const bool rows_on = [] { const char* e = getenv("AHA_ROPE_ROWS"); return e ? atoi(e) != 0 : true; }();
   if (rows_on && a.kv_start_host >= 0 && a.kv.page_ptrs != nullptr && a.d == 128 && a.S >= 16) {
-    const int nqk = a.nh + a.kvh, nchunk = (nqk + ROPE_ROWS_CHUNK - 1) / ROPE_ROWS_CHUNK;
+    static const int chunk_env = [] { const char* e = getenv("AHA_ROPE_CHUNK"); return e ? atoi(e) : 8; }();
+    const int chunk = chunk_env == 10 ? 10 : 8;
+    const int nqk = a.nh + a.kvh, nchunk = (nqk + chunk - 1) / chunk;
     const int64_t qk_waves = (int64_t)((a.S + 3) / 4) * nchunk;
     const int n_qk_blocks = (int)((qk_waves + 3) / 4);
     const int npages = (a.kv_start_host + a.S - 1) / KV_PAGE_TOKENS - a.kv_start_host / KV_PAGE_TOKENS + 1;
     const int n_v_blocks = (npages * a.kvh * 128 + 255) / 256;
-    hipLaunchKernelGGL(qknorm_rope_rows_kernel, dim3((unsigned)(n_qk_blocks + n_v_blocks)), dim3(256), 0, st, a, n_qk_blocks);
+    const dim3 grid((unsigned)(n_qk_blocks + n_v_blocks));
+    if (chunk == 8) hipLaunchKernelGGL(qknorm_rope_rows_kernel<8>, grid, dim3(256), 0, st, a, n_qk_blocks);
+    else hipLaunchKernelGGL(qknorm_rope_rows_kernel<10>, grid, dim3(256), 0, st, a, n_qk_blocks);
     return;
   }
   const int64_t waves = (int64_t)a.S * ((a.nh + 2 * a.kvh + ROPE_SLOTS_PER_WAVE - 1) / ROPE_SLOTS_PER_WAVE);
