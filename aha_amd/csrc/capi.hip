@@ -364,6 +364,21 @@ int aha_hip_gemm(const void* A, const void* W, void* C, int32_t M, int32_t N, in
   return AHA_OK;
 }
 
+int aha_hip_debug_gemm_grouped(const void* A, const void* W, void* C, int32_t M, int32_t N, int32_t K, int32_t ldc, int32_t act,
+                               int32_t groups, int32_t a_gstride, int32_t c_gstride, int32_t c_row0, int32_t m_total, void* stream) {
+  if (!A || !W || !C || M <= 0 || N <= 0 || K % 8 || N % 8 || ldc % 4 || (act != ACT_NONE && act != ACT_SILU_MUL_PAIRS) || groups < 1 ||
+      a_gstride < M || c_gstride < 0 || c_row0 < 0 || m_total < 0 || (act == ACT_SILU_MUL_PAIRS && N % 32)) {
+    set_error("debug_gemm_grouped: bad argument");
+    return AHA_ERR_INVALID;
+  }
+  GemmArgs g{};
+  g.A = A; g.W = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = ldc; g.act = act;
+  g.groups = groups; g.a_gstride = a_gstride; g.c_gstride = c_gstride; g.c_row0 = c_row0; g.m_total = m_total;
+  launch_gemm_grouped(g, (hipStream_t)stream);
+  AHA_HIP_CHECK(hipGetLastError());
+  return AHA_OK;
+}
+
 int aha_hip_qknorm_rope(const void* qkv, const void* q_norm_w, const void* k_norm_w, const int32_t* pos,
                         const int32_t* axis_map, void* q_out, void* k_out, void* v_out, int32_t S, int32_t nh,
                         int32_t kvh, int32_t d, float eps, float theta, void* stream) {

@@ -158,8 +158,15 @@ struct GemmArgs {
                                  // persistent kernel, kernels_gemm_sk.hip; every launch leaves them zero again)
   int tile_group = 8;            // band width of the grouped tile order inside an XCD's run (kernels_gemm.hip tile_of_block); 0 = plain
   int partial_rows = 1;          // ACT_PARTIAL_F32 on the four-wave kernel: f32 sums stored in row order through LDS (0: fragment order; A/B)
+  // Row groups (launch_gemm_grouped; tensor-parallel prefill: the staging layout of the chunked all-gather, csrc/model.hip
+  // norm_gather_gemm): `groups` row segments of M rows each share W.  Segment g reads A rows [g * a_gstride, + M) and writes C rows
+  // [c_row0 + g * c_gstride, + M), clipped to rows < m_total.
+  int groups = 1, a_gstride = 0, c_gstride = 0, c_row0 = 0, m_total = 0;
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
+// One launch over all row segments on the four-wave 256 x 256 / 256 x 192 kernels (plain and gate+up epilogues, whole K tiles, M >= 256);
+// any other shape: one launch_gemm per segment.  Every output element is the same K-ordered sum as in an ungrouped GEMM over its row.
+void launch_gemm_grouped(const GemmArgs& a, hipStream_t st);
 // split-K scratch used by launch_gemm calls of this THREAD whose GemmArgs carry none (the model sets it per forward)
 void set_gemm_workspace(void* ws, size_t bytes, void* sk_counters = nullptr);
 // ---- the persistent, segment-table-driven kernel (kernels_gemm_sk.hip) ----

@@ -296,7 +296,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs a, const void
 
 // ---- variant 5: the 256 x 256 x 64 tile on FOUR waves (gemm256_body.h gemm256q_mainloop: schedule, LDS plan, counted waits) ---------
 // ROW5 (gemm256_body.h): rows5 = M mod 256 (1..32) rows ride as a fifth fragment row of the last row tile; the grid has M / 256 row tiles.
-template <int ACT, bool HAS_BIAS, bool HAS_RES, bool BAR2 = true, int ABL = 0, bool NF3 = false, bool ROW5 = false>
+// GRP (launch_gemm_grouped): row groups -- GemmArgs::groups segments of M rows, the tile grid runs over groups x ceil(M / 256) row tiles.
+template <int ACT, bool HAS_BIAS, bool HAS_RES, bool BAR2 = true, int ABL = 0, bool NF3 = false, bool ROW5 = false, bool GRP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256q_kernel(GemmArgs a, int kt_per_slice, int rows5) {
   char* const smem = gemm_smem;  // [stage][A0 | A1 | W0 | W1] x 16 KiB
   constexpr int TN = NF3 ? 192 : 256, WC = TN / 2;   // tile columns, columns per wave
@@ -308,6 +309,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     GemmArgs at = a;
     at.M = a.M - rows5;   // the tiling covers the multiple of 256; the last row tile owns the rest
     tile_of_block<BM2, TN>(at, m0, n0);
+  } else if (GRP) {
+    // row groups (GemmArgs::groups): a tile never straddles two segments
+    const int seg = (a.M + BM2 - 1) / BM2 * BM2;
+    GemmArgs at = a;
+    at.M = a.groups * seg;
+    tile_of_block<BM2, TN>(at, m0, n0);
+    const int g = m0 / seg;
+    m0 -= g * seg;
+    const int crow = a.c_row0 + g * a.c_gstride;
+    a.A = (const bf16_t*)a.A + (int64_t)g * a.a_gstride * a.lda;
+    a.C = (bf16_t*)a.C + (int64_t)crow * a.ldc;
+    a.M = max(0, min(a.M, a.m_total - crow));
+    if (m0 >= a.M) return;   // (block-uniform: a segment past the end of the sequence)
   } else {
     tile_of_block<BM2, TN>(a, m0, n0);
   }
@@ -887,6 +901,57 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t st) {
   bool norm_fused = false;
   launch_planned(a, plan, st, a.norm_w && fuse_norm ? &norm_fused : nullptr);
   if (a.norm_w && !norm_fused) launch_rmsnorm_rows(a.C, a.norm_w, a.norm_out, a.M, a.N, a.ldc, a.N, a.norm_eps, st);
+}
+
+void launch_gemm_grouped(const GemmArgs& a_in, hipStream_t st) {
+  if (a_in.M <= 0 || a_in.N <= 0 || a_in.groups <= 0) return;
+  static const int e_grp = [] { const char* e = getenv("AHA_GEMM_GROUP"); return e ? atoi(e) : 8; }();
+  static const bool n192_on = [] { const char* e = getenv("AHA_GEMM_N192"); return e ? atoi(e) != 0 : true; }();
+  static const bool fast_on = [] { const char* e = getenv("AHA_GEMM_GROUPED"); return e ? atoi(e) != 0 : true; }();
+  GemmArgs a = a_in;
+  a.tile_group = e_grp;
+  const bool fast = fast_on && a.groups > 1 && a.M >= BM2 && a.K % BK == 0 && !a.bias && !a.residual && !a.norm_w &&
+                    (a.act == ACT_NONE || a.act == ACT_SILU_MUL_PAIRS) && 256.0 * 2.0 * (double)std::max(a.lda, a.ldw) < 1.0e9 &&
+                    (g_force_tile == 0 || g_force_tile == 256 || g_force_tile == 192);
+  if (!fast) {
+    for (int g = 0; g < a.groups; ++g) {
+      GemmArgs s = a_in;
+      s.groups = 1;
+      const int crow = a.c_row0 + g * a.c_gstride;
+      s.A = (const bf16_t*)a.A + (int64_t)g * a.a_gstride * a.lda;
+      s.C = (bf16_t*)a.C + (int64_t)crow * a.ldc;
+      if (a.residual) s.residual = (const bf16_t*)a.residual + (int64_t)crow * a.ldc;
+      s.M = std::max(0, std::min(a.M, a.m_total - crow));
+      if (s.M > 0) launch_gemm(s, st);
+    }
+    return;
+  }
+  // tile width by rounds, as plan_gemm does for one segment: a round of 192-column tiles costs ~0.8 of a round of 256^2 ones
+  const int rows = a.groups * ((a.M + BM2 - 1) / BM2), cus = gemm_streamk_cus();
+  const int t256 = rows * ((a.N + 255) / 256), t192 = rows * ((a.N + 191) / 192);
+  bool n192 = n192_on && 0.8 * ((t192 + cus - 1) / cus) < 1.0 * ((t256 + cus - 1) / cus);
+  if (g_force_tile == 192) n192 = true;
+  if (g_force_tile == 256) n192 = false;
+  const size_t lds = 4 * TILE2_BYTES;
+  const int nk = a.K / BK;
+  const dim3 grid((unsigned)(n192 ? t192 : t256));
+#define AHA_GROUPED(ACT_, NF3_)                                                                                                      \
+  do {                                                                                                                                \
+    static bool once = false;                                                                                                         \
+    if (!once) {                                                                                                                      \
+      hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_, false, false, true, 0, NF3_, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      once = true;                                                                                                                    \
+    }                                                                                                                                 \
+    hipLaunchKernelGGL((gemm256q_kernel<ACT_, false, false, true, 0, NF3_, false, true>), grid, dim3(256), lds, st, a, nk, 0);        \
+  } while (0)
+  if (a.act == ACT_NONE) {
+    if (n192) AHA_GROUPED(ACT_NONE, true);
+    else AHA_GROUPED(ACT_NONE, false);
+  } else {
+    if (n192) AHA_GROUPED(ACT_SILU_MUL_PAIRS, true);
+    else AHA_GROUPED(ACT_SILU_MUL_PAIRS, false);
+  }
+#undef AHA_GROUPED
 }
 
 static void launch_planned(const GemmArgs& a, const GemmPlan& plan, hipStream_t st, bool* norm_fused) {

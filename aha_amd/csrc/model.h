@@ -129,11 +129,13 @@ struct aha_model {
   // gemm_row_parallel): RCCL runs on its own high-priority stream, ordered against the compute stream by events
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_gemm[8] = {};
+  hipEvent_t ev_ag[8] = {};   // chunk i of a chunked all-gather has landed (norm_gather_gemm)
   hipEvent_t ev_comm = nullptr;
   int async_rc = 0;             // first error of an all-reduce issued from inside an enqueue helper
   int lm_rows = 0, lm_row0 = 0; // lm_head rows this rank streams (vocab-parallel under TP) and the first of them
   float* d_partial = nullptr;   // decode: (hidden) f32 partial projection; also the 2T-float argmax pair exchange
   float* p_partial = nullptr;   // prefill: (S, hidden) f32
+  void* p_hstage = nullptr;     // tensor-parallel prefill: staging of the chunked all-gather, [chunk][rank][rows] bf16 (norm_gather_gemm)
   unsigned head_ctr_base = 0;       // value every kv head's split-arrival counter has reached after all launches so far
   unsigned* d_bar = nullptr;        // split-arrival counters of the fused decode attention (kernels.h DECODE_SYNC_BYTES)
   unsigned long long* d_gemv_trace = nullptr;  // AHA_GEMV_TRACE timeline
@@ -201,7 +203,7 @@ int weights_open(const char* dir, aha_weights** out);
 int model_load(aha_ctx* ctx, const char* dir, size_t kv_reserve_tokens, aha_model** out);
 int rccl_allreduce(aha_model* m, float* buf, size_t count);  // tp_rccl.hip
 int rccl_reduce_scatter(aha_model* m, float* buf, size_t count_per_rank, hipStream_t st = nullptr);   // in place: rank r keeps slice r; st: stream (default: the model's)
-int rccl_all_gather(aha_model* m, void* buf, size_t bytes_per_rank);        // in place: slice r is rank r's contribution
+int rccl_all_gather(aha_model* m, void* buf, size_t bytes_per_rank, hipStream_t st = nullptr);   // in place: slice r is rank r's contribution
 int tp_unique_id(void* out128);
 int tp_init_rccl(aha_model* m, const void* id128);
 void tp_destroy(aha_model* m);

@@ -29,9 +29,9 @@ int rccl_reduce_scatter(aha_model* m, float* buf, size_t count_per_rank, hipStre
   }
   return AHA_OK;
 }
-int rccl_all_gather(aha_model* m, void* buf, size_t bytes_per_rank) {
+int rccl_all_gather(aha_model* m, void* buf, size_t bytes_per_rank, hipStream_t st) {
   ncclResult_t r = ncclAllGather((const char*)buf + (size_t)m->tp_rank * bytes_per_rank, buf, bytes_per_rank, ncclUint8,
-                                 (ncclComm_t)m->rccl_comm, m->stream);
+                                 (ncclComm_t)m->rccl_comm, st ? st : m->stream);
   if (r != ncclSuccess) {
     set_error(std::string("ncclAllGather failed: ") + ncclGetErrorString(r));
     return AHA_ERR_HIP;
@@ -73,6 +73,10 @@ void tp_destroy(aha_model* m) {
   if (m->comm_stream) hipStreamDestroy(m->comm_stream);
   m->comm_stream = nullptr;
   for (auto& e : m->ev_gemm) {
+    if (e) hipEventDestroy(e);
+    e = nullptr;
+  }
+  for (auto& e : m->ev_ag) {
     if (e) hipEventDestroy(e);
     e = nullptr;
   }

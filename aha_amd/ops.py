@@ -78,6 +78,15 @@ def gemm_plan(tile: int = 0, splitk: int = 0) -> None:
     check(lib().aha_hip_debug_gemm_plan(tile, splitk))
 
 
+def gemm_grouped(A: torch.Tensor, W: torch.Tensor, Cm: torch.Tensor, M: int, groups: int, a_gstride: int, c_gstride: int, c_row0: int,
+                 m_total: int, act: int = _lib.ACT_NONE) -> None:
+    """Test entry (aha_hip_debug_gemm_grouped): segment g = A rows [g * a_gstride, + M) -> Cm rows [c_row0 + g * c_gstride, + M) < m_total."""
+    _chk(A, W, Cm)
+    N, K = W.shape
+    check(lib().aha_hip_debug_gemm_grouped(_ptr(A), _ptr(W), _ptr(Cm), M, N, K, Cm.shape[1], act, groups, a_gstride, c_gstride, c_row0, m_total,
+                                           _stream()))
+
+
 def attn_variant(smx: int = -1) -> None:
     """Test hook: the prefill attention's score-chain variant (aha_hip_debug_attn_variant); -1 = default."""
     check(lib().aha_hip_debug_attn_variant(smx))

@@ -115,7 +115,7 @@ def broadcast_bytes(payload, src: int = 0):
 # library profiler classes (csrc/model.hip ProfScope: HIP events on the model's stream around each launch group) -> phase names
 PREFILL_PHASE_CLASSES = (("gemm", "gemm_s"), ("attn_prefill", "attn_s"), ("attn_vit", "vit_attn_s"), ("elem", "rowwise_s"),
                          ("reduce_scatter", "reduce_scatter_s"), ("rs_wait", "reduce_scatter_wait_s"), ("all_gather", "all_gather_s"),
-                         ("allreduce", "allreduce_s"), ("gemv", "lm_head_s"))
+                         ("ag_wait", "all_gather_wait_s"), ("allreduce", "allreduce_s"), ("gemv", "lm_head_s"))
 
 
 def read_prefill_phases(model, ph: dict) -> dict:

@@ -234,13 +234,13 @@ def sharded_prefill_bench(rank, world, local_rank, n_images=8, image_px=2048, pr
         phases_max = {k: round(float(v), 5) for k, v in zip(keys, vec.tolist())}
     return {"metric": METRICS["qwen3vl8b-cfg5-tp"], "value": round(value, 1), "unit": "tokens/s", "prefill_s": round(worst, 4),
             "prompt_tokens": len(ids), "n_images": n_images, "image": image_px, "scaling": "strong",
-            "parallelism": f"tp{world} (sequence-parallel: RCCL reduce-scatter of the row-parallel partial sums in column blocks overlapped with "
-                           "the GEMMs + all-gather of the normalised rows) + image-parallel ViT (all-gather) + KV gather to rank 0 for decode",
+            "parallelism": f"tp{world} (sequence-parallel: RCCL reduce-scatter of the row-parallel partial sums in column blocks and all-gather of "
+                           "the normalised rows in row chunks, both overlapped with the GEMMs) + image-parallel ViT (all-gather) + KV gather to rank 0 for decode",
             "rccl_ranks": world, "first_token_equal_on_all_ranks": same, **handback,
             "phases_rank0": phases, "phases_max_over_ranks": phases_max,
             "phases_note": "one extra UNTIMED prefill with the library profiler on (HIP events per launch group on the model's stream; host-side phases "
                            "bracketed by device synchronisation): vit_s / embeds_all_gather_s / stack_s are wall clock, the rest event time inside stack_s; "
-                           "reduce_scatter_wait_s = what the compute stream waited for the collectives overlapped on the communication stream"}
+                           "reduce_scatter_wait_s / all_gather_wait_s = what the compute stream waited for the collectives overlapped on the communication stream"}
 
 SHARDED_LEG_TIMEOUT_S = int(os.environ.get("AHA_BENCH_SHARDED_TIMEOUT_S", "420"))
 

@@ -318,6 +318,11 @@ int aha_hip_debug_last_hidden(aha_model* m, float* out, size_t n);
  * run-to-run identical results when its launch is simply repeated and different ones behind different poisons
  * (tests/test_ops_gpu.py::test_kernels_do_not_consume_unstaged_lds). */
 int aha_hip_debug_poison_lds(uint32_t seed, void* stream);
+/* Test entry of the row-grouped GEMM behind the tensor-parallel prefill's chunked all-gather (csrc/kernels.h launch_gemm_grouped): `groups`
+ * row segments of M rows each, all x W^T (N, K): segment g reads A rows [g * a_gstride, + M) (row pitch K) and writes C rows
+ * [c_row0 + g * c_gstride, + M) (row pitch ldc), clipped to rows < m_total.  act: plain (0) or gate+up pairs (4). */
+int aha_hip_debug_gemm_grouped(const void* A, const void* W, void* C, int32_t M, int32_t N, int32_t K, int32_t ldc, int32_t act,
+                               int32_t groups, int32_t a_gstride, int32_t c_gstride, int32_t c_row0, int32_t m_total, void* stream);
 /* Test hook: whether the `* scaling` multiply of the prefill attention's score rounding chain (modules.rs:782-783) runs on the matrix
  * pipe (1: csrc/attn_common.h mfma_diag, the default) or in the vector ALU (0); both give the same bits.  -1 = the default
  * (AHA_ATTN_SMX). */

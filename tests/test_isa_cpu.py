@@ -77,9 +77,12 @@ def test_register_budgets_the_design_counts_on(kernels):
     # variant (the 256 x 192 tile needs only 424): a smaller claim lets a wave of another stream's kernel onto the SIMD, and such
     # co-residents were measured to compute wrong packed-f32 sums (profiles/r03_simd_coresidency.md; kernels_gemm.hip gemm256q_kernel)
     assert fam["gemm256q_kernel"] and all(k["vgpr_count"] == 512 and k["max_flat_workgroup_size"] == 256 for n, k in fam["gemm256q_kernel"])
-    # the 192-column instantiations (gate+up, plain), each without and with the fifth fragment row (last template argument)
-    assert sum(n.endswith("Lb1ELb0EEEvNS_8GemmArgsEii") for n, _ in fam["gemm256q_kernel"]) == 2
-    assert sum(n.endswith("Lb1ELb1EEEvNS_8GemmArgsEii") for n, _ in fam["gemm256q_kernel"]) == 2
+    # the 192-column instantiations (template arguments NF3, ROW5, GRP): gate+up, plain and the f32 split-K slabs; gate+up and plain with
+    # the fifth fragment row; gate+up and plain with row groups (launch_gemm_grouped), which also exist on the 256-column tile
+    assert sum(n.endswith("Lb1ELb0ELb0EEEvNS_8GemmArgsEii") for n, _ in fam["gemm256q_kernel"]) == 3
+    assert sum(n.endswith("Lb1ELb1ELb0EEEvNS_8GemmArgsEii") for n, _ in fam["gemm256q_kernel"]) == 2
+    assert sum(n.endswith("Lb1ELb0ELb1EEEvNS_8GemmArgsEii") for n, _ in fam["gemm256q_kernel"]) == 2
+    assert sum(n.endswith("Lb0ELb0ELb1EEEvNS_8GemmArgsEii") for n, _ in fam["gemm256q_kernel"]) == 2
     # 128 KiB of dynamic LDS per 256^2 block is requested at launch; nothing static on top
     assert all(k["group_segment_fixed_size"] == 0 for _, k in fam["gemm256q_kernel"])
     # the persistent form of the same tile: the same claim (one workgroup per CU is what its planner counts on)
@@ -193,10 +196,10 @@ def test_counted_waits_in_the_mfma_loops(tmp_path):
     assert len(q) >= 20
     n192 = 0
     for n, (n_mfma, drains, counted) in q.items():
-        # 2 x (2 + 1) tiles x 64 MFMAs; the 256 x 192 tile (NF3 true: ...Lb1ELb?EEEv...) has 48 per K tile, and its ROW5 form a third copy
-        # of the k loop with 48 + 12 per K tile (the wave row that owns a fifth fragment row)
-        is192 = n.endswith("Lb1ELb0EEEvNS_8GemmArgsEii")
-        is5 = n.endswith("Lb1ELb1EEEvNS_8GemmArgsEii")
+        # 2 x (2 + 1) tiles x 64 MFMAs; the 256 x 192 tile (NF3 true: ...Lb1ELb?ELb?EEEv..., without / with row groups) has 48 per K tile,
+        # and its ROW5 form a third copy of the k loop with 48 + 12 per K tile (the wave row that owns a fifth fragment row)
+        is192 = n.endswith("Lb1ELb0ELb0EEEvNS_8GemmArgsEii") or n.endswith("Lb1ELb0ELb1EEEvNS_8GemmArgsEii")
+        is5 = n.endswith("Lb1ELb1ELb0EEEvNS_8GemmArgsEii")
         n192 += int(is192 or is5)
         assert n_mfma == (468 if is5 else 288 if is192 else 384) and drains == 0 and counted >= 8, (n, n_mfma, drains, counted)
     assert n192 >= 4, "the 256 x 192 instantiations (gate+up, plain; without / with the fifth fragment row) are missing"

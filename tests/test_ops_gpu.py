@@ -235,6 +235,39 @@ def test_gemm_256x192_tile_equals_the_256_tile_bitwise(gpu):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("seg,groups,N,K,act", [(512, 3, 768, 1024, 0), (300, 2, 1536, 512, 0), (600, 4, 1152, 320, 4), (256, 8, 192, 64, 0), (88, 2, 512, 512, 0),
+                                                 (1283, 2, 3072, 1024, 4)])
+def test_gemm_row_groups_equal_one_gemm_per_segment_bitwise(gpu, seg, groups, N, K, act):
+    """launch_gemm_grouped (csrc/kernels_gemm.hip; the tensor-parallel prefill's chunked all-gather reads its staging layout through it):
+    `groups` segments of `seg` rows, packed in A, written to rows c_row0 + g * c_gstride of a larger output and clipped at m_total -- one
+    launch on the four-wave kernels (256- and 192-column tiles, plain and gate+up epilogues) against one plain GEMM per segment on the same
+    kernel: bit-identical, and rows outside the segments / past m_total untouched.  (seg = 88: below one row tile -> the per-segment path.)"""
+    from aha_amd import ops, _lib
+    a_gs, c_gs, c_row0 = seg, seg + 137, 45
+    m_total = c_row0 + (groups - 1) * c_gs + seg - 7          # the last segment loses its last 7 rows
+    A = rnd((groups * a_gs, K), 111).to(gpu)
+    W = rnd((N, K), 112, 0.05).to(gpu)
+    n_out = N // 2 if act == _lib.ACT_SILU_MUL_PAIRS else N
+    for tile in (256, 192):
+        ops.gemm_plan(tile, 1)
+        try:
+            out = torch.full((m_total + 64, n_out), 7.0, dtype=torch.bfloat16, device=gpu)
+            ops.gemm_grouped(A, W, out, seg, groups, a_gs, c_gs, c_row0, m_total, act)
+            ref = torch.full_like(out, 7.0)
+            for g in range(groups):
+                r = c_row0 + g * c_gs
+                rows = min(seg, m_total - r)
+                ref[r:r + rows] = ops.gemm(A[g * a_gs:g * a_gs + rows].contiguous(), W, act=act)
+        finally:
+            ops.gemm_plan(0, 0)
+        assert torch.equal(out, ref), f"tile {tile}"
+    # the automatic tile choice gives one of the two
+    out = torch.full((m_total + 64, n_out), 7.0, dtype=torch.bfloat16, device=gpu)
+    ops.gemm_grouped(A, W, out, seg, groups, a_gs, c_gs, c_row0, m_total, act)
+    if seg >= 256:
+        assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("M,N,K,sk", [(4096, 1152, 4352, 2), (1542, 1000, 2048, 3), (300, 328, 1024, 4), (600, 576, 1280, 2)])
 def test_gemm_256x192_tile_split_k_equals_the_256_tile_split_bitwise(gpu, M, N, K, sk):
     """Split-K on the 192-column tile (gemm256q_kernel<ACT_PARTIAL_F32, .., NF3>; round 4, the ViT fc2 plan): the same K slices, the

@@ -419,6 +419,55 @@ def test_tp2_column_chunked_reduce_scatter_equals_the_unchunked_paths(gpu, S, mo
         np.testing.assert_array_equal(outs[mode][1], outs["allreduce"][1])
 
 
+@pytest.mark.parametrize("S,tile", [(1200, 256), (1201, 256), (1100, 192), (700, 128)])
+def test_tp2_chunked_all_gather_equals_the_single_all_gather(gpu, S, tile, monkeypatch):
+    """Round 4 (model.hip norm_gather_gemm): the all-gather of the normalised rows in front of the column-parallel projections runs in row
+    chunks (whole row tiles of every rank's slice; on the RCCL communication stream beside the previous chunk's GEMM -- through the host
+    callbacks here, which serialise it but move the same data), each chunk consumed by ONE row-grouped GEMM out of the staging layout
+    [chunk][rank][rows].  A GEMM's rows are independent, so on the same kernel every output element is the same K-ordered sum: logits of
+    the prefill and of a decode step (i.e. the KV cache) bit-identical to the single-gather path.  The tile is forced so that both paths
+    run the same kernel (256 / 192: the grouped launch; 128: one launch per segment); S = 1201: ragged slices, the last rank one row
+    short; 2 chunks of 512 + 88 / 89 rows per rank."""
+    from aha_amd import ops
+    from aha_amd.model import HipInferenceModel
+    cfg = tiny_qwen3(layers=2, hidden=512, heads=4, kv_heads=2, inter=1536, vocab=1024)
+    w = qwen3_text_weights(cfg, seed=0)
+    ids = [int(x) for x in np.random.default_rng(S).integers(0, cfg.vocab_size, size=S)]
+    monkeypatch.setenv("AHA_TP_AG_CHUNKS", "2")
+    outs = {}
+    ops.gemm_plan(tile, 1)
+    try:
+        for mode in ("single", "chunked"):
+            monkeypatch.setenv("AHA_TP_AG_MIN_ROWS", "64" if mode == "chunked" else "100000000")
+            red = TwoRankSum()
+            ranks = [HipInferenceModel(cfg, w, tp_rank=r, tp_size=2, allreduce=lambda p, n, r=r: red.allreduce(r, p, n),
+                                       reduce_scatter=lambda p, n, r=r: red.reduce_scatter(r, p, n),
+                                       all_gather=lambda p, n, r=r: red.all_gather(r, p, n)) for r in range(2)]
+            got = run_ranks([lambda m=m: m.forward_initial(ids, 0)[0].copy() for m in ranks])
+            np.testing.assert_array_equal(got[0], got[1])
+            # two gathers per layer (qkv, gate+up), each in two chunks; x 2 ranks' callbacks
+            assert red.ag_calls == 2 * 2 * cfg.num_hidden_layers * (2 if mode == "chunked" else 1)
+            tok = int(np.argmax(got[0]))
+            step = run_ranks([lambda m=m: m.forward_step(tok, S)[0].copy() for m in ranks])
+            outs[mode] = (got[0], step[0])
+            for m in ranks:
+                m.close()
+    finally:
+        ops.gemm_plan(0, 0)
+    np.testing.assert_array_equal(outs["chunked"][0], outs["single"][0])
+    np.testing.assert_array_equal(outs["chunked"][1], outs["single"][1])
+    # and with the automatic plans (the two paths may then run different kernels): the sharded-vs-unsharded bound
+    monkeypatch.setenv("AHA_TP_AG_MIN_ROWS", "64")
+    red = TwoRankSum()
+    ranks = [HipInferenceModel(cfg, w, tp_rank=r, tp_size=2, allreduce=lambda p, n, r=r: red.allreduce(r, p, n),
+                               reduce_scatter=lambda p, n, r=r: red.reduce_scatter(r, p, n),
+                               all_gather=lambda p, n, r=r: red.all_gather(r, p, n)) for r in range(2)]
+    got = run_ranks([lambda m=m: m.forward_initial(ids, 0)[0].copy() for m in ranks])
+    for m in ranks:
+        m.close()
+    close(got[0], outs["single"][0], "chunked all-gather, automatic plans")
+
+
 def test_tp2_prefill_with_reserved_cus_runs_the_persistent_gemm_and_keeps_the_bits(gpu, monkeypatch):
     """Round 4: when the RCCL communication stream is set up the library reserves 16 CUs for it (aha_hip_set_gemm_reserved_cus) and
     every eligible GEMM of the rank -- the f32-partial row-parallel projections included -- then runs as the persistent kernel on
