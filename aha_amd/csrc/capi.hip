@@ -713,6 +713,37 @@ int aha_hip_tp_init_rccl(aha_model* m, const void* unique_id128) {
   API_GUARD_END
 }
 
+int aha_hip_set_context_parallel(aha_model* m, int32_t rank, int32_t world, aha_all_gather_fn all_gather, void* user) {
+  if (!m || world < 1 || world > 8 || rank < 0 || rank >= world) {
+    set_error("set_context_parallel: rank in [0, world), world in 1..8");
+    return AHA_ERR_INVALID;
+  }
+  if (m->tp_size > 1 && world > 1) {
+    set_error("set_context_parallel: the model is tensor-parallel (sharded weights); context parallelism needs the full weights on every rank");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  if (m->desc.head_dim != 128 && world > 1) {
+    set_error("set_context_parallel: head_dim 128 only");
+    return AHA_ERR_UNSUPPORTED;
+  }
+  if (m->rccl_comm && (world != m->cp_size || rank != m->cp_rank)) {
+    set_error("set_context_parallel: the RCCL communicator of this model was created for another (rank, world)");
+    return AHA_ERR_STATE;
+  }
+  if (world != m->cp_size) m->pf_cap = 0;   // the prefill scratch carries the exchange's staging buffer: re-plan it on the next prefill
+  m->cp_rank = rank;
+  m->cp_size = world;
+  m->cp_all_gather_cb = all_gather;
+  m->cp_user = user;
+  return AHA_OK;
+}
+int aha_hip_cp_init_rccl(aha_model* m, const void* unique_id128) {
+  API_GUARD_BEGIN
+  if (!m || !unique_id128) return AHA_ERR_INVALID;
+  return cp_init_rccl(m, unique_id128);
+  API_GUARD_END
+}
+
 int aha_hip_debug_allreduce(aha_model* m, void* buf, size_t count) {
   API_GUARD_BEGIN
   if (!m || !buf) return AHA_ERR_INVALID;

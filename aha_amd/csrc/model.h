@@ -135,6 +135,14 @@ struct aha_model {
   int lm_rows = 0, lm_row0 = 0; // lm_head rows this rank streams (vocab-parallel under TP) and the first of them
   float* d_partial = nullptr;   // decode: (hidden) f32 partial projection; also the 2T-float argmax pair exchange
   float* p_partial = nullptr;   // prefill: (S, hidden) f32
+  // Context-parallel prefill (aha_hip_set_context_parallel; model.hip cp_make_plan): every rank holds the FULL weights (tp_size 1) and
+  // owns two page-aligned row chunks of the prompt; the only exchange is one all-gather of the layer's K / V pages per layer
+  int cp_rank = 0, cp_size = 1;
+  int comm_rank = 0;              // this rank's index in rccl_comm (tp_rank or cp_rank)
+  aha_all_gather_fn cp_all_gather_cb = nullptr;   // host-callback seam (tests); RCCL otherwise
+  void* cp_user = nullptr;
+  void* p_cp_stage = nullptr;     // [rank][page slot][kv heads][K | V] of ONE layer, bf16
+  size_t cp_stage_bytes = 0;
   void* p_hstage = nullptr;     // tensor-parallel prefill: staging of the chunked all-gather, [chunk][rank][rows] bf16 (norm_gather_gemm)
   unsigned head_ctr_base = 0;       // value every kv head's split-arrival counter has reached after all launches so far
   unsigned* d_bar = nullptr;        // split-arrival counters of the fused decode attention (kernels.h DECODE_SYNC_BYTES)
@@ -206,6 +214,7 @@ int rccl_reduce_scatter(aha_model* m, float* buf, size_t count_per_rank, hipStre
 int rccl_all_gather(aha_model* m, void* buf, size_t bytes_per_rank, hipStream_t st = nullptr);   // in place: slice r is rank r's contribution
 int tp_unique_id(void* out128);
 int tp_init_rccl(aha_model* m, const void* id128);
+int cp_init_rccl(aha_model* m, const void* id128);
 void tp_destroy(aha_model* m);
 
 // helpers shared with vision.hip

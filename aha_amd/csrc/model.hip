@@ -807,7 +807,12 @@ static int ensure_prefill_scratch(aha_model* m, size_t S) {
   if ((rc = al(cap * nq * 2, &m->p_attn))) return rc;
   if ((rc = al(cap * I * 2, &m->p_act))) return rc;
   if (m->tp_size > 1 && (rc = al((cap + 64) * H * 4, (void**)&m->p_partial))) return rc;
-  if (m->tp_size > 1 && (rc = al((cap + 64) * H * 2, &m->p_hstage))) return rc;   // chunked all-gather: [chunk][rank][rows of the chunk]
+  if (m->tp_size > 1 && (rc = al((cap + 64) * H * 2, &m->p_hstage))) return rc;
+  if (m->cp_size > 1) {   // one layer's K / V of every rank's pages: cp_size x (max pages of a rank) x kv heads x (K | V) 16-KB blocks
+    const size_t pages = cap / KV_PAGE_TOKENS + 1, pmax = pages / m->cp_size + 4;
+    m->cp_stage_bytes = std::max((size_t)m->cp_size * pmax * nkv / 128 * 2 * KV_BLOCK_BYTES, (size_t)m->cp_size * H * 2);
+    if ((rc = al(m->cp_stage_bytes, &m->p_cp_stage))) return rc;
+  }   // chunked all-gather: [chunk][rank][rows of the chunk]
   m->gemm_ws_bytes = std::min((size_t)12 * cap * H * 4, (size_t)1 << 30);  // split-K slabs (up to 8 slices of an N = hidden GEMM, 6 of the qkv one)
   if ((rc = al(m->gemm_ws_bytes, &m->p_gemm_ws))) return rc;
   m->pf_cap = cap;
@@ -1168,6 +1173,80 @@ static int norm_gather_gemm(aha_model* m, const void* norm_w, const GemmArgs& g,
     ProfScope ps(m, "gemm", ((double)T * wc * g.K + (double)g.N * g.K + (double)T * wc * g.ldc) * 2, 2.0 * T * wc * g.N * g.K);
     launch_gemm_grouped(gc, m->stream);
   }
+  return AHA_OK;
+}
+
+// ---- context-parallel prefill (round 4) ----------------------------------------------------------------------------------------------
+// MI355X has 288 GB per GPU and the 8B checkpoint is 16 GB: for the long-context prefill of BASELINE cfg 5 every rank can hold the FULL
+// weights, own a share of the prompt's ROWS, and run every GEMM / norm / rope on its own rows with no collective at all -- a GEMM's rows
+// are independent.  The one op that couples rows is causal attention, which needs the K / V of every earlier position: per layer, the
+// ranks all-gather the layer's K / V pages (8B: 147 456 B per position and layer -> 40 980 tokens = 168 MB per layer, 7/8 of it inbound
+// per rank, against 2 x 294 MB of bf16 all-gather + 2 x 587 MB of f32 reduce-scatter per layer and rank in the tensor-parallel form).
+// Ownership: the prompt's KV pages (64 tokens) are cut into 2 x world contiguous chunks; rank r owns chunks r and 2 x world - 1 - r (the
+// "zigzag" that balances causal attention: an early chunk with few visible keys rides with a late one with many), so every page is
+// written by exactly one rank, chunk boundaries are page boundaries, and rank 0 owns the LAST rows -- it ends the prefill holding the
+// last hidden row, and, like every rank, the complete KV cache: decode continues on it without a hand-back.
+// Results: every output row is computed by the same kernels on the same values as in the single-GPU prefill; with the GEMM plan pinned
+// (plans depend on M) the logits and the cache are bit-identical to it (tests/test_cp_gpu.py).
+struct CpPlan { int world, pmax; int a0[8], an[8], b0[8], bn[8]; };   // rank r's two page ranges [a0, a0 + an), [b0, b0 + bn)
+struct RowSeg { int r0, len; };                                         // prompt rows [r0, r0 + len)
+static bool cp_make_plan(int S, int world, int rank, CpPlan* p, std::vector<RowSeg>* segs) {
+  const int P = (S + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS, nc = 2 * world;
+  if (world < 2 || world > 8 || P < 2 * nc) return false;   // at least two pages per chunk
+  auto edge = [&](int j) { return (int)((int64_t)j * P / nc); };
+  p->world = world;
+  p->pmax = 0;
+  for (int r = 0; r < world; ++r) {
+    p->a0[r] = edge(r); p->an[r] = edge(r + 1) - edge(r);
+    p->b0[r] = edge(nc - 1 - r); p->bn[r] = edge(nc - r) - edge(nc - 1 - r);
+    p->pmax = std::max(p->pmax, p->an[r] + p->bn[r]);
+  }
+  segs->clear();
+  for (int k = 0; k < 2; ++k) {
+    const int pg0 = k ? p->b0[rank] : p->a0[rank], n = k ? p->bn[rank] : p->an[rank];
+    const int r0 = pg0 * KV_PAGE_TOKENS, r1 = std::min(S, (pg0 + n) * KV_PAGE_TOKENS);
+    segs->push_back(RowSeg{r0, r1 - r0});
+  }
+  return true;
+}
+// staging slot s = rank * pmax + j  <->  the j-th page rank owns; one block copies 4 KB of the page's layer slice (kv heads x (K | V) x 16 KB)
+__global__ __launch_bounds__(256) void kv_cp_copy_kernel(const uint64_t* __restrict__ page_ptrs, uint64_t layer_off, int slice_bytes,
+                                                         char* __restrict__ stage, CpPlan p, int only_rank, int skip_rank, int to_pages) {
+  const int rank = (int)blockIdx.x / p.pmax, j = (int)blockIdx.x % p.pmax;
+  if ((only_rank >= 0 && rank != only_rank) || rank == skip_rank) return;
+  int page;
+  if (j < p.an[rank]) page = p.a0[rank] + j;
+  else if (j < p.an[rank] + p.bn[rank]) page = p.b0[rank] + (j - p.an[rank]);
+  else return;
+  char* pg = reinterpret_cast<char*>(page_ptrs[page] + layer_off) + (size_t)blockIdx.y * 4096;
+  char* sg = stage + (size_t)blockIdx.x * slice_bytes + (size_t)blockIdx.y * 4096;
+  const u32x4_t v = *reinterpret_cast<const u32x4_t*>((to_pages ? sg : pg) + threadIdx.x * 16);
+  *reinterpret_cast<u32x4_t*>((to_pages ? pg : sg) + threadIdx.x * 16) = v;
+}
+static int cp_all_gather(aha_model* m, void* buf, size_t bytes_per_rank) {
+  if (m->rccl_comm) return rccl_all_gather(m, buf, bytes_per_rank, m->stream);
+  AHA_HIP_CHECK(hipStreamSynchronize(m->stream));
+  if (!m->cp_all_gather_cb || m->cp_all_gather_cb(buf, bytes_per_rank, m->cp_user) != 0) {
+    set_error("context-parallel all-gather callback failed");
+    return AHA_ERR_STATE;
+  }
+  return AHA_OK;
+}
+// after the layer's rope + KV append on the owned rows: every rank's pages of this layer to every rank
+static int cp_gather_kv(aha_model* m, int li, const CpPlan& p) {
+  const KvLayer kv = model_kv_layer(m, li);
+  const int slice = m->desc.num_key_value_heads * 2 * KV_BLOCK_BYTES;
+  const size_t per_rank = (size_t)p.pmax * slice;
+  if ((size_t)p.world * per_rank > m->cp_stage_bytes) {
+    set_error("context-parallel staging buffer too small");
+    return AHA_ERR_STATE;
+  }
+  ProfScope ps(m, "cp_kv_gather", (double)p.world * per_rank, 0);
+  const dim3 grid((unsigned)(p.world * p.pmax), (unsigned)(slice / 4096));
+  hipLaunchKernelGGL(kv_cp_copy_kernel, grid, dim3(256), 0, m->stream, kv.page_ptrs, (uint64_t)kv.layer_off, slice, (char*)m->p_cp_stage, p, m->cp_rank, -1, 0);
+  int rc = cp_all_gather(m, m->p_cp_stage, per_rank);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kv_cp_copy_kernel, grid, dim3(256), 0, m->stream, kv.page_ptrs, (uint64_t)kv.layer_off, slice, (char*)m->p_cp_stage, p, -1, m->cp_rank, 1);
   return AHA_OK;
 }
 
@@ -1589,6 +1668,15 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
   if (d == 128) launch_rope_table(m->p_pos, S, m->d_inv_freq, m->d_axis_map, S, m->p_rope, st);   // cos / sin once for all layers
   // sequence-parallel tensor parallelism: rank r owns rows [r * spr, (r+1) * spr) of the residual stream between the GEMMs
   const int spr = seq_parallel_on(m) ? (S + m->tp_size - 1) / m->tp_size : 0;
+  // context-parallel prefill (cp_make_plan above): this rank's two row chunks; everything row-wise below runs per segment.  A fresh cache
+  // only (offset 0), prompts of at least AHA_CP_MIN_ROWS tokens; otherwise every rank simply computes the whole prompt (same results).
+  std::vector<RowSeg> segs;
+  CpPlan cpp{};
+  static const int cp_min_rows = [] { const char* e = getenv("AHA_CP_MIN_ROWS"); return e ? atoi(e) : 2048; }();
+  const bool cp = m->cp_size > 1 && m->tp_size <= 1 && kv_off == 0 && d == 128 && S >= cp_min_rows && (m->rccl_comm || m->cp_all_gather_cb) &&
+                  cp_make_plan(S, m->cp_size, m->cp_rank, &cpp, &segs);
+  if (!cp) segs.assign(1, RowSeg{0, S});
+  auto rows = [](const void* base, int64_t r0, int64_t row_elems) { return (void*)((char*)base + r0 * row_elems * 2); };   // bf16 rows
   // Single GPU: the RMSNorm that follows o_proj / down_proj + residual rides on the GEMM call (GemmArgs::norm_w: inside the
   // split-K reduce pass where the plan has one, a separate launch otherwise -- the same values).  Not across a DeepStack add,
   // which changes the rows between down_proj and the next layer's norm.
@@ -1596,71 +1684,91 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
   bool in_norm_done = false;
   for (int li = 0; li < c.num_hidden_layers; ++li) {
     const LayerWeights& L = m->layers[li];
-    {
+    if (spr > 0) {   // sequence-parallel: norm of this rank's rows, all-gather in chunks, GEMM per chunk (norm_gather_gemm)
       GemmArgs g{};
       g.A = m->p_h; g.W = L.wqkv; g.C = m->p_qkv; g.M = S; g.N = nq + 2 * nkv; g.K = H; g.lda = H; g.ldw = H; g.ldc = g.N; g.act = ACT_NONE;
-      if (spr > 0) {   // sequence-parallel: norm of this rank's rows, all-gather in chunks, GEMM per chunk (norm_gather_gemm)
-        if ((rc = norm_gather_gemm(m, L.in_norm, g, S, spr))) return rc;
-      } else {
-        if (!in_norm_done && (rc = prefill_norm(m, L.in_norm, S, spr))) return rc;
+      if ((rc = norm_gather_gemm(m, L.in_norm, g, S, spr))) return rc;
+    } else {
+      for (const RowSeg& sg : segs) {
+        if (!in_norm_done) {
+          ProfScope ps(m, "elem", (double)sg.len * H * 4, 0);
+          launch_rmsnorm_rows(rows(m->p_x, sg.r0, H), L.in_norm, rows(m->p_h, sg.r0, H), sg.len, H, H, H, c.rms_norm_eps, st);
+        }
+        GemmArgs g{};
+        g.A = rows(m->p_h, sg.r0, H); g.W = L.wqkv; g.C = rows(m->p_qkv, sg.r0, nq + 2 * nkv); g.M = sg.len; g.N = nq + 2 * nkv; g.K = H;
+        g.lda = H; g.ldw = H; g.ldc = g.N; g.act = ACT_NONE;
         ProfScope ps(m, "gemm", ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N) * 2, 2.0 * g.M * g.N * g.K);
         launch_gemm(g, st);
       }
-      in_norm_done = false;
     }
-    {
+    in_norm_done = false;
+    for (const RowSeg& sg : segs) {
       RopeArgs r{};
-      r.qkv = m->p_qkv; r.ld = nq + 2 * nkv; r.q_norm_w = L.q_norm; r.k_norm_w = L.k_norm;
-      r.pos = m->p_pos; r.pos_ld = S; r.inv_freq = m->d_inv_freq; r.axis_map = m->d_axis_map;
-      r.q_out = m->p_q; r.kv = model_kv_layer(m, li); r.kv_start = &m->d_state->kv_start;
-      r.S = S; r.nh = nh; r.kvh = kvh; r.d = d; r.eps = c.rms_norm_eps;
-      r.kv_start_host = kv_off;   // == d_state->kv_start (push_state above)
-      r.rope_tab = m->p_rope;
-      ProfScope ps(m, "elem", (double)S * (nq + 2 * nkv) * 4, 0);
+      r.qkv = rows(m->p_qkv, sg.r0, nq + 2 * nkv); r.ld = nq + 2 * nkv; r.q_norm_w = L.q_norm; r.k_norm_w = L.k_norm;
+      r.pos = m->p_pos + sg.r0; r.pos_ld = S; r.inv_freq = m->d_inv_freq; r.axis_map = m->d_axis_map;
+      r.q_out = rows(m->p_q, sg.r0, nq); r.kv = model_kv_layer(m, li); r.kv_start = &m->d_state->kv_start;
+      r.S = sg.len; r.nh = nh; r.kvh = kvh; r.d = d; r.eps = c.rms_norm_eps;
+      r.kv_start_host = kv_off + sg.r0;   // == d_state->kv_start (push_state above) for the whole prompt
+      r.rope_tab = m->p_rope ? rows(m->p_rope, sg.r0, 128) : nullptr;
+      ProfScope ps(m, "elem", (double)sg.len * (nq + 2 * nkv) * 4, 0);
       launch_qknorm_rope(r, st);
     }
-    {
+    if (cp && (rc = cp_gather_kv(m, li, cpp))) return rc;
+    for (const RowSeg& sg : segs) {
       AttnPrefillArgs a{};
-      a.q = m->p_q; a.kv = model_kv_layer(m, li); a.o = m->p_attn; a.S = S; a.nh = nh; a.kvh = kvh; a.d = d;
-      a.kv_offset = kv_off; a.kv_total = kv_off + S; a.causal = 1; a.scale = m->attn_scale;
-      const double Lk = kv_off + S;
-      ProfScope ps(m, "attn_prefill", (double)S * nq * 4 + Lk * nkv * 4, 4.0 * S * (kv_off + 0.5 * S) * nq);
+      a.q = rows(m->p_q, sg.r0, nq); a.kv = model_kv_layer(m, li); a.o = rows(m->p_attn, sg.r0, nq); a.S = sg.len; a.nh = nh; a.kvh = kvh; a.d = d;
+      a.kv_offset = kv_off + sg.r0; a.kv_total = kv_off + sg.r0 + sg.len; a.causal = 1; a.scale = m->attn_scale;
+      const double Lk = a.kv_total;
+      ProfScope ps(m, "attn_prefill", (double)sg.len * nq * 4 + Lk * nkv * 4, 4.0 * sg.len * (a.kv_offset + 0.5 * sg.len) * nq);
       launch_attn_prefill(a, st);
     }
-    {
+    for (const RowSeg& sg : segs) {
       GemmArgs g{};
-      g.A = m->p_attn; g.W = L.wo; g.C = m->p_x; g.residual = m->p_x; g.M = S; g.N = H; g.K = nq; g.lda = nq; g.ldw = nq; g.ldc = H; g.act = ACT_NONE;
-      if (norm_in_gemm) { g.norm_w = L.post_norm; g.norm_out = m->p_h; g.norm_eps = c.rms_norm_eps; }
+      g.A = rows(m->p_attn, sg.r0, nq); g.W = L.wo; g.C = rows(m->p_x, sg.r0, H); g.residual = g.C; g.M = sg.len; g.N = H; g.K = nq;
+      g.lda = nq; g.ldw = nq; g.ldc = H; g.act = ACT_NONE;
+      if (norm_in_gemm) { g.norm_w = L.post_norm; g.norm_out = rows(m->p_h, sg.r0, H); g.norm_eps = c.rms_norm_eps; }
       ProfScope ps(m, "gemm", ((double)g.M * g.K + (double)g.N * g.K + 2.0 * g.M * g.N) * 2, 2.0 * g.M * g.N * g.K);
       if ((rc = gemm_row_parallel(m, g, spr))) return rc;
     }
-    {
+    if (spr > 0) {
       GemmArgs g{};
       g.A = m->p_h; g.W = L.wgu; g.C = m->p_act; g.M = S; g.N = 2 * I; g.K = H; g.lda = H; g.ldw = H; g.ldc = I; g.act = ACT_SILU_MUL_PAIRS;
-      if (spr > 0) {
-        if ((rc = norm_gather_gemm(m, L.post_norm, g, S, spr))) return rc;
-      } else {
-        if (!norm_in_gemm && (rc = prefill_norm(m, L.post_norm, S, spr))) return rc;
+      if ((rc = norm_gather_gemm(m, L.post_norm, g, S, spr))) return rc;
+    } else {
+      if (!norm_in_gemm && (rc = prefill_norm(m, L.post_norm, S, spr))) return rc;
+      for (const RowSeg& sg : segs) {
+        GemmArgs g{};
+        g.A = rows(m->p_h, sg.r0, H); g.W = L.wgu; g.C = rows(m->p_act, sg.r0, I); g.M = sg.len; g.N = 2 * I; g.K = H;
+        g.lda = H; g.ldw = H; g.ldc = I; g.act = ACT_SILU_MUL_PAIRS;
         ProfScope ps(m, "gemm", ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * I) * 2, 2.0 * g.M * g.N * g.K);
         launch_gemm(g, st);
       }
     }
-    {
+    const bool fuse_next_norm = norm_in_gemm && li + 1 < c.num_hidden_layers && !(has_image && vision_has_deepstack(m, li));
+    for (const RowSeg& sg : segs) {
       GemmArgs g{};
-      g.A = m->p_act; g.W = L.wdown; g.C = m->p_x; g.residual = m->p_x; g.M = S; g.N = H; g.K = I; g.lda = I; g.ldw = I; g.ldc = H; g.act = ACT_NONE;
-      if (norm_in_gemm && li + 1 < c.num_hidden_layers && !(has_image && vision_has_deepstack(m, li))) {
-        g.norm_w = m->layers[li + 1].in_norm; g.norm_out = m->p_h; g.norm_eps = c.rms_norm_eps;
-        in_norm_done = true;
-      }
+      g.A = rows(m->p_act, sg.r0, I); g.W = L.wdown; g.C = rows(m->p_x, sg.r0, H); g.residual = g.C; g.M = sg.len; g.N = H; g.K = I;
+      g.lda = I; g.ldw = I; g.ldc = H; g.act = ACT_NONE;
+      if (fuse_next_norm) { g.norm_w = m->layers[li + 1].in_norm; g.norm_out = rows(m->p_h, sg.r0, H); g.norm_eps = c.rms_norm_eps; }
       ProfScope ps(m, "gemm", ((double)g.M * g.K + (double)g.N * g.K + 2.0 * g.M * g.N) * 2, 2.0 * g.M * g.N * g.K);
       if ((rc = gemm_row_parallel(m, g, spr))) return rc;
     }
+    if (fuse_next_norm) in_norm_done = true;
     if (has_image) {
       // DeepStack: add visual feature k to the visual rows after decoder layer k (qwen3vl/model.rs:806-822)
+      // (context-parallel: also on rows this rank does not own -- they hold stale values nobody reads)
       if ((rc = vision_deepstack_add(m, li, m->p_x))) return rc;
     }
   }
   const void* x_last = (const char*)m->p_x + (size_t)(S - 1) * H * 2;
+  if (cp) {
+    // rank 0 owns the last chunk, hence the last row: every rank contributes its (stale, except rank 0's) copy of that row to one small
+    // all-gather and takes slot 0 -- a broadcast; the final norm + lm_head then run replicated (full weights everywhere)
+    AHA_HIP_CHECK(hipMemcpyAsync((char*)m->p_cp_stage + (size_t)m->cp_rank * H * 2, x_last, (size_t)H * 2, hipMemcpyDeviceToDevice, st));
+    if ((rc = cp_all_gather(m, m->p_cp_stage, (size_t)H * 2))) return rc;
+    AHA_HIP_CHECK(hipMemcpyAsync(m->d_x, m->p_cp_stage, (size_t)H * 2, hipMemcpyDeviceToDevice, st));
+    x_last = m->d_x;
+  }
   if (spr > 0) {
     // the last position lives on the rank that owns row S-1: every rank contributes that row as f32 (zeros elsewhere) to one
     // H-float all-reduce -- a broadcast, exact (bf16 -> f32 -> + 0 -> bf16)

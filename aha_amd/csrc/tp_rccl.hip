@@ -21,7 +21,7 @@ int rccl_allreduce(aha_model* m, float* buf, size_t count) {
 // recvbuff == sendbuff + rank * recvcount), and the bf16 rows of the next GEMM's input are gathered in place
 // (sendbuff == recvbuff + rank * sendcount).
 int rccl_reduce_scatter(aha_model* m, float* buf, size_t count_per_rank, hipStream_t st) {
-  ncclResult_t r = ncclReduceScatter(buf, buf + (size_t)m->tp_rank * count_per_rank, count_per_rank, ncclFloat, ncclSum,
+  ncclResult_t r = ncclReduceScatter(buf, buf + (size_t)m->comm_rank * count_per_rank, count_per_rank, ncclFloat, ncclSum,
                                      (ncclComm_t)m->rccl_comm, st ? st : m->stream);
   if (r != ncclSuccess) {
     set_error(std::string("ncclReduceScatter failed: ") + ncclGetErrorString(r));
@@ -30,7 +30,7 @@ int rccl_reduce_scatter(aha_model* m, float* buf, size_t count_per_rank, hipStre
   return AHA_OK;
 }
 int rccl_all_gather(aha_model* m, void* buf, size_t bytes_per_rank, hipStream_t st) {
-  ncclResult_t r = ncclAllGather((const char*)buf + (size_t)m->tp_rank * bytes_per_rank, buf, bytes_per_rank, ncclUint8,
+  ncclResult_t r = ncclAllGather((const char*)buf + (size_t)m->comm_rank * bytes_per_rank, buf, bytes_per_rank, ncclUint8,
                                  (ncclComm_t)m->rccl_comm, st ? st : m->stream);
   if (r != ncclSuccess) {
     set_error(std::string("ncclAllGather failed: ") + ncclGetErrorString(r));
@@ -64,6 +64,27 @@ int tp_init_rccl(aha_model* m, const void* id128) {
     return AHA_ERR_HIP;
   }
   m->rccl_comm = comm;
+  m->comm_rank = m->tp_rank;
+  return AHA_OK;
+}
+// the communicator of a context-parallel group (aha_hip_set_context_parallel: full weights on every rank)
+int cp_init_rccl(aha_model* m, const void* id128) {
+  if (m->rccl_comm) return AHA_OK;
+  if (m->cp_size <= 1 || m->tp_size > 1) {
+    set_error("cp_init_rccl: call aha_hip_set_context_parallel(rank, world > 1) on an un-sharded model first");
+    return AHA_ERR_STATE;
+  }
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  ncclComm_t comm;
+  AHA_HIP_CHECK(hipSetDevice(m->ctx->device));
+  ncclResult_t r = ncclCommInitRank(&comm, m->cp_size, id, m->cp_rank);
+  if (r != ncclSuccess) {
+    set_error(std::string("ncclCommInitRank failed: ") + ncclGetErrorString(r));
+    return AHA_ERR_HIP;
+  }
+  m->rccl_comm = comm;
+  m->comm_rank = m->cp_rank;
   return AHA_OK;
 }
 

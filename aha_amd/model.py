@@ -174,6 +174,28 @@ class HipInferenceModel:
         self.vocab = self.text_cfg.vocab_size
         self._logits = np.empty(self.vocab, dtype=np.float32)
 
+    def set_context_parallel(self, rank: int, world: int, all_gather=None, rccl_unique_id: Optional[bytes] = None) -> None:
+        """Context-parallel prefill (include/aha_hip.h aha_hip_set_context_parallel): this model holds the FULL weights (tp_size 1) and
+        owns two row chunks of every prompt of a fresh cache; per layer the ranks all-gather the layer's K / V pages -- over RCCL
+        (rccl_unique_id: 128 bytes from tp_unique_id(), the same on every rank) or through the host callback
+        all_gather(ptr: int, bytes_per_rank: int) (in place: rank r's slice is its contribution).  After forward_initial every rank holds
+        the whole cache and the last position's logits.  world = 1 switches it off."""
+        self._cp_ag_c = None
+        if all_gather is not None:
+            def _c(ptr, n, _user):
+                try:
+                    all_gather(int(ptr), int(n))
+                    return 0
+                except Exception:  # noqa: BLE001 -- must not unwind through C frames
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._cp_ag_c = _lib.ALL_GATHER_FN(_c)
+        check(lib().aha_hip_set_context_parallel(self.handle, rank, world, self._cp_ag_c, None))
+        if rccl_unique_id is not None:
+            buf = C.create_string_buffer(bytes(rccl_unique_id), 128)
+            check(lib().aha_hip_cp_init_rccl(self.handle, buf))
+
     @classmethod
     def from_pretrained(cls, path: str, ctx: Optional[HipContext] = None, device: int = 0, kv_reserve_tokens: int = 0):
         """== XxxGenerateModel::init(path, device, dtype) minus tokenizer / chat template (qwen3/generate.rs:22-50): the

@@ -275,6 +275,19 @@ int aha_hip_tp_init_rccl(aha_model* m, const void* unique_id128);
 typedef int (*aha_reduce_scatter_fn)(void* buf_f32_dev, size_t count_per_rank, void* user);
 typedef int (*aha_all_gather_fn)(void* buf_dev, size_t bytes_per_rank, void* user);
 int aha_hip_set_seq_parallel(aha_model* m, aha_reduce_scatter_fn reduce_scatter, aha_all_gather_fn all_gather, void* user);
+/* Context-parallel prefill (round 4; the 288-GB design of SURVEY.md section 8e row 3 "long-context text prefill": an 8B checkpoint is
+ * 16 GB, so every GPU holds the FULL weights -- create the model with tp_size 1 on every rank -- and the PROMPT is sharded instead).
+ * The prompt's 64-token KV pages are cut into 2 * world contiguous chunks; rank r owns chunks r and 2 * world - 1 - r (balanced causal
+ * work) and runs every GEMM / norm / rope of the prefill on its own rows only; per layer the ranks all-gather that layer's K / V pages
+ * (the one op that couples rows is attention).  After the call EVERY rank holds the complete KV cache and the last position's logits
+ * (rank 0 owns the last row; it is broadcast), so decode continues on any rank -- rank 0 by convention -- with no hand-back.
+ * Inbound bytes per rank and layer at 41 k tokens on 8 GPUs: 147 MB, against 1.76 GB for the tensor-parallel form above.
+ * Every rank calls aha_hip_forward_initial with the same ids (offset 0: a fresh cache; other calls run unsharded on every rank).
+ * Collective: an RCCL communicator owned by the library (aha_hip_tp_unique_id on rank 0, then aha_hip_cp_init_rccl on every rank), or
+ * the host callback `all_gather` (same contract as aha_hip_set_seq_parallel's; tests).  world = 1 switches it off.
+ * Prompts below AHA_CP_MIN_ROWS (default 2048) tokens or with fewer than 4 * world pages run unsharded. */
+int aha_hip_set_context_parallel(aha_model* m, int32_t rank, int32_t world, aha_all_gather_fn all_gather, void* user);
+int aha_hip_cp_init_rccl(aha_model* m, const void* unique_id128);
 /* KV hand-back after a sharded prefill ("for single-GPU decode afterwards, all-gather KV to GPU 0";
  * north_star: decode stays single-GPU).  A tensor-parallel prefill leaves every rank with the K / V of ITS kv heads, in its own
  * pages.  aha_hip_kv_export packs them into a contiguous device buffer

@@ -1,0 +1,185 @@
+"""-m gpu: context-parallel prefill (include/aha_hip.h aha_hip_set_context_parallel; csrc/model.hip cp_make_plan / cp_gather_kv).
+Every rank holds the FULL weights and owns two page-aligned row chunks of the prompt (chunks r and 2W-1-r of 2W); the only exchange is
+one all-gather of the layer's K / V pages per layer, plus the broadcast of the last hidden row.  W model handles live on the one GPU of
+the test box, each driven by its own thread; the collective is the host-callback seam (a barrier + device copies).
+
+What must hold: a GEMM's rows, a norm's rows and a query row's attention are independent of which other rows run beside them, so with
+the GEMM plan pinned (the automatic plan depends on M, and the ranks run M = their own rows) every rank's logits AND its KV cache -- hence
+every later decode step, on any rank -- are BIT-identical to the single-GPU prefill; with automatic plans they agree within the
+sharded-vs-unsharded bound of tests/test_tp_gpu.py."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from aha_amd.configs import tiny_qwen3, tiny_qwen3vl
+from aha_amd.weights import qwen3_text_weights, qwen3vl_weights
+from tests.test_tp_gpu import close, run_ranks
+
+pytestmark = pytest.mark.gpu
+
+
+class Gather:
+    """all_gather(rank, ptr, bytes_per_rank) in place over W ranks' device buffers (slice r = rank r's contribution)."""
+
+    def __init__(self, n):
+        self.n = n
+        self.bar = threading.Barrier(n, timeout=120)
+        self.slots = [None] * n
+        self.calls = 0
+        self.bytes = 0
+
+    def view(self, ptr, nbytes):
+        iface = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+        holder = type("H", (), {"__cuda_array_interface__": iface})()
+        return torch.as_tensor(holder, device="cuda:0")
+
+    def all_gather(self, rank, ptr, bytes_per_rank):
+        self.slots[rank] = self.view(ptr, bytes_per_rank * self.n)
+        self.bar.wait()
+        for r in range(self.n):
+            if r != rank:
+                sl = slice(r * bytes_per_rank, (r + 1) * bytes_per_rank)
+                self.slots[rank][sl].copy_(self.slots[r][sl])
+        torch.cuda.synchronize()
+        if rank == 0:
+            self.calls += 1
+            self.bytes += bytes_per_rank * self.n
+        self.bar.wait()
+
+
+def make_ranks(cfg, w, world, g):
+    from aha_amd.model import HipInferenceModel
+    ranks = [HipInferenceModel(cfg, w) for _ in range(world)]
+    for r, m in enumerate(ranks):
+        m.set_context_parallel(r, world, all_gather=lambda p, n, r=r: g.all_gather(r, p, n))
+    return ranks
+
+
+@pytest.mark.parametrize("S,world,tile", [(1100, 2, 256), (1543, 2, 128), (2100, 4, 256), (1030, 3, 128)])
+def test_context_parallel_prefill_is_bit_identical_to_one_gpu(gpu, S, world, tile, monkeypatch):
+    from aha_amd import ops
+    from aha_amd.model import HipInferenceModel
+    cfg = tiny_qwen3(layers=3, hidden=512, heads=4, kv_heads=2, inter=1024, vocab=1024)
+    w = qwen3_text_weights(cfg, seed=0)
+    ids = [int(x) for x in np.random.default_rng(S).integers(0, cfg.vocab_size, size=S)]
+    monkeypatch.setenv("AHA_CP_MIN_ROWS", "64")
+    ops.gemm_plan(tile, 1)
+    try:
+        single = HipInferenceModel(cfg, w)
+        ref, ref_tok = single.forward_initial(ids, 0)
+        ref = ref.copy()
+        g = Gather(world)
+        ranks = make_ranks(cfg, w, world, g)
+        got = run_ranks([lambda m=m: m.forward_initial(ids, 0) for m in ranks])
+        assert g.calls == cfg.num_hidden_layers + 1                      # one K / V exchange per layer + the last-row broadcast
+        for r in range(world):
+            np.testing.assert_array_equal(got[r][0], ref, err_msg=f"rank {r} logits")
+            assert got[r][1] == ref_tok
+        # decode continues on EVERY rank from its own copy of the cache: the same logits as the single-GPU model, step after step
+        tok, off = int(ref_tok), S
+        for step in range(4):
+            want = single.forward_step(tok, off)[0].copy()
+            for r, m in enumerate(ranks):
+                np.testing.assert_array_equal(m.forward_step(tok, off)[0], want, err_msg=f"rank {r} decode step {step}")
+            tok, off = int(np.argmax(want)), off + 1
+        # a second prompt on the same handles (cache cleared): the plan is per call
+        for m in ranks + [single]:
+            m.clear_cache()
+        ids2 = ids[: S - 130]
+        ref2 = single.forward_initial(ids2, 0)[0].copy()
+        got2 = run_ranks([lambda m=m: m.forward_initial(ids2, 0)[0].copy() for m in ranks])
+        for r in range(world):
+            np.testing.assert_array_equal(got2[r], ref2)
+        for m in ranks + [single]:
+            m.close()
+    finally:
+        ops.gemm_plan(0, 0)
+
+
+def test_context_parallel_with_automatic_plans_and_short_prompts(gpu, monkeypatch):
+    """Automatic GEMM plans (the ranks' M differs from the single GPU's): the sharded-vs-unsharded bound.  Prompts below the row / page
+    thresholds run unsharded on every rank (no collective at all) and prompts into a non-empty cache as well."""
+    from aha_amd.model import HipInferenceModel
+    cfg = tiny_qwen3(layers=2, hidden=512, heads=4, kv_heads=2, inter=1024, vocab=1024)
+    w = qwen3_text_weights(cfg, seed=1)
+    monkeypatch.setenv("AHA_CP_MIN_ROWS", "64")
+    single = HipInferenceModel(cfg, w)
+    g = Gather(2)
+    ranks = make_ranks(cfg, w, 2, g)
+    S = 1500
+    ids = [int(x) for x in np.random.default_rng(3).integers(0, cfg.vocab_size, size=S)]
+    ref = single.forward_initial(ids, 0)[0].copy()
+    got = run_ranks([lambda m=m: m.forward_initial(ids, 0)[0].copy() for m in ranks])
+    np.testing.assert_array_equal(got[0], got[1])
+    close(got[0], ref, "context-parallel prefill, automatic plans")
+    calls = g.calls
+    assert calls == cfg.num_hidden_layers + 1
+    # a continuation (offset = S: the cache is not empty) and a 200-token prompt (3 pages < 4 x world) run unsharded: no new collectives
+    more = ids[:70]
+    a = single.forward_initial(more, S)[0].copy()
+    b = run_ranks([lambda m=m: m.forward_initial(more, S)[0].copy() for m in ranks])
+    close(b[0], a, "continuation after a context-parallel prefill")
+    for m in ranks + [single]:
+        m.clear_cache()
+    short = ids[:200]
+    a = single.forward_initial(short, 0)[0].copy()
+    b = run_ranks([lambda m=m: m.forward_initial(short, 0)[0].copy() for m in ranks])
+    np.testing.assert_array_equal(b[0], a)
+    assert g.calls == calls
+    for m in ranks + [single]:
+        m.close()
+
+
+def test_context_parallel_vl_prompt(gpu, monkeypatch):
+    """Qwen3-VL: M-RoPE positions, image rows scattered into the prompt and the DeepStack adds run on the full buffers of every rank; the
+    owned rows must come out as on one GPU (plan pinned: bit-identical logits; rope_delta identical, so decode positions agree)."""
+    from aha_amd import ops
+    from aha_amd.model import HipInferenceModel, MultiModalData
+    from oracle import qwen3vl as ov
+    from oracle.numerics import Numerics
+    monkeypatch.setenv("AHA_CP_MIN_ROWS", "64")
+    cfg = tiny_qwen3vl()
+    w = qwen3vl_weights(cfg, seed=0)
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, size=(256, 320, 3), dtype=np.uint8)
+    pv, grid = ov.process_images(Numerics("bf16"), [img])
+    n_img = int(grid[0, 1] * grid[0, 2]) // 4
+    ids = [int(x) for x in rng.integers(10, 200, size=300)] + [cfg.vision_start_token_id] + [cfg.image_token_id] * n_img + \
+          [cfg.vision_end_token_id] + [int(x) for x in rng.integers(10, 200, size=400)]
+    ops.gemm_plan(128, 1)
+    try:
+        single = HipInferenceModel(cfg, w)
+        ref, tok = single.forward_initial(ids, 0, MultiModalData(pv.to(torch.bfloat16), grid))
+        ref = ref.copy()
+        g = Gather(2)
+        ranks = make_ranks(cfg, w, 2, g)
+        got = run_ranks([lambda m=m: m.forward_initial(ids, 0, MultiModalData(pv.to(torch.bfloat16), grid)) for m in ranks])
+        assert g.calls == cfg.text.num_hidden_layers + 1
+        for r in range(2):
+            np.testing.assert_array_equal(got[r][0], ref)
+        want = single.forward_step(int(tok), len(ids))[0].copy()
+        np.testing.assert_array_equal(ranks[1].forward_step(int(tok), len(ids))[0], want)
+        for m in ranks + [single]:
+            m.close()
+    finally:
+        ops.gemm_plan(0, 0)
+
+
+def test_context_parallel_argument_checks(gpu):
+    from aha_amd._lib import AhaHipError
+    from aha_amd.model import HipInferenceModel
+    cfg = tiny_qwen3()
+    w = qwen3_text_weights(cfg, seed=0)
+    m = HipInferenceModel(cfg, w)
+    with pytest.raises(AhaHipError):
+        m.set_context_parallel(2, 2)
+    with pytest.raises(AhaHipError):
+        m.set_context_parallel(0, 9)
+    m.set_context_parallel(0, 1)       # off
+    m.close()
+    t = HipInferenceModel(cfg, w, tp_rank=0, tp_size=2, allreduce=lambda p, n: None)
+    with pytest.raises(AhaHipError, match="tensor-parallel"):
+        t.set_context_parallel(0, 2)
+    t.close()
