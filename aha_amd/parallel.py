@@ -115,7 +115,7 @@ def broadcast_bytes(payload, src: int = 0):
 # library profiler classes (csrc/model.hip ProfScope: HIP events on the model's stream around each launch group) -> phase names
 PREFILL_PHASE_CLASSES = (("gemm", "gemm_s"), ("attn_prefill", "attn_s"), ("attn_vit", "vit_attn_s"), ("elem", "rowwise_s"),
                          ("reduce_scatter", "reduce_scatter_s"), ("rs_wait", "reduce_scatter_wait_s"), ("all_gather", "all_gather_s"),
-                         ("ag_wait", "all_gather_wait_s"), ("allreduce", "allreduce_s"), ("gemv", "lm_head_s"))
+                         ("ag_wait", "all_gather_wait_s"), ("cp_kv_gather", "kv_all_gather_s"), ("allreduce", "allreduce_s"), ("gemv", "lm_head_s"))
 
 
 def read_prefill_phases(model, ph: dict) -> dict:
@@ -129,10 +129,13 @@ def read_prefill_phases(model, ph: dict) -> dict:
 
 
 def sharded_prefill(cfg, weights, input_ids, data, rank: int, world: int, device_index: int, kv_reserve_tokens: int = 0,
-                    repeats: int = 1, phases_out: Optional[dict] = None):
+                    repeats: int = 1, phases_out: Optional[dict] = None, mode: str = "tp"):
     """BASELINE cfg 5's sharded path on `world` GPUs of one node, one process per GPU:
-      * the ranks form ONE tensor-parallel group: every rank passes the full checkpoint, the library keeps its q/k/v heads,
+      * mode "tp": the ranks form ONE tensor-parallel group: every rank passes the full checkpoint, the library keeps its q/k/v heads,
         gate/up rows and o/down columns, and all-reduces the row-parallel partial sums over RCCL (aha_hip_tp_init_rccl);
+        mode "cp" (context-parallel, include/aha_hip.h aha_hip_set_context_parallel): every rank keeps the FULL weights and owns two
+        row chunks of the prompt; the only exchange in the decoder stack is one all-gather of the layer's K / V pages per layer, every
+        rank ends with the whole cache (no hand-back) and the lm_head runs replicated;
       * the ViT runs image-parallel: rank r encodes images shard_units(n, world, r), one all_gather moves the merged +
         DeepStack embeddings (encode_images_sharded), and every rank scatters all of them into its prompt;
       * lm_head is vocabulary-parallel inside the library (arg-max pair exchange).
@@ -151,8 +154,15 @@ def sharded_prefill(cfg, weights, input_ids, data, rank: int, world: int, device
     uid = None
     if world > 1:
         uid = broadcast_bytes(tp_unique_id() if rank == 0 else None)
-    model = HipInferenceModel(cfg, weights, device=device_index, kv_reserve_tokens=kv_reserve_tokens,
-                              tp_rank=rank if world > 1 else 0, tp_size=world, rccl_unique_id=uid)
+    if mode not in ("tp", "cp"):
+        raise ValueError("mode must be 'tp' or 'cp'")
+    if mode == "cp":
+        model = HipInferenceModel(cfg, weights, device=device_index, kv_reserve_tokens=kv_reserve_tokens)
+        if world > 1:
+            model.set_context_parallel(rank, world, rccl_unique_id=uid)
+    else:
+        model = HipInferenceModel(cfg, weights, device=device_index, kv_reserve_tokens=kv_reserve_tokens,
+                                  tp_rank=rank if world > 1 else 0, tp_size=world, rccl_unique_id=uid)
     grid = None if data is None else np.asarray(data.image_grid_thw, dtype=np.uint32).reshape(-1, 3)
 
     def one_prefill(ph=None):

@@ -37,6 +37,7 @@ METRICS = {
     "qwen3vl8b-text": "decode tokens/s (greedy, batch 1) -- Qwen3-VL-8B text stack, 1542-token prompt; prefill tok/s alongside",
     "qwen3-0.6b": "decode tokens/s (greedy, batch 1) -- Qwen3-0.6B, 2048-token prompt (BASELINE cfg 2); prefill tok/s alongside",
     "qwen3vl8b-cfg5-tp": "prefill tokens/s -- Qwen3-VL-8B, 8 x 2048^2 images + 8192-token prompt (BASELINE cfg 5), tensor-parallel decoder stack + image-parallel ViT over all ranks",
+    "qwen3vl8b-cfg5-cp": "prefill tokens/s -- Qwen3-VL-8B, 8 x 2048^2 images + 8192-token prompt (BASELINE cfg 5), context-parallel decoder stack (full weights per GPU, one K/V all-gather per layer) + image-parallel ViT over all ranks",
     "qwen3-asr": "decode tokens/s (greedy, batch 1) -- Qwen3-ASR-0.6B, 30 s of 16 kHz audio (BASELINE cfg 4); prefill (log-mel + audio encoder + text) alongside",
 }
 
@@ -170,10 +171,12 @@ def cpu_baseline(cfg, sample_secs=20.0):
                       f"lm_head, extrapolated x{depth} (the host could not hold the full stack); Candle CPU reference not buildable here"}
 
 
-def sharded_prefill_bench(rank, world, local_rank, n_images=8, image_px=2048, prompt=8192, repeats=1):
-    """BASELINE cfg 5 through the sharded path: one tensor-parallel group over all ranks (RCCL
-    all-reduce over xGMI inside the library), the ViT image-parallel with one all-gather.  Strong scaling: the request is the
-    same for every N, value = prompt tokens / slowest rank's prefill seconds.  N = 1 is the single-GPU cfg 5 prefill."""
+def sharded_prefill_bench(rank, world, local_rank, n_images=8, image_px=2048, prompt=8192, repeats=1, mode="tp"):
+    """BASELINE cfg 5 through the sharded path, the ViT image-parallel with one all-gather and the decoder stack
+    either as one tensor-parallel group over all ranks (mode "tp": RCCL reduce-scatter / all-gather over xGMI inside the library, KV
+    gathered to rank 0 afterwards) or context-parallel (mode "cp": full weights on every rank, the prompt's rows sharded, one K / V
+    all-gather per layer, every rank ends with the whole cache).  Strong scaling: the request is the same for every N, value = prompt
+    tokens / slowest rank's prefill seconds.  N = 1 is the single-GPU cfg 5 prefill."""
     import torch
     from aha_amd import configs, parallel
     from aha_amd import weights as W
@@ -186,13 +189,13 @@ def sharded_prefill_bench(rank, world, local_rank, n_images=8, image_px=2048, pr
     torch.cuda.synchronize()
     phases = {}
     tok, secs, model = parallel.sharded_prefill(cfg, w, ids, data, rank, world, local_rank, kv_reserve_tokens=len(ids) + 4096,
-                                                repeats=repeats, phases_out=phases)
+                                                repeats=repeats, phases_out=phases, mode=mode)
     # BASELINE cfg 5 is "prefill + 16 tokens", and decode stays single-GPU (north_star): the head-sharded KV cache is gathered into an
     # un-sharded model on rank 0 (parallel.gather_kv_to_rank0: one RCCL gather of the packed pages), which decodes the 16 tokens alone
     from aha_amd.model import HipInferenceModel
     handback = {}
     full = model
-    if world > 1:
+    if world > 1 and mode == "tp":
         full = HipInferenceModel(cfg, w, device=local_rank, kv_reserve_tokens=len(ids) + 4096) if rank == 0 else None
         import torch.distributed as dist
         dist.barrier()
@@ -232,15 +235,19 @@ def sharded_prefill_bench(rank, world, local_rank, n_images=8, image_px=2048, pr
         vec = torch.tensor([float(phases.get(k, 0.0)) for k in keys], dtype=torch.float64, device=dev)
         dist.all_reduce(vec, op=dist.ReduceOp.MAX)
         phases_max = {k: round(float(v), 5) for k, v in zip(keys, vec.tolist())}
-    return {"metric": METRICS["qwen3vl8b-cfg5-tp"], "value": round(value, 1), "unit": "tokens/s", "prefill_s": round(worst, 4),
+    par = (f"tp{world} (sequence-parallel: RCCL reduce-scatter of the row-parallel partial sums in column blocks and all-gather of "
+           "the normalised rows in row chunks, both overlapped with the GEMMs) + image-parallel ViT (all-gather) + KV gather to rank 0 for decode") if mode == "tp" else \
+          (f"cp{world} (context-parallel: full weights on every GPU, two zigzag row chunks of the prompt per rank, one RCCL all-gather of the layer's K / V "
+           "pages per layer; every rank ends with the whole KV cache, rank 0 decodes) + image-parallel ViT (all-gather)")
+    return {"metric": METRICS["qwen3vl8b-cfg5-" + mode], "value": round(value, 1), "unit": "tokens/s", "prefill_s": round(worst, 4),
             "prompt_tokens": len(ids), "n_images": n_images, "image": image_px, "scaling": "strong",
-            "parallelism": f"tp{world} (sequence-parallel: RCCL reduce-scatter of the row-parallel partial sums in column blocks and all-gather of "
-                           "the normalised rows in row chunks, both overlapped with the GEMMs) + image-parallel ViT (all-gather) + KV gather to rank 0 for decode",
+            "parallelism": par,
             "rccl_ranks": world, "first_token_equal_on_all_ranks": same, **handback,
             "phases_rank0": phases, "phases_max_over_ranks": phases_max,
             "phases_note": "one extra UNTIMED prefill with the library profiler on (HIP events per launch group on the model's stream; host-side phases "
                            "bracketed by device synchronisation): vit_s / embeds_all_gather_s / stack_s are wall clock, the rest event time inside stack_s; "
-                           "reduce_scatter_wait_s / all_gather_wait_s = what the compute stream waited for the collectives overlapped on the communication stream"}
+                           "reduce_scatter_wait_s / all_gather_wait_s = what the compute stream waited for the collectives overlapped on the communication stream; "
+                           "kv_all_gather_s = the context-parallel form's per-layer K / V exchange (pack + all-gather + unpack, on the compute stream)"}
 
 SHARDED_LEG_TIMEOUT_S = int(os.environ.get("AHA_BENCH_SHARDED_TIMEOUT_S", "420"))
 
@@ -393,10 +400,10 @@ def main():
 
     import __graft_entry__
     __graft_entry__.build()
-    if args.workload == "qwen3vl8b-cfg5-tp":   # the sharded path as the metric itself (strong scaling over --gpus)
+    if args.workload in ("qwen3vl8b-cfg5-tp", "qwen3vl8b-cfg5-cp"):   # the sharded path as the metric itself (strong scaling over --gpus)
         if shared_device:
-            raise SystemExit("qwen3vl8b-cfg5-tp needs one GPU per rank (RCCL)")
-        sp = sharded_prefill_bench(rank, world, local_rank, repeats=max(1, min(args.steps, 3)))
+            raise SystemExit(args.workload + " needs one GPU per rank (RCCL)")
+        sp = sharded_prefill_bench(rank, world, local_rank, repeats=max(1, min(args.steps, 3)), mode=args.workload[-2:])
         if rank == 0:
             line = {"metric": sp["metric"], "value": sp["value"], "unit": "tokens/s", "n_gpus": world, "steps": max(1, min(args.steps, 3)),
                     "warmup": 1, "ms_per_step": round(1e3 * sp["prefill_s"], 2), "higher_is_better": True, "scaling": "strong",
@@ -587,7 +594,11 @@ def main():
                 line["sharded_prefill"] = {"error": f"did not finish within {SHARDED_LEG_TIMEOUT_S} s (watchdog); replica decode numbers above are complete"}
                 line["sharded_ok"] = False
                 print(json.dumps(line), flush=True)
-        sp, err = guarded(lambda: sharded_prefill_bench(rank, world, local_rank), SHARDED_LEG_TIMEOUT_S, on_timeout)
+        # Two forms of the sharded decoder stack, each with its own watchdog: context-parallel first (one collective type, on the compute
+        # stream: the form with the least that can go wrong on first contact with more than one GPU -- and, by the byte counts, the
+        # faster one), then the tensor-parallel form of BASELINE cfg 5's name.  "sharded_prefill" is the context-parallel object,
+        # "sharded_prefill_tp" the tensor-parallel one; each has its own top-level ok flag.
+        sp, err = guarded(lambda: sharded_prefill_bench(rank, world, local_rank, mode="cp"), SHARDED_LEG_TIMEOUT_S, on_timeout)
         if err is None and sp["rccl_ranks"] != args.gpus:
             err = f"rccl_ranks {sp['rccl_ranks']} != --gpus {args.gpus}"
         clean = err is None
@@ -596,6 +607,19 @@ def main():
             # top level, next to the replica numbers: the process exits 0 either way (the replica line must reach the driver), so a
             # consumer that reads only the exit code would otherwise see success after a failed or hung sharded leg
             line["sharded_ok"] = bool(clean and sp["first_token_equal_on_all_ranks"])
+        if clean and world > 1:
+            def on_timeout_tp():
+                if rank == 0:
+                    line["sharded_prefill_tp"] = {"error": f"did not finish within {SHARDED_LEG_TIMEOUT_S} s (watchdog); the context-parallel object above is complete"}
+                    line["sharded_tp_ok"] = False
+                    print(json.dumps(line), flush=True)
+            sp2, err2 = guarded(lambda: sharded_prefill_bench(rank, world, local_rank, mode="tp"), SHARDED_LEG_TIMEOUT_S, on_timeout_tp)
+            if err2 is None and sp2["rccl_ranks"] != args.gpus:
+                err2 = f"rccl_ranks {sp2['rccl_ranks']} != --gpus {args.gpus}"
+            clean = err2 is None
+            if rank == 0:
+                line["sharded_prefill_tp"] = sp2 if err2 is None else {"error": err2}
+                line["sharded_tp_ok"] = bool(clean and sp2["first_token_equal_on_all_ranks"])
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
