@@ -144,6 +144,7 @@ SIGNATURES = {
     "aha_hip_tp_init_rccl": (C.c_int, [_P, _P]),
     "aha_hip_set_context_parallel": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     "aha_hip_cp_init_rccl": (C.c_int, [_P, _P]),
+    "aha_hip_debug_cp_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     "aha_hip_debug_allreduce": (C.c_int, [_P, _P, C.c_size_t]),
     "aha_hip_vision_encode": (C.c_int, [_P, C.POINTER(MmInput), _P, C.POINTER(C.c_int64)]),
     "aha_hip_debug_audio_embeds": (C.c_int, [_P, C.POINTER(C.c_float), C.c_size_t]),

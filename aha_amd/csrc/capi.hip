@@ -737,6 +737,16 @@ int aha_hip_set_context_parallel(aha_model* m, int32_t rank, int32_t world, aha_
   m->cp_user = user;
   return AHA_OK;
 }
+int aha_hip_debug_cp_plan(int32_t n_tokens, int32_t world, int32_t rank, int32_t* out5) {
+  if (!out5 || n_tokens <= 0) {
+    set_error("debug_cp_plan: bad argument");
+    return AHA_ERR_INVALID;
+  }
+  int o[5];
+  if (debug_cp_plan(n_tokens, world, rank, o) != 0) return 1;   // not sharded (too few pages, world out of range)
+  for (int i = 0; i < 5; ++i) out5[i] = o[i];
+  return AHA_OK;
+}
 int aha_hip_cp_init_rccl(aha_model* m, const void* unique_id128) {
   API_GUARD_BEGIN
   if (!m || !unique_id128) return AHA_ERR_INVALID;

@@ -215,6 +215,7 @@ int rccl_all_gather(aha_model* m, void* buf, size_t bytes_per_rank, hipStream_t 
 int tp_unique_id(void* out128);
 int tp_init_rccl(aha_model* m, const void* id128);
 int cp_init_rccl(aha_model* m, const void* id128);
+int debug_cp_plan(int S, int world, int rank, int* out5);
 void tp_destroy(aha_model* m);
 
 // helpers shared with vision.hip

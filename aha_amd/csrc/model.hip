@@ -1209,6 +1209,13 @@ static bool cp_make_plan(int S, int world, int rank, CpPlan* p, std::vector<RowS
   }
   return true;
 }
+int debug_cp_plan(int S, int world, int rank, int* out5) {   // host only (tests): {r0_a, len_a, r0_b, len_b, pmax}; -1: this prompt is not sharded
+  CpPlan p{};
+  std::vector<RowSeg> segs;
+  if (rank < 0 || rank >= world || !cp_make_plan(S, world, rank, &p, &segs)) return -1;
+  out5[0] = segs[0].r0; out5[1] = segs[0].len; out5[2] = segs[1].r0; out5[3] = segs[1].len; out5[4] = p.pmax;
+  return 0;
+}
 // staging slot s = rank * pmax + j  <->  the j-th page rank owns; one block copies 4 KB of the page's layer slice (kv heads x (K | V) x 16 KB)
 __global__ __launch_bounds__(256) void kv_cp_copy_kernel(const uint64_t* __restrict__ page_ptrs, uint64_t layer_off, int slice_bytes,
                                                          char* __restrict__ stage, CpPlan p, int only_rank, int skip_rank, int to_pages) {

@@ -288,6 +288,10 @@ int aha_hip_set_seq_parallel(aha_model* m, aha_reduce_scatter_fn reduce_scatter,
  * Prompts below AHA_CP_MIN_ROWS (default 2048) tokens or with fewer than 4 * world pages run unsharded. */
 int aha_hip_set_context_parallel(aha_model* m, int32_t rank, int32_t world, aha_all_gather_fn all_gather, void* user);
 int aha_hip_cp_init_rccl(aha_model* m, const void* unique_id128);
+/* Host only (no GPU): the rows rank `rank` of `world` owns in a context-parallel prefill of n_tokens -- out5 = {first row and length of
+ * its early chunk, first row and length of its late chunk, page slots per rank of the exchange's staging buffer}.  Returns 1 (and leaves
+ * out5 alone) when such a prompt is not sharded (fewer than 4 * world pages, world outside 2..8). */
+int aha_hip_debug_cp_plan(int32_t n_tokens, int32_t world, int32_t rank, int32_t* out5);
 /* KV hand-back after a sharded prefill ("for single-GPU decode afterwards, all-gather KV to GPU 0";
  * north_star: decode stays single-GPU).  A tensor-parallel prefill leaves every rank with the K / V of ITS kv heads, in its own
  * pages.  aha_hip_kv_export packs them into a contiguous device buffer

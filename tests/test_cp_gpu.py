@@ -183,3 +183,20 @@ def test_context_parallel_argument_checks(gpu):
     with pytest.raises(AhaHipError, match="tensor-parallel"):
         t.set_context_parallel(0, 2)
     t.close()
+
+
+def test_context_parallel_two_processes_gloo(gpu):
+    """The context-parallel seam across PROCESSES (one per rank, as on a multi-GPU node; here both on the box's single GPU): the K / V
+    pages staged through host memory and gathered by torch.distributed/gloo inside the callback, image-parallel ViT with a gloo
+    all-gather (tests/tools/cp_worker.py).  Ranks must agree bit for bit on logits and greedy tokens; rank 0 checks them against the
+    unsharded model; the per-phase diagnosis carries the exchange."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "tests", "tools", "cp_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "CP_WORKER_OK" in r.stdout and "kv_all_gather_s" in r.stdout, r.stdout[-2000:]

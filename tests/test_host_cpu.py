@@ -260,3 +260,35 @@ def test_gemm_plans_of_the_baseline_shapes(hip_lib):
     assert plan(40980, 6144, 4096) == (256, 1, 0) and plan(40980, 4096, 12288, res=1) == (256, 1, 0)
     with pytest.raises(Exception):
         assert hip_lib.aha_hip_debug_plan_gemm(0, 1, 1, 0, 0, 0, 0, (ctypes.c_int32 * 3)()) == 0
+
+
+@pytest.mark.parametrize("S", [512, 1542, 2048, 8192, 40980, 131072])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+def test_context_parallel_plan_partitions_the_prompt(hip_lib, S, world):
+    """csrc/model.hip cp_make_plan (aha_hip_set_context_parallel): the 64-token pages of the prompt are cut into 2 x world chunks, rank r
+    owns chunks r and 2 x world - 1 - r.  Every row belongs to exactly one rank, chunk boundaries are page boundaries, rank 0 owns the last
+    row, the causal attention work (sum over owned rows of the keys they see) is balanced, and the staging slot count covers every rank."""
+    P = -(-S // 64)
+    owner = np.full(S, -1)
+    work, pages = [], []
+    for r in range(world):
+        o = (ctypes.c_int32 * 5)()
+        rc = hip_lib.aha_hip_debug_cp_plan(S, world, r, o)
+        if P < 4 * world:
+            assert rc == 1
+            return
+        assert rc == 0
+        (a0, an, b0, bn, pmax) = tuple(o)
+        assert a0 % 64 == 0 and b0 % 64 == 0 and an > 0 and bn > 0 and a0 + an <= b0
+        assert (a0 + an) % 64 == 0 and ((b0 + bn) % 64 == 0 or b0 + bn == S)
+        for (x0, n) in ((a0, an), (b0, bn)):
+            assert np.all(owner[x0:x0 + n] == -1)
+            owner[x0:x0 + n] = r
+        rows = np.concatenate([np.arange(a0, a0 + an), np.arange(b0, b0 + bn)])
+        work.append(float((rows + 1).sum()))
+        pages.append(-(-an // 64) + -(-bn // 64))
+        assert pages[-1] <= pmax
+    assert np.all(owner >= 0) and owner[S - 1] == 0
+    assert max(pages) == pmax
+    # zigzag: no rank has more than ~(1 + 2 / pages-per-chunk) x the mean causal work
+    assert max(work) <= np.mean(work) * (1.0 + 2.5 * 2 * world / P), (work, P)

@@ -1,0 +1,103 @@
+"""Worker of tests/test_cp_gpu.py::test_context_parallel_two_processes_gloo: one of WORLD_SIZE processes that share the test box's single
+GPU, each holding the FULL tiny Qwen3-VL model as one context-parallel rank (aha_hip_set_context_parallel).  The per-layer K / V exchange
+goes through the host-callback seam: this rank's slice staged through host memory, gathered with torch.distributed (gloo).  The ViT runs
+image-parallel with one gloo all-gather (aha_amd.parallel.encode_images_sharded).  Every rank must end with the same logits and first
+token, rank 0 checks them against an unsharded model, and a decode on rank 1's copy of the cache must match rank 0's -- the cache is whole
+everywhere, nothing is handed back."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ["AHA_CP_MIN_ROWS"] = "64"
+    dist.init_process_group("gloo")
+    torch.cuda.set_device(0)
+    from aha_amd import parallel
+    from aha_amd.configs import tiny_qwen3vl
+    from aha_amd.model import HipInferenceModel, MultiModalData
+    from aha_amd.weights import qwen3vl_weights
+    from oracle.numerics import Numerics
+    from oracle import qwen3vl as ov
+
+    cfg = tiny_qwen3vl()
+    w = qwen3vl_weights(cfg, seed=0)
+    calls = [0, 0]
+
+    def all_gather(ptr, bytes_per_rank):
+        iface = {"shape": (bytes_per_rank * world,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+        dev = torch.as_tensor(type("H", (), {"__cuda_array_interface__": iface})(), device="cuda:0")
+        mine = dev[rank * bytes_per_rank:(rank + 1) * bytes_per_rank].cpu()
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        dev.copy_(torch.cat(parts))
+        torch.cuda.synchronize()
+        calls[0] += 1
+        calls[1] += bytes_per_rank * world
+
+    m = HipInferenceModel(cfg, w)
+    m.set_context_parallel(rank, world, all_gather=all_gather)
+    g = np.random.default_rng(7)
+    imgs = [g.integers(0, 256, size=(h, wd, 3), dtype=np.uint8) for (h, wd) in [(192, 160), (64, 64), (128, 256)]]
+    pv, grid = ov.process_images(Numerics("bf16"), imgs)
+    ids = [int(x) for x in g.integers(0, 1900, size=150)]
+    for gi in grid.tolist():
+        ids += [cfg.vision_start_token_id] + [cfg.image_token_id] * (gi[0] * gi[1] * gi[2] // 4) + [cfg.vision_end_token_id]
+    ids += [int(x) for x in g.integers(0, 1900, size=330)]
+    assert len(ids) >= 64 * 4 * world
+    pvb = pv.to(torch.bfloat16)
+    toks = [int(a * b * c) // 4 for a, b, c in grid.tolist()]
+    patches = np.cumsum([0] + [int(a * b * c) for a, b, c in grid.tolist()])
+
+    def enc(idx):
+        a, b = idx[0], idx[-1] + 1
+        return m.vision_encode(MultiModalData(pvb[patches[a]:patches[b]].cuda(), grid[a:b])).cpu()   # gloo gathers host tensors
+
+    ph = {}
+    emb = parallel.encode_images_sharded(enc, list(range(len(imgs))), toks, world, rank, timings=ph).cuda().contiguous()
+    m.set_profiling(True)
+    got, tok = m.forward_initial(ids, 0, MultiModalData(image_grid_thw=grid, image_embeds=emb))
+    got = got.copy()
+    parallel.read_prefill_phases(m, ph)
+    m.set_profiling(False)
+    L = cfg.text.num_hidden_layers
+    assert calls[0] == L + 1, calls                     # one K / V exchange per layer + the last-row broadcast
+    assert ph.get("kv_all_gather_launches") == L and all(k in ph for k in ("gemm_s", "attn_s", "rowwise_s", "vit_s")), ph
+    dec, off = [tok], len(ids)
+    for _ in range(6):                                   # every rank decodes on ITS copy of the cache: no collective, no hand-back
+        lg, t = m.forward_step(dec[-1], off)
+        dec.append(t)
+        off += 1
+    assert calls[0] == L + 1
+    all_dec = [None] * world
+    dist.all_gather_object(all_dec, (dec, got.tobytes()))
+    assert all(d == all_dec[0] for d in all_dec), "ranks disagree on the prefill logits or the greedy tokens"
+    if rank == 0:
+        single = HipInferenceModel(cfg, w)
+        ref, rtok = single.forward_initial(ids, 0, MultiModalData(pvb, grid))
+        s = float(ref.std())
+        assert float(np.abs(got - ref).max()) <= 0.02 * s, f"context-parallel prefill logits: {np.abs(got - ref).max() / s:.4f} std"
+        rdec, o2 = [rtok], len(ids)
+        for i in range(6):                               # teacher-forced with the sharded run's tokens: same inputs on both sides
+            rl, t = single.forward_step(dec[i], o2)
+            rdec.append(t)
+            o2 += 1
+        s2 = float(rl.std())
+        assert float(np.abs(lg - rl).max()) <= 0.03 * s2, "decode on the context-parallel cache drifted from the single-GPU run"
+        print(f"CP_WORKER_OK tokens_equal={dec == rdec} all_gather_calls={calls[0]} bytes={calls[1]} phases={sorted(k for k in ph if k.endswith('_s'))}",
+              flush=True)
+        single.close()
+    m.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
