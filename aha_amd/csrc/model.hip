@@ -1679,7 +1679,8 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
   // only (offset 0), prompts of at least AHA_CP_MIN_ROWS tokens; otherwise every rank simply computes the whole prompt (same results).
   std::vector<RowSeg> segs;
   CpPlan cpp{};
-  static const int cp_min_rows = [] { const char* e = getenv("AHA_CP_MIN_ROWS"); return e ? atoi(e) : 2048; }();
+  const char* e_cp = getenv("AHA_CP_MIN_ROWS");   // (read per call, like the AHA_TP_* thresholds: every rank's host sets it before the call)
+  const int cp_min_rows = e_cp ? atoi(e_cp) : 2048;
   const bool cp = m->cp_size > 1 && m->tp_size <= 1 && kv_off == 0 && d == 128 && S >= cp_min_rows && (m->rccl_comm || m->cp_all_gather_cb) &&
                   cp_make_plan(S, m->cp_size, m->cp_rank, &cpp, &segs);
   if (!cp) segs.assign(1, RowSeg{0, S});

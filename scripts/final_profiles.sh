@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 timeout 300 bash scripts/prof_kernels.sh cfg3 bench.py --steps 32 --warmup 4 --no-cpu-baseline > gpurun_out/prof_cfg3.txt 2>&1
 timeout 300 bash scripts/collect_pmc.sh > gpurun_out/pmc.log 2>&1
 timeout 300 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-for w in qwen3vl8b-cfg5 qwen3-0.6b qwen3-asr qwen3vl8b-text qwen3vl8b-cfg5-tp qwen3vl8b-video; do
+for w in qwen3vl8b-cfg5 qwen3-0.6b qwen3-asr qwen3vl8b-text qwen3vl8b-video; do
   timeout 400 python bench.py --workload $w --steps 32 --warmup 4 --no-cpu-baseline > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err
 done
 timeout 120 python scripts/bench_gemm.py > gpurun_out/gemm_ours.txt 2>&1
