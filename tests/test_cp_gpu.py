@@ -200,3 +200,44 @@ def test_context_parallel_two_processes_gloo(gpu):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "CP_WORKER_OK" in r.stdout and "kv_all_gather_s" in r.stdout, r.stdout[-2000:]
+
+
+def test_context_parallel_eight_ranks_at_the_cfg5_prompt_length(gpu, monkeypatch):
+    """BASELINE cfg 5's text side at full WIDTH and LENGTH (8B widths: hidden 4096, 32 / 8 heads, MLP 12 288, vocab 151 936; 40 980
+    tokens = 641 pages; 3 of the 36 layers to bound the run) as EIGHT context-parallel ranks -- eight full models on the one GPU, one
+    thread each.  Sixteen chunks of 40 / 41 pages, 81 staging slots per rank, 2.6 MB per page and layer through the exchange; the default
+    thresholds (no environment override), automatic GEMM plans.  Every rank must end with the single-GPU logits (the bound of the other
+    full-size property tests: the ranks' GEMMs run other plans than a 40 980-row GEMM) and the same first token; decode then runs on
+    rank 0 and, as a check that every cache is whole, on rank 5."""
+    from aha_amd.configs import qwen3vl_8b_text
+    from aha_amd.model import HipInferenceModel
+    from tests.test_fullsize_gpu import close as close_full, rnd_ids
+    monkeypatch.delenv("AHA_CP_MIN_ROWS", raising=False)
+    cfg = qwen3vl_8b_text()
+    cfg.num_hidden_layers = 3
+    w = qwen3_text_weights(cfg, seed=2, device=gpu)
+    S, W = 40980, 8
+    ids = rnd_ids(cfg.vocab_size, S, 9)
+    single = HipInferenceModel(cfg, w)
+    ref, rtok = single.forward_initial(ids, 0)
+    ref = ref.copy()
+    g = Gather(W)
+    ranks = make_ranks(cfg, w, W, g)
+    del w
+    torch.cuda.empty_cache()
+    got = run_ranks([lambda m=m: (lambda r: (r[0].copy(), r[1]))(m.forward_initial(ids, 0)) for m in ranks])
+    assert g.calls == cfg.num_hidden_layers + 1
+    slice_bytes = cfg.num_key_value_heads * 2 * 64 * 128 * 2
+    assert g.bytes == cfg.num_hidden_layers * W * 81 * slice_bytes + W * cfg.hidden_size * 2
+    for r in range(W):
+        np.testing.assert_array_equal(got[r][0], got[0][0])           # the broadcast last row -> the same replicated lm_head everywhere
+        assert got[r][1] == got[0][1]
+    close_full(got[0][0], ref, "8-rank context-parallel prefill at 40 980 tokens vs one GPU")
+    tok, off = int(got[0][1]), S
+    for step in range(3):
+        want = single.forward_step(tok, off)[0].copy()
+        for r in (0, 5):
+            close_full(ranks[r].forward_step(tok, off)[0], want, f"decode step {step} on rank {r}'s cache")
+        tok, off = int(np.argmax(want)), off + 1
+    for m in ranks + [single]:
+        m.close()
