@@ -504,3 +504,44 @@ def test_tp2_prefill_with_reserved_cus_runs_the_persistent_gemm_and_keeps_the_bi
             s = float(ref.std())
             assert float(np.abs(got - ref).max()) <= 0.04 * s and float(np.sqrt(((got - ref) ** 2).mean())) <= 0.01 * s, what
     np.testing.assert_array_equal(outs[1][0], outs[2][0])    # 240 and 160 workers: whole tiles either way -> the same bits
+
+
+def test_tp8_sequence_parallel_prefill_at_the_cfg5_prompt_length(gpu, monkeypatch):
+    """The tensor-parallel form at BASELINE cfg 5's geometry, which no 2-rank tiny-model test reaches: EIGHT ranks (one kv head + four q
+    heads each, MLP columns 1536), 8B widths, 40 980 tokens, 3 of the 36 layers -- and NO environment overrides, so the thresholds and
+    chunk counts are the ones the first multi-GPU run will use: row-parallel projections in 4 column blocks of 1024 with one reduce-scatter
+    each, the all-gather of the normalised rows in 4 row chunks of 1536 / 515 rows per rank, each consumed by one row-grouped GEMM launch
+    (8 segments).  Host-callback seam (the collectives serialise; the data movement and the GEMM launches are the real ones).  All ranks
+    must agree bit for bit, and match the single-GPU prefill within the full-size bound; a decode step on the sharded stack follows."""
+    from aha_amd.configs import qwen3vl_8b_text
+    from aha_amd.model import HipInferenceModel
+    from tests.test_fullsize_gpu import close as close_full, rnd_ids
+    for k in ("AHA_TP_AG_CHUNKS", "AHA_TP_AG_MIN_ROWS", "AHA_TP_OVERLAP_CHUNKS", "AHA_TP_OVERLAP_MIN_ROWS", "AHA_TP_SP"):
+        monkeypatch.delenv(k, raising=False)
+    cfg = qwen3vl_8b_text()
+    cfg.num_hidden_layers = 3
+    w = qwen3_text_weights(cfg, seed=2, device=gpu)
+    S, T = 40980, 8
+    ids = rnd_ids(cfg.vocab_size, S, 9)
+    single = HipInferenceModel(cfg, w)
+    ref, rtok = single.forward_initial(ids, 0)
+    ref = ref.copy()
+    red = TwoRankSum(T)
+    ranks = [HipInferenceModel(cfg, w, tp_rank=r, tp_size=T, allreduce=lambda p, n, r=r: red.allreduce(r, p, n),
+                               reduce_scatter=lambda p, n, r=r: red.reduce_scatter(r, p, n),
+                               all_gather=lambda p, n, r=r: red.all_gather(r, p, n)) for r in range(T)]
+    del w
+    torch.cuda.empty_cache()
+    got = run_ranks([lambda m=m: m.forward_initial(ids, 0)[0].copy() for m in ranks])
+    L = cfg.num_hidden_layers
+    assert red.rs_calls == 2 * L * 4, red.rs_calls                      # o_proj and down_proj, 4 column blocks each
+    assert red.ag_calls == 2 * L * 4 * T, red.ag_calls                  # qkv and gate+up inputs, 4 row chunks each, counted per rank
+    for r in range(1, T):
+        np.testing.assert_array_equal(got[r], got[0])
+    close_full(got[0], ref, "8-rank sequence-parallel TP prefill at 40 980 tokens vs one GPU")
+    tok = int(np.argmax(ref))
+    want = single.forward_step(tok, S)[0].copy()
+    step = run_ranks([lambda m=m: m.forward_step(tok, S)[0].copy() for m in ranks])
+    close_full(step[0], want, "decode step on the 8-way sharded stack")
+    for m in ranks + [single]:
+        m.close()
