@@ -187,6 +187,16 @@ pub mod sys {
         pub fn aha_hip_kv_export(m: *mut AhaModel, out_dev: *mut c_void, out_bytes: usize, bytes_needed: *mut usize, n_tokens: *mut usize, rope_delta: *mut i64) -> i32;
         pub fn aha_hip_kv_import(m: *mut AhaModel, in_dev: *const c_void, in_bytes: usize, src_heads: i32, src_head0: i32, dst_head0: i32, n_heads: i32, n_tokens: usize, rope_delta: i64) -> i32;
         pub fn aha_hip_set_gemm_reserved_cus(n: i32) -> i32;
+        /// context-parallel prefill: full weights on every rank, the prompt's rows sharded, one K / V all-gather per layer
+        pub fn aha_hip_tp_unique_id(out128: *mut c_void) -> i32;
+        pub fn aha_hip_set_context_parallel(
+            m: *mut AhaModel,
+            rank: i32,
+            world: i32,
+            all_gather: Option<unsafe extern "C" fn(buf_dev: *mut c_void, bytes_per_rank: usize, user: *mut c_void) -> i32>,
+            user: *mut c_void,
+        ) -> i32;
+        pub fn aha_hip_cp_init_rccl(m: *mut AhaModel, unique_id128: *const c_void) -> i32;
         pub fn aha_hip_embed(m: *mut AhaModel, ids: *const u32, n_ids: usize, out: *mut f32) -> i32;
         pub fn aha_hip_cache_len(m: *const AhaModel) -> usize;
         pub fn aha_hip_audio_resample(
