@@ -452,6 +452,24 @@ impl Model {
         assert!(out.len() >= self.vocab);
         check(unsafe { sys::aha_hip_last_logits(self.model, out.as_mut_ptr()) })
     }
+
+    /// 128 bytes that identify an RCCL communicator: rank 0 makes them, the host sends them to every rank
+    pub fn rccl_unique_id() -> Result<[u8; 128], Error> {
+        let mut id = [0u8; 128];
+        check(unsafe { sys::aha_hip_tp_unique_id(id.as_mut_ptr() as *mut std::ffi::c_void) })?;
+        Ok(id)
+    }
+
+    /// Context-parallel prefill over `world` GPUs of one node (one process / one `Model` with the FULL weights per GPU): after this,
+    /// every rank calls `forward_initial` with the same prompt at offset 0; each ends with the whole KV cache and the same logits, and
+    /// decode continues on rank 0 exactly as after a single-GPU prefill (no hand-back).  `unique_id`: `rccl_unique_id()` of rank 0.
+    pub fn set_context_parallel(&mut self, rank: usize, world: usize, unique_id: &[u8; 128]) -> Result<(), Error> {
+        check(unsafe { sys::aha_hip_set_context_parallel(self.model, rank as i32, world as i32, None, std::ptr::null_mut()) })?;
+        if world > 1 {
+            check(unsafe { sys::aha_hip_cp_init_rccl(self.model, unique_id.as_ptr() as *const std::ffi::c_void) })?;
+        }
+        Ok(())
+    }
 }
 
 impl Drop for Model {
