@@ -142,6 +142,9 @@ struct aha_model {
   aha_all_gather_fn cp_all_gather_cb = nullptr;   // host-callback seam (tests); RCCL otherwise
   void* cp_user = nullptr;
   void* p_cp_stage = nullptr;     // [rank][page slot][kv heads][K | V] of ONE layer, bf16
+  // context-parallel prefill in flight: prompt row -> row of this rank's (compacted) activation buffers, or the scratch row behind them
+  // for rows another rank owns; empty otherwise.  The vision tower's scatter / DeepStack adds go through it (vision_tower.hip).
+  std::vector<int32_t> cp_row_map;
   size_t cp_stage_bytes = 0;
   void* p_hstage = nullptr;     // tensor-parallel prefill: staging of the chunked all-gather, [chunk][rank][rows] bf16 (norm_gather_gemm)
   unsigned head_ctr_base = 0;       // value every kv head's split-arrival counter has reached after all launches so far

@@ -1189,7 +1189,7 @@ static int norm_gather_gemm(aha_model* m, const void* norm_w, const GemmArgs& g,
 // Results: every output row is computed by the same kernels on the same values as in the single-GPU prefill; with the GEMM plan pinned
 // (plans depend on M) the logits and the cache are bit-identical to it (tests/test_cp_gpu.py).
 struct CpPlan { int world, pmax; int a0[8], an[8], b0[8], bn[8]; };   // rank r's two page ranges [a0, a0 + an), [b0, b0 + bn)
-struct RowSeg { int r0, len; };                                         // prompt rows [r0, r0 + len)
+struct RowSeg { int r0, len, l0; };                                     // prompt rows [r0, r0 + len) = rows [l0, l0 + len) of the rank's activation buffers
 static bool cp_make_plan(int S, int world, int rank, CpPlan* p, std::vector<RowSeg>* segs) {
   const int P = (S + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS, nc = 2 * world;
   if (world < 2 || world > 8 || P < 2 * nc) return false;   // at least two pages per chunk
@@ -1205,7 +1205,7 @@ static bool cp_make_plan(int S, int world, int rank, CpPlan* p, std::vector<RowS
   for (int k = 0; k < 2; ++k) {
     const int pg0 = k ? p->b0[rank] : p->a0[rank], n = k ? p->bn[rank] : p->an[rank];
     const int r0 = pg0 * KV_PAGE_TOKENS, r1 = std::min(S, (pg0 + n) * KV_PAGE_TOKENS);
-    segs->push_back(RowSeg{r0, r1 - r0});
+    segs->push_back(RowSeg{r0, r1 - r0, 0});
   }
   return true;
 }
@@ -1640,6 +1640,30 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
   GemmWorkspaceScope ws_scope(m->p_gemm_ws, m->gemm_ws_bytes, m->d_sk_ctrs);  // split-K slabs / persistent-kernel chunks of this thread's GEMM launches
   if ((rc = model_ensure_pages(m, m->cache_len + n))) return rc;
 
+  // Context-parallel prefill (cp_make_plan above): this rank owns two row chunks of the prompt.  Its activation buffers are COMPACT --
+  // buffer row l0 + i holds prompt row r0 + i of a segment -- so every norm and GEMM below runs ONCE over all of the rank's rows; only
+  // rope / KV append and attention, which need the rows' cache positions, run per segment.  A fresh cache only (offset 0), prompts of at
+  // least AHA_CP_MIN_ROWS tokens, no audio rows; otherwise every rank simply computes the whole prompt (same results).
+  const int kv_off = (int)m->cache_len;
+  std::vector<RowSeg> segs;
+  CpPlan cpp{};
+  const char* e_cp = getenv("AHA_CP_MIN_ROWS");   // (read per call, like the AHA_TP_* thresholds: every rank's host sets it before the call)
+  const int cp_min_rows = e_cp ? atoi(e_cp) : 2048;
+  const bool cp = m->cp_size > 1 && m->tp_size <= 1 && kv_off == 0 && d == 128 && S >= cp_min_rows && !has_audio &&
+                  (m->rccl_comm || m->cp_all_gather_cb) && cp_make_plan(S, m->cp_size, m->cp_rank, &cpp, &segs);
+  if (!cp) segs.assign(1, RowSeg{0, S, 0});
+  int Mloc = 0;
+  for (RowSeg& sg : segs) { sg.l0 = Mloc; Mloc += sg.len; }
+  struct MapGuard {   // the vision tower's scatter / DeepStack rows go through m->cp_row_map while this prefill runs
+    aha_model* m;
+    ~MapGuard() { m->cp_row_map.clear(); }
+  } map_guard{m};
+  if (cp) {
+    m->cp_row_map.assign((size_t)S, Mloc);   // rows of other ranks -> the scratch row behind this rank's rows
+    for (const RowSeg& sg : segs)
+      for (int i = 0; i < sg.len; ++i) m->cp_row_map[(size_t)sg.r0 + i] = sg.l0 + i;
+  }
+
   // positions: 1-D arange(offset, offset+S) on all three rows (rope.rs:599-604), or get_rope_index for Qwen3-VL
   std::vector<int32_t> pos(3 * (size_t)S);
   const bool has_image = mm && (mm->n_images > 0 || mm->n_videos > 0 || mm->image_embeds);   // images and / or videos
@@ -1653,15 +1677,30 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
     for (int a = 0; a < 3; ++a)
       for (int i = 0; i < S; ++i) pos[(size_t)a * S + i] = (int32_t)(offset + i);
   }
-  AHA_HIP_CHECK(hipMemcpyAsync(m->p_ids, ids, n * 4, hipMemcpyHostToDevice, st));
-  AHA_HIP_CHECK(hipMemcpyAsync(m->p_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, st));
   const int64_t p0[3] = {pos[0], pos[S], pos[2 * (size_t)S]};
+  std::vector<uint32_t> ids_loc;
+  std::vector<int32_t> pos_loc;
+  const uint32_t* ids_up = ids;
+  const int32_t* pos_up = pos.data();
+  if (cp) {   // this rank's rows of the ids and of the three position rows
+    ids_loc.resize((size_t)Mloc);
+    pos_loc.resize(3 * (size_t)Mloc);
+    for (const RowSeg& sg : segs) {
+      std::copy(ids + sg.r0, ids + sg.r0 + sg.len, ids_loc.begin() + sg.l0);
+      for (int a = 0; a < 3; ++a)
+        std::copy(pos.begin() + (size_t)a * S + sg.r0, pos.begin() + (size_t)a * S + sg.r0 + sg.len, pos_loc.begin() + (size_t)a * Mloc + sg.l0);
+    }
+    ids_up = ids_loc.data();
+    pos_up = pos_loc.data();
+  }
+  AHA_HIP_CHECK(hipMemcpyAsync(m->p_ids, ids_up, (size_t)Mloc * 4, hipMemcpyHostToDevice, st));
+  AHA_HIP_CHECK(hipMemcpyAsync(m->p_pos, pos_up, 3 * (size_t)Mloc * 4, hipMemcpyHostToDevice, st));
   if ((rc = push_state(m, ids[n - 1], p0, m->cache_len, m->cache_len + n))) return rc;
   AHA_HIP_CHECK(hipStreamSynchronize(st));  // pos / ids are pageable host memory
 
   {
-    ProfScope ps(m, "elem", (double)S * H * 4, 0);
-    launch_embed_gather(m->embed, m->p_ids, m->p_x, S, H, st);
+    ProfScope ps(m, "elem", (double)Mloc * H * 4, 0);
+    launch_embed_gather(m->embed, m->p_ids, m->p_x, Mloc, H, st);
   }
   if (has_image) {
     // ViT -> masked_scatter of image embeds into the <|image_pad|> rows (qwen3vl/model.rs:1166-1190)
@@ -1671,19 +1710,9 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
     // audio tower -> masked_scatter into the <|audio_pad|> rows (qwen3_asr/model.rs:343-358)
     if ((rc = audio_forward_and_scatter(m, ids, n, mm, m->p_x))) return rc;
   }
-  const int kv_off = (int)m->cache_len;
-  if (d == 128) launch_rope_table(m->p_pos, S, m->d_inv_freq, m->d_axis_map, S, m->p_rope, st);   // cos / sin once for all layers
+  if (d == 128) launch_rope_table(m->p_pos, Mloc, m->d_inv_freq, m->d_axis_map, Mloc, m->p_rope, st);   // cos / sin once for all layers
   // sequence-parallel tensor parallelism: rank r owns rows [r * spr, (r+1) * spr) of the residual stream between the GEMMs
   const int spr = seq_parallel_on(m) ? (S + m->tp_size - 1) / m->tp_size : 0;
-  // context-parallel prefill (cp_make_plan above): this rank's two row chunks; everything row-wise below runs per segment.  A fresh cache
-  // only (offset 0), prompts of at least AHA_CP_MIN_ROWS tokens; otherwise every rank simply computes the whole prompt (same results).
-  std::vector<RowSeg> segs;
-  CpPlan cpp{};
-  const char* e_cp = getenv("AHA_CP_MIN_ROWS");   // (read per call, like the AHA_TP_* thresholds: every rank's host sets it before the call)
-  const int cp_min_rows = e_cp ? atoi(e_cp) : 2048;
-  const bool cp = m->cp_size > 1 && m->tp_size <= 1 && kv_off == 0 && d == 128 && S >= cp_min_rows && (m->rccl_comm || m->cp_all_gather_cb) &&
-                  cp_make_plan(S, m->cp_size, m->cp_rank, &cpp, &segs);
-  if (!cp) segs.assign(1, RowSeg{0, S});
   auto rows = [](const void* base, int64_t r0, int64_t row_elems) { return (void*)((char*)base + r0 * row_elems * 2); };   // bf16 rows
   // Single GPU: the RMSNorm that follows o_proj / down_proj + residual rides on the GEMM call (GemmArgs::norm_w: inside the
   // split-K reduce pass where the plan has one, a separate launch otherwise -- the same values).  Not across a DeepStack add,
@@ -1692,19 +1721,13 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
   bool in_norm_done = false;
   for (int li = 0; li < c.num_hidden_layers; ++li) {
     const LayerWeights& L = m->layers[li];
-    if (spr > 0) {   // sequence-parallel: norm of this rank's rows, all-gather in chunks, GEMM per chunk (norm_gather_gemm)
+    {
       GemmArgs g{};
-      g.A = m->p_h; g.W = L.wqkv; g.C = m->p_qkv; g.M = S; g.N = nq + 2 * nkv; g.K = H; g.lda = H; g.ldw = H; g.ldc = g.N; g.act = ACT_NONE;
-      if ((rc = norm_gather_gemm(m, L.in_norm, g, S, spr))) return rc;
-    } else {
-      for (const RowSeg& sg : segs) {
-        if (!in_norm_done) {
-          ProfScope ps(m, "elem", (double)sg.len * H * 4, 0);
-          launch_rmsnorm_rows(rows(m->p_x, sg.r0, H), L.in_norm, rows(m->p_h, sg.r0, H), sg.len, H, H, H, c.rms_norm_eps, st);
-        }
-        GemmArgs g{};
-        g.A = rows(m->p_h, sg.r0, H); g.W = L.wqkv; g.C = rows(m->p_qkv, sg.r0, nq + 2 * nkv); g.M = sg.len; g.N = nq + 2 * nkv; g.K = H;
-        g.lda = H; g.ldw = H; g.ldc = g.N; g.act = ACT_NONE;
+      g.A = m->p_h; g.W = L.wqkv; g.C = m->p_qkv; g.M = Mloc; g.N = nq + 2 * nkv; g.K = H; g.lda = H; g.ldw = H; g.ldc = g.N; g.act = ACT_NONE;
+      if (spr > 0) {   // sequence-parallel: norm of this rank's rows, all-gather in chunks, GEMM per chunk (norm_gather_gemm)
+        if ((rc = norm_gather_gemm(m, L.in_norm, g, S, spr))) return rc;
+      } else {
+        if (!in_norm_done && (rc = prefill_norm(m, L.in_norm, Mloc, 0))) return rc;
         ProfScope ps(m, "gemm", ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N) * 2, 2.0 * g.M * g.N * g.K);
         launch_gemm(g, st);
       }
@@ -1712,63 +1735,59 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
     in_norm_done = false;
     for (const RowSeg& sg : segs) {
       RopeArgs r{};
-      r.qkv = rows(m->p_qkv, sg.r0, nq + 2 * nkv); r.ld = nq + 2 * nkv; r.q_norm_w = L.q_norm; r.k_norm_w = L.k_norm;
-      r.pos = m->p_pos + sg.r0; r.pos_ld = S; r.inv_freq = m->d_inv_freq; r.axis_map = m->d_axis_map;
-      r.q_out = rows(m->p_q, sg.r0, nq); r.kv = model_kv_layer(m, li); r.kv_start = &m->d_state->kv_start;
+      r.qkv = rows(m->p_qkv, sg.l0, nq + 2 * nkv); r.ld = nq + 2 * nkv; r.q_norm_w = L.q_norm; r.k_norm_w = L.k_norm;
+      r.pos = m->p_pos + sg.l0; r.pos_ld = Mloc; r.inv_freq = m->d_inv_freq; r.axis_map = m->d_axis_map;
+      r.q_out = rows(m->p_q, sg.l0, nq); r.kv = model_kv_layer(m, li); r.kv_start = &m->d_state->kv_start;
       r.S = sg.len; r.nh = nh; r.kvh = kvh; r.d = d; r.eps = c.rms_norm_eps;
       r.kv_start_host = kv_off + sg.r0;   // == d_state->kv_start (push_state above) for the whole prompt
-      r.rope_tab = m->p_rope ? rows(m->p_rope, sg.r0, 128) : nullptr;
+      r.rope_tab = rows(m->p_rope, sg.l0, 128);
       ProfScope ps(m, "elem", (double)sg.len * (nq + 2 * nkv) * 4, 0);
       launch_qknorm_rope(r, st);
     }
     if (cp && (rc = cp_gather_kv(m, li, cpp))) return rc;
     for (const RowSeg& sg : segs) {
       AttnPrefillArgs a{};
-      a.q = rows(m->p_q, sg.r0, nq); a.kv = model_kv_layer(m, li); a.o = rows(m->p_attn, sg.r0, nq); a.S = sg.len; a.nh = nh; a.kvh = kvh; a.d = d;
+      a.q = rows(m->p_q, sg.l0, nq); a.kv = model_kv_layer(m, li); a.o = rows(m->p_attn, sg.l0, nq); a.S = sg.len; a.nh = nh; a.kvh = kvh; a.d = d;
       a.kv_offset = kv_off + sg.r0; a.kv_total = kv_off + sg.r0 + sg.len; a.causal = 1; a.scale = m->attn_scale;
       const double Lk = a.kv_total;
       ProfScope ps(m, "attn_prefill", (double)sg.len * nq * 4 + Lk * nkv * 4, 4.0 * sg.len * (a.kv_offset + 0.5 * sg.len) * nq);
       launch_attn_prefill(a, st);
     }
-    for (const RowSeg& sg : segs) {
+    {
       GemmArgs g{};
-      g.A = rows(m->p_attn, sg.r0, nq); g.W = L.wo; g.C = rows(m->p_x, sg.r0, H); g.residual = g.C; g.M = sg.len; g.N = H; g.K = nq;
-      g.lda = nq; g.ldw = nq; g.ldc = H; g.act = ACT_NONE;
-      if (norm_in_gemm) { g.norm_w = L.post_norm; g.norm_out = rows(m->p_h, sg.r0, H); g.norm_eps = c.rms_norm_eps; }
+      g.A = m->p_attn; g.W = L.wo; g.C = m->p_x; g.residual = m->p_x; g.M = Mloc; g.N = H; g.K = nq; g.lda = nq; g.ldw = nq; g.ldc = H; g.act = ACT_NONE;
+      if (norm_in_gemm) { g.norm_w = L.post_norm; g.norm_out = m->p_h; g.norm_eps = c.rms_norm_eps; }
       ProfScope ps(m, "gemm", ((double)g.M * g.K + (double)g.N * g.K + 2.0 * g.M * g.N) * 2, 2.0 * g.M * g.N * g.K);
       if ((rc = gemm_row_parallel(m, g, spr))) return rc;
     }
-    if (spr > 0) {
+    {
       GemmArgs g{};
-      g.A = m->p_h; g.W = L.wgu; g.C = m->p_act; g.M = S; g.N = 2 * I; g.K = H; g.lda = H; g.ldw = H; g.ldc = I; g.act = ACT_SILU_MUL_PAIRS;
-      if ((rc = norm_gather_gemm(m, L.post_norm, g, S, spr))) return rc;
-    } else {
-      if (!norm_in_gemm && (rc = prefill_norm(m, L.post_norm, S, spr))) return rc;
-      for (const RowSeg& sg : segs) {
-        GemmArgs g{};
-        g.A = rows(m->p_h, sg.r0, H); g.W = L.wgu; g.C = rows(m->p_act, sg.r0, I); g.M = sg.len; g.N = 2 * I; g.K = H;
-        g.lda = H; g.ldw = H; g.ldc = I; g.act = ACT_SILU_MUL_PAIRS;
+      g.A = m->p_h; g.W = L.wgu; g.C = m->p_act; g.M = Mloc; g.N = 2 * I; g.K = H; g.lda = H; g.ldw = H; g.ldc = I; g.act = ACT_SILU_MUL_PAIRS;
+      if (spr > 0) {
+        if ((rc = norm_gather_gemm(m, L.post_norm, g, S, spr))) return rc;
+      } else {
+        if (!norm_in_gemm && (rc = prefill_norm(m, L.post_norm, Mloc, 0))) return rc;
         ProfScope ps(m, "gemm", ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * I) * 2, 2.0 * g.M * g.N * g.K);
         launch_gemm(g, st);
       }
     }
-    const bool fuse_next_norm = norm_in_gemm && li + 1 < c.num_hidden_layers && !(has_image && vision_has_deepstack(m, li));
-    for (const RowSeg& sg : segs) {
+    {
       GemmArgs g{};
-      g.A = rows(m->p_act, sg.r0, I); g.W = L.wdown; g.C = rows(m->p_x, sg.r0, H); g.residual = g.C; g.M = sg.len; g.N = H; g.K = I;
-      g.lda = I; g.ldw = I; g.ldc = H; g.act = ACT_NONE;
-      if (fuse_next_norm) { g.norm_w = m->layers[li + 1].in_norm; g.norm_out = rows(m->p_h, sg.r0, H); g.norm_eps = c.rms_norm_eps; }
+      g.A = m->p_act; g.W = L.wdown; g.C = m->p_x; g.residual = m->p_x; g.M = Mloc; g.N = H; g.K = I; g.lda = I; g.ldw = I; g.ldc = H; g.act = ACT_NONE;
+      if (norm_in_gemm && li + 1 < c.num_hidden_layers && !(has_image && vision_has_deepstack(m, li))) {
+        g.norm_w = m->layers[li + 1].in_norm; g.norm_out = m->p_h; g.norm_eps = c.rms_norm_eps;
+        in_norm_done = true;
+      }
       ProfScope ps(m, "gemm", ((double)g.M * g.K + (double)g.N * g.K + 2.0 * g.M * g.N) * 2, 2.0 * g.M * g.N * g.K);
       if ((rc = gemm_row_parallel(m, g, spr))) return rc;
     }
-    if (fuse_next_norm) in_norm_done = true;
     if (has_image) {
       // DeepStack: add visual feature k to the visual rows after decoder layer k (qwen3vl/model.rs:806-822)
-      // (context-parallel: also on rows this rank does not own -- they hold stale values nobody reads)
+      // (context-parallel: the rows of other ranks all land on the scratch row behind this rank's rows)
       if ((rc = vision_deepstack_add(m, li, m->p_x))) return rc;
     }
   }
-  const void* x_last = (const char*)m->p_x + (size_t)(S - 1) * H * 2;
+  const void* x_last = (const char*)m->p_x + (size_t)(Mloc - 1) * H * 2;   // the prompt's last row (context-parallel: on rank 0, which owns the last chunk)
   if (cp) {
     // rank 0 owns the last chunk, hence the last row: every rank contributes its (stale, except rank 0's) copy of that row to one small
     // all-gather and takes slot 0 -- a broadcast; the final norm + lm_head then run replicated (full weights everywhere)

@@ -267,6 +267,8 @@ int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, cons
     AHA_HIP_CHECK(hipMemcpyAsync(v->merged, mm->image_embeds, bytes, hipMemcpyDefault, s0));
     for (size_t k = 0; k < v->deep.size(); ++k)
       AHA_HIP_CHECK(hipMemcpyAsync(v->deep[k], (const char*)mm->image_embeds + (k + 1) * bytes, bytes, hipMemcpyDefault, s0));
+    if (!m->cp_row_map.empty())   // context-parallel prefill: the text buffers hold this rank's rows only (model.hip)
+      for (auto& r : rows) r = m->cp_row_map[r];
     AHA_HIP_CHECK(hipMemcpyAsync(v->d_vis_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, s0));
     AHA_HIP_CHECK(hipStreamSynchronize(s0));
     v->n_merged = n4;
@@ -407,6 +409,8 @@ int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, cons
     }
   AHA_HIP_CHECK(hipMemcpyAsync(v->d_page_first, page_first.data(), page_first.size() * 4, hipMemcpyHostToDevice, st));
   AHA_HIP_CHECK(hipMemcpyAsync(v->d_page_cnt, page_cnt.data(), page_cnt.size() * 4, hipMemcpyHostToDevice, st));
+  if (!m->cp_row_map.empty())
+    for (auto& r : vis_rows) r = m->cp_row_map[r];
   AHA_HIP_CHECK(hipMemcpyAsync(v->d_vis_rows, vis_rows.data(), vis_rows.size() * 4, hipMemcpyHostToDevice, st));
   AHA_HIP_CHECK(hipStreamSynchronize(st));  // host vectors are pageable
 
