@@ -131,6 +131,7 @@ struct AttnPrefillArgs {
   float scale;
   int64_t q_ld;            // elements between consecutive q rows; 0 => nh * padded head dim
   int nqb;                 // set by the launcher: > 0 selects the XCD-aware 1-D block order over nqb q blocks x nh heads
+  int epi_rows = 0;        // set by the launcher: output rows stored in row order through LDS (16 B per lane)
 };
 void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st);
 void set_attn_variant_override(int smx);   // test hook: -1 = the environment's / default choice

@@ -277,12 +277,38 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
       trace[(wave >> 2) * 8 + 7] = (unsigned long long)ntiles;
     }
   }
+  // Epilogue.  The accumulator layout gives a lane 4 consecutive dims of ONE q row per fragment: stored from there, an instruction
+  // writes 8-byte pieces 32 bytes apart on 16 rows.  Row order instead (a.epi_rows; the lesson of the GEMM epilogues, DESIGN.md
+  // section 5 round 4): the wave passes its 16 x DV tile through its own slice of the (now free) staging LDS and stores whole rows,
+  // 16 bytes per lane, 256-byte (text) / 144-byte (ViT) runs.
+  constexpr int EPITCH = DV * 2 + 16;   // bytes per LDS row: 16-byte aligned, rows 4 dwords apart in the banks
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     const float lt = group_sum(l[t]);
+    const float inv = 1.0f / lt;
+    if (a.epi_rows) {
+      char* wb = smem + wave * (16 * EPITCH);
+#pragma unroll
+      for (int ds = 0; ds < DS; ++ds) {
+        uint2 w;
+        w.x = pack_bf(o[t][ds][0] * inv, o[t][ds][1] * inv);
+        w.y = pack_bf(o[t][ds][2] * inv, o[t][ds][3] * inv);
+        *reinterpret_cast<uint2*>(wb + c * EPITCH + (ds * 16 + G * 4) * 2) = w;
+      }
+      // (same wave wrote and reads: no barrier, the LDS queue is in order)
+      const int chunk = lane & 15;              // 16-byte piece of a row
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 4 + (lane >> 4), qr = q0 + t * 16 + row;
+        if (qr < a.S && chunk * 8 < a.d) {     // a.d = real head dim of the output rows: a multiple of 8 on this path (launcher)
+          const u32x4_t v = *reinterpret_cast<const u32x4_t*>(wb + row * EPITCH + chunk * 16);
+          *reinterpret_cast<u32x4_t*>((bf16_t*)a.o + ((int64_t)qr * a.nh + head) * a.d + chunk * 8) = v;
+        }
+      }
+      continue;
+    }
     const int qr = q0 + t * 16 + c;
     if (qr < a.S) {
-      const float inv = 1.0f / lt;
       bf16_t* op = (bf16_t*)a.o + ((int64_t)qr * a.nh + head) * a.d;  // a.d = real head dim of the output rows
 #pragma unroll
       for (int ds = 0; ds < DS; ++ds) {
@@ -459,6 +485,10 @@ void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
   sb.f = a.scale;
   const uint32_t scale_bits = sb.u;
   const int smx = (scale_bits & 0xffffu) == 0 ? (g_attn_smx_override >= 0 ? g_attn_smx_override : smx_env) : 0;
+  // row-order epilogue stores (AHA_ATTN_EPI_ROWS=0: from the accumulator fragments): 16-byte pieces need head dims in multiples of 8
+  // and 16-byte aligned output rows
+  static const int epi_env = [] { const char* e = getenv("AHA_ATTN_EPI_ROWS"); return e ? atoi(e) : 1; }();
+  a.epi_rows = epi_env && a.d % 8 == 0 && ((uintptr_t)a.o & 15) == 0;
 #define ATTN_LAUNCH(DQK_, DV_)                                                                                                   \
   do {                                                                                                                           \
     if (nwv == 8) {                                                                                                              \

@@ -88,8 +88,11 @@ def test_register_budgets_the_design_counts_on(kernels):
     # the persistent form of the same tile: the same claim (one workgroup per CU is what its planner counts on)
     assert len(fam["gemm256s_kernel"]) >= 7 and all(k["vgpr_count"] == 512 and k["max_flat_workgroup_size"] == 256 and k["group_segment_fixed_size"] == 0
                                                     for _, k in fam["gemm256s_kernel"])
-    # prefill attention: 128 VGPRs => two 8-wave blocks per CU (non-trace instantiations)
-    assert all(k["vgpr_count"] <= 128 for n, k in fam["attn_prefill_kernel"] if "Lb0E" in n)
+    # prefill attention: 128 VGPRs => two 8-wave blocks per CU (non-trace instantiations); the 4-wave 128 / 128 text instantiation runs three
+    # blocks per CU (amdgpu_waves_per_eu 3): up to 168
+    for n, k in fam["attn_prefill_kernel"]:
+        if "Lb0E" in n:
+            assert k["vgpr_count"] <= (168 if "ILi128ELi128ELi1ELi4E" in n else 128), (n, k["vgpr_count"])
     # 8-wave 256^2 GEMM: two waves per SIMD => at most 256 registers; 128^2 kernel: four blocks of four waves per CU => at most 128 + accumulators in 168
     assert all(k["vgpr_count"] <= 256 for _, k in fam["gemm256p_kernel"])
     assert all(k["vgpr_count"] <= 168 for _, k in fam["gemm_glds_kernel"])
