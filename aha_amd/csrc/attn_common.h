@@ -36,6 +36,11 @@ __device__ __forceinline__ f32x4_t mfma_diag(s16x4_t dg, uint32_t lo, uint32_t h
   x.u[0] = lo; x.u[1] = hi;
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dg, x.s, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 }
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 __device__ __forceinline__ float group_max(float v) {  // across the 4 lane groups (same column c)
   // v_permlane32_swap / v_permlane16_swap instead of __shfl_xor (ds_bpermute: an LDS round trip in the middle of the softmax's
   // dependency chain, once per tile); max is exact in any order
@@ -66,6 +71,32 @@ template <int SMX = 0, typename ValidFn>
 __device__ __forceinline__ void softmax_scores(f32x4_t (&st)[4], float scale, ValidFn valid, int G, float& m, float& alpha, float& m2,
                                                s16x4_t dg = s16x4_t{0, 0, 0, 0}) {
   float tmax = -INFINITY;
+  constexpr float LOG2E = 1.4426950408889634f;
+  if constexpr (SMX == 3) {
+    // f32 score chain (round 5): the scores stay the f32 QK^T accumulators -- no bf16(q.k), no bf16(. * scale) -- through mask, maximum
+    // and exponential (the decode kernel's convention; the reference's eager path rounds twice, modules.rs:782-783, the oracle's
+    // `attn_scores_rounded` switch).  The running maximum is kept in RAW score units (scale > 0) and the scale rides the exponent's
+    // fma: p = exp2(s * (scale log2 e) - m * (scale log2 e)).  ~40 of the ~92 vector instructions per tile go away.
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (!valid(sub * 16 + G * 4 + r)) st[sub][r] = -INFINITY;
+    // v_max3_f32 by hand: fmaxf on an MFMA output makes clang canonicalise it first (v_max_f32 x, x)
+    auto sv = [&](int i) { return st[i >> 2][i & 3]; };
+    tmax = max3(sv(0), sv(1), sv(2));
+#pragma unroll
+    for (int i = 3; i < 15; i += 2) tmax = max3(tmax, sv(i), sv(i + 1));
+    tmax = max3(tmax, sv(15), sv(15));
+    tmax = group_max(tmax);
+    const float m_new = fmaxf(m, tmax);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float c2 = scale * LOG2E;
+    alpha = __builtin_amdgcn_exp2f((m - m_use) * c2);         // m = -inf -> 0
+    m2 = m_use * c2;
+    m = m_new;
+    return;
+  }
   if constexpr (SMX >= 1) {
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub)   // matmul output -> bf16 (v_cvt_pk), x bf16(scaling) exactly in f32
@@ -85,15 +116,16 @@ __device__ __forceinline__ void softmax_scores(f32x4_t (&st)[4], float scale, Va
   const float m_new = fmaxf(m, tmax);
   const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: keep everything at zero
   alpha = __expf(m - m_use);                               // m = -inf -> 0
-  constexpr float LOG2E = 1.4426950408889634f;
   m2 = m_use * LOG2E;
   m = m_new;
 }
-__device__ __forceinline__ void softmax_probs(const f32x4_t (&st)[4], float m2, float alpha, float& l, bf16x8_t (&pf)[2]) {
-  constexpr float LOG2E = 1.4426950408889634f;
+// k2s = the factor on the score inside the exponent: log2 e for the rounded chains (the scale is already in the scores), scale * log2 e
+// for the f32 chain (SMX 3)
+__device__ __forceinline__ void softmax_probs(const f32x4_t (&st)[4], float m2, float alpha, float& l, bf16x8_t (&pf)[2],
+                                              float k2s = 1.4426950408889634f) {
   // two scores per instruction where the ISA has a packed f32 form: e^(s - m) = exp2(fma(s, log2 e, -m log2 e)) as v_pk_fma_f32,
   // the row sum as v_pk_add_f32 on two running halves (8 + 8 instead of 16 + 16 issue slots of a VALU-bound loop)
-  const f32x2_t k2 = {LOG2E, LOG2E}, nm2 = {-m2, -m2};
+  const f32x2_t k2 = {k2s, k2s}, nm2 = {-m2, -m2};
   f32x2_t psum2 = {0.f, 0.f};
   uint32_t pk[2][4];
 #pragma unroll

@@ -233,8 +233,8 @@ int aha_hip_debug_poison_lds(uint32_t seed, void* stream) {
   API_GUARD_END
 }
 int aha_hip_debug_attn_variant(int32_t smx) {
-  if (smx < -1 || smx > 1) {
-    set_error("debug_attn_variant: smx -1..1");
+  if (smx < -1 || smx > 3 || smx == 2) {
+    set_error("debug_attn_variant: smx -1 (default), 0, 1 or 3");
     return AHA_ERR_INVALID;
   }
   set_attn_variant_override(smx);
@@ -471,14 +471,32 @@ int aha_hip_attn_decode(const void* q, const void* k, const void* v, void* o, in
 int aha_hip_attn_prefill(const void* q, const void* k, const void* v, void* o, int32_t S, int32_t L, int32_t nh,
                          int32_t kvh, int32_t d, int32_t kv_offset, int32_t causal, float scale, void* stream) {
   API_GUARD_BEGIN
-  if (d != 128 || L <= 0 || S <= 0 || nh % kvh) {
-    set_error("attn_prefill: head_dim must be 128");
+  if ((d != 128 && d != 64) || L <= 0 || S <= 0 || nh % kvh || (d == 64 && nh != kvh)) {
+    set_error("attn_prefill: head_dim must be 128, or 64 with nh == kvh (the audio encoder's geometry)");
     return AHA_ERR_UNSUPPORTED;
   }
   hipStream_t st = (hipStream_t)stream;
   TmpPages t;
-  int rc = build_tmp_pages(t, k, v, L, kvh, d, st);
-  if (rc) return rc;
+  void* fused = nullptr;
+  if (d == 128) {
+    int rc = build_tmp_pages(t, k, v, L, kvh, d, st);
+    if (rc) return rc;
+  } else {   // head_dim 64: pages through the audio tower's own packer (K | V of a fused row)
+    const int npages = (L + KV_PAGE_TOKENS - 1) / KV_PAGE_TOKENS;
+    const size_t page_bytes = (size_t)2 * kvh * KV_PAGE_TOKENS * d * 2, row = (size_t)kvh * d * 2;
+    AHA_HIP_CHECK(hipMalloc(&t.store, page_bytes * npages));
+    AHA_HIP_CHECK(hipMemsetAsync(t.store, 0, page_bytes * npages, st));
+    std::vector<uint64_t> ptrs(npages);
+    for (int i = 0; i < npages; ++i) ptrs[i] = (uint64_t)(uintptr_t)t.store + (size_t)(npages - 1 - i) * page_bytes;
+    AHA_HIP_CHECK(hipMalloc((void**)&t.d_ptrs, npages * 8));
+    AHA_HIP_CHECK(hipMemcpy(t.d_ptrs, ptrs.data(), npages * 8, hipMemcpyHostToDevice));
+    t.kv.page_ptrs = t.d_ptrs; t.kv.layer_off = 0; t.kv.kvh = kvh; t.kv.d = d;
+    AHA_HIP_CHECK(hipMalloc(&fused, row * 2 * L));
+    AHA_HIP_CHECK(hipMemcpy2DAsync(fused, row * 2, k, row, row, L, hipMemcpyDeviceToDevice, st));
+    AHA_HIP_CHECK(hipMemcpy2DAsync((char*)fused + row, row * 2, v, row, row, L, hipMemcpyDeviceToDevice, st));
+    launch_kv_pack_generic(fused, (int64_t)2 * kvh * d, 0, kvh * d, t.kv, L, kvh, d, st);
+    AHA_HIP_CHECK(hipGetLastError());
+  }
   AttnPrefillArgs a{};
   a.q = q; a.kv = t.kv; a.o = o; a.S = S; a.nh = nh; a.kvh = kvh; a.d = d; a.kv_offset = kv_offset; a.kv_total = L;
   a.causal = causal; a.scale = scale;
@@ -498,6 +516,7 @@ int aha_hip_attn_prefill(const void* q, const void* k, const void* v, void* o, i
   }
   hipError_t e = hipGetLastError();
   hipStreamSynchronize(st);
+  if (fused) hipFree(fused);
   AHA_HIP_CHECK(e);
   return AHA_OK;
   API_GUARD_END

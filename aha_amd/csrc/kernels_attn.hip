@@ -32,7 +32,7 @@ namespace {
 // blocks: the kernel is held to 128 VGPRs (amdgpu_waves_per_eu 4) so that two 8-wave blocks are resident per CU.
 // TRACE (debug, AHA_ATTN_PTRACE=1): waves 0 and 4 of the middle block add up the shader cycles they spend in each part of the loop body
 // ABL (debug, AHA_ATTN_ABL, results wrong by construction): 2 = no softmax arithmetic, 3 = no staging of the next tile, 4 = no MFMAs
-// SMX: which parts of the score rounding chain run on the matrix pipe (attn_common.h softmax_scores)
+// SMX: the score chain (attn_common.h softmax_scores): 0 / 1 the reference's two roundings (1: scale multiply on the matrix pipe), 3 f32
 template <int DQK, int DV, int QT, int NWV, bool TRACE = false, int ABL = 0, int SMX = 0>
 __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV == 8 || DQK < 128) ? 4 : 3, 4))) void attn_prefill_kernel(AttnPrefillArgs a, unsigned long long* trace = nullptr) {
   constexpr int KS = DQK / 32, DS = DV / 16;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
         pf[t][0] = as_frag(u0); pf[t][1] = as_frag(u1);
         l[t] += 1.f;
       } else
-      softmax_probs(st[t], m2[t], alpha[t], l[t], pf[t]);
+      softmax_probs(st[t], m2[t], alpha[t], l[t], pf[t], SMX == 3 ? a.scale * 1.4426950408889634f : 1.4426950408889634f);
       // once the running max has settled alpha is exactly 1 in every lane of the wave: skip the DS*4 multiplies (x * 1 == x)
       if (__builtin_amdgcn_ballot_w64(alpha[t] != 1.f) != 0) {
 #pragma unroll
@@ -478,13 +478,18 @@ void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
   const int nqb = (a.S + 16 * qt * nwv - 1) / (16 * qt * nwv);
   a.nqb = (sched_env && a.kvh % 8 == 0 && a.nh % a.kvh == 0) ? nqb : 0;
   dim3 grid = a.nqb ? dim3(nqb * a.nh) : dim3(nqb, a.nh), block(nwv * 64);
-  // AHA_ATTN_SMX: parts of the score rounding chain on the matrix pipe (0 none, 1 the scale multiply);
-  // needs a bf16-exact scale (every model path has one; an op-level caller with another scale gets the vector-ALU chain)
-  static const int smx_env = [] { const char* e = getenv("AHA_ATTN_SMX"); return e ? atoi(e) : 1; }();
+  // AHA_ATTN_SMX: the score chain.
+  //   3 (default since round 5) = the f32 score chain: the scores stay the f32 QK^T accumulators through scale, mask, maximum and
+  //       exponential; P is rounded to bf16 once for the P.V MFMA (attn_common.h softmax_scores<3>)
+  //   0 = the reference's rounding chain bf16(bf16(q.k) * bf16(scale)) (modules.rs:782-783) in the vector ALU, 1 = the same bits with the
+  //       scale multiply on the matrix pipe (needs a bf16-exact scale: every model path has one; an op-level caller with another scale
+  //       gets 0) -- the bit-faithful forms, kept for A/B and for the parity tables of rounds 1-4
+  static const int smx_env = [] { const char* e = getenv("AHA_ATTN_SMX"); return e ? atoi(e) : 3; }();
   union { float f; uint32_t u; } sb;
   sb.f = a.scale;
   const uint32_t scale_bits = sb.u;
-  const int smx = (scale_bits & 0xffffu) == 0 ? (g_attn_smx_override >= 0 ? g_attn_smx_override : smx_env) : 0;
+  int smx = g_attn_smx_override >= 0 ? g_attn_smx_override : smx_env;
+  if (smx == 1 && (scale_bits & 0xffffu) != 0) smx = 0;
   // row-order epilogue stores (AHA_ATTN_EPI_ROWS=0: from the accumulator fragments): 16-byte pieces need head dims in multiples of 8
   // and 16-byte aligned output rows
   static const int epi_env = [] { const char* e = getenv("AHA_ATTN_EPI_ROWS"); return e ? atoi(e) : 1; }();
@@ -492,10 +497,12 @@ void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
 #define ATTN_LAUNCH(DQK_, DV_)                                                                                                   \
   do {                                                                                                                           \
     if (nwv == 8) {                                                                                                              \
-      if (smx == 1) hipLaunchKernelGGL((attn_prefill_kernel<DQK_, DV_, 1, 8, false, 0, 1>), grid, block, lds, st, a, nullptr); \
+      if (smx == 3) hipLaunchKernelGGL((attn_prefill_kernel<DQK_, DV_, 1, 8, false, 0, 3>), grid, block, lds, st, a, nullptr); \
+      else if (smx == 1) hipLaunchKernelGGL((attn_prefill_kernel<DQK_, DV_, 1, 8, false, 0, 1>), grid, block, lds, st, a, nullptr); \
       else hipLaunchKernelGGL((attn_prefill_kernel<DQK_, DV_, 1, 8>), grid, block, lds, st, a, nullptr);                         \
     } else {                                                                                                                     \
-      if (smx == 1) hipLaunchKernelGGL((attn_prefill_kernel<DQK_, DV_, 1, 4, false, 0, 1>), grid, block, lds, st, a, nullptr); \
+      if (smx == 3) hipLaunchKernelGGL((attn_prefill_kernel<DQK_, DV_, 1, 4, false, 0, 3>), grid, block, lds, st, a, nullptr); \
+      else if (smx == 1) hipLaunchKernelGGL((attn_prefill_kernel<DQK_, DV_, 1, 4, false, 0, 1>), grid, block, lds, st, a, nullptr); \
       else hipLaunchKernelGGL((attn_prefill_kernel<DQK_, DV_, 1, 4>), grid, block, lds, st, a, nullptr);                         \
     }                                                                                                                            \
   } while (0)
@@ -528,7 +535,8 @@ void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
     ATTN_LAUNCH(128, 128);
   } else if (a.d == 64) {  // Qwen3-ASR audio encoder
     const size_t lds = 2 * KV_PAGE_TOKENS * 2 * (64 + 64);
-    if (smx == 1) hipLaunchKernelGGL((attn_prefill_kernel<64, 64, 1, 4, false, 0, 1>), grid, block, lds, st, a, nullptr);
+    if (smx == 3) hipLaunchKernelGGL((attn_prefill_kernel<64, 64, 1, 4, false, 0, 3>), grid, block, lds, st, a, nullptr);
+    else if (smx == 1) hipLaunchKernelGGL((attn_prefill_kernel<64, 64, 1, 4, false, 0, 1>), grid, block, lds, st, a, nullptr);
     else hipLaunchKernelGGL((attn_prefill_kernel<64, 64, 1, 4>), grid, block, lds, st, a, nullptr);
   } else {  // head_dim 72 (Qwen3-VL ViT): Q/K rows padded to 96, V block to 80
     const size_t lds = 2 * KV_PAGE_TOKENS * 2 * (96 + 80);

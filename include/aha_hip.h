@@ -392,7 +392,8 @@ int aha_hip_qknorm_rope(const void* qkv, const void* q_norm_w, const void* k_nor
 int aha_hip_attn_decode(const void* q, const void* k, const void* v, void* o, int32_t nh, int32_t kvh, int32_t d,
                         int32_t L, float scale, void* stream);
 /* D7 prefill attention, causal with q position i attending to k positions <= kv_offset + i; q (S, nh*d),
- * k/v (L, kvh*d) token-major, L = kv_offset + S.  causal = 0 gives full (ViT) attention. */
+ * k/v (L, kvh*d) token-major, L = kv_offset + S.  causal = 0 gives full (ViT / audio encoder) attention.  d = 128, or 64 with
+ * nh == kvh (the Qwen3-ASR audio encoder's geometry). */
 int aha_hip_attn_prefill(const void* q, const void* k, const void* v, void* o, int32_t S, int32_t L, int32_t nh,
                          int32_t kvh, int32_t d, int32_t kv_offset, int32_t causal, float scale, void* stream);
 /* V0-pre, host arithmetic: img_smart_resize (src/utils/img_utils.rs:294-331) -- the size Qwen3VLProcessor::process_img

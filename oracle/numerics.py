@@ -13,7 +13,8 @@ a Candle op, which is an assumption ("[unverified]"):
     (T = bf16 on the GPU target, f16 on the reference's CPU default -- utils/mod.rs:107 -- or f32).
 
 Known candle-CPU sub-op roundings that this model does not apply by default are exposed as switches so their
-effect can be measured: ``rmsnorm_in_T`` (m -> T, x/m -> T, *w -> T).
+effect can be measured: ``rmsnorm_in_T`` (m -> T, x/m -> T, *w -> T), ``attn_probs_rounded`` / ``attn_scores_rounded`` (the eager
+attention's intermediate tensors).
 """
 from __future__ import annotations
 
@@ -29,6 +30,8 @@ class Numerics:
     dtype: str = "bf16"          # model dtype T
     rmsnorm_in_T: bool = False   # candle-nn CPU rms_norm: m cast to T, then x / m * w evaluated in T
     attn_probs_rounded: bool = True   # softmax output materialised in T before P.V (eager path, modules.rs:788)
+    attn_scores_rounded: bool = True  # q.k^T materialised in T, then `* scaling` materialised in T (eager path, modules.rs:782-783);
+                                      # False = the scores stay f32 through scale, mask and softmax (the HIP f32 score chain, round 5)
     matmul_f64: bool = False     # accumulate GEMMs in f64 (ideal) instead of f32 (order-dependent)
     attn_row_block: int = 0      # > 0: eager attention evaluated `attn_row_block` query rows at a time (same arithmetic per row --
                                  # every row's softmax is independent -- without the (h, S, S) score tensor: 17 GB at N = 16 384)

@@ -101,11 +101,18 @@ def eager_attention_forward(nm: Numerics, q, k, v, n_rep: int, mask, scale: floa
     blk = nm.attn_row_block if (nm.attn_row_block > 0 and S > nm.attn_row_block) else 0
     if not blk and isinstance(mask, str):
         mask = prepare_causal_attention_mask(S)
+    def scores(qq, kt):   # q.k^T -> T, * scaling -> T (modules.rs:782-783); attn_scores_rounded = False: no materialisation in T
+        if nm.attn_scores_rounded:
+            return nm.r(nm.matmul(qq, kt) * scale)
+        return ((qq.double() @ kt.double()).float() if nm.matmul_f64 else qq @ kt) * scale
+
+    def rr(x):            # the mask add's materialisation
+        return nm.r(x) if nm.attn_scores_rounded else x
+
     if not blk:
-        w = nm.matmul(q, k.transpose(-2, -1))
-        w = nm.r(w * scale)
+        w = scores(q, k.transpose(-2, -1))
         if mask is not None:
-            w = nm.r(w + mask)
+            w = rr(w + mask)
         p = torch.softmax(w, dim=-1)
         if nm.attn_probs_rounded:
             p = nm.r(p)
@@ -120,12 +127,11 @@ def eager_attention_forward(nm: Numerics, q, k, v, n_rep: int, mask, scale: floa
     for a in range(0, S, blk):
         b = min(S, a + blk)
         kv_hi = b if causal else k.shape[2]
-        w = nm.matmul(q[:, :, a:b], kt[..., :kv_hi])
-        w = nm.r(w * scale)
+        w = scores(q[:, :, a:b], kt[..., :kv_hi])
         if causal:
             rows = torch.arange(a, b).reshape(-1, 1)
             cols = torch.arange(0, kv_hi).reshape(1, -1)
-            w = nm.r(w + torch.where(cols > rows, float("-inf"), 0.0)[None, None])
+            w = rr(w + torch.where(cols > rows, float("-inf"), 0.0)[None, None])
         p = torch.softmax(w, dim=-1)
         if nm.attn_probs_rounded:
             p = nm.r(p)

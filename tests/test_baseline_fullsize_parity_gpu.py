@@ -160,6 +160,22 @@ def test_cfg3_full_vit_and_all_36_layers(vl8b):
         rep["oracle_f64_prefill_seconds"] = time.time() - t1
         rep["prefill_logits_vs_f64_oracle"] = rel(got, ref64)
         rep["f32_oracle_vs_f64_oracle"] = rel(ref, ref64)
+        # Round 5 (round-4 verdict, next-round item 1b): the same request on each score chain of the prefill attention -- 1 = the
+        # reference's two bf16 roundings of the scores (modules.rs:782-783; the default of rounds 1-4), 3 = the f32 score chain (the
+        # default now) -- against the same two oracles: the error table that decides the default (profiles/r05_attn_prefill.md).
+        from aha_amd import ops
+        by_chain = {}
+        try:
+            for smx in (1, 3):
+                ops.attn_variant(smx)
+                m.clear_cache()
+                g_s, _ = m.forward_initial(ids, 0, MultiModalData(pv.to(torch.bfloat16), grid))
+                by_chain[str(smx)] = dict(vs_f64_oracle=rel(g_s, ref64), vs_f32_oracle=rel(g_s, ref),
+                                          image_embeds=rel(m.debug_image_embeds(0, 1024), o.last_image_embeds.numpy()))
+        finally:
+            ops.attn_variant(-1)
+            m.clear_cache()
+        rep["prefill_by_score_chain"] = by_chain
         rep["oracle_total_seconds"] = time.time() - t0
         REPORT["cfg3_vit27_N4096_text36layers_S1542"] = rep
         _flush_report()
@@ -167,6 +183,9 @@ def test_cfg3_full_vit_and_all_36_layers(vl8b):
         hip64, floor = rep["prefill_logits_vs_f64_oracle"], rep["f32_oracle_vs_f64_oracle"]
         assert hip64[0] <= FLOOR_FACTOR * floor[0] and hip64[1] <= FLOOR_FACTOR * floor[1], \
             f"36 layers, S = 1542: HIP vs f64 oracle {hip64}, f32 oracle vs f64 oracle {floor} (bound: {FLOOR_FACTOR} x the floor)"
+        for smx, e in by_chain.items():   # both chains inside the same bound of the same centre
+            assert e["vs_f64_oracle"][0] <= FLOOR_FACTOR * floor[0] and e["vs_f64_oracle"][1] <= FLOOR_FACTOR * floor[1], (smx, e, floor)
+            assert e["image_embeds"][0] <= TOWER_MAX and e["image_embeds"][1] <= TOWER_RMS, (smx, e)
         assert rep["prefill_logits"][0] <= DEEP_MAX and rep["prefill_logits"][1] <= DEEP_RMS, f"36 layers, S = 1542: {rep['prefill_logits']}"
         if rep["margin_std"] > 2 * DEEP_MAX:
             assert rep["argmax_equal"]

@@ -14,6 +14,21 @@ def test_cpu_baseline_times_the_full_depth_stack():
     r = bench.cpu_baseline(cfg, sample_secs=0.5)
     assert r["kind"] == "port" and r["unit"] == "tokens/s" and r["value"] > 0 and r["cores"] >= 1
     assert "full 3-layer" in r["sample"] and "end to end" in r["sample"], r["sample"]   # not the one-layer extrapolation
+    assert "prefill_tok_s" not in r                     # no prompt named: the decode half alone
+
+
+def test_cpu_baseline_has_a_prefill_half_at_the_requests_shape():
+    """BASELINE's metric is decode tokens/s AND prefill tokens/s (the reference's prompt_secs / completion_tps,
+    /root/reference/src/models/common/generate.rs:123-158): the baseline object carries both, the decode half over a cache of the GPU
+    line's kv_len_mid, the prefill half sampled (text layers at the prompt length, one ViT block at the image's patch count) and
+    extrapolated over the depth -- and says so."""
+    import bench
+    from aha_amd import configs
+    cfg = configs.tiny_qwen3vl()
+    r = bench.cpu_baseline(cfg, sample_secs=0.5, kv_len=77, prompt_tokens=300, vit_patches=64)
+    assert r["decode_kv_len"] == 77 and "77-token cache" in r["sample"]
+    assert r["prefill_tok_s"] > 0 and r["prefill_seconds_extrapolated"] >= 0
+    assert "EXTRAPOLATED" in r["prefill_sample"] and "S = 300" in r["prefill_sample"] and "64 patches" in r["prefill_sample"]
 
 
 def test_decode_bytes_per_token_formula():

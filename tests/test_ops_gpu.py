@@ -482,7 +482,8 @@ def test_qknorm_rope(gpu, mrope):
     assert_close_ulps(k, rk, 2, 0.97, "k rope")
 
 
-def _attn_ref(q, k, v, nh, kvh, d, causal, kv_offset):
+def _attn_ref(q, k, v, nh, kvh, d, causal, kv_offset, nm=None):
+    nm = nm or NM
     S, L = q.shape[0], k.shape[0]
     qq = q.float().reshape(1, S, nh, d).transpose(1, 2)
     kk = k.float().reshape(1, L, kvh, d).transpose(1, 2)
@@ -492,8 +493,11 @@ def _attn_ref(q, k, v, nh, kvh, d, causal, kv_offset):
         i = torch.arange(S)[:, None] + kv_offset
         j = torch.arange(L)[None, :]
         mask = torch.zeros(S, L).masked_fill(j > i, float("-inf"))[None, None]
-    o = oq.eager_attention_forward(NM, qq, kk, vv, nh // kvh, mask, oq.attn_scale(NM, d))
+    o = oq.eager_attention_forward(nm, qq, kk, vv, nh // kvh, mask, oq.attn_scale(NM, d))
     return o.reshape(S, nh * d)
+
+
+NM_F32SCORES = Numerics("bf16", matmul_f64=True, attn_scores_rounded=False)   # the f32 score chain's own rounding points
 
 
 @pytest.mark.parametrize("L", [1, 63, 64, 65, 200, 1000, 4133])
@@ -526,16 +530,18 @@ def test_attn_prefill_causal(gpu, S, off, nh, kvh):
     from aha_amd import ops
     d, L = 128, S + off
     q, k, v = rnd((S, nh * d), 40), rnd((L, kvh * d), 41), rnd((L, kvh * d), 42)
-    ref = _attn_ref(q, k, v, nh, kvh, d, True, off)
+    # the library's default score chain is the f32 one since round 5 (test_attn_prefill_f32_score_chain): its own rounding points
+    ref = _attn_ref(q, k, v, nh, kvh, d, True, off, NM_F32SCORES)
     got = ops.attn_prefill(q.to(gpu), k.to(gpu), v.to(gpu), nh, kvh, d, off, True)
     assert_close_ulps(got, ref, 3, None, "attn_prefill", row_scale=True)
+    assert_close_ulps(got, _attn_ref(q, k, v, nh, kvh, d, True, off), 4, None, "attn_prefill vs the eager oracle", row_scale=True)
 
 
 def test_attn_prefill_full(gpu):
     from aha_amd import ops
     S, nh, kvh, d = 150, 4, 4, 128
     q, k, v = rnd((S, nh * d), 43), rnd((S, kvh * d), 44), rnd((S, kvh * d), 45)
-    ref = _attn_ref(q, k, v, nh, kvh, d, False, 0)
+    ref = _attn_ref(q, k, v, nh, kvh, d, False, 0, NM_F32SCORES)
     got = ops.attn_prefill(q.to(gpu), k.to(gpu), v.to(gpu), nh, kvh, d, 0, False)
     assert_close_ulps(got, ref, 3, None, "attn_prefill full", row_scale=True)
 
@@ -560,6 +566,70 @@ def test_attn_prefill_score_chain_on_the_matrix_pipe_gives_the_same_bits(gpu, S,
     assert torch.equal(outs[1], outs[0]), "the matrix-pipe scale multiply differs from the vector-ALU chain"
     if S <= 300:
         assert_close_ulps(outs[1], _attn_ref(q, k, v, nh, kvh, d, causal, off), 3, None, "attn_prefill smx 1", row_scale=True)
+
+
+@pytest.mark.parametrize("smx", [3])
+@pytest.mark.parametrize("S,off", [(1, 0), (5, 0), (31, 0), (32, 0), (33, 0), (64, 0), (65, 0), (130, 0), (300, 0), (17, 100), (64, 64), (100, 333)])
+@pytest.mark.parametrize("nh,kvh", [(4, 2), (8, 2)])
+def test_attn_prefill_f32_score_chain(gpu, smx, S, off, nh, kvh):
+    """Round 5 (AHA_ATTN_SMX=3, the default): the scores stay the f32 QK^T accumulators through scale, mask, maximum and exponential;
+    P is rounded to bf16 once for the P.V MFMA.  Against the oracle with its score roundings
+    OFF (the chain's own rounding points: <= 3 bf16 ulp of the row scale, the bound the bit-faithful chain is held to against the eager
+    oracle) and ON (the reference's eager path, modules.rs:782-783: <= 4 ulp)."""
+    from aha_amd import ops
+    d, L = 128, S + off
+    q, k, v = rnd((S, nh * d), 40), rnd((L, kvh * d), 41), rnd((L, kvh * d), 42)
+    try:
+        ops.attn_variant(smx)
+        got = ops.attn_prefill(q.to(gpu), k.to(gpu), v.to(gpu), nh, kvh, d, off, True)
+        full = ops.attn_prefill(q.to(gpu), k.to(gpu), v.to(gpu), nh, kvh, d, off, False) if off == 0 else None
+    finally:
+        ops.attn_variant(-1)
+    assert_close_ulps(got, _attn_ref(q, k, v, nh, kvh, d, True, off, NM_F32SCORES), 3, None, f"attn_prefill smx {smx} vs f32-score oracle", row_scale=True)
+    # (4 ulp: a score that the eager path's two roundings move across a bf16 boundary shifts its probability by up to 2^-8 relative)
+    assert_close_ulps(got, _attn_ref(q, k, v, nh, kvh, d, True, off), 4, None, f"attn_prefill smx {smx} vs eager oracle", row_scale=True)
+    if full is not None:
+        assert_close_ulps(full, _attn_ref(q, k, v, nh, kvh, d, False, 0, NM_F32SCORES), 3, None, f"attn_prefill full smx {smx}", row_scale=True)
+
+
+@pytest.mark.parametrize("smx", [3])
+def test_attn_prefill_f32_score_chain_peaky_and_long(gpu, smx):
+    """The rescale path of the online softmax (a key that dominates late, after the running maximum had settled and the rescale was
+    being skipped) and a launch long enough for 8-wave / XCD-ordered blocks (S = 2048 x 32 heads)."""
+    from aha_amd import ops
+    nh, kvh, d, S = 8, 2, 128, 700
+    q, k, v = rnd((S, nh * d), 33), rnd((S, kvh * d), 34, 0.3), rnd((S, kvh * d), 35)
+    k[650] = (q[690, :d] * 2.0).repeat(kvh)   # spikes for the late rows, in tile 10
+    k[40] = (q[300, :d] * 1.5).repeat(kvh)
+    try:
+        ops.attn_variant(smx)
+        got = ops.attn_prefill(q.to(gpu), k.to(gpu), v.to(gpu), nh, kvh, d, 0, True)
+        S2, nh2, kvh2 = 2048, 32, 8
+        q2, k2, v2 = rnd((S2, nh2 * d), 36), rnd((S2, kvh2 * d), 37), rnd((S2, kvh2 * d), 38)
+        got2 = ops.attn_prefill(q2.to(gpu), k2.to(gpu), v2.to(gpu), nh2, kvh2, d, 0, True)
+    finally:
+        ops.attn_variant(-1)
+    assert_close_ulps(got, _attn_ref(q, k, v, nh, kvh, d, True, 0, NM_F32SCORES), 3, None, f"attn_prefill peaky smx {smx}", row_scale=True)
+    ref2 = _attn_ref(q2[:, :4 * d], k2[:, :d], v2[:, :d], 4, 1, d, True, 0, NM_F32SCORES)   # the q heads of kv head 0
+    assert_close_ulps(got2[:, :4 * d], ref2, 3, None, f"attn_prefill S=2048 smx {smx}", row_scale=True)
+    ref2b = _attn_ref(q2[:, 28 * d:], k2[:, 7 * d:], v2[:, 7 * d:], 4, 1, d, True, 0, NM_F32SCORES)   # ... and of kv head 7
+    assert_close_ulps(got2[:, 28 * d:], ref2b, 3, None, f"attn_prefill S=2048 smx {smx} (last kv head)", row_scale=True)
+
+
+@pytest.mark.parametrize("smx", [0, 1, 3])
+@pytest.mark.parametrize("S", [13, 64, 390, 777])
+def test_attn_prefill_head_dim_64_full(gpu, smx, S):
+    """The Qwen3-ASR audio encoder's geometry (qwen3_asr/model.rs:218-220: global attention, no mask; head_dim 64, nh == kvh) on every
+    score-chain variant, 390 = the token count of 30 s of audio."""
+    from aha_amd import ops
+    nh, d = 14, 64
+    q, k, v = rnd((S, nh * d), 51), rnd((S, nh * d), 52), rnd((S, nh * d), 53)
+    try:
+        ops.attn_variant(smx)
+        got = ops.attn_prefill(q.to(gpu), k.to(gpu), v.to(gpu), nh, nh, d, 0, False)
+    finally:
+        ops.attn_variant(-1)
+    assert_close_ulps(got, _attn_ref(q, k, v, nh, nh, d, False, 0, NM if smx <= 1 else NM_F32SCORES), 3, None, f"attn d=64 smx {smx}", row_scale=True)
 
 
 def test_argmax_first_max(gpu):

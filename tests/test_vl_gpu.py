@@ -255,3 +255,27 @@ def test_vit_attention_score_chain_variants_give_the_same_bits(vl, gpu):
     finally:
         ops.attn_variant(-1)
     assert torch.equal(embs[1], embs[0])
+
+
+@pytest.mark.parametrize("smx", [0, 1, 3])
+def test_vit_tower_on_every_score_chain_variant(vl, gpu, smx):
+    """head_dim 72 (Q / K rows padded to 96, V block to 80) on every score chain of the prefill attention -- 0 / 1 = the reference's
+    rounding chain (vector ALU / scale multiply on the matrix pipe), 3 = the f32 score chain (round 5 default) -- against the oracle's
+    tower, segments of 60 / 32 / 196 patches, the same bound as every other tower test."""
+    from aha_amd import ops
+    from aha_amd.model import MultiModalData
+    cfg, m, o = vl
+    imgs, pv, grid, ids = make_request(cfg, [(160, 96), (64, 128), (224, 224)], 6, 31)
+    o.clear_cache()
+    o.forward_initial(ids, 0, (pv, grid))
+    ref = o.last_image_embeds.numpy()
+    try:
+        ops.attn_variant(smx)
+        emb = m.vision_encode(MultiModalData(pv.to(torch.bfloat16), grid))
+    finally:
+        ops.attn_variant(-1)
+    e_max, e_rms = rel_err(emb[0].float().cpu().numpy(), ref)
+    assert e_max < 0.08 and e_rms < 0.02, f"smx {smx}: visual embeds off: max {e_max:.4f} rms {e_rms:.4f} (in std units)"
+    for k in range(len(cfg.vision.deepstack_visual_indexes)):
+        d_max, d_rms = rel_err(emb[k + 1].float().cpu().numpy(), o.last_deepstack[k].numpy())
+        assert d_max < 0.08 and d_rms < 0.02, f"smx {smx}: deepstack {k} off: max {d_max:.4f} rms {d_rms:.4f}"
