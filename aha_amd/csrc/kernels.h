@@ -178,6 +178,7 @@ bool launch_gemm_streamk(const GemmArgs& a, int tile_n, hipStream_t st);        
 void set_streamk_forced_cut(int code);  // tests: style * 10 + cuts of the last round's tiles (style 0 = equal pieces, 1 = big + remainder); 0 = automatic
 int gemm_streamk_workers();
 int gemm_streamk_cus();                // CUs of the device, rounded down to a multiple of 8            // workgroups of the persistent kernel = CUs - reserved, a multiple of 8
+int get_gemm_reserved_cus();           // the raw setting (-1 = unset)
 void set_gemm_reserved_cus(int n);     // CUs the persistent GEMM leaves free (RCCL beside the GEMMs under TP); < 0: AHA_GEMM_RESERVE_CUS
 int debug_streamk_plan(int M, int N, int K, int tile_n, int workers, int group, size_t ws_bytes, int* out, int cap, int* off_out, int* info);
 void debug_plan_gemm(int M, int N, int K, int act, bool has_bias, bool has_res, size_t ws_bytes, int* out);   // host only: {tile, splitk, n_split}

@@ -148,7 +148,9 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(RopeArgs a) {
       dst[lane + 64] = b1;
       continue;
     }
-    const int tok = *a.kv_start + s;
+    // the cache offset the host named for this call (chunked / context-parallel prefill: the segment's first position) wins over the
+    // step state's, exactly as in the rows kernel (round-4 advisor: with AHA_ROPE_ROWS=0 a second segment landed on pages [0, len))
+    const int tok = (a.kv_start_host >= 0 ? a.kv_start_host : *a.kv_start) + s;
     const int page = tok / KV_PAGE_TOKENS, t = tok % KV_PAGE_TOKENS;
     char* base = reinterpret_cast<char*>(a.kv.page_ptrs[page] + a.kv.layer_off);
     if (is_k) {

@@ -15,6 +15,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -25,6 +26,18 @@
 #include "kernels.h"
 
 namespace aha {
+
+// hipFuncSetAttribute acts on the CURRENT device's copy of a kernel: "once" flags are one bit per device id (a process may drive several
+// GPUs through the device= argument of the Python API).
+struct DevOnce {
+  std::atomic<unsigned long long> mask{0};
+  bool first() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) (void)hipGetLastError();
+    const unsigned long long bit = 1ull << (dev & 63);
+    return !(mask.fetch_or(bit) & bit);
+  }
+};
 
 namespace {
 
@@ -526,11 +539,10 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
   // (> 64 KiB of dynamic LDS needs the opt-in once per kernel instance)
   if constexpr (has_n192<ACT, B, R>()) {
     if (n192 && splitk <= 1 && a.K % BK == 0 && 256.0 * 2.0 * (double)std::max(a.lda, a.ldw) < 1.0e9) {
-      static bool once192 = false;
-      if (!once192) {
+      static DevOnce once192;
+      if (once192.first()) {
         hipFuncSetAttribute((const void*)gemm256q_kernel<ACT, B, R, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute((const void*)gemm256q_kernel<ACT, B, R, true, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        once192 = true;
       }
       // M = 256 q + r with 1 <= r <= 32: the r rows ride as a fifth fragment row of the last row tile (one row of tiles less) -- where
       // that saves a ROUND.  A tile with a fifth row costs 1.28 x a plain one (its wm = 1 waves issue 60 MFMAs per K tile instead of 48),
@@ -556,29 +568,26 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
     // (its staging addresses are 32-bit offsets from the block's first row: 256 rows of an operand must span < 1 GiB)
     const bool q_addr_ok = 256.0 * 2.0 * (double)std::max(a.lda, a.ldw) < 1.0e9;
     if (quad && q_addr_ok && a.K % BK == 0 && (nk >= 32 || !R || (!B && ACT != ACT_GELU_TANH && ACT != ACT_GELU_ERF))) {
-      static bool onceq = false;
-      if (!onceq) {
+      static DevOnce onceq;
+      if (onceq.first()) {
         hipFuncSetAttribute((const void*)gemm256q_kernel<ACT, B, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        onceq = true;
       }
       static const bool bar2 = [] { const char* e = getenv("AHA_GEMM_BAR2"); return e ? atoi(e) != 0 : true; }();
       if (!bar2 && ACT == ACT_NONE && !B && !R) {   // A/B: one barrier per phase
-        static bool once1 = false;
-        if (!once1) {
+        static DevOnce once1;
+        if (once1.first()) {
           hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_NONE, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-          once1 = true;
         }
         hipLaunchKernelGGL((gemm256q_kernel<ACT_NONE, false, false, false>), dim3(ntm * ntn), dim3(256), lds, st, a, nk, 0);
         return;
       }
       static const int abl = [] { const char* e = getenv("AHA_GEMM_ABL"); return e ? atoi(e) : 0; }();
       if (abl >= 1 && abl <= 3 && ACT == ACT_NONE && !B && !R) {   // ablations (debug; results are wrong by construction)
-        static bool once2 = false;
-        if (!once2) {
+        static DevOnce once2;
+        if (once2.first()) {
           hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_NONE, false, false, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
           hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_NONE, false, false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
           hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_NONE, false, false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-          once2 = true;
         }
         if (abl == 1) hipLaunchKernelGGL((gemm256q_kernel<ACT_NONE, false, false, true, 1>), dim3(ntm * ntn), dim3(256), lds, st, a, nk, 0);
         if (abl == 2) hipLaunchKernelGGL((gemm256q_kernel<ACT_NONE, false, false, true, 2>), dim3(ntm * ntn), dim3(256), lds, st, a, nk, 0);
@@ -589,19 +598,17 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
       return;
     }
     {
-      static bool once2 = false;
-      if (!once2) {
+      static DevOnce once2;
+      if (once2.first()) {
         hipFuncSetAttribute((const void*)gemm256p_kernel<ACT, B, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        once2 = true;
       }
       static const int mode = [] { const char* e = getenv("AHA_GEMM_MODE"); return e ? atoi(e) : 0; }();
       if (mode >= 2 && mode <= 4 && ACT == ACT_NONE && !B && !R) {   // ablations (debug; results are wrong by construction)
-        static bool once3 = false;
-        if (!once3) {
+        static DevOnce once3;
+        if (once3.first()) {
           hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_NONE, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
           hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_NONE, false, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
           hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_NONE, false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-          once3 = true;
         }
         if (mode == 2) hipLaunchKernelGGL((gemm256p_kernel<ACT_NONE, false, false, 2>), dim3(ntm * ntn), dim3(512), lds, st, a, zero_block(), nk, nullptr);
         if (mode == 3) hipLaunchKernelGGL((gemm256p_kernel<ACT_NONE, false, false, 3>), dim3(ntm * ntn), dim3(512), lds, st, a, zero_block(), nk, nullptr);
@@ -633,10 +640,9 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
     }
     return;
   }
-  static bool once_p = false;
-  if (!once_p) {
+  static DevOnce once_p;
+  if (once_p.first()) {
     hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_PARTIAL_F32, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    once_p = true;
   }
   GemmArgs p = a;  // pass 1: f32 slabs [splitk][M][N] in the caller's workspace
   p.C = a.workspace;
@@ -647,11 +653,10 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
   const int kps = (nk + splitk - 1) / splitk;
   static const bool quad_sk = [] { const char* e = getenv("AHA_GEMM_QUAD"); return e ? atoi(e) != 0 : true; }();
   if (quad_sk && a.K % BK == 0 && 256.0 * 2.0 * (double)std::max(a.lda, a.ldw) < 1.0e9) {
-    static bool onceq = false;
-    if (!onceq) {
+    static DevOnce onceq;
+    if (onceq.first()) {
       hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_PARTIAL_F32, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_PARTIAL_F32, false, false, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      onceq = true;
     }
     if (n192) hipLaunchKernelGGL((gemm256q_kernel<ACT_PARTIAL_F32, false, false, true, 0, true>), dim3(ntm * ((a.N + 191) / 192), splitk), dim3(256), lds, st, p, kps, 0);
     else hipLaunchKernelGGL((gemm256q_kernel<ACT_PARTIAL_F32, false, false>), dim3(ntm * ntn, splitk), dim3(256), lds, st, p, kps, 0);
@@ -937,11 +942,9 @@ void launch_gemm_grouped(const GemmArgs& a_in, hipStream_t st) {
   const dim3 grid((unsigned)(n192 ? t192 : t256));
 #define AHA_GROUPED(ACT_, NF3_)                                                                                                      \
   do {                                                                                                                                \
-    static bool once = false;                                                                                                         \
-    if (!once) {                                                                                                                      \
+    static DevOnce once;                                                                                                              \
+    if (once.first())                                                                                                                 \
       hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_, false, false, true, 0, NF3_, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      once = true;                                                                                                                    \
-    }                                                                                                                                 \
     hipLaunchKernelGGL((gemm256q_kernel<ACT_, false, false, true, 0, NF3_, false, true>), grid, dim3(256), lds, st, a, nk, 0);        \
   } while (0)
   if (a.act == ACT_NONE) {

@@ -22,7 +22,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <tuple>
 #include <vector>
@@ -297,7 +299,7 @@ SkPlan sk_plan_one(int M, int N, int K, int tile_n, int G, int group, int style,
   return pl;
 }
 
-int g_sk_force_cut = 0;   // tests (set_streamk_forced_cut): style * 10 + cuts; 0 = the planner's choice
+std::atomic<int> g_sk_force_cut{0};   // tests (set_streamk_forced_cut): style * 10 + cuts; 0 = the planner's choice
 
 // best cut of the last round for this shape (all whole tiles when the rounds are full)
 SkPlan sk_plan(int M, int N, int K, int tile_n, int G, int group, size_t ws_bytes, int max_ctrs) {
@@ -306,8 +308,9 @@ SkPlan sk_plan(int M, int N, int K, int tile_n, int G, int group, size_t ws_byte
   SkPlan best;
   const int nk = K / 64;
   for (const auto& cd : cand) {
-    if (g_sk_force_cut > 0 && (cd[0] != g_sk_force_cut / 10 || cd[1] != g_sk_force_cut % 10)) continue;
-    if (g_sk_force_cut == 0 && cd[1] > 1 && nk / (cd[0] ? 2 * cd[1] + 1 : cd[1]) < 4) continue;   // pieces of at least 4 K tiles
+    const int force_cut = g_sk_force_cut.load();
+    if (force_cut > 0 && (cd[0] != force_cut / 10 || cd[1] != force_cut % 10)) continue;
+    if (force_cut == 0 && cd[1] > 1 && nk / (cd[0] ? 2 * cd[1] + 1 : cd[1]) < 4) continue;   // pieces of at least 4 K tiles
     SkPlan p = sk_plan_one(M, N, K, tile_n, G, group, cd[0], cd[1], c);
     if ((size_t)p.n_chunks * SK_CHUNK_BYTES > ws_bytes || p.n_ctrs > max_ctrs) continue;
     if (!best.ok || p.makespan < best.makespan - 1e-9) best = std::move(p);
@@ -315,18 +318,24 @@ SkPlan sk_plan(int M, int N, int K, int tile_n, int G, int group, size_t ws_byte
   return best;
 }
 
-int g_reserved_cus = -1;   // set_gemm_reserved_cus; -1: AHA_GEMM_RESERVE_CUS or 0
+std::atomic<int> g_reserved_cus{-1};   // set_gemm_reserved_cus; -1: AHA_GEMM_RESERVE_CUS or 0
 
+// CU count of the CURRENT device (a process may run GEMMs on several GPUs: the Python API takes device=): cached per device
 int sk_num_cus() {
-  static const int n = [] {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
-      (void)hipGetLastError();
-      cus = 256;
-    }
-    return cus;
-  }();
-  return n;
+  static std::mutex mu;
+  static std::map<int, int> by_dev;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) (void)hipGetLastError();
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = by_dev.find(dev);
+  if (it != by_dev.end()) return it->second;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+    (void)hipGetLastError();
+    cus = 256;
+  }
+  by_dev[dev] = cus;
+  return cus;
 }
 
 // ---- plan cache: one table per (shape, tile, workers) on the device, uploaded on the stream that needs it first --------------------------
@@ -339,29 +348,55 @@ struct SkEntry {
   hipStream_t st = nullptr;
   bool landed = false;
 };
+// Everything below is per DEVICE (round-4 advisor: one process-wide arena put device 1's tables into device 0's memory): the cache key
+// carries the device, every device has its own table arena, and an arena is recycled only after ITS device has been synchronised.
+// Entries are shared_ptr and g_sk_mu is held from the lookup THROUGH the launch (launch_gemm_streamk), so no eviction -- cache limit,
+// arena wrap, set_streamk_forced_cut -- can delete an entry or hand its arena space to another table between a thread's lookup and
+// its kernel launch.
 std::mutex g_sk_mu;
-std::map<std::tuple<int, int, int, int, int, int, int, size_t>, SkEntry*> g_sk_cache;
-char* g_sk_arena = nullptr;
-size_t g_sk_arena_used = 0;
+typedef std::tuple<int, int, int, int, int, int, int, size_t> SkKey;   // (device, M, N, K, tile_n, workers, group, workspace class)
+std::map<SkKey, std::shared_ptr<SkEntry>> g_sk_cache;
+struct SkArena { char* base = nullptr; size_t used = 0; };
+std::map<int, SkArena> g_sk_arena;
 constexpr size_t SK_ARENA_BYTES = (size_t)64 << 20;
 
-// st == nullptr-like "no upload" is expressed by upload = false (the cost estimate of plan_gemm needs the plan only)
-SkEntry* sk_lookup(int M, int N, int K, int tile_n, int G, int group, size_t ws_bytes, hipStream_t st, bool upload) {
+// g_sk_mu held.  Drops the cached plans of `dev` (all devices: dev < 0) after synchronising the device(s) that may still read their tables.
+void sk_drop_entries_locked(int dev, const SkEntry* keep = nullptr) {
+  int cur = 0;
+  if (hipGetDevice(&cur) != hipSuccess) (void)hipGetLastError();
+  std::vector<int> devs;
+  for (auto& kv : g_sk_cache) {
+    const int d = std::get<0>(kv.first);
+    if ((dev < 0 || d == dev) && std::find(devs.begin(), devs.end(), d) == devs.end()) devs.push_back(d);
+  }
+  for (int d : devs) {
+    if (hipSetDevice(d) != hipSuccess || hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+  }
+  if (!devs.empty() && hipSetDevice(cur) != hipSuccess) (void)hipGetLastError();
+  for (auto it = g_sk_cache.begin(); it != g_sk_cache.end();) {
+    const int d = std::get<0>(it->first);
+    if ((dev < 0 || d == dev) && it->second.get() != keep) {
+      if (it->second->ev) hipEventDestroy(it->second->ev);
+      it = g_sk_cache.erase(it);
+    } else {
+      ++it;
+    }
+  }
+  for (auto& kv : g_sk_arena)
+    if (dev < 0 || kv.first == dev) kv.second.used = 0;
+}
+
+// g_sk_mu held by the caller.  upload = false: the plan only (the cost estimate of plan_gemm), no device table.
+std::shared_ptr<SkEntry> sk_lookup_locked(int M, int N, int K, int tile_n, int G, int group, size_t ws_bytes, hipStream_t st, bool upload) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) (void)hipGetLastError();
   const size_t ws_class = std::min<size_t>(ws_bytes / SK_CHUNK_BYTES, 1 << 20);
-  const auto key = std::make_tuple(dev, M, N, K, tile_n, G, group, ws_class);
-  std::lock_guard<std::mutex> lk(g_sk_mu);
+  const SkKey key = std::make_tuple(dev, M, N, K, tile_n, G, group, ws_class);
   auto it = g_sk_cache.find(key);
-  SkEntry* e = it == g_sk_cache.end() ? nullptr : it->second;
+  std::shared_ptr<SkEntry> e = it == g_sk_cache.end() ? nullptr : it->second;
   if (!e) {
-    if (g_sk_cache.size() > 8192) {   // plans without a table are plain host memory; tables are dropped with the arena below
-      (void)hipDeviceSynchronize();
-      for (auto& kv : g_sk_cache) { if (kv.second->ev) hipEventDestroy(kv.second->ev); delete kv.second; }
-      g_sk_cache.clear();
-      g_sk_arena_used = 0;
-    }
-    e = new SkEntry();
+    if (g_sk_cache.size() > 8192) sk_drop_entries_locked(-1);
+    e = std::make_shared<SkEntry>();
     e->plan = sk_plan(M, N, K, tile_n, G, group, ws_bytes, SK_MAX_COUNTERS);
     g_sk_cache[key] = e;
   }
@@ -372,22 +407,19 @@ SkEntry* sk_lookup(int M, int N, int K, int tile_n, int G, int group, size_t ws_
     memcpy(e->h_tab.data(), e->plan.off.data(), (G + 1) * sizeof(int));
     memcpy(e->h_tab.data() + e->hdr, e->plan.segs.data(), e->plan.segs.size() * sizeof(SkSeg));
     const size_t bytes = (e->h_tab.size() * sizeof(int) + 255) / 256 * 256;
-    if (!g_sk_arena && hipMalloc((void**)&g_sk_arena, SK_ARENA_BYTES) != hipSuccess) {
+    SkArena& ar = g_sk_arena[dev];
+    if (!ar.base && hipMalloc((void**)&ar.base, SK_ARENA_BYTES) != hipSuccess) {   // on the CURRENT device = the one the kernel runs on
       (void)hipGetLastError();
+      ar.base = nullptr;
       e->plan.ok = false;
       return e;
     }
-    if (g_sk_arena_used + bytes > SK_ARENA_BYTES) {   // (thousands of shapes later) nothing in flight may still read a table: start over
-      (void)hipDeviceSynchronize();
-      for (auto& kv : g_sk_cache)
-        if (kv.second != e) { if (kv.second->ev) hipEventDestroy(kv.second->ev); delete kv.second; }
-      g_sk_cache.clear();
-      g_sk_cache[key] = e;
-      g_sk_arena_used = 0;
+    if (ar.used + bytes > SK_ARENA_BYTES) {   // (thousands of shapes later) start this device's arena over: nothing in flight may still read a table
+      sk_drop_entries_locked(dev, e.get());
       if (bytes > SK_ARENA_BYTES) { e->plan.ok = false; return e; }
     }
-    e->d_tab = reinterpret_cast<int*>(g_sk_arena + g_sk_arena_used);
-    g_sk_arena_used += bytes;
+    e->d_tab = reinterpret_cast<int*>(ar.base + ar.used);
+    ar.used += bytes;
     // pageable source: the runtime stages the copy before it returns; h_tab lives as long as the entry anyway
     if (hipMemcpyAsync(e->d_tab, e->h_tab.data(), e->h_tab.size() * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(e->ev, st) != hipSuccess) {
@@ -407,11 +439,14 @@ SkEntry* sk_lookup(int M, int N, int K, int tile_n, int G, int group, size_t ws_
 
 template <int ACT, bool B, bool R, bool NF3>
 void sk_launch_one(const GemmArgs& a, const SkEntry* e, hipStream_t st) {
-  static bool once = false;
+  static std::atomic<unsigned long long> done{0};   // the dynamic-LDS attribute is per device: one bit per device id
   const size_t lds = 4 * TILE2_BYTES;
-  if (!once) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) (void)hipGetLastError();
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(done.load() & bit)) {
     hipFuncSetAttribute((const void*)gemm256s_kernel<ACT, B, R, NF3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    once = true;
+    done.fetch_or(bit);
   }
   hipLaunchKernelGGL((gemm256s_kernel<ACT, B, R, NF3>), dim3(e->plan.G), dim3(256), lds, st, a, (const int*)e->d_tab, e->hdr, (float*)a.workspace,
                      (unsigned*)a.sk_counters);
@@ -419,22 +454,18 @@ void sk_launch_one(const GemmArgs& a, const SkEntry* e, hipStream_t st) {
 
 }  // namespace
 
-void set_gemm_reserved_cus(int n) { g_reserved_cus = n; }
+void set_gemm_reserved_cus(int n) { g_reserved_cus.store(n); }
+int get_gemm_reserved_cus() { return g_reserved_cus.load(); }
 void set_streamk_forced_cut(int code) {
   std::lock_guard<std::mutex> lk(g_sk_mu);
-  if (code != g_sk_force_cut) {   // cached plans were made under the other setting: drop them (tables stay in the arena until it wraps)
-    (void)hipDeviceSynchronize();
-    (void)hipGetLastError();
-    for (auto& kv : g_sk_cache) { if (kv.second->ev) hipEventDestroy(kv.second->ev); delete kv.second; }
-    g_sk_cache.clear();
-  }
-  g_sk_force_cut = code;
+  if (code != g_sk_force_cut.load()) sk_drop_entries_locked(-1);   // cached plans were made under the other setting
+  g_sk_force_cut.store(code);
 }
 
 int gemm_streamk_cus() { return sk_num_cus() / 8 * 8; }
 
 int gemm_streamk_workers() {
-  int res = g_reserved_cus;
+  int res = g_reserved_cus.load();
   if (res < 0) {
     static const int env = [] { const char* e = getenv("AHA_GEMM_RESERVE_CUS"); return e ? atoi(e) : 0; }();
     res = env;
@@ -459,7 +490,8 @@ bool streamk_has_kernel(int act, bool has_bias, bool has_res, bool n192) {
 // chunks of the cut tiles, no counters).  *n_chunks / *n_split: what the plan would publish.
 double streamk_estimate(const GemmArgs& a, int tile_n, int* n_chunks, int* n_split) {
   if (a.K % 64 || !a.workspace || !a.sk_counters) return -1.0;
-  const SkEntry* e = sk_lookup(a.M, a.N, a.K, tile_n, gemm_streamk_workers(), a.tile_group, a.workspace_bytes, nullptr, false);
+  std::lock_guard<std::mutex> lk(g_sk_mu);
+  const std::shared_ptr<SkEntry> e = sk_lookup_locked(a.M, a.N, a.K, tile_n, gemm_streamk_workers(), a.tile_group, a.workspace_bytes, nullptr, false);
   if (!e || !e->plan.ok) return -1.0;
   if (n_chunks) *n_chunks = e->plan.n_chunks;
   if (n_split) *n_split = e->plan.n_split_tiles;
@@ -469,7 +501,10 @@ double streamk_estimate(const GemmArgs& a, int tile_n, int* n_chunks, int* n_spl
 bool launch_gemm_streamk(const GemmArgs& a, int tile_n, hipStream_t st) {
   const bool n192 = tile_n == 192;
   if (!streamk_has_kernel(a.act, a.bias != nullptr, a.residual != nullptr, n192) || a.K % 64 || !a.workspace || !a.sk_counters) return false;
-  const SkEntry* e = sk_lookup(a.M, a.N, a.K, tile_n, gemm_streamk_workers(), a.tile_group, a.workspace_bytes, st, true);
+  const int workers = gemm_streamk_workers();
+  std::lock_guard<std::mutex> lk(g_sk_mu);   // from the lookup through the launch: see the plan cache
+  const std::shared_ptr<SkEntry> ep = sk_lookup_locked(a.M, a.N, a.K, tile_n, workers, a.tile_group, a.workspace_bytes, st, true);
+  const SkEntry* e = ep.get();
   if (!e || !e->plan.ok) return false;
   const bool B = a.bias != nullptr, R = a.residual != nullptr;
   if (n192) {

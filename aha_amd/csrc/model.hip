@@ -995,8 +995,14 @@ static int ensure_comm_stream(aha_model* m) {
   // RCCL's kernels run on the communication stream BESIDE the next column block's GEMM.  A grid of one-tile blocks fills every CU with
   // a 512-register wave per SIMD + 128 KiB of LDS, so nothing else can be placed until a block retires; the persistent GEMM kernel takes
   // a worker count instead (kernels_gemm_sk.hip).  Leave 16 CUs (two per XCD) to the collective unless the caller chose a number
-  // (aha_hip_set_gemm_reserved_cus / AHA_GEMM_RESERVE_CUS); process-wide, so it also applies to this rank's other GEMMs from here on.
-  if (!getenv("AHA_GEMM_RESERVE_CUS") && gemm_streamk_workers() == gemm_streamk_cus()) set_gemm_reserved_cus(16);
+  // (aha_hip_set_gemm_reserved_cus / AHA_GEMM_RESERVE_CUS); process-wide while this model's communicator lives.
+  // The setting is restored when this model's communicator is torn down (tp_rccl.hip): un-sharded models and op-level GEMMs of the same
+  // process are planned on all CUs again from then on (round-4 advisor).
+  if (!getenv("AHA_GEMM_RESERVE_CUS") && gemm_streamk_workers() == gemm_streamk_cus()) {
+    m->reserved_cus_prev = get_gemm_reserved_cus();
+    m->reserved_cus_set = true;
+    set_gemm_reserved_cus(16);
+  }
   int lo = 0, hi = 0;
   AHA_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // (numerically lowest = highest priority)
   AHA_HIP_CHECK(hipStreamCreateWithPriority(&m->comm_stream, hipStreamNonBlocking, hi));

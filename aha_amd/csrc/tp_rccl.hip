@@ -93,6 +93,10 @@ void tp_destroy(aha_model* m) {
   m->rccl_comm = nullptr;
   if (m->comm_stream) hipStreamDestroy(m->comm_stream);
   m->comm_stream = nullptr;
+  if (m->reserved_cus_set) {   // the CU reservation of ensure_comm_stream (model.hip) ends with the communication stream
+    set_gemm_reserved_cus(m->reserved_cus_prev);
+    m->reserved_cus_set = false;
+  }
   for (auto& e : m->ev_gemm) {
     if (e) hipEventDestroy(e);
     e = nullptr;

@@ -348,6 +348,51 @@ def guarded(fn, seconds, on_timeout):
         done.set()
 
 
+SHARDED_KEYS = {"cp": ("sharded_prefill", "sharded_ok"), "tp": ("sharded_prefill_tp", "sharded_tp_ok")}
+
+
+def run_sharded_legs(order, run_leg, rank, world, gpus, line, timeout_s, agree=None):
+    """The sharded forms of BASELINE cfg 5's prefill, one leg per entry of `order` ("tp" = ONE tensor-parallel group over all ranks, the
+    form cfg 5 names: RCCL reduce-scatter / all-gather, KV handed back to rank 0; "cp" = context-parallel: full weights per rank, the
+    prompt's rows sharded, one K / V all-gather per layer).  Each leg runs under its own watchdog, writes its own object
+    (`sharded_prefill_tp` / `sharded_prefill`) and its own top-level flag (`sharded_tp_ok` / `sharded_ok`) into `line` on rank 0, builds its
+    own model and communicator (run_leg(mode)), and -- round-4 verdict, item 4c -- an EXCEPTION in one leg does not cost the next one its
+    measurement: before a later leg every rank passes `agree()` (a barrier on the launcher's process group) INSIDE that leg's watchdog, so a
+    rank that is still stuck in the failed leg's collective ends the run through the watchdog instead of deadlocking the next leg.  A hang
+    ends the process (os._exit from the watchdog after rank 0 printed what it has).  Returns True when every leg that ran was clean."""
+    all_clean = True
+    ran = 0
+    for mode in order:
+        if mode not in SHARDED_KEYS:
+            raise SystemExit(f"--sharded-order: unknown leg {mode!r} (cp, tp)")
+        if mode == "tp" and world <= 1:
+            continue                      # one rank: the tensor-parallel form is the single-GPU prefill the context-parallel leg already times
+        key, okkey = SHARDED_KEYS[mode]
+
+        def on_timeout(key=key, okkey=okkey):
+            if rank == 0:
+                line[key] = {"error": f"did not finish within {timeout_s} s (watchdog); everything above this object is complete"}
+                line[okkey] = False
+                print(json.dumps(line), flush=True)
+
+        def leg(mode=mode, first=(ran == 0)):
+            if not first and agree is not None:
+                agree()
+            return run_leg(mode)
+
+        sp, err = guarded(leg, timeout_s, on_timeout)
+        ran += 1
+        if err is None and sp.get("rccl_ranks") != gpus:
+            err = f"rccl_ranks {sp.get('rccl_ranks')} != --gpus {gpus}"
+        if rank == 0:
+            line[key] = sp if err is None else {"error": err}
+            # top level, next to the replica numbers: the process exits 0 either way (the replica line must reach the driver), so a
+            # consumer that reads only the exit code would otherwise see success after a failed or hung sharded leg
+            line[okkey] = bool(err is None and sp["first_token_equal_on_all_ranks"])
+        all_clean = all_clean and err is None
+    return all_clean
+
+
 def self_launch(n: int) -> int:
     """Re-executes this command under torch.distributed.run with n ranks on 127.0.0.1 (a free port) and returns its exit code."""
     import socket
@@ -442,6 +487,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prompt", type=int, default=0, help="override the workload's text prompt length (diagnostics; the JSON names it)")
     ap.add_argument("--host-loop", action="store_true", help="drive decode with forward_step (one host sync per token)")
+    ap.add_argument("--sharded-order", default="tp,cp",
+                    help="order of the sharded cfg 5 legs of a multi-rank run: tp = the tensor-parallel form BASELINE cfg 5 names, cp = context-parallel")
     ap.add_argument("--sharded-prefill", action="store_true",
                     help="also run BASELINE cfg 5 through the TP + image-parallel path (always done when WORLD_SIZE > 1)")
     args = ap.parse_args()
@@ -659,40 +706,15 @@ def main():
     # replica decode number whenever there is more than one rank, so a scaling run of this command covers both.
     clean = True
     if (world > 1 or args.sharded_prefill) and args.workload == "qwen3vl8b" and not shared_device:
-        # This leg has never run on more than one GPU (no multi-GPU box in the build loop): the replica decode numbers above must reach the
-        # driver whatever happens in it.  An exception becomes an "error" entry; a hang (a collective that never completes) is ended by a
-        # watchdog on EVERY rank -- rank 0 prints the line it has, all ranks leave with os._exit so that the launcher returns.
-        def on_timeout():
-            if rank == 0:
-                line["sharded_prefill"] = {"error": f"did not finish within {SHARDED_LEG_TIMEOUT_S} s (watchdog); replica decode numbers above are complete"}
-                line["sharded_ok"] = False
-                print(json.dumps(line), flush=True)
-        # Two forms of the sharded decoder stack, each with its own watchdog: context-parallel first (one collective type, on the compute
-        # stream: the form with the least that can go wrong on first contact with more than one GPU -- and, by the byte counts, the
-        # faster one), then the tensor-parallel form of BASELINE cfg 5's name.  "sharded_prefill" is the context-parallel object,
-        # "sharded_prefill_tp" the tensor-parallel one; each has its own top-level ok flag.
-        sp, err = guarded(lambda: sharded_prefill_bench(rank, world, local_rank, mode="cp"), SHARDED_LEG_TIMEOUT_S, on_timeout)
-        if err is None and sp["rccl_ranks"] != args.gpus:
-            err = f"rccl_ranks {sp['rccl_ranks']} != --gpus {args.gpus}"
-        clean = err is None
-        if rank == 0:
-            line["sharded_prefill"] = sp if err is None else {"error": err}
-            # top level, next to the replica numbers: the process exits 0 either way (the replica line must reach the driver), so a
-            # consumer that reads only the exit code would otherwise see success after a failed or hung sharded leg
-            line["sharded_ok"] = bool(clean and sp["first_token_equal_on_all_ranks"])
-        if clean and world > 1:
-            def on_timeout_tp():
-                if rank == 0:
-                    line["sharded_prefill_tp"] = {"error": f"did not finish within {SHARDED_LEG_TIMEOUT_S} s (watchdog); the context-parallel object above is complete"}
-                    line["sharded_tp_ok"] = False
-                    print(json.dumps(line), flush=True)
-            sp2, err2 = guarded(lambda: sharded_prefill_bench(rank, world, local_rank, mode="tp"), SHARDED_LEG_TIMEOUT_S, on_timeout_tp)
-            if err2 is None and sp2["rccl_ranks"] != args.gpus:
-                err2 = f"rccl_ranks {sp2['rccl_ranks']} != --gpus {args.gpus}"
-            clean = err2 is None
-            if rank == 0:
-                line["sharded_prefill_tp"] = sp2 if err2 is None else {"error": err2}
-                line["sharded_tp_ok"] = bool(clean and sp2["first_token_equal_on_all_ranks"])
+        # These legs have never run on more than one GPU (no multi-GPU box in the build loop): the replica decode numbers above must reach
+        # the driver whatever happens in them (run_sharded_legs: an exception becomes an "error" entry and the NEXT leg still runs; a hang
+        # is ended by a watchdog on every rank).
+        def agree():
+            if world > 1:
+                dist.barrier()
+        order = [x for x in args.sharded_order.split(",") if x]
+        clean = run_sharded_legs(order, lambda mode: sharded_prefill_bench(rank, world, local_rank, mode=mode), rank, world, args.gpus, line,
+                                 SHARDED_LEG_TIMEOUT_S, agree)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

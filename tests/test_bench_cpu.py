@@ -133,3 +133,38 @@ def test_guarded_leg_result_exception_and_watchdog():
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
     assert p.returncode == 0 and "line printed by the watchdog" in p.stdout and "not reached" not in p.stdout
     assert time.time() - t0 < 25
+
+
+def test_sharded_legs_order_and_survival_of_an_exception():
+    """bench.run_sharded_legs (round-4 verdict, item 4c): the tensor-parallel leg -- the form BASELINE cfg 5 names -- runs first by default, an
+    exception in one leg becomes that leg's "error" object and the other leg is still measured (behind an agreement barrier inside its
+    watchdog), each leg has its own top-level flag, and one rank skips the tensor-parallel form."""
+    import bench
+    calls, agreed = [], []
+
+    def run_leg(mode, fail=()):
+        calls.append(mode)
+        if mode in fail:
+            raise RuntimeError(f"{mode} broke")
+        return {"rccl_ranks": 8, "first_token_equal_on_all_ranks": True, "mode": mode}
+
+    line = {}
+    assert bench.run_sharded_legs(["tp", "cp"], run_leg, 0, 8, 8, line, 30, lambda: agreed.append(1)) is True
+    assert calls == ["tp", "cp"] and agreed == [1]            # the agreement precedes the SECOND leg only
+    assert line["sharded_tp_ok"] is True and line["sharded_ok"] is True and line["sharded_prefill"]["mode"] == "cp"
+    # the first leg raises: its object carries the error, its flag is False, the second leg still runs and is clean on its own
+    calls.clear(); agreed.clear(); line = {}
+    clean = bench.run_sharded_legs(["cp", "tp"], lambda m: run_leg(m, fail=("cp",)), 0, 8, 8, line, 30, lambda: agreed.append(1))
+    assert clean is False and calls == ["cp", "tp"] and agreed == [1]
+    assert "cp broke" in line["sharded_prefill"]["error"] and line["sharded_ok"] is False
+    assert line["sharded_tp_ok"] is True and line["sharded_prefill_tp"]["mode"] == "tp"
+    # a communicator smaller than --gpus is an error of that leg
+    line = {}
+    assert bench.run_sharded_legs(["cp"], run_leg, 0, 8, 4, line, 30) is False and "rccl_ranks 8 != --gpus 4" in line["sharded_prefill"]["error"]
+    # one rank: only the context-parallel object (= the single-GPU cfg 5 prefill); other ranks write nothing
+    calls.clear(); line = {}
+    bench.run_sharded_legs(["tp", "cp"], lambda m: dict(run_leg(m), rccl_ranks=1), 0, 1, 1, line, 30)
+    assert calls == ["cp"] and "sharded_prefill_tp" not in line
+    line = {}
+    bench.run_sharded_legs(["tp", "cp"], run_leg, 3, 8, 8, line, 30)
+    assert line == {}
