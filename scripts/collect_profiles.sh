@@ -1,9 +1,9 @@
 #!/bin/bash
-# gpurun_out/ (merged back from the GPU box by gpurun) -> the tracked summaries of the round (ROUND=r04 by default) under profiles/.
+# gpurun_out/ (merged back from the GPU box by gpurun) -> the tracked summaries of the round (ROUND=r05 by default) under profiles/.
 # Run in the build container.
 set -e
 cd "$(dirname "$0")/.."
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 python scripts/stats_to_md.py gpurun_out/prof_cfg3 "rocprofv3 --kernel-trace --stats -- python bench.py --steps 32 --warmup 4 --no-cpu-baseline ($R)" 32 > profiles/${R}_cfg3_kernel_stats.md
 ROUND=$R python scripts/pmc_summary.py > /dev/null
 for w in default qwen3vl8b-cfg5 qwen3-0.6b qwen3-asr qwen3vl8b-text qwen3vl8b-cfg5-tp qwen3vl8b-cfg5-cp qwen3vl8b-video; do

@@ -44,7 +44,11 @@ __device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
 // DQK / DV: padded head dims of the page layout (K fragments per token sub-tile = DQK / 32, V fragments per page = 2 * DV / 16);
 // KST: 16-dim k steps of QK^T that hold non-zero dims (text 8, ViT head_dim 72: 5, audio 4); NWV waves x 32 q rows per block.
 // ABL (debug, results wrong by construction): 2 = no softmax arithmetic, 3 = no staging of the next tile, 4 = no MFMAs.
-template <int DQK, int DV, int KST, int NWV, int ABL = 0>
+// STG: 0 = the next tile travels global -> LDS by LDS-DMA (global_load_lds_dwordx4); 1 = through registers (global_load_dwordx4 at the top
+// of the tile, ds_write_b128 in front of the barrier that ends it)
+// PF: prefetch distance in tiles (LDS stages = PF + 1): 2 = the tile after next is requested at the top of a tile, the end-of-tile wait
+// leaves its pieces in flight (counted vmcnt)
+template <int DQK, int DV, int KST, int NWV, int ABL = 0, int STG = 0, int PF = 1>
 __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DQK >= 128 ? 2 : 3, DQK >= 128 ? 2 : 3))) void attn_prefill32_kernel(AttnPrefillArgs a) {
   constexpr int KSF = DQK / 32, DSF = DV / 16, DT = (DV + 31) / 32;
   constexpr int RING = 6;
@@ -108,8 +112,10 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DQK >=
   typedef const __attribute__((address_space(4))) uint64_t* cptr64_t;
   const cptr64_t ptab = (cptr64_t)(uintptr_t)a.kv.page_ptrs;
   gload(ptab[0], 0);
-  uint64_t pg_next = ptab[__builtin_amdgcn_readfirstlane(min(1, ntiles - 1))];
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the q fragments and the first tile (kernels_attn.hip: why once, here)
+  if (PF == 2) gload(ptab[__builtin_amdgcn_readfirstlane(min(1, ntiles - 1))], 1);
+  uint64_t pg_next = ptab[__builtin_amdgcn_readfirstlane(min(PF, ntiles - 1))];
+  if (PF == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | ((KB + VB + NWV - 1) / NWV));   // vmcnt(pieces of tile 1): tile 0 and the q fragments have landed
+  else __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the q fragments and the first tile (kernels_attn.hip: why once, here)
   __syncthreads();
 
   // lane parts of the fragment addresses (bytes inside a K / V^T tile image)
@@ -123,13 +129,25 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DQK >=
 
   for (int tile = 0; tile < ntiles; ++tile) {
     // unconditional prefetch of the next tile into the other stage (the last iteration re-requests its own tile; nobody reads it)
-    if (ABL != 3) gload(pg_next, (tile + 1) & 1);
-    pg_next = ptab[__builtin_amdgcn_readfirstlane(min(tile + 2, ntiles - 1))];
+    constexpr int NPK = (KB + NWV - 1) / NWV, NPV = (VB + NWV - 1) / NWV;
+    u32x4_t stg[NPK + NPV];
+    if (STG == 0) {
+      if (ABL != 3) gload(pg_next, PF == 2 ? (tile + 2) % 3 : (tile + 1) & 1);
+    } else {
+      const uint64_t kb = pg_next + a.kv.layer_off + (uint64_t)kvhd * KV_PAGE_TOKENS * (DQK * 2);
+      const uint64_t vb = pg_next + a.kv.layer_off + (uint64_t)a.kvh * KV_PAGE_TOKENS * (DQK * 2) + (uint64_t)kvhd * DV * (KV_PAGE_TOKENS * 2);
+#pragma unroll
+      for (int i = 0; i < NPK; ++i) stg[i] = ld16_global(kb + (uint64_t)(min(wave + i * NWV, KB - 1) * 1024 + lane * 16));
+#pragma unroll
+      for (int i = 0; i < NPV; ++i) stg[NPK + i] = ld16_global(vb + (uint64_t)(min(wave + i * NWV, VB - 1) * 1024 + lane * 16));
+    }
+    pg_next = ptab[__builtin_amdgcn_readfirstlane(min(tile + 1 + PF, ntiles - 1))];
     const int t0 = tile * KV_PAGE_TOKENS;
     const bool act = !a.causal || t0 <= a.kv_offset + q0 + 31;   // wave-uniform: the wave's rows see something of the tile
     if (act) {
-      const char* ks_base = smem + (tile & 1) * STAGE_BYTES + k_lane;
-      const char* vs_base = smem + (tile & 1) * STAGE_BYTES + KP * 16;
+      const int stage_cur = PF == 2 ? tile % 3 : (tile & 1);
+      const char* ks_base = smem + stage_cur * STAGE_BYTES + k_lane;
+      const char* vs_base = smem + stage_cur * STAGE_BYTES + KP * 16;
       // ---- S^T = K . Q^T: 2 token halves x KST k steps; consecutive MFMAs alternate between the two accumulators ----------------
       f32x16_t st[2];
 #pragma unroll
@@ -242,7 +260,23 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DQK >=
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's share of the next tile has landed
+    if (STG == 1) {
+      char* dst = smem + ((tile + 1) & 1) * STAGE_BYTES;
+#pragma unroll
+      for (int i = 0; i < NPK; ++i) {
+        const int blk = wave + i * NWV;
+        if (KB % NWV == 0 || blk < KB) *reinterpret_cast<u32x4_t*>(dst + blk * 1024 + lane * 16) = stg[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NPV; ++i) {
+        const int blk = wave + i * NWV;
+        if (VB % NWV == 0 || blk < VB) *reinterpret_cast<u32x4_t*>(dst + KP * 16 + blk * 1024 + lane * 16) = stg[NPK + i];
+      }
+    } else if (PF == 2) {
+      __builtin_amdgcn_s_waitcnt(0x0F70 | ((KB + VB + NWV - 1) / NWV));   // the next tile has landed, the one after it may stay in flight
+    } else {
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's share of the next tile has landed
+    }
     __syncthreads();
   }
 
@@ -670,6 +704,8 @@ void launch_attn_prefill32(const AttnPrefillArgs& a_in, hipStream_t st, bool pip
   a.nqb = (sched_env && a.kvh % 8 == 0 && a.nh % a.kvh == 0) ? nqb : 0;
   dim3 grid = a.nqb ? dim3(nqb * a.nh) : dim3(nqb, a.nh), block(nwv * 64);
   static const int abl = [] { const char* e = getenv("AHA_ATTN_ABL"); return e ? atoi(e) : 0; }();
+  static const int stg_env = [] { const char* e = getenv("AHA_ATTN32_STG"); return e ? atoi(e) : 0; }();
+  static const int pf_env = [] { const char* e = getenv("AHA_ATTN32_PF"); return e ? atoi(e) : 1; }();
   if (a.d == 128) {
     // two stages, or the epilogue's row buffers (32 rows x 272 B per wave) where those are larger (8 waves)
     const size_t lds = std::max<size_t>(2 * KV_PAGE_TOKENS * 2 * (128 + 128), (size_t)nwv * 32 * (4 * 64 + 16));
@@ -679,6 +715,14 @@ void launch_attn_prefill32(const AttnPrefillArgs& a_in, hipStream_t st, bool pip
     } else if (abl == 2 && nwv == 4) hipLaunchKernelGGL((attn_prefill32_kernel<128, 128, 8, 4, 2>), grid, block, lds, st, a);
     else if (abl == 3 && nwv == 4) hipLaunchKernelGGL((attn_prefill32_kernel<128, 128, 8, 4, 3>), grid, block, lds, st, a);
     else if (abl == 4 && nwv == 4) hipLaunchKernelGGL((attn_prefill32_kernel<128, 128, 8, 4, 4>), grid, block, lds, st, a);
+    else if (pf_env == 2 && nwv == 8) {
+      const size_t lds3 = 3 * KV_PAGE_TOKENS * 2 * (128 + 128);
+      static bool once = false;
+      if (!once) { hipFuncSetAttribute((const void*)attn_prefill32_kernel<128, 128, 8, 8, 0, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); once = true; }
+      hipLaunchKernelGGL((attn_prefill32_kernel<128, 128, 8, 8, 0, 0, 2>), grid, block, lds3, st, a);
+    }
+    else if (stg_env && nwv == 8) hipLaunchKernelGGL((attn_prefill32_kernel<128, 128, 8, 8, 0, 1>), grid, block, lds, st, a);
+    else if (stg_env && nwv == 4) hipLaunchKernelGGL((attn_prefill32_kernel<128, 128, 8, 4, 0, 1>), grid, block, lds, st, a);
     else if (nwv == 8) hipLaunchKernelGGL((attn_prefill32_kernel<128, 128, 8, 8>), grid, block, lds, st, a);
     else if (nwv == 2) hipLaunchKernelGGL((attn_prefill32_kernel<128, 128, 8, 2>), grid, block, lds, st, a);
     else hipLaunchKernelGGL((attn_prefill32_kernel<128, 128, 8, 4>), grid, block, lds, st, a);

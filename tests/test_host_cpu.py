@@ -258,6 +258,16 @@ def test_gemm_plans_of_the_baseline_shapes(hip_lib):
     # below one 256-row tile everything stays on the 128^2 kernel; a 41 k-token prompt fills whole rounds unsplit
     assert plan(70, 512, 512) == (128, 1, 0) and plan(255, 4096, 4096)[0] == 128
     assert plan(40980, 6144, 4096) == (256, 1, 0) and plan(40980, 4096, 12288, res=1) == (256, 1, 0)
+    # the other BASELINE configs, as README.md tabulates them (round-4 verdict, item 7): cfg 1 stays on the 128^2 kernel, cfg 2 / cfg 4 (0.6B
+    # widths) and one context-parallel rank of cfg 5 (~5200 compact rows)
+    P = _lib.ACT_SILU_MUL_PAIRS
+    assert [plan(128, 4096, 1024)[0], plan(128, 1024, 2048, res=1)[0], plan(128, 6144, 1024, act=P)[0], plan(128, 1024, 3072, res=1)[0]] == [128] * 4
+    assert (plan(2048, 4096, 1024), plan(2048, 1024, 2048, res=1), plan(2048, 6144, 1024, act=P), plan(2048, 1024, 3072, res=1)) == \
+        ((192, 1, 0), (256, 4, 0), (192, 1, 0), (192, 3, 0))
+    assert (plan(406, 4096, 1024), plan(406, 1024, 2048, res=1), plan(406, 6144, 1024, act=P), plan(406, 1024, 3072, res=1)) == \
+        ((192, 1, 0), (256, 4, 0), (192, 1, 0), (256, 6, 0))
+    assert (plan(5184, 6144, 4096), plan(5184, 4096, 4096, res=1), plan(5184, 24576, 4096, act=P), plan(5184, 4096, 12288, res=1)) == \
+        ((256, 1, 0), (256, 1, 0), (256, 1, 0), (256, 3, 0))
     with pytest.raises(Exception):
         assert hip_lib.aha_hip_debug_plan_gemm(0, 1, 1, 0, 0, 0, 0, (ctypes.c_int32 * 3)()) == 0
 
