@@ -340,9 +340,11 @@ int aha_hip_debug_poison_lds(uint32_t seed, void* stream);
  * [c_row0 + g * c_gstride, + M) (row pitch ldc), clipped to rows < m_total.  act: plain (0) or gate+up pairs (4). */
 int aha_hip_debug_gemm_grouped(const void* A, const void* W, void* C, int32_t M, int32_t N, int32_t K, int32_t ldc, int32_t act,
                                int32_t groups, int32_t a_gstride, int32_t c_gstride, int32_t c_row0, int32_t m_total, void* stream);
-/* Test hook: whether the `* scaling` multiply of the prefill attention's score rounding chain (modules.rs:782-783) runs on the matrix
- * pipe (1: csrc/attn_common.h mfma_diag, the default) or in the vector ALU (0); both give the same bits.  -1 = the default
- * (AHA_ATTN_SMX). */
+/* Test hook: the prefill attention's score chain.  3 (the default since round 5; env AHA_ATTN_SMX) = the scores stay the f32 QK^T
+ * accumulators through scale, mask, maximum and exponential, P is rounded to bf16 once for the P.V product; 1 / 0 = the reference's
+ * eager path, which materialises `q.k^T` and `* scaling` in bf16 (modules.rs:782-783), with the scale multiply on the matrix pipe
+ * (csrc/attn_common.h mfma_diag) / in the vector ALU -- the same bits as each other, the bit-faithful forms.  -1 = back to the
+ * default.  Both chains are held to the same parity bounds (profiles/r05_attn_prefill.md). */
 int aha_hip_debug_attn_variant(int32_t smx);
 /* Test hook: force the GEMM tile (128 or 256) and split-K factor of every following GEMM launch of the process;
  * (0, 0) restores the automatic choice (csrc/kernels_gemm.hip plan_gemm).  tile 1256 / 1192: the persistent kernel on 256- /
