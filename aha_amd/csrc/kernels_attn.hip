@@ -3,7 +3,9 @@
 // /root/reference/src/models/common/modules.rs:757-813; repeat_kv /root/reference/src/utils/tensor_utils.rs:108-124;
 // causal mask tensor_utils.rs:78-106):
 //     scores = bf16(q . k^T) ; scores = bf16(scores * scale) ; (+ -inf above the diagonal) ; softmax ; P . v ; -> bf16
-// q head i reads kv head i / g.  Softmax runs online in f32; P feeds the MFMA as bf16.
+// q head i reads kv head i / g.  Softmax runs online in f32; P feeds the MFMA as bf16.  The two bf16 roundings of the scores are what
+// the DECODE kernels and the prefill kernel's score chains 0 / 1 reproduce; the prefill kernel's default chain since round 5 (SMX 3)
+// keeps the scores in f32 through scale, mask, maximum and exponential (attn_common.h; DESIGN.md section 2, deviation (iii)).
 //
 // Fragment scheme (v_mfma_f32_16x16x32_bf16, wave64; G = lane>>4, c = lane&15):
 //   S^T tile = K . Q^T :  A = K   (row = token c, k = dims G*8..+8  -> 16 B piece `lane` of a fragment-major K fragment)

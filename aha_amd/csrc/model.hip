@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 
 #include "common.h"
 #include "audio.h"
@@ -1637,6 +1638,13 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
   }
   if (n == 1 && !mm) return model_forward_step(m, ids[0], offset, logits_out, argmax_out);
   AHA_HIP_CHECK(hipSetDevice(m->ctx->device));
+  // AHA_PREFILL_TRACE=1: host wall clock of this call's stages on stderr (where the prefill's host side spends its time: the launches
+  // themselves are asynchronous)
+  static const bool ptrace = [] { const char* e = getenv("AHA_PREFILL_TRACE"); return e && atoi(e) != 0; }();
+  const auto pt0 = std::chrono::steady_clock::now();
+  auto pstamp = [&](const char* what) {
+    if (ptrace) fprintf(stderr, "[prefill trace] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - pt0).count());
+  };
   const int S = (int)n;
   const int H = c.hidden_size, I = c.intermediate_size, d = c.head_dim, nh = c.num_attention_heads, kvh = c.num_key_value_heads;
   const int nq = nh * d, nkv = kvh * d;
@@ -1702,7 +1710,9 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
   AHA_HIP_CHECK(hipMemcpyAsync(m->p_ids, ids_up, (size_t)Mloc * 4, hipMemcpyHostToDevice, st));
   AHA_HIP_CHECK(hipMemcpyAsync(m->p_pos, pos_up, 3 * (size_t)Mloc * 4, hipMemcpyHostToDevice, st));
   if ((rc = push_state(m, ids[n - 1], p0, m->cache_len, m->cache_len + n))) return rc;
+  pstamp("ids / positions enqueued");
   AHA_HIP_CHECK(hipStreamSynchronize(st));  // pos / ids are pageable host memory
+  pstamp("... and landed");
 
   {
     ProfScope ps(m, "elem", (double)Mloc * H * 4, 0);
@@ -1711,6 +1721,7 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
   if (has_image) {
     // ViT -> masked_scatter of image embeds into the <|image_pad|> rows (qwen3vl/model.rs:1166-1190)
     if ((rc = vision_forward_and_scatter(m, ids, n, mm, m->p_x))) return rc;
+    pstamp("vision tower enqueued");
   }
   if (has_audio) {
     // audio tower -> masked_scatter into the <|audio_pad|> rows (qwen3_asr/model.rs:343-358)
@@ -1821,7 +1832,10 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
   m->cache_len += n;
   AHA_HIP_CHECK(hipGetLastError());
   if (m->async_rc) { const int e = m->async_rc; m->async_rc = 0; return e; }   // e.g. a failed vocab-parallel all-reduce
-  return fetch_outputs(m, logits_out, argmax_out);
+  pstamp("decoder stack enqueued");
+  rc = fetch_outputs(m, logits_out, argmax_out);
+  pstamp("outputs fetched (GPU done)");
+  return rc;
 }
 
 }  // namespace aha
