@@ -125,6 +125,7 @@ struct aha_model {
   aha_all_gather_fn all_gather_cb = nullptr;
   void* sp_user = nullptr;
   void* rccl_comm = nullptr;
+  void* rccl_comm_side = nullptr;   // a second communicator of the same ranks (ncclCommSplit) for the collectives enqueued on comm_stream
   // sequence-parallel prefill with the collectives of a row-parallel projection overlapped with its GEMM (model.hip
   // gemm_row_parallel): RCCL runs on its own high-priority stream, ordered against the compute stream by events
   hipStream_t comm_stream = nullptr;

@@ -1,7 +1,10 @@
-// RCCL binding of the tensor-parallel seam: one communicator per model, the all-reduce is enqueued
-// on the model's stream.  "nccl" on ROCm is RCCL; rings run over xGMI (7 links x ~153 GB/s per GPU), so the f32 partial
+// RCCL binding of the tensor-parallel seam: the all-reduce is enqueued on the model's stream with the model's
+// communicator; the chunked reduce-scatters / all-gathers that overlap the GEMMs run on the communication stream with a SECOND communicator
+// of the same ranks (ncclCommSplit at init: round-4 advisor -- one communicator shared by two streams was the one construct of the overlap
+// that had never met a second rank; two communicators are independent by construction, at the price of a second set of RCCL buffers).  "nccl" on ROCm is RCCL; rings run over xGMI (7 links x ~153 GB/s per GPU), so the f32 partial
 // of a long prefill (S x 4096 x 4 B) is bandwidth-bound per link -- sized in DESIGN.md.
 #include <rccl/rccl.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "model.h"
@@ -20,9 +23,13 @@ int rccl_allreduce(aha_model* m, float* buf, size_t count) {
 // Sequence-parallel prefill: the same f32 sums as the all-reduce, but each rank receives only its row slice (in place:
 // recvbuff == sendbuff + rank * recvcount), and the bf16 rows of the next GEMM's input are gathered in place
 // (sendbuff == recvbuff + rank * sendcount).
+// the communicator a collective on stream `st` uses: the side one on the communication stream (when it exists), else the model's
+static ncclComm_t comm_for(aha_model* m, hipStream_t st) {
+  return (ncclComm_t)((st && st == m->comm_stream && m->rccl_comm_side) ? m->rccl_comm_side : m->rccl_comm);
+}
 int rccl_reduce_scatter(aha_model* m, float* buf, size_t count_per_rank, hipStream_t st) {
   ncclResult_t r = ncclReduceScatter(buf, buf + (size_t)m->comm_rank * count_per_rank, count_per_rank, ncclFloat, ncclSum,
-                                     (ncclComm_t)m->rccl_comm, st ? st : m->stream);
+                                     comm_for(m, st), st ? st : m->stream);
   if (r != ncclSuccess) {
     set_error(std::string("ncclReduceScatter failed: ") + ncclGetErrorString(r));
     return AHA_ERR_HIP;
@@ -31,7 +38,7 @@ int rccl_reduce_scatter(aha_model* m, float* buf, size_t count_per_rank, hipStre
 }
 int rccl_all_gather(aha_model* m, void* buf, size_t bytes_per_rank, hipStream_t st) {
   ncclResult_t r = ncclAllGather((const char*)buf + (size_t)m->comm_rank * bytes_per_rank, buf, bytes_per_rank, ncclUint8,
-                                 (ncclComm_t)m->rccl_comm, st ? st : m->stream);
+                                 comm_for(m, st), st ? st : m->stream);
   if (r != ncclSuccess) {
     set_error(std::string("ncclAllGather failed: ") + ncclGetErrorString(r));
     return AHA_ERR_HIP;
@@ -65,6 +72,13 @@ int tp_init_rccl(aha_model* m, const void* id128) {
   }
   m->rccl_comm = comm;
   m->comm_rank = m->tp_rank;
+  // the communication stream's own communicator (every rank is here together: the split is a collective on `comm`).  AHA_TP_SIDE_COMM=0
+  // or a failing split leaves the one communicator to both streams (RCCL then orders the two streams' operations itself).
+  const char* e = getenv("AHA_TP_SIDE_COMM");
+  if ((m->tp_size > 1 || (e && atoi(e) == 2)) && !(e && atoi(e) == 0)) {   // (2: also for a group of one -- the world-size-1 smoke test)
+    ncclComm_t side = nullptr;
+    if (ncclCommSplit(comm, 0, m->tp_rank, &side, nullptr) == ncclSuccess && side) m->rccl_comm_side = side;
+  }
   return AHA_OK;
 }
 // the communicator of a context-parallel group (aha_hip_set_context_parallel: full weights on every rank)
@@ -89,6 +103,8 @@ int cp_init_rccl(aha_model* m, const void* id128) {
 }
 
 void tp_destroy(aha_model* m) {
+  if (m->rccl_comm_side) ncclCommDestroy((ncclComm_t)m->rccl_comm_side);
+  m->rccl_comm_side = nullptr;
   if (m->rccl_comm) ncclCommDestroy((ncclComm_t)m->rccl_comm);
   m->rccl_comm = nullptr;
   if (m->comm_stream) hipStreamDestroy(m->comm_stream);

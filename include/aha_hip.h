@@ -266,7 +266,9 @@ int aha_hip_tp_init_rccl(aha_model* m, const void* unique_id128);
  * o_proj / down_proj are REDUCE-SCATTERED over rows (same f32 sums as the all-reduce: identical numerics), the residual add and
  * the next RMSNorm run on the owned rows only, and the normalised bf16 rows are ALL-GATHERED for the next column-parallel
  * GEMM -- (T-1)/T * (4 + 2) bytes per element and rank instead of 2 * (T-1)/T * 4 for the ring all-reduce.
- * Used automatically when the library owns an RCCL communicator (aha_hip_tp_init_rccl); with the host-callback seam install:
+ * Used automatically when the library owns an RCCL communicator (aha_hip_tp_init_rccl; the collectives it overlaps with GEMMs on its
+ * communication stream run on a second communicator of the same ranks, split off at init -- AHA_TP_SIDE_COMM=0 shares the first one);
+ * with the host-callback seam install:
  *   reduce_scatter(buf, count_per_rank): buf holds T * count_per_rank f32 on the device; on return rank r's slice
  *       buf[r*count_per_rank ..) must hold the sum over ranks of that slice (the other slices are undefined);
  *   all_gather(buf, bytes_per_rank): rank r's slice of buf (T * bytes_per_rank bytes) is its contribution; on return every

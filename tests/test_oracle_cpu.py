@@ -140,6 +140,14 @@ def test_bf16_rounding_points_are_small_but_real():
     assert 0 < float((a - b).abs().max()) < 0.1 * std          # bf16 rounding points matter ...
     assert float((a - c).abs().max()) < 0.05 * std              # ... accumulation order barely does
     assert float((a - d).abs().max()) < 0.08 * std              # candle-CPU sub-op rounding of rms_norm: same class
+    # round 5: the eager attention's two score roundings (modules.rs:782-783) as a switch -- what the HIP prefill attention's default
+    # chain leaves out since then.  Same class of effect as the other sub-op roundings.
+    e = oq.OracleQwen3(cfg, w, Numerics("bf16", attn_scores_rounded=False)).forward(ids, 0).reshape(-1)
+    assert 0 < float((a - e).abs().max()) < 0.08 * std
+    # ... and the row-blocked evaluation of the same switch is the same arithmetic
+    e2 = oq.OracleQwen3(cfg, w, Numerics("bf16", matmul_f64=True, attn_scores_rounded=False, attn_row_block=16)).forward(ids, 0).reshape(-1)
+    e1 = oq.OracleQwen3(cfg, w, Numerics("bf16", matmul_f64=True, attn_scores_rounded=False)).forward(ids, 0).reshape(-1)
+    assert torch.equal(e1, e2)
     assert torch.equal(a, torch.tensor(a).bfloat16().float())   # logits are materialised in bf16
 
 

@@ -284,6 +284,17 @@ def test_rccl_world1_smoke(gpu):
     m.debug_allreduce(t)
     assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float32))
     m.close()
+    # round 5: the communication stream's own communicator (ncclCommSplit of the model's at init; tp_rccl.hip) -- forced for a group of one:
+    # the split, the all-reduce beside it and the teardown of both communicators run on this RCCL build
+    import os
+    os.environ["AHA_TP_SIDE_COMM"] = "2"
+    try:
+        m = HipInferenceModel(cfg, qwen3_text_weights(cfg, seed=0), rccl_unique_id=tp_unique_id())
+        m.debug_allreduce(t)
+        assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float32))
+        m.close()
+    finally:
+        del os.environ["AHA_TP_SIDE_COMM"]
 
 
 def test_tp2_two_processes_gloo(gpu):

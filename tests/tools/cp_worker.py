@@ -83,7 +83,12 @@ def main():
         single = HipInferenceModel(cfg, w)
         ref, rtok = single.forward_initial(ids, 0, MultiModalData(pvb, grid))
         s = float(ref.std())
-        assert float(np.abs(got - ref).max()) <= 0.02 * s, f"context-parallel prefill logits: {np.abs(got - ref).max() / s:.4f} std"
+        # sharded vs un-sharded: the ranks' GEMMs run other automatic plans (M-dependent) than the whole prompt's, i.e. other f32 summation
+        # orders -- the bound of tests/test_tp_gpu.py's sharded-vs-unsharded checks (max 0.04 / rms 0.01 std).  (Through round 4 this read
+        # max <= 0.02: the eager path's two bf16 roundings of the scores snapped most of that noise away; with the f32 score chain of round 5
+        # it passes through to the logits -- 0.024 / see the printed rms.)
+        e_max, e_rms = float(np.abs(got - ref).max()) / s, float(np.sqrt(((got - ref) ** 2).mean())) / s
+        assert e_max <= 0.04 and e_rms <= 0.01, f"context-parallel prefill logits: max {e_max:.4f} rms {e_rms:.4f} std"
         rdec, o2 = [rtok], len(ids)
         for i in range(6):                               # teacher-forced with the sharded run's tokens: same inputs on both sides
             rl, t = single.forward_step(dec[i], o2)
@@ -91,7 +96,7 @@ def main():
             o2 += 1
         s2 = float(rl.std())
         assert float(np.abs(lg - rl).max()) <= 0.03 * s2, "decode on the context-parallel cache drifted from the single-GPU run"
-        print(f"CP_WORKER_OK tokens_equal={dec == rdec} all_gather_calls={calls[0]} bytes={calls[1]} phases={sorted(k for k in ph if k.endswith('_s'))}",
+        print(f"CP_WORKER_OK prefill_err_max={e_max:.4f} prefill_err_rms={e_rms:.4f} tokens_equal={dec == rdec} all_gather_calls={calls[0]} bytes={calls[1]} phases={sorted(k for k in ph if k.endswith('_s'))}",
               flush=True)
         single.close()
     m.close()
