@@ -1,6 +1,7 @@
 #!/bin/bash
-# SQ / TCC counters of the prefill attention kernels (scripts/bench_attn.py at S = 8192 causal), one counter group per pass, no tracing
-# domains next to --pmc.  usage (GPU box): bash scripts/r05_attn_pmc.sh <smx> [waves32]   -> gpurun_out/r05_attn_pmc_<smx>_<waves>.txt
+# SQ / TCC counters of the prefill attention kernel (scripts/bench_attn.py at S = 8192 causal), one counter group per pass, no tracing
+# domains next to --pmc.  usage (GPU box): bash scripts/r05_attn_pmc.sh <smx: 0 | 1 | 3> [tag]   -> gpurun_out/r05_attn_pmc_<smx>_<tag>.txt
+# (the second argument was the block shape of the round's retired 32-row experiment; it only names the output now)
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 smx=$1; w=${2:-0}
