@@ -121,6 +121,9 @@ __device__ __forceinline__ void softmax_scores(f32x4_t (&st)[4], float scale, Va
 }
 // k2s = the factor on the score inside the exponent: log2 e for the rounded chains (the scale is already in the scores), scale * log2 e
 // for the f32 chain (SMX 3)
+// SUM = false: no row sum here (the ViT instantiation of the f32 chain takes it from the matrix pipe: a ones row in the V^T pad,
+// kernels_vit.hip vit_rope_pack_kernel) -- 8 packed adds and the l update less per tile
+template <bool SUM = true>
 __device__ __forceinline__ void softmax_probs(const f32x4_t (&st)[4], float m2, float alpha, float& l, bf16x8_t (&pf)[2],
                                               float k2s = 1.4426950408889634f) {
   // two scores per instruction where the ISA has a packed f32 form: e^(s - m) = exp2(fma(s, log2 e, -m log2 e)) as v_pk_fma_f32,
@@ -134,12 +137,14 @@ __device__ __forceinline__ void softmax_probs(const f32x4_t (&st)[4], float m2, 
     const f32x2_t a01 = __builtin_elementwise_fma(s01, k2, nm2), a23 = __builtin_elementwise_fma(s23, k2, nm2);
     const f32x2_t p01 = {__builtin_amdgcn_exp2f(a01[0]), __builtin_amdgcn_exp2f(a01[1])};
     const f32x2_t p23 = {__builtin_amdgcn_exp2f(a23[0]), __builtin_amdgcn_exp2f(a23[1])};
-    psum2 += p01;
-    psum2 += p23;
+    if (SUM) {
+      psum2 += p01;
+      psum2 += p23;
+    }
     pk[sub >> 1][(sub & 1) * 2 + 0] = pack_bf(p01[0], p01[1]);
     pk[sub >> 1][(sub & 1) * 2 + 1] = pack_bf(p23[0], p23[1]);
   }
-  l = l * alpha + (psum2[0] + psum2[1]);
+  if (SUM) l = l * alpha + (psum2[0] + psum2[1]);
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
     u32x4_t u = {pk[kk][0], pk[kk][1], pk[kk][2], pk[kk][3]};

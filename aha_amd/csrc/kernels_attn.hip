@@ -38,6 +38,12 @@ namespace {
 template <int DQK, int DV, int QT, int NWV, bool TRACE = false, int ABL = 0, int SMX = 0>
 __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV == 8 || DQK < 128) ? 4 : 3, 4))) void attn_prefill_kernel(AttnPrefillArgs a, unsigned long long* trace = nullptr) {
   constexpr int KS = DQK / 32, DS = DV / 16;
+  // LSUM (ViT, f32 chain): the softmax row sum comes out of the P.V MFMAs -- V^T row 72 (a pad dim: head_dim 72 in an 80-row block) is 1.0
+  // on every real token (kernels_vit.hip), so output row 72 = sum of the bf16 probabilities the numerator uses, rescaled with it: 8 packed
+  // adds and the l update less per tile.  Same box, A B A B: 120.3 / 120.4 against 128.9 / 128.5 us for the cfg 3 ViT launch.
+  // (Also tried there: the third 32-dim step of QK^T -- 8 real dims + 24 zeros -- as ONE v_mfma_f32_16x16x16_bf16 over dims 64..79 with
+  // 8-byte operands: 126.4 against 116.2 us, slower -- four dependent MFMAs behind 8-byte LDS reads outside the fragment ring.)
+  constexpr bool LSUM = SMX == 3 && DQK == 96 && DV == 80;
   constexpr int RING = (DQK >= 128) ? 6 : 4;  // LDS fragment reads in flight ahead of the MFMA that consumes them
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x [K tile | V^T tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, c = lane & 15;
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
         pf[t][0] = as_frag(u0); pf[t][1] = as_frag(u1);
         l[t] += 1.f;
       } else
-      softmax_probs(st[t], m2[t], alpha[t], l[t], pf[t], SMX == 3 ? a.scale * 1.4426950408889634f : 1.4426950408889634f);
+      softmax_probs<!LSUM>(st[t], m2[t], alpha[t], l[t], pf[t], SMX == 3 ? a.scale * 1.4426950408889634f : 1.4426950408889634f);
       // once the running max has settled alpha is exactly 1 in every lane of the wave: skip the DS*4 multiplies (x * 1 == x)
       if (__builtin_amdgcn_ballot_w64(alpha[t] != 1.f) != 0) {
 #pragma unroll
@@ -286,7 +292,8 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
   constexpr int EPITCH = DV * 2 + 16;   // bytes per LDS row: 16-byte aligned, rows 4 dwords apart in the banks
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    const float lt = group_sum(l[t]);
+    // LSUM: row 72 = fragment ds 4, lane group G = 2, register 0 of q column c
+    const float lt = LSUM ? __shfl(o[t][DS - 1][0], 32 + c, 64) : group_sum(l[t]);
     const float inv = 1.0f / lt;
     if (a.epi_rows) {
       char* wb = smem + wave * (16 * EPITCH);

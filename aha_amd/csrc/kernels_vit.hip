@@ -118,8 +118,8 @@ void launch_pos_embed_add(void* x, const void* table, const int32_t* idx, const 
 // every store is 8 bytes (half a piece of the fragment-major K page, or of the padded q row).  The first 6 lanes of a unit also
 // zero the pad elements 72..95.  cos / sin come from the per-image table (launch_vit_rope_table).
 // V rows take the second block role: 80 lanes per (page, head) -- (token-slot half kk, lane group G, 8-dim chunk) -- load 8 tokens x
-// 8 dims, transpose 8 x 8 in registers and store eight 16-byte pieces of the fragment-major V block; pad dims 72..79 and the
-// slots of a tail page past its last token are written as zeros (they must be finite).
+// 8 dims, transpose 8 x 8 in registers and store eight 16-byte pieces of the fragment-major V block; pad dim 72 is 1.0 on real tokens
+// (the row-sum column, see below), pad dims 73..79 and the slots of a tail page past its last token are zeros (they must be finite).
 // (The first version moved 2 bytes per lane and instruction and ran at 1.5 TB/s: 29 us per call at N = 4096, 2.7 ms at 8 x 2048^2.)
 __global__ __launch_bounds__(256) void vit_rope_pack_kernel(VitRopeArgs a, int n_qk_blocks) {
   const int lane = threadIdx.x & 63;
@@ -193,6 +193,10 @@ __global__ __launch_bounds__(256) void vit_rope_pack_kernel(VitRopeArgs a, int n
     u32x4_t v = {0u, 0u, 0u, 0u};
     if (tslot < cnt && dchunk < 9)
       v = ld16((const bf16_t*)a.qkv + (int64_t)(first + tslot) * 3 * D + 2 * (int64_t)D + (int64_t)h * hd + dchunk * 8);
+    // pad dim 72 = 1.0 on every real token (round 5): V^T . P^T then delivers the softmax row sum in output row 72 -- rescaled with the
+    // accumulators, from the SAME rounded probabilities as the numerator -- and the f32-chain attention kernel drops its own sum
+    // (kernels_attn.hip LSUM).  Rows 72..79 of the output are never stored.
+    if (tslot < cnt && dchunk == 9) v[0] = 0x3F80u;
     in[e][0] = v[0]; in[e][1] = v[1]; in[e][2] = v[2]; in[e][3] = v[3];
   }
   bf16_t* vd = reinterpret_cast<bf16_t*>(a.kv.page_ptrs[page] + a.kv.layer_off) + (int64_t)a.nh * KV_PAGE_TOKENS * VIT_DQK +
