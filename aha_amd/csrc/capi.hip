@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 #include <vector>
 
 #include "common.h"
@@ -344,21 +345,24 @@ int aha_hip_gemm(const void* A, const void* W, void* C, int32_t M, int32_t N, in
   }
   GemmArgs g{};
   g.A = A; g.W = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.bias = bias; g.residual = residual; g.act = act;
-  // op-level entry (tests, scripts): one process-wide split-K scratch, grown on demand; not for concurrent callers
-  static void* ws = nullptr;
-  static size_t ws_bytes = 0;
+  // op-level entry (tests, scripts): one split-K scratch per DEVICE, grown on demand; not for concurrent callers
+  struct OpScratch { void* ws = nullptr; size_t ws_bytes = 0; void* ctrs = nullptr; };
+  static std::map<int, OpScratch> scratch_by_dev;
+  int cur_dev = 0;
+  if (hipGetDevice(&cur_dev) != hipSuccess) (void)hipGetLastError();
+  OpScratch& sc = scratch_by_dev[cur_dev];
   const size_t want = std::max((size_t)4 * M * N * 4, (size_t)96 << 20);   // split-K slabs / >= 384 chunks of the persistent kernel
-  if (want > ws_bytes && want <= ((size_t)1 << 30)) {
-    if (ws) hipFree(ws);
-    ws = nullptr;
-    ws_bytes = 0;
-    if (hipMalloc(&ws, want) == hipSuccess) ws_bytes = want;
+  if (want > sc.ws_bytes && want <= ((size_t)1 << 30)) {
+    if (sc.ws) hipFree(sc.ws);
+    sc.ws = nullptr;
+    sc.ws_bytes = 0;
+    if (hipMalloc(&sc.ws, want) == hipSuccess) sc.ws_bytes = want;
   }
-  static void* ctrs = nullptr;   // the persistent kernel's per-tile counters (zero between launches)
-  if (!ctrs && (hipMalloc(&ctrs, SK_MAX_COUNTERS * 4) != hipSuccess || hipMemset(ctrs, 0, SK_MAX_COUNTERS * 4) != hipSuccess)) ctrs = nullptr;
-  g.workspace = ws;
-  g.workspace_bytes = ws_bytes;
-  g.sk_counters = ws ? ctrs : nullptr;
+  // the persistent kernel's per-tile counters (zero between launches)
+  if (!sc.ctrs && (hipMalloc(&sc.ctrs, SK_MAX_COUNTERS * 4) != hipSuccess || hipMemset(sc.ctrs, 0, SK_MAX_COUNTERS * 4) != hipSuccess)) sc.ctrs = nullptr;
+  g.workspace = sc.ws;
+  g.workspace_bytes = sc.ws_bytes;
+  g.sk_counters = sc.ws ? sc.ctrs : nullptr;
   launch_gemm(g, (hipStream_t)stream);
   AHA_HIP_CHECK(hipGetLastError());
   return AHA_OK;

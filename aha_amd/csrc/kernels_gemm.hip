@@ -16,6 +16,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <map>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -496,12 +498,19 @@ bool launch_reduce_norm(const GemmArgs& a, const float* slabs, int nsl, hipStrea
   }
 }
 
+// 256 zero bytes on the CURRENT device (the K tail of the LDS-DMA kernels reads them): one block per device -- a process may drive several
+// GPUs (round-4 advisor's finding on the stream-K arena, the same construct)
 const void* zero_block() {
-  static void* z = nullptr;
-  if (!z) {
-    hipMalloc(&z, 256);
-    hipMemset(z, 0, 256);
-  }
+  static std::mutex mu;
+  static std::map<int, void*> by_dev;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) (void)hipGetLastError();
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = by_dev.find(dev);
+  if (it != by_dev.end()) return it->second;
+  void* z = nullptr;
+  if (hipMalloc(&z, 256) != hipSuccess || hipMemset(z, 0, 256) != hipSuccess) (void)hipGetLastError();
+  by_dev[dev] = z;
   return z;
 }
 
