@@ -131,6 +131,10 @@ struct AttnPrefillArgs {
   float scale;
   int64_t q_ld;            // elements between consecutive q rows; 0 => nh * padded head dim
   int nqb;                 // set by the launcher: > 0 selects the XCD-aware 1-D block order over nqb q blocks x nh heads
+  // Optional second causal segment in the same launch (context-parallel rank: its late chunk): q / o rows [S, S + S2) of the same
+  // buffers, row S + i sees cache positions <= kv_offset2 + i, < kv_total2.  Needs causal; one launch where the XCD-aware order
+  // applies (the late segment's blocks first, the early one's fill its last round), else two launches.
+  int S2 = 0, kv_offset2 = 0, kv_total2 = 0;
   int epi_rows = 0;        // set by the launcher: output rows stored in row order through LDS (16 B per lane)
 };
 void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st);

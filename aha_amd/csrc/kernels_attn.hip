@@ -53,13 +53,23 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
   // K / V^T pages of one kv head in near lockstep and each page crosses the fabric once per XCD instead of once per block
   // (at 41 k tokens the per-kv-head K/V is 21 MB: in grid order the blocks drift apart and every tile comes from Infinity Cache).
   // Causal launches hand out the long (late) q blocks first.
-  int head, qblk;
+  // Two causal segments in one launch (a.S2 > 0: a context-parallel rank's early and late chunk, csrc/model.hip): q / o rows
+  // [0, S) see the cache through kv_offset, rows [S, S + S2) through kv_offset2; a block belongs to ONE segment, the late segment's
+  // (longer) blocks go first and the early segment's fill the tail of the late one's last round.
+  int head, qblk, seg_rows = a.S, seg_off = a.kv_offset, seg_tot = a.kv_total, seg_row0 = 0;
   if (a.nqb > 0) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int g = a.nh / a.kvh, hpx = a.nh >> 3;  // q heads per kv head / q heads per XCD
     const int hq = slot % hpx, qi = slot / hpx;
     head = (xcd + 8 * (hq / g)) * g + hq % g;
     qblk = a.causal ? a.nqb - 1 - qi : qi;
+    if (a.S2 > 0) {  // launcher: causal, nqb = q blocks of both segments
+      const int nqb2 = (a.S2 + 16 * QT * NWV - 1) / (16 * QT * NWV);
+      if (qi < nqb2) {
+        qblk = nqb2 - 1 - qi;
+        seg_rows = a.S2, seg_off = a.kv_offset2, seg_tot = a.kv_total2, seg_row0 = a.S;
+      }
+    }
   } else {
     head = blockIdx.y;
     qblk = blockIdx.x;
@@ -73,13 +83,13 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
   bf16x8_t qf[QT][KS];
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    const int qrow = min(q0 + t * 16 + c, a.S - 1);
+    const int qrow = seg_row0 + min(q0 + t * 16 + c, seg_rows - 1);
     const bf16_t* qp = (const bf16_t*)a.q + (int64_t)qrow * (a.q_ld ? a.q_ld : (int64_t)a.nh * DQK) + (int64_t)head * DQK;
 #pragma unroll
     for (int k4 = 0; k4 < KS; ++k4) qf[t][k4] = as_frag(ld16(qp + k4 * 32 + G * 8));
   }
-  const int blk_last_q = min(qb + 16 * QT * NWV - 1, a.S - 1);
-  const int last_tok = a.causal ? min(a.kv_offset + blk_last_q, a.kv_total - 1) : a.kv_total - 1;
+  const int blk_last_q = min(qb + 16 * QT * NWV - 1, seg_rows - 1);
+  const int last_tok = a.causal ? min(seg_off + blk_last_q, seg_tot - 1) : seg_tot - 1;
   const int ntiles = last_tok / KV_PAGE_TOKENS + 1;
 
   float m[QT], l[QT];
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
     any = false;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-      act[t] = !a.causal || t0 <= a.kv_offset + q0 + t * 16 + 15;
+      act[t] = !a.causal || t0 <= seg_off + q0 + t * 16 + 15;
       any |= act[t];
     }
     if (!any) return;
@@ -197,11 +207,11 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
       if (!act[t]) continue;
-      const int qpos = a.kv_offset + q0 + t * 16 + c;  // cache position of this lane's q row
-      const int lim = a.causal ? min(qpos, a.kv_total - 1) : a.kv_total - 1;
+      const int qpos = seg_off + q0 + t * 16 + c;  // cache position of this lane's q row
+      const int lim = a.causal ? min(qpos, seg_tot - 1) : seg_tot - 1;
       // Interior tiles (every token visible to every q row of the sub-tile: all but the diagonal / last tile) skip the
       // per-element predicate -- two compares and a select per score in a VALU-bound softmax.
-      const int lim_min = a.causal ? min(a.kv_offset + q0 + t * 16, a.kv_total - 1) : a.kv_total - 1;
+      const int lim_min = a.causal ? min(seg_off + q0 + t * 16, seg_tot - 1) : seg_tot - 1;
       if (ABL == 2) { alpha[t] = 1.f; m2[t] = 0.f; continue; }
       if (t0 + KV_PAGE_TOKENS - 1 <= lim_min)
         softmax_scores<SMX>(st[t], a.scale, [](int) { return true; }, G, m[t], alpha[t], m2[t], dg);
@@ -309,16 +319,16 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int row = it * 4 + (lane >> 4), qr = q0 + t * 16 + row;
-        if (qr < a.S && chunk * 8 < a.d) {     // a.d = real head dim of the output rows: a multiple of 8 on this path (launcher)
+        if (qr < seg_rows && chunk * 8 < a.d) {     // a.d = real head dim of the output rows: a multiple of 8 on this path (launcher)
           const u32x4_t v = *reinterpret_cast<const u32x4_t*>(wb + row * EPITCH + chunk * 16);
-          *reinterpret_cast<u32x4_t*>((bf16_t*)a.o + ((int64_t)qr * a.nh + head) * a.d + chunk * 8) = v;
+          *reinterpret_cast<u32x4_t*>((bf16_t*)a.o + ((int64_t)(seg_row0 + qr) * a.nh + head) * a.d + chunk * 8) = v;
         }
       }
       continue;
     }
     const int qr = q0 + t * 16 + c;
-    if (qr < a.S) {
-      bf16_t* op = (bf16_t*)a.o + ((int64_t)qr * a.nh + head) * a.d;  // a.d = real head dim of the output rows
+    if (qr < seg_rows) {
+      bf16_t* op = (bf16_t*)a.o + ((int64_t)(seg_row0 + qr) * a.nh + head) * a.d;  // a.d = real head dim of the output rows
 #pragma unroll
       for (int ds = 0; ds < DS; ++ds) {
         if (ds * 16 + G * 4 < a.d) {  // head dims come in multiples of 4, so a 4-wide group is all-in or all-out
@@ -478,14 +488,27 @@ void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
   constexpr int qt = 1;  // 2 q sub-tiles per wave were measured slower (300 registers: one wave per SIMD)
   // 8 waves (128 q rows) per staged tile once that still fills the chip's 512 block slots (two 8-wave blocks per CU); below
   // that, 64-row blocks balance a causal launch better (S = 1542 x 32 heads: 44 vs 48 us; equal at 2048, 8 waves ahead from there)
-  int nwv = (a.d != 64 && (int64_t)((a.S + 127) / 128) * a.nh >= 512) ? 8 : 4;
+  int nwv = (a.d != 64 && (int64_t)((a.S + 127) / 128 + (a.S2 + 127) / 128) * a.nh >= 512) ? 8 : 4;
   if (nw_env == 4 || (nw_env == 8 && a.d != 64)) nwv = nw_env;
   static const int sched_env = [] {
     const char* e = getenv("AHA_ATTN_SCHED");
     return e ? atoi(e) : 1;
   }();
-  const int nqb = (a.S + 16 * qt * nwv - 1) / (16 * qt * nwv);
-  a.nqb = (sched_env && a.kvh % 8 == 0 && a.nh % a.kvh == 0) ? nqb : 0;
+  const bool xcd_order = sched_env && a.kvh % 8 == 0 && a.nh % a.kvh == 0;
+  // AHA_ATTN_SEG2=0: a second segment always as its own launch (A/B)
+  static const int seg2_env = [] { const char* e = getenv("AHA_ATTN_SEG2"); return e ? atoi(e) : 1; }();
+  if (a.S2 > 0 && !(a.causal && xcd_order && seg2_env)) {
+    AttnPrefillArgs b = a;
+    b.S2 = 0;
+    launch_attn_prefill(b, st);
+    b.q = (const char*)a.q + (int64_t)a.S * (a.q_ld ? a.q_ld : (int64_t)a.nh * (a.d == 72 ? 96 : a.d)) * 2;
+    b.o = (char*)a.o + (int64_t)a.S * a.nh * a.d * 2;
+    b.S = a.S2, b.kv_offset = a.kv_offset2, b.kv_total = a.kv_total2;
+    launch_attn_prefill(b, st);
+    return;
+  }
+  const int nqb = (a.S + 16 * qt * nwv - 1) / (16 * qt * nwv) + (a.S2 + 16 * qt * nwv - 1) / (16 * qt * nwv);
+  a.nqb = xcd_order ? nqb : 0;
   dim3 grid = a.nqb ? dim3(nqb * a.nh) : dim3(nqb, a.nh), block(nwv * 64);
   // AHA_ATTN_SMX: the score chain.
   //   3 (default since round 5) = the f32 score chain: the scores stay the f32 QK^T accumulators through scale, mask, maximum and

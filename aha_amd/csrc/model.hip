@@ -1762,13 +1762,24 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
       launch_qknorm_rope(r, st);
     }
     if (cp && (rc = cp_gather_kv(m, li, cpp))) return rc;
-    for (const RowSeg& sg : segs) {
+    // A context-parallel rank's two chunks (early + late, adjacent local rows) go out as ONE launch: each alone is a few hundred
+    // blocks -- block rounds and ramp, not tile work, set its time (profiles/r05_shard_rank_time.txt) -- together the early chunk's
+    // short blocks fill the late chunk's last round (kernels_attn.hip, AttnPrefillArgs::S2).
+    const bool one_launch = segs.size() == 2 && segs[1].l0 == segs[0].l0 + segs[0].len && segs[1].r0 > segs[0].r0;
+    for (size_t si = 0; si < segs.size(); ++si) {
+      const RowSeg& sg = segs[si];
       AttnPrefillArgs a{};
       a.q = rows(m->p_q, sg.l0, nq); a.kv = model_kv_layer(m, li); a.o = rows(m->p_attn, sg.l0, nq); a.S = sg.len; a.nh = nh; a.kvh = kvh; a.d = d;
       a.kv_offset = kv_off + sg.r0; a.kv_total = kv_off + sg.r0 + sg.len; a.causal = 1; a.scale = m->attn_scale;
-      const double Lk = a.kv_total;
-      ProfScope ps(m, "attn_prefill", (double)sg.len * nq * 4 + Lk * nkv * 4, 4.0 * sg.len * (a.kv_offset + 0.5 * sg.len) * nq);
+      double Lk = a.kv_total, flops = 4.0 * sg.len * (a.kv_offset + 0.5 * sg.len) * nq, rows_io = sg.len;
+      if (one_launch) {
+        const RowSeg& s2 = segs[1];
+        a.S2 = s2.len; a.kv_offset2 = kv_off + s2.r0; a.kv_total2 = kv_off + s2.r0 + s2.len;
+        Lk = a.kv_total2; flops += 4.0 * s2.len * (a.kv_offset2 + 0.5 * s2.len) * nq; rows_io += s2.len;
+      }
+      ProfScope ps(m, "attn_prefill", rows_io * nq * 4 + Lk * nkv * 4, flops);
       launch_attn_prefill(a, st);
+      if (one_launch) break;
     }
     {
       GemmArgs g{};
