@@ -57,11 +57,14 @@ def make_ranks(cfg, w, world, g):
     return ranks
 
 
-@pytest.mark.parametrize("S,world,tile", [(1100, 2, 256), (1543, 2, 128), (2100, 4, 256), (1030, 3, 128)])
-def test_context_parallel_prefill_is_bit_identical_to_one_gpu(gpu, S, world, tile, monkeypatch):
+# heads (4, 2): a rank's two chunks go out as two attention launches; (16, 8): the XCD-aware block order applies and both chunks ride in
+# ONE launch (csrc/kernels_attn.hip AttnPrefillArgs::S2) -- 64-row blocks at the short prompts, 128-row blocks at 8200 tokens (ragged last page)
+@pytest.mark.parametrize("S,world,tile,heads,kv_heads", [(1100, 2, 256, 4, 2), (1543, 2, 128, 4, 2), (2100, 4, 256, 4, 2), (1030, 3, 128, 4, 2),
+                                                         (1100, 2, 256, 16, 8), (2100, 4, 128, 16, 8), (1030, 3, 256, 16, 8), (8200, 2, 256, 16, 8)])
+def test_context_parallel_prefill_is_bit_identical_to_one_gpu(gpu, S, world, tile, heads, kv_heads, monkeypatch):
     from aha_amd import ops
     from aha_amd.model import HipInferenceModel
-    cfg = tiny_qwen3(layers=3, hidden=512, heads=4, kv_heads=2, inter=1024, vocab=1024)
+    cfg = tiny_qwen3(layers=3, hidden=512, heads=heads, kv_heads=kv_heads, inter=1024, vocab=1024)
     w = qwen3_text_weights(cfg, seed=0)
     ids = [int(x) for x in np.random.default_rng(S).integers(0, cfg.vocab_size, size=S)]
     monkeypatch.setenv("AHA_CP_MIN_ROWS", "64")
@@ -185,8 +188,11 @@ def test_context_parallel_argument_checks(gpu):
     t.close()
 
 
-def test_context_parallel_two_processes_gloo(gpu):
-    """The context-parallel seam across PROCESSES (one per rank, as on a multi-GPU node; here both on the box's single GPU): the K / V
+@pytest.mark.parametrize("seg2", ["1", "0"])
+def test_context_parallel_two_processes_gloo(gpu, seg2):
+    """(seg2: a rank's two chunks in ONE attention launch -- the default -- or in two, AHA_ATTN_SEG2=0: the launcher's fallback for
+    head counts the XCD-aware block order does not cover, csrc/kernels_attn.hip launch_attn_prefill.)
+    The context-parallel seam across PROCESSES (one per rank, as on a multi-GPU node; here both on the box's single GPU): the K / V
     pages staged through host memory and gathered by torch.distributed/gloo inside the callback, image-parallel ViT with a gloo
     all-gather (tests/tools/cp_worker.py).  Ranks must agree bit for bit on logits and greedy tokens; rank 0 checks them against the
     unsharded model; the per-phase diagnosis carries the exchange."""
@@ -194,9 +200,9 @@ def test_context_parallel_two_processes_gloo(gpu):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", AHA_ATTN_SEG2=seg2)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(root, "tests", "tools", "cp_worker.py")]
+           "--master-port", "29541" if seg2 == "1" else "29543", os.path.join(root, "tests", "tools", "cp_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "CP_WORKER_OK" in r.stdout and "kv_all_gather_s" in r.stdout, r.stdout[-2000:]
