@@ -124,6 +124,7 @@ SIGNATURES = {
     "aha_hip_debug_poison_lds": (C.c_int, [C.c_uint32, _P]),
     "aha_hip_debug_gemm_plan": (C.c_int, [C.c_int32, C.c_int32]),
     "aha_hip_debug_attn_variant": (C.c_int, [C.c_int32]),
+    "aha_hip_debug_attn_form": (C.c_int, [C.c_int32]),
     "aha_hip_debug_gemm_grouped": (C.c_int, [_P, _P, _P] + [C.c_int32] * 10 + [_P]),
     "aha_hip_debug_streamk_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_size_t, _P, C.c_int32, _P, _P]),
     "aha_hip_set_gemm_reserved_cus": (C.c_int, [C.c_int32]),

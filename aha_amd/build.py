@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libaha_hip.so")
-SOURCES = ["kernels_elem.hip", "kernels_gemv.hip", "kernels_attn.hip", "kernels_gemm.hip", "kernels_gemm_sk.hip", "kernels_vit.hip", "kernels_audio.hip", "kernels_sample.hip", "sampler_rng.hip", "audio_tower.hip", "audio_pre.hip", "image_pre.hip", "tp_rccl.hip", "loader.hip", "model.hip",
+SOURCES = ["kernels_elem.hip", "kernels_gemv.hip", "kernels_attn.hip", "kernels_attn64.hip", "kernels_gemm.hip", "kernels_gemm_sk.hip", "kernels_vit.hip", "kernels_audio.hip", "kernels_sample.hip", "sampler_rng.hip", "audio_tower.hip", "audio_pre.hip", "image_pre.hip", "tp_rccl.hip", "loader.hip", "model.hip",
            "vision.hip", "vision_tower.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value",
          "-Wno-unused-result"]

@@ -241,6 +241,14 @@ int aha_hip_debug_attn_variant(int32_t smx) {
   set_attn_variant_override(smx);
   return AHA_OK;
 }
+int aha_hip_debug_attn_form(int32_t form) {
+  if (form != -1 && form != 16 && form != 64 && form != 65) {
+    set_error("debug_attn_form: -1 (automatic), 16, 64 or 65");
+    return AHA_ERR_INVALID;
+  }
+  set_attn_form_override(form);
+  return AHA_OK;
+}
 int aha_hip_debug_gemm_plan(int32_t tile, int32_t splitk) {
   const bool sk = tile == 1256 || tile == 1192;   // the persistent kernel; splitk = style * 10 + cuts of the last round (0 = the planner's)
   if ((tile != 0 && tile != 128 && tile != 256 && tile != 192 && !sk) || splitk < 0 || (!sk && splitk > 8) ||

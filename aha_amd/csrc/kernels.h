@@ -136,8 +136,15 @@ struct AttnPrefillArgs {
   // applies (the late segment's blocks first, the early one's fill its last round), else two launches.
   int S2 = 0, kv_offset2 = 0, kv_total2 = 0;
   int epi_rows = 0;        // set by the launcher: output rows stored in row order through LDS (16 B per lane)
+  // head_dim 72 only: every real token's V^T pad row 72 holds 1.0 (kernels_vit.hip vit_rope_pack_kernel), so output row 72 of V^T . P^T is
+  // the softmax row sum and the f32-chain kernels may drop their own.  Only the packer that wrote the pages can promise it: unset, the
+  // kernels keep the f32 sum of the probabilities.
+  int v_ones_row = 0;
 };
 void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st);
+// the one-wave-per-SIMD, 64-q-rows-per-wave form (kernels_attn64.hip); false = not a shape of that kernel, nothing launched
+bool launch_attn_prefill64(const AttnPrefillArgs& a, hipStream_t st, int pipe);
+void set_attn_form_override(int form);     // test hook: -1 = automatic, 16 = the 16-rows-per-wave kernel, 64 / 65 = the 64-row kernel (plain / pipelined)
 void set_attn_variant_override(int smx);   // test hook: -1 = the environment's / default choice
 
 // ACT_PARTIAL_F32: tensor-parallel row-split projection -- C is (M,N) f32, the un-rounded partial sums over this rank's K slice

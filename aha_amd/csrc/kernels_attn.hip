@@ -43,6 +43,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
   // adds and the l update less per tile.  Same box, A B A B: 120.3 / 120.4 against 128.9 / 128.5 us for the cfg 3 ViT launch.
   // (Also tried there: the third 32-dim step of QK^T -- 8 real dims + 24 zeros -- as ONE v_mfma_f32_16x16x16_bf16 over dims 64..79 with
   // 8-byte operands: 126.4 against 116.2 us, slower -- four dependent MFMAs behind 8-byte LDS reads outside the fragment ring.)
+  // Only the packer that wrote the pages can promise the ones row: a.v_ones_row (set by vision_tower.hip); without it the kernel keeps its own sum.
   constexpr bool LSUM = SMX == 3 && DQK == 96 && DV == 80;
   constexpr int RING = (DQK >= 128) ? 6 : 4;  // LDS fragment reads in flight ahead of the MFMA that consumes them
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x [K tile | V^T tile]
@@ -241,7 +242,8 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
         pf[t][0] = as_frag(u0); pf[t][1] = as_frag(u1);
         l[t] += 1.f;
       } else
-      softmax_probs<!LSUM>(st[t], m2[t], alpha[t], l[t], pf[t], SMX == 3 ? a.scale * 1.4426950408889634f : 1.4426950408889634f);
+      if (LSUM && a.v_ones_row) softmax_probs<false>(st[t], m2[t], alpha[t], l[t], pf[t], a.scale * 1.4426950408889634f);
+      else softmax_probs<true>(st[t], m2[t], alpha[t], l[t], pf[t], SMX == 3 ? a.scale * 1.4426950408889634f : 1.4426950408889634f);
       // once the running max has settled alpha is exactly 1 in every lane of the wave: skip the DS*4 multiplies (x * 1 == x)
       if (__builtin_amdgcn_ballot_w64(alpha[t] != 1.f) != 0) {
 #pragma unroll
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     // LSUM: row 72 = fragment ds 4, lane group G = 2, register 0 of q column c
-    const float lt = LSUM ? __shfl(o[t][DS - 1][0], 32 + c, 64) : group_sum(l[t]);
+    const float lt = (LSUM && a.v_ones_row) ? __shfl(o[t][DS - 1][0], 32 + c, 64) : group_sum(l[t]);
     const float inv = 1.0f / lt;
     if (a.epi_rows) {
       char* wb = smem + wave * (16 * EPITCH);
@@ -477,6 +479,8 @@ void launch_attn_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t st) {
 
 static int g_attn_smx_override = -1;
 void set_attn_variant_override(int smx) { g_attn_smx_override = smx; }
+static int g_attn_form_override = -1;
+void set_attn_form_override(int form) { g_attn_form_override = form; }
 
 void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
   if (a_in.S <= 0) return;
@@ -522,6 +526,17 @@ void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
   const uint32_t scale_bits = sb.u;
   int smx = g_attn_smx_override >= 0 ? g_attn_smx_override : smx_env;
   if (smx == 1 && (scale_bits & 0xffffu) != 0) smx = 0;
+  if (smx == 3 && !(a.scale > 0.f)) smx = 0;   // the f32 chain keeps its running maximum in raw score units: needs a positive scale
+  // The kernel form.  AHA_ATTN_FORM / set_attn_form_override: 16 = this file's 16-rows-per-wave kernel, 64 = the one-wave-per-SIMD kernel
+  // with 64 rows per wave (kernels_attn64.hip), 65 = the same software-pipelined inside the wave; unset = automatic: the 64-row form
+  // (f32 chain only) once its 256-row blocks fill the chip.
+  static const int form_env = [] { const char* e = getenv("AHA_ATTN_FORM"); return e ? atoi(e) : -1; }();
+  const int form = g_attn_form_override >= 0 ? g_attn_form_override : form_env;
+  if (smx == 3 && form != 16) {
+    const int64_t blocks64 = (int64_t)((a.S + 255) / 256 + (a.S2 + 255) / 256) * a.nh;
+    const bool auto64 = blocks64 >= 256 && (a.d == 128 || a.d == 72);
+    if ((form == 64 || form == 65 || (form < 0 && auto64)) && launch_attn_prefill64(a_in, st, form == 65 ? 1 : 0)) return;
+  }
   // row-order epilogue stores (AHA_ATTN_EPI_ROWS=0: from the accumulator fragments): 16-byte pieces need head dims in multiples of 8
   // and 16-byte aligned output rows
   static const int epi_env = [] { const char* e = getenv("AHA_ATTN_EPI_ROWS"); return e ? atoi(e) : 1; }();

@@ -449,6 +449,7 @@ int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, cons
       a.o = (char*)v->attn + (size_t)s.start * v->D * 2;
       a.S = (int)s.len; a.nh = v->nh; a.kvh = v->nh; a.d = v->hd; a.kv_offset = 0; a.kv_total = (int)s.len; a.causal = 0;
       a.scale = v->scale;
+      a.v_ones_row = 1;   // launch_vit_rope_pack above wrote 1.0 into V^T pad row 72 of every real token
       ProfScope ps(m, "attn_vit", (double)s.len * v->D * 8, 4.0 * s.len * s.len * v->D);
       launch_attn_prefill(a, st);
     }

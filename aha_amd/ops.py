@@ -92,6 +92,11 @@ def attn_variant(smx: int = -1) -> None:
     check(lib().aha_hip_debug_attn_variant(smx))
 
 
+def attn_form(form: int = -1) -> None:
+    """Test hook: the prefill attention's kernel form (aha_hip_debug_attn_form): 16, 64, 65 (64 pipelined) or -1 = automatic."""
+    check(lib().aha_hip_debug_attn_form(form))
+
+
 def interleave_gate_up(Wg: torch.Tensor, Wu: torch.Tensor) -> torch.Tensor:
     """The model loader's fused layout: 16-row blocks alternating gate / up (csrc/model.hip upload_gate_up)."""
     I, K = Wg.shape

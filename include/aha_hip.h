@@ -348,6 +348,12 @@ int aha_hip_debug_gemm_grouped(const void* A, const void* W, void* C, int32_t M,
  * (csrc/attn_common.h mfma_diag) / in the vector ALU -- the same bits as each other, the bit-faithful forms.  -1 = back to the
  * default.  Both chains are held to the same parity bounds (profiles/r05_attn_prefill.md). */
 int aha_hip_debug_attn_variant(int32_t smx);
+/* Test hook: the prefill attention's kernel form (env AHA_ATTN_FORM).  16 = 16 q rows per wave, two 8-wave (or 4-wave) workgroups per CU
+ * (csrc/kernels_attn.hip: every score chain, every head dim); 64 = one wave per SIMD, 64 q rows per wave on 32x32x16 MFMAs, 256-row
+ * workgroups (csrc/kernels_attn64.hip: f32 score chain, head_dim 128 and the ViT's 72); 65 = the same, software-pipelined inside the wave;
+ * -1 = automatic (the 64-row form once its 256-row blocks fill the chip).  Same rounding points in every form; the accumulation order of
+ * the two MFMA shapes differs, so outputs agree to the parity bound, not bit for bit. */
+int aha_hip_debug_attn_form(int32_t form);
 /* Test hook: force the GEMM tile (128 or 256) and split-K factor of every following GEMM launch of the process;
  * (0, 0) restores the automatic choice (csrc/kernels_gemm.hip plan_gemm).  tile 1256 / 1192: the persistent kernel on 256- /
  * 192-column tiles wherever it has an instantiation and a workspace (128^2 kernel elsewhere). */

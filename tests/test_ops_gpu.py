@@ -616,6 +616,58 @@ def test_attn_prefill_f32_score_chain_peaky_and_long(gpu, smx):
     assert_close_ulps(got2[:, 28 * d:], ref2b, 3, None, f"attn_prefill S=2048 smx {smx} (last kv head)", row_scale=True)
 
 
+@pytest.mark.parametrize("form", [64, 65])
+@pytest.mark.parametrize("S,off", [(1, 0), (5, 0), (31, 0), (32, 0), (33, 0), (64, 0), (65, 0), (130, 0), (255, 0), (256, 0), (257, 0), (300, 0), (600, 0),
+                                   (17, 100), (64, 64), (100, 333), (300, 37)])
+@pytest.mark.parametrize("nh,kvh", [(4, 2), (8, 2), (16, 8)])
+def test_attn_prefill_64_rows_per_wave(gpu, form, S, off, nh, kvh):
+    """Round 6: the one-wave-per-SIMD form of the prefill attention (csrc/kernels_attn64.hip: 256-row workgroups, 64 q rows per wave on
+    v_mfma_f32_32x32x16_bf16, three-stage LDS-DMA ring; 65 = software-pipelined inside the wave) on the f32 score chain's bounds: <= 3 bf16
+    ulp of the row scale against the oracle with the chain's own rounding points, <= 4 against the eager oracle (modules.rs:782-783), causal
+    with offsets and full, ragged lengths around the 32- / 64- / 256-row boundaries, grid order (kvh 2) and XCD order (kvh 8)."""
+    from aha_amd import ops
+    d, L = 128, S + off
+    q, k, v = rnd((S, nh * d), 40), rnd((L, kvh * d), 41), rnd((L, kvh * d), 42)
+    try:
+        ops.attn_form(form)
+        got = ops.attn_prefill(q.to(gpu), k.to(gpu), v.to(gpu), nh, kvh, d, off, True)
+        full = ops.attn_prefill(q.to(gpu), k.to(gpu), v.to(gpu), nh, kvh, d, off, False) if off == 0 else None
+    finally:
+        ops.attn_form(-1)
+    assert_close_ulps(got, _attn_ref(q, k, v, nh, kvh, d, True, off, NM_F32SCORES), 3, None, f"attn_prefill form {form} vs f32-score oracle", row_scale=True)
+    assert_close_ulps(got, _attn_ref(q, k, v, nh, kvh, d, True, off), 4, None, f"attn_prefill form {form} vs eager oracle", row_scale=True)
+    if full is not None:
+        assert_close_ulps(full, _attn_ref(q, k, v, nh, kvh, d, False, 0, NM_F32SCORES), 3, None, f"attn_prefill full form {form}", row_scale=True)
+
+
+@pytest.mark.parametrize("form", [64, 65])
+def test_attn_prefill_64_rows_per_wave_peaky_and_long(gpu, form):
+    """The rescale path (a key that dominates late, after the running maximum had settled and the rescale was being skipped; with the
+    in-wave pipeline the rescale of tile t + 1 follows P.V of tile t) and S = 2048 x 32 heads: 8 blocks per head in the XCD order."""
+    from aha_amd import ops
+    nh, kvh, d, S = 8, 2, 128, 700
+    q, k, v = rnd((S, nh * d), 33), rnd((S, kvh * d), 34, 0.3), rnd((S, kvh * d), 35)
+    k[650] = (q[690, :d] * 2.0).repeat(kvh)   # spikes for the late rows, in tile 10
+    k[40] = (q[300, :d] * 1.5).repeat(kvh)
+    try:
+        ops.attn_form(form)
+        got = ops.attn_prefill(q.to(gpu), k.to(gpu), v.to(gpu), nh, kvh, d, 0, True)
+        S2, nh2, kvh2 = 2048, 32, 8
+        q2, k2, v2 = rnd((S2, nh2 * d), 36), rnd((S2, kvh2 * d), 37), rnd((S2, kvh2 * d), 38)
+        got2 = ops.attn_prefill(q2.to(gpu), k2.to(gpu), v2.to(gpu), nh2, kvh2, d, 0, True)
+        ops.attn_form(16)
+        old2 = ops.attn_prefill(q2.to(gpu), k2.to(gpu), v2.to(gpu), nh2, kvh2, d, 0, True)
+    finally:
+        ops.attn_form(-1)
+    assert_close_ulps(got, _attn_ref(q, k, v, nh, kvh, d, True, 0, NM_F32SCORES), 3, None, f"attn_prefill peaky form {form}", row_scale=True)
+    ref2 = _attn_ref(q2[:, :4 * d], k2[:, :d], v2[:, :d], 4, 1, d, True, 0, NM_F32SCORES)   # the q heads of kv head 0
+    assert_close_ulps(got2[:, :4 * d], ref2, 3, None, f"attn_prefill S=2048 form {form}", row_scale=True)
+    ref2b = _attn_ref(q2[:, 28 * d:], k2[:, 7 * d:], v2[:, 7 * d:], 4, 1, d, True, 0, NM_F32SCORES)   # ... and of kv head 7
+    assert_close_ulps(got2[:, 28 * d:], ref2b, 3, None, f"attn_prefill S=2048 form {form} (last kv head)", row_scale=True)
+    # every head of the long launch against the 16-row kernel (same rounding points, another accumulation order)
+    assert_close_ulps(got2, old2.float().cpu(), 3, None, f"attn_prefill S=2048 form {form} vs the 16-row kernel", row_scale=True)
+
+
 @pytest.mark.parametrize("smx", [0, 1, 3])
 @pytest.mark.parametrize("S", [13, 64, 390, 777])
 def test_attn_prefill_head_dim_64_full(gpu, smx, S):
