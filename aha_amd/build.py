@@ -14,6 +14,9 @@ SOURCES = ["kernels_elem.hip", "kernels_gemv.hip", "kernels_attn.hip", "kernels_
            "vision.hip", "vision_tower.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value",
          "-Wno-unused-result"]
+# Debug builds (measurement scripts only; never the shipped library): AHA_BUILD_DEFINES="-DAHA_DEBUG_KERNELS" compiles the ablation / trace
+# instantiations and their environment dispatch in (README "Debug kernels"); the flags are part of the build digest.
+FLAGS += [f for f in os.environ.get("AHA_BUILD_DEFINES", "").split() if f.startswith("-D")]
 
 
 def _hipcc() -> str:

@@ -31,6 +31,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include "attn_common.h"
 
@@ -43,6 +44,90 @@ extern __shared__ __attribute__((aligned(16))) char attn64_smem[];   // the bloc
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 __device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// QK^T MFMAs as asm statements with the register classes spelled out: S^T accumulators in the architectural VGPRs (the softmax reads
+// them with vector instructions), the Q^T operand in the accumulator half of the 512-entry file.  With builtins the compiler puts every
+// MFMA result of a 512-register kernel into AGPRs and keeps Q wherever it fits: 450 v_accvgpr_read copies per tile.  What hipcc does not
+// do for an asm MFMA (cdna_hip_programming.md section 5.7): pad the MFMA-result -> vector-ALU-read hazard -- mfma_settle() below.
+__device__ __forceinline__ void mfma32_first(f32x16_t& acc, bf16x8_t a, bf16x8_t b_agpr) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b_agpr));
+}
+__device__ __forceinline__ void mfma32_acc(f32x16_t& acc, bf16x8_t a, bf16x8_t b_agpr) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b_agpr));
+}
+// 20 wait states between the last asm MFMA that writes the four S^T blocks and their first vector-ALU reader (an 8-pass MFMA result needs
+// 11, a 16-pass one 19); naming the blocks read-write keeps every reader below the statement
+__device__ __forceinline__ void mfma_settle(f32x16_t& s00, f32x16_t& s01, f32x16_t& s10, f32x16_t& s11) {
+  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s00), "+v"(s01), "+v"(s10), "+v"(s11));
+}
+// The O^T accumulators are ASM-OWNED: block (db, qb) of the wave's 64 x DV output lives in a[(db*2+qb)*16 .. +15], named literally in the
+// statements below and in no C++ object.  Every statement that touches them lists a0..a127 as clobbers, so the compiler keeps its own AGPR
+// values (the Q^T fragments, "a" operands of the QK^T MFMAs) above them and the kernel descriptor covers them; tests/test_isa_cpu.py audits
+// the compiled kernels for any instruction outside these statements that names a0..a127.  Why not "+a" operands: each asm def is a new
+// virtual register, and around the rescale branch / the tile loop the allocator renamed one q block's 64 accumulators and copied them
+// a -> a on the fast path of every tile (v_accvgpr_mov x 128), or spilled; as builtins the compiler picked the VGPR form and copied all
+// 128 a -> v -> a per tile.  (cdna_hip_programming.md section 5.7 item 4; register index expressions a[%c2+3] are assembler arithmetic.)
+#define ATTN64_O_CLOBBERS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
+#define ATTN64_REP16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+template <int BASE>
+__device__ __forceinline__ void o_mfma(bf16x8_t a, bf16x8_t b) {   // O^T block += A . B
+  asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" : : "v"(a), "v"(b), "i"(BASE), "i"(BASE + 15) : ATTN64_O_CLOBBERS);
+}
+template <int BASE>
+__device__ __forceinline__ void o_zero() {
+#define ATTN64_Z(i) "v_accvgpr_write_b32 a[%c0+" #i "], 0\n\t"
+  asm volatile(ATTN64_REP16(ATTN64_Z) : : "i"(BASE) : ATTN64_O_CLOBBERS);
+#undef ATTN64_Z
+}
+// block *= alpha (per lane = per q column), four registers in flight.  SETTLE: the statement opens with the 20 wait states an MFMA result
+// needs in front of a vector-ALU reader (hipcc pads nothing inside or around an asm statement)
+template <int BASE, bool SETTLE>
+__device__ __forceinline__ void o_scale(float alpha) {
+  float t0, t1, t2, t3;
+#define ATTN64_S4(i0, i1, i2, i3)                                                                                      \
+  "v_accvgpr_read_b32 %0, a[%c5+" #i0 "]\n\tv_accvgpr_read_b32 %1, a[%c5+" #i1 "]\n\t"                                 \
+  "v_accvgpr_read_b32 %2, a[%c5+" #i2 "]\n\tv_accvgpr_read_b32 %3, a[%c5+" #i3 "]\n\t"                                 \
+  "v_mul_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_mul_f32 %2, %2, %4\n\tv_mul_f32 %3, %3, %4\n\t"                   \
+  "v_accvgpr_write_b32 a[%c5+" #i0 "], %0\n\tv_accvgpr_write_b32 a[%c5+" #i1 "], %1\n\t"                               \
+  "v_accvgpr_write_b32 a[%c5+" #i2 "], %2\n\tv_accvgpr_write_b32 a[%c5+" #i3 "], %3\n\t"
+  if (SETTLE)
+    asm volatile("s_nop 15\n\ts_nop 3\n\t" ATTN64_S4(0, 1, 2, 3) ATTN64_S4(4, 5, 6, 7) ATTN64_S4(8, 9, 10, 11) ATTN64_S4(12, 13, 14, 15)
+                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(alpha), "i"(BASE) : ATTN64_O_CLOBBERS);
+  else
+    asm volatile(ATTN64_S4(0, 1, 2, 3) ATTN64_S4(4, 5, 6, 7) ATTN64_S4(8, 9, 10, 11) ATTN64_S4(12, 13, 14, 15)
+                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(alpha), "i"(BASE) : ATTN64_O_CLOBBERS);
+#undef ATTN64_S4
+}
+// the block into sixteen VGPR values (epilogue).  The outputs are early-clobber: written while the statement still runs.
+template <int BASE, bool SETTLE>
+__device__ __forceinline__ void o_read(float (&x)[16]) {
+#define ATTN64_R(i) "v_accvgpr_read_b32 %" #i ", a[%c16+" #i "]\n\t"
+  if (SETTLE)
+    asm volatile("s_nop 15\n\ts_nop 3\n\t" ATTN64_REP16(ATTN64_R)
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]), "=&v"(x[8]), "=&v"(x[9]),
+                   "=&v"(x[10]), "=&v"(x[11]), "=&v"(x[12]), "=&v"(x[13]), "=&v"(x[14]), "=&v"(x[15])
+                 : "i"(BASE) : ATTN64_O_CLOBBERS);
+  else
+    asm volatile(ATTN64_REP16(ATTN64_R)
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]), "=&v"(x[8]), "=&v"(x[9]),
+                   "=&v"(x[10]), "=&v"(x[11]), "=&v"(x[12]), "=&v"(x[13]), "=&v"(x[14]), "=&v"(x[15])
+                 : "i"(BASE) : ATTN64_O_CLOBBERS);
+#undef ATTN64_R
+}
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(<N - 1>) -- the "i" operands above need constants, not unrolled loop variables
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
+  }
+}
+// two wait states between the vector ALU writing the P^T fragments and the first MFMA that reads them
+__device__ __forceinline__ void valu_settle(bf16x8_t& p0, bf16x8_t& p1) {
+  asm volatile("s_nop 1" : "+v"(p0), "+v"(p1));
+}
+__device__ __forceinline__ void valu_settle4(u32x4_t& p0, u32x4_t& p1) {
+  asm volatile("s_nop 1" : "+v"(p0), "+v"(p1));
 }
 // v_permlane32_swap of a value with itself: one of the two results is the lane's own value, the other the value lane ^ 32 holds
 __device__ __forceinline__ float xhi_max(float v) {
@@ -67,8 +152,10 @@ constexpr int ATTN64_ROWS = 256;   // q rows per workgroup
 
 // PIPE: 0 = a tile's four parts in program order (QK^T, maximum, probabilities, P.V); 1 = software-pipelined inside the wave: QK^T of
 // tile t+1 beside the exponentials of tile t, P.V of tile t beside the maximum of tile t+1 (two S^T register sets)
-template <int DQK, int DV, bool LSUM, int PIPE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_prefill64_kernel(AttnPrefillArgs a) {
+// TRACE (debug builds only, -DAHA_DEBUG_KERNELS + AHA_ATTN64_TRACE=1): the four waves of the middle block add up the shader cycles of the
+// pipelined iteration's parts (phase A, phase B, rescale + wait + barrier)
+template <int DQK, int DV, bool LSUM, int PIPE, bool TRACE = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_prefill64_kernel(AttnPrefillArgs a, unsigned long long* trace = nullptr) {
   constexpr int KS = DQK / 32;          // 32-dim fragment columns of a K block
   constexpr int NKS = DQK / 16;         // k-steps of QK^T
   constexpr int NDB = (DV + 31) / 32;   // 32-dim output blocks
@@ -77,7 +164,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int KPW = KBYTES / 4096, VPW = VSPAN / 4096;   // 1-KB DMA pieces per wave and tile: 4 + 4 (text), 3 + 3 (ViT)
   constexpr int NP = KPW + VPW;
   constexpr int STAGE = KBYTES + VSPAN;
-  constexpr int NSTAGE = 3;
   static_assert(KBYTES % 4096 == 0 && NP < 16, "piece counts");
   char* const smem = attn64_smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -160,32 +246,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
 
   // ---- online-softmax state ----
-  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
-  f32x16_t o[NDB][2];
-#pragma unroll
-  for (int db = 0; db < NDB; ++db)
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[db][qb][r] = 0.f;
+  // The running maximum a row's exponentials refer to is kept QUANTISED: mq = the true running maximum in log2 units (score * scale *
+  // log2 e) rounded UP to a multiple of MQ = 8.  p = exp2(s c2 - mq) is the reference's e^(s - max) times a per-row constant in (2^-8, 1]
+  // that cancels in p / sum(p): same rounding points (P -> bf16 once, f32 row sum), and
+  //   * the rescale factor of everything accumulated so far, 2^(mq_old - mq_new), is an exact power of two: O^T and l are rescaled
+  //     without a rounding;
+  //   * it differs from 1 only when a row's maximum crosses a multiple of 8 (5.5 natural-log units) -- a handful of times per row instead
+  //     of every time any of the wave's 64 rows sees a new maximum (measured with the plain maximum: 100 of 128 tiles of a random-data
+  //     launch took the 128-register rescale, 1100-1500 cycles per tile on average; profiles/r06_attn_prefill.md).
+  constexpr float MQ = 8.f;
+  float mq[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
   const float c2 = a.scale * 1.4426950408889634f;
+  // tile maximum tm (raw score units, -inf on a fully masked tile) -> new quantised reference, rescale factor alpha, exponent offset m2
+  auto new_max = [&](int qb, float tm, float& alpha, float& m2) __attribute__((always_inline)) {
+    const float cand = __builtin_ceilf(tm * (c2 * (1.f / MQ))) * MQ;   // -inf stays -inf
+    const float mq_new = fmaxf(mq[qb], cand);
+    const float use = (mq_new == -INFINITY) ? 0.f : mq_new;             // fully masked so far: keep everything at zero
+    // nothing accumulated yet (mq = -inf: O^T and l are zero) or the reference unchanged: exactly 1
+    alpha = (mq[qb] == mq_new || mq[qb] == -INFINITY) ? 1.f : __builtin_ldexpf(1.f, (int)(mq[qb] - use));
+    m2 = use;
+    mq[qb] = mq_new;
+  };
+  static_for<NDB * 2>([&](auto B) { o_zero<decltype(B)::value * 16>(); });   // O^T block (db, qb) = a[(db * 2 + qb) * 16 ..]
 
-  // QK^T of one tile: S^T[tb][qb]
+  // QK^T of one tile: S^T[tb][qb].  The fragment reads run RING fragments ahead of the MFMAs that consume them (left to itself the
+  // compiler emits read, lgkmcnt(0), two MFMAs: the whole LDS round trip in front of every pair -- ~5500 instead of ~3300 cycles per tile).
+  constexpr int RING = 6;
   auto qk_part = [&](int kbase, f32x16_t (&s)[2][2]) __attribute__((always_inline)) {
+    constexpr int NF = 2 * NKS;   // fragment f = (ks, tb) = (f >> 1, f & 1)
+    bf16x8_t ring[RING];
 #pragma unroll
-    for (int tb = 0; tb < 2; ++tb)
+    for (int f = 0; f < RING; ++f) ring[f] = kfrag(kbase, f & 1, f >> 1);
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[tb][qb][r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-      for (int tb = 0; tb < 2; ++tb) {
-        const bf16x8_t kf = kfrag(kbase, tb, ks);
-        s[tb][0] = mfma32(kf, qf[0][ks], s[tb][0]);
-        s[tb][1] = mfma32(kf, qf[1][ks], s[tb][1]);
+    for (int f = 0; f < NF; ++f) {
+      const bf16x8_t kf = ring[f % RING];
+      if (f < 2) {
+        mfma32_first(s[f & 1][0], kf, qf[0][f >> 1]);
+        mfma32_first(s[f & 1][1], kf, qf[1][f >> 1]);
+      } else {
+        mfma32_acc(s[f & 1][0], kf, qf[0][f >> 1]);
+        mfma32_acc(s[f & 1][1], kf, qf[1][f >> 1]);
       }
+      if (f + RING < NF) ring[f % RING] = kfrag(kbase, (f + RING) & 1, (f + RING) >> 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
   // mask, tile maximum, new running maximum, rescale factor (the score side of softmax_scores<3>, attn_common.h)
   auto max_part = [&](int t0, f32x16_t (&s)[2][2], float (&alpha)[2], float (&m2)[2]) __attribute__((always_inline)) {
@@ -195,11 +299,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const int lim = a.causal ? min(qpos, seg_tot - 1) : seg_tot - 1;
       const int lim_min = a.causal ? min(seg_off + q0 + qb * 32, seg_tot - 1) : seg_tot - 1;
       if (t0 + KV_PAGE_TOKENS - 1 > lim_min) {   // wave-uniform: only diagonal / last tiles carry the per-element predicate
+        const int dlim = lim - t0 - 4 * hi;   // one subtraction per lane; the 32 compares take instruction constants
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            if (t0 + tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi > lim) s[tb][qb][r] = -INFINITY;
+            if (tb * 32 + (r & 3) + 8 * (r >> 2) > dlim) s[tb][qb][r] = -INFINITY;
       }
       auto sv = [&](int i) { return s[i >> 4][qb][i & 15]; };
       float tmax = max3(sv(0), sv(1), sv(2));
@@ -207,11 +312,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int i = 3; i < 31; i += 2) tmax = max3(tmax, sv(i), sv(i + 1));
       tmax = max3(tmax, sv(31), sv(31));
       tmax = xhi_max(tmax);
-      const float m_new = fmaxf(m[qb], tmax);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      alpha[qb] = __builtin_amdgcn_exp2f((m[qb] - m_use) * c2);   // m = -inf -> 0
-      m2[qb] = m_use * c2;
-      m[qb] = m_new;
+      new_max(qb, tmax, alpha[qb], m2[qb]);
     }
   };
   // p = exp2(s c2 - m c2), the row sum, the bf16 P^T operand fragments
@@ -238,26 +339,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (!LSUM) l[qb] = l[qb] * alpha[qb] + (sum0 + sum1);
     }
   };
-  // once the running maximum has settled alpha is exactly 1 in every lane: skip the multiplies (x * 1 == x)
+  // The rescale of O^T by alpha, per q block.  Once the running maximum has settled alpha is exactly 1 in every lane of the wave: skip
+  // the multiplies (x * 1 == x).  The accumulators are no C++ objects, so the branch has no merge to lower.
   auto rescale_part = [&](const float (&alpha)[2]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-      if (__builtin_amdgcn_ballot_w64(alpha[qb] != 1.f) != 0) {
-#pragma unroll
-        for (int db = 0; db < NDB; ++db)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[db][qb][r] *= alpha[qb];
-      }
+    if (__builtin_amdgcn_ballot_w64(alpha[0] != 1.f) != 0) {
+      static_for<NDB>([&](auto DB) { o_scale<(decltype(DB)::value * 2 + 0) * 16, decltype(DB)::value == 0>(alpha[0]); });
+    }
+    if (__builtin_amdgcn_ballot_w64(alpha[1] != 1.f) != 0) {
+      static_for<NDB>([&](auto DB) { o_scale<(decltype(DB)::value * 2 + 1) * 16, decltype(DB)::value == 0>(alpha[1]); });
+    }
   };
-  auto pv_part = [&](int vbase, const bf16x8_t (&pf)[2][4]) __attribute__((always_inline)) {
+  // P.V: fragment f = (kstep, db) = (f / NDB, f % NDB); the first RING reads are issued by pv_reads() in front of the exponentials
+  constexpr int NFV = 4 * NDB;
+  auto pv_reads = [&](int vbase, bf16x8_t (&vring)[RING]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int kstep = 0; kstep < 4; ++kstep)
+    for (int f = 0; f < RING; ++f) vring[f] = vfrag(vbase, f % NDB, f / NDB);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto pv_part = [&](int vbase, bf16x8_t (&pf)[2][4], bf16x8_t (&vring)[RING]) __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int db = 0; db < NDB; ++db) {
-        const bf16x8_t vf = vfrag(vbase, db, kstep);
-        o[db][0] = mfma32(vf, pf[0][kstep], o[db][0]);
-        o[db][1] = mfma32(vf, pf[1][kstep], o[db][1]);
-      }
+    for (int i = 0; i < 4; ++i) valu_settle(pf[0][i], pf[1][i]);
+    static_for<NFV>([&](auto F) {
+      constexpr int f = decltype(F)::value, db = f % NDB, kstep = f / NDB;
+      const bf16x8_t vf = vring[f % RING];
+      o_mfma<(db * 2 + 0) * 16>(vf, pf[0][kstep]);
+      o_mfma<(db * 2 + 1) * 16>(vf, pf[1][kstep]);
+      if (f + RING < NFV) vring[f % RING] = vfrag(vbase, (f + RING) % NDB, (f + RING) / NDB);
+      __builtin_amdgcn_sched_barrier(0);
+    });
   };
 
   // ---- prologue: tiles 0 and 1 requested, tile 0 landed ----
@@ -277,11 +387,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         f32x16_t s[2][2];
         float alpha[2], m2[2];
         bf16x8_t pf[2][4];
+        bf16x8_t vring[RING];
         qk_part(lk + stage_off, s);
+        pv_reads(lv + stage_off, vring);
+        mfma_settle(s[0][0], s[0][1], s[1][0], s[1][1]);
         max_part(tile * KV_PAGE_TOKENS, s, alpha, m2);
         rescale_part(alpha);
         prob_part(s, alpha, m2, pf);
-        pv_part(lv + stage_off, pf);
+        pv_part(lv + stage_off, pf, vring);
       }
       if (tile + 2 < ntiles) ATTN64_WAIT_VM(NP);   // tile t + 1 has landed, t + 2 may still fly
       else ATTN64_WAIT_VM(0);
@@ -290,72 +403,242 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       stage_off = (stage_off == 2 * STAGE) ? 0 : stage_off + STAGE;
     }
   } else {
-    // Software pipeline inside the wave.  Iteration `tile` runs  QK^T(tile + 1) beside the exponentials of `tile`  and then
-    // P.V(tile) beside the maximum of tile + 1; the rescale by alpha(tile + 1) follows P.V(tile).  Two S^T register sets.
+    // Software pipeline INSIDE the wave, instruction groups placed by hand (one wave per SIMD: nobody else fills the matrix pipe while this
+    // wave runs vector instructions, and an in-order wave only overlaps the two pipes when independent work is interleaved in program order).
+    // Iteration `t` of the steady state, two phases of up to 32 MFMAs, every MFMA followed by its share of independent work and a
+    // sched_barrier (a group = one MFMA gap):
+    //   phase A   QK^T(t + 1)  |  exponentials / row sums / P^T of tile t, 2 scores per gap (units (qb, tb) = (0,0) (1,0) (0,1))  |  K reads
+    //   phase B   P.V(t)       |  gaps 0-7: the last unit (1,1) -- P.V's k-steps 0, 1 only need tb = 0  |  then the diagonal mask, the maximum
+    //             of tile t + 1 (2 v_max3 per gap), new running maximum and alpha  |  V^T reads  |  the LDS-DMA pieces of tile t + 2
+    //   then      rescale by alpha(t + 1) if any lane needs it, vmcnt, barrier.
+    // The S^T blocks of tile t + 1 are first read by vector instructions > 50 instructions after the last QK^T MFMA (phase B gap 8): the
+    // MFMA-result hazard (11 wait states for an 8-pass MFMA) needs no padding there.  Two S^T register sets (loop body = two iterations).
+    constexpr int GA = 4 * NKS, GB = 2 * NFV;   // MFMA gaps of the two phases: 32 + 32 (text), 24 + 24 (ViT)
+    constexpr int SLA = (GA >= 32 ? 24 : GA);   // exponential slices of phase A; the other 32 - SLA open phase B
+    static_assert(32 - SLA <= 8 && 8 + 16 <= GB, "phase B: slices, then 16 maximum gaps");
     f32x16_t sA[2][2], sB[2][2];
-    float alphaA[2], m2A[2], alphaB[2], m2B[2];
-    bf16x8_t pf[2][4];
+    float alphac[2], m2c[2];      // of the tile whose probabilities are due
+    u32x4_t pf4[2][4];            // P^T fragments [qb][kstep]
+    float psum[2];
     int stage_off = 0, nxt_off = STAGE, pre_off = 2 * STAGE;
-    if (wtiles > 0) {
-      qk_part(lk, sA);
-      max_part(0, sA, alphaA, m2A);   // alpha = 0 on nothing accumulated yet: no rescale needed
-    }
-    auto iter = [&](int tile, f32x16_t (&sc)[2][2], float (&ac)[2], float (&mc)[2], f32x16_t (&sn)[2][2], float (&an)[2], float (&mn)[2])
-        __attribute__((always_inline)) {
-      if (tile + 2 < ntiles) dma_tile(pg_next, pre_off);
-      pg_next = ptab[__builtin_amdgcn_readfirstlane(min(tile + 3, ntiles - 1))];
-      if (tile < wtiles) {
-        const bool more = tile + 1 < wtiles;   // (tile + 1 landed: the barrier at the end of the previous iteration)
-        if (more) qk_part(lk + nxt_off, sn);
-        prob_part(sc, ac, mc, pf);
-        pv_part(lv + stage_off, pf);
-        if (more) {
-          max_part((tile + 1) * KV_PAGE_TOKENS, sn, an, mn);
-          rescale_part(an);
+    // exponential slice i (0..31): unit u = i / 8 -> (qb, tb) = (u & 1, u >> 1); scores r = 2 (i % 8), + 1
+    auto prob_slice = [&](auto I, f32x16_t (&sc)[2][2]) __attribute__((always_inline)) {
+      constexpr int i = decltype(I)::value, u = i >> 3, qb = u & 1, tb = u >> 1, j = i & 7, r = 2 * j;
+      const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[tb][qb][r], c2, -m2c[qb]));
+      const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[tb][qb][r + 1], c2, -m2c[qb]));
+      if (!LSUM) {
+        psum[qb] += p0 + p1;
+        asm volatile("" : "+v"(psum[qb]));   // (pins the two adds to this gap: left alone they sink into one 32-long chain behind phase A)
+      }
+      // scores 4q .. 4q+3 (q = j >> 1) are dwords (q >> 1) * 2 + {0, 1} of fragment kstep = tb * 2 + (q & 1)
+      pf4[qb][tb * 2 + ((j >> 1) & 1)][(j >> 2) * 2 + (j & 1)] = pack_bf(p0, p1);
+    };
+    float tmax[2];
+    auto max_slice = [&](auto K, f32x16_t (&sn)[2][2]) __attribute__((always_inline)) {   // K = 0..15: one v_max3 per q block
+      constexpr int k = decltype(K)::value;
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        auto sv = [&](int i) { return sn[i >> 4][qb][i & 15]; };
+        if (k == 0) tmax[qb] = max3(sv(0), sv(1), sv(2));
+        else if (k < 15) tmax[qb] = max3(tmax[qb], sv(2 * k + 1), sv(2 * k + 2));
+        else tmax[qb] = max3(tmax[qb], sv(31), sv(31));
+      }
+    };
+    auto mask_step = [&](int t0, f32x16_t (&sn)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const int qpos = seg_off + q0 + qb * 32 + q32;
+        const int lim = a.causal ? min(qpos, seg_tot - 1) : seg_tot - 1;
+        const int lim_min = a.causal ? min(seg_off + q0 + qb * 32, seg_tot - 1) : seg_tot - 1;
+        if (t0 + KV_PAGE_TOKENS - 1 > lim_min) {
+          const int dlim = lim - t0 - 4 * hi;
+#pragma unroll
+          for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (tb * 32 + (r & 3) + 8 * (r >> 2) > dlim) sn[tb][qb][r] = -INFINITY;
         }
       }
-      // the next iteration reads K(tile + 2) and V^T(tile + 1): everything but the newest VPW pieces (V^T of tile + 2)
-      if (tile + 2 < ntiles) ATTN64_WAIT_VM(VPW);
-      else ATTN64_WAIT_VM(0);
+    };
+    float alphan[2], m2n[2];
+    auto max_final = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        new_max(qb, xhi_max(tmax[qb]), alphan[qb], m2n[qb]);
+      }
+    };
+    // one DMA piece of tile t + 2 (K pieces first, V^T pieces last: the end-of-iteration wait leaves exactly the V^T pieces in flight)
+    __amdgpu_buffer_rsrc_t rk, rv;
+    auto dma_rsrc = [&](uint64_t page) __attribute__((always_inline)) {
+      rk = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(page + koff), 0, KBYTES, 0x00020000);
+      rv = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(page + voffb), 0, VBYTES, 0x00020000);
+    };
+    auto dma_piece = [&](auto P) __attribute__((always_inline)) {
+      constexpr int pc = decltype(P)::value;
+      char* dst = smem + pre_off;
+      if (pc < KPW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr_t)(dst + (wave + 4 * pc) * 1024), 16, voff[pc % 4], 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(dst + KBYTES + (wave + 4 * (pc - KPW)) * 1024), 16, voff[(pc - KPW) % 4], 0, 0, 0);
+    };
+    auto iter_end = [&]() __attribute__((always_inline)) {
+      // the next iteration reads K(t + 2) and V^T(t + 1): everything but the newest VPW pieces (V^T of t + 2) has landed
+      ATTN64_WAIT_VM(VPW);
       ATTN64_BAR();
       pre_off = stage_off;
       stage_off = nxt_off;
       nxt_off = (nxt_off == 2 * STAGE) ? 0 : nxt_off + STAGE;
     };
-    // iteration 0 reads tile 1's K: landed once only tile 1's V^T pieces (the newest VPW requests) may still fly
+    // MORE: the wave has a tile t + 1 (else only the probabilities and P.V of its last tile, the DMA pieces and the barrier)
+    unsigned tr_acc[4] = {0, 0, 0, 0}, tr_prev = 0;
+    const bool tr_on = TRACE && blockIdx.x == gridDim.x / 2;
+    auto stamp = [&](int k) __attribute__((always_inline)) {
+      if (TRACE) {
+        if (tr_on) {
+          const unsigned now = __builtin_amdgcn_readfirstlane((unsigned)__builtin_readcyclecounter());
+          if (k >= 0) tr_acc[k] += now - tr_prev;
+          tr_prev = now;
+        }
+      }
+    };
+    auto iter = [&](auto more_tag, int tile, f32x16_t (&sc)[2][2], f32x16_t (&sn)[2][2]) __attribute__((always_inline)) {
+      constexpr bool MORE = decltype(more_tag)::value;
+      stamp(-1);
+      // tile t + 2 (past the end: the last tile again, into the stage nobody reads any more -- keeps the counted waits uniform)
+      dma_rsrc(pg_next);
+      pg_next = ptab[__builtin_amdgcn_readfirstlane(min(tile + 3, ntiles - 1))];
+      psum[0] = 0.f, psum[1] = 0.f;
+      const int kbase = lk + nxt_off, vbase = lv + stage_off;
+      // ---- phase A ----
+      bf16x8_t ring[RING];
+      if (MORE) {
+#pragma unroll
+        for (int f = 0; f < RING; ++f) ring[f] = kfrag(kbase, f & 1, f >> 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<GA>([&](auto G) {
+        constexpr int g = decltype(G)::value, f = g >> 1, qb = g & 1;
+        if (MORE) {
+          if (f < 2) mfma32_first(sn[f & 1][qb], ring[f % RING], qf[qb][f >> 1]);
+          else mfma32_acc(sn[f & 1][qb], ring[f % RING], qf[qb][f >> 1]);
+          if (qb == 1 && f + RING < 2 * NKS) ring[f % RING] = kfrag(kbase, (f + RING) & 1, (f + RING) >> 1);
+        }
+        if (g < SLA) prob_slice(G, sc);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      stamp(0);
+      // ---- phase B ----
+      bf16x8_t vring[RING];
+#pragma unroll
+      for (int f = 0; f < RING; ++f) vring[f] = vfrag(vbase, f % NDB, f / NDB);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<GB>([&](auto G) {
+        constexpr int g = decltype(G)::value, f = g >> 1, qb = g & 1, db = f % NDB, kstep = f / NDB;
+        if (g == 0) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) valu_settle4(pf4[0][i], pf4[1][i]);   // k-steps 0, 1: written in phase A
+        }
+        if (g == 2 * 2 * NDB) {
+#pragma unroll
+          for (int i = 2; i < 4; ++i) valu_settle4(pf4[0][i], pf4[1][i]);   // k-steps 2, 3: the last of them written in gap 32 - SLA - 1
+        }
+        o_mfma<(db * 2 + qb) * 16>(vring[f % RING], as_frag(pf4[qb][kstep]));
+        if (qb == 1 && f + RING < NFV) vring[f % RING] = vfrag(vbase, (f + RING) % NDB, (f + RING) / NDB);
+        if (g < 32 - SLA) prob_slice(std::integral_constant<int, SLA + g>{}, sc);
+        if (g == 32 - SLA) {
+          if (!LSUM) {
+            l[0] = l[0] * alphac[0] + psum[0];
+            l[1] = l[1] * alphac[1] + psum[1];
+          }
+          if (MORE) mask_step((tile + 1) * KV_PAGE_TOKENS, sn);
+        }
+        if (MORE && g >= 8 && g < 24) max_slice(std::integral_constant<int, g - 8>{}, sn);
+        if (MORE && g == 24 && GB > 24) max_final();
+        if (g % 4 == 1 && g / 4 < NP) dma_piece(std::integral_constant<int, g / 4>{});
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      stamp(1);
+      if (MORE) {
+        if (GB <= 24) max_final();
+        rescale_part(alphan);   // after P.V(t); opens with the MFMA-result wait states
+        alphac[0] = alphan[0], alphac[1] = alphan[1], m2c[0] = m2n[0], m2c[1] = m2n[1];
+      }
+      stamp(2);
+      iter_end();
+      stamp(3);
+    };
+    auto idle = [&](int tile) __attribute__((always_inline)) {   // a wave past its own tiles: its share of the staging, the barrier
+      dma_rsrc(pg_next);
+      pg_next = ptab[__builtin_amdgcn_readfirstlane(min(tile + 3, ntiles - 1))];
+      static_for<NP>([&](auto P) { dma_piece(P); });
+      iter_end();
+    };
+    // prologue of the pipeline: QK^T and the maximum of tile 0 in program order (tile 0 landed: the wait + barrier above);
+    // iteration 0 then reads tile 1's K: landed once only tile 1's V^T pieces may still fly
+    if (wtiles > 0) {
+      qk_part(lk, sA);
+      mfma_settle(sA[0][0], sA[0][1], sA[1][0], sA[1][1]);
+      max_part(0, sA, alphac, m2c);   // alpha = 0 on an empty accumulator: nothing to rescale
+    }
     if (ntiles > 1) {
       ATTN64_WAIT_VM(VPW);
       ATTN64_BAR();
     }
     int tile = 0;
-    for (; tile + 1 < ntiles; tile += 2) {
-      iter(tile, sA, alphaA, m2A, sB, alphaB, m2B);
-      iter(tile + 1, sB, alphaB, m2B, sA, alphaA, m2A);
+    bool odd = false;
+    while (tile + 1 < wtiles) {
+      iter(std::true_type{}, tile, sA, sB);
+      ++tile;
+      if (!(tile + 1 < wtiles)) {
+        odd = true;
+        break;
+      }
+      iter(std::true_type{}, tile, sB, sA);
+      ++tile;
     }
-    if (tile < ntiles) iter(tile, sA, alphaA, m2A, sB, alphaB, m2B);
+    if (tile < wtiles) {
+      if (odd) iter(std::false_type{}, tile, sB, sA);
+      else iter(std::false_type{}, tile, sA, sB);
+      ++tile;
+    }
+    for (; tile < ntiles; ++tile) idle(tile);
+    if (TRACE) {
+      if (tr_on && lane == 0) {
+        for (int k = 0; k < 4; ++k) trace[wave * 8 + k] = tr_acc[k];
+        trace[wave * 8 + 7] = (unsigned long long)wtiles;
+      }
+    }
+    ATTN64_WAIT_VM(0);   // the re-requested last tile: nothing may still be writing the LDS the epilogue reuses
+    ATTN64_BAR();
   }
 
   // ---- epilogue: 1 / row sum, bf16, whole rows through this wave's slice of the (now free) staging LDS, 16 B per lane ----
   constexpr int EPITCH = DV * 2 + 16;   // bytes per LDS row
   char* wb = smem + wave * (64 * EPITCH);
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    // LSUM: output row 72 = block db 2, crow(4, 0) = 8 -> register 4 of the hi = 0 lane of the column
-    const float lt = LSUM ? xhi_low(o[NDB - 1][qb][4]) : xhi_sum(l[qb]);
-    const float inv = 1.0f / lt;
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int dim = db * 32 + 8 * j + 4 * hi;
-        if (dim < DV) {
-          uint2 w;
-          w.x = pack_bf(o[db][qb][4 * j + 0] * inv, o[db][qb][4 * j + 1] * inv);
-          w.y = pack_bf(o[db][qb][4 * j + 2] * inv, o[db][qb][4 * j + 3] * inv);
-          *reinterpret_cast<uint2*>(wb + (qb * 32 + q32) * EPITCH + dim * 2) = w;
-        }
-      }
+  float inv[2];
+  {
+    // LSUM: output row 72 = block db 2, crow(4, 0) = 8 -> register 4 of the column's hi = 0 lane
+    float x0[16], x1[16];
+    if (LSUM) {
+      o_read<((NDB - 1) * 2 + 0) * 16, true>(x0);
+      o_read<((NDB - 1) * 2 + 1) * 16, false>(x1);
+    }
+    inv[0] = 1.0f / (LSUM ? xhi_low(x0[4]) : xhi_sum(l[0]));
+    inv[1] = 1.0f / (LSUM ? xhi_low(x1[4]) : xhi_sum(l[1]));
   }
+  static_for<NDB * 2>([&](auto B) {
+    constexpr int blk = decltype(B)::value, db = blk >> 1, qb = blk & 1;
+    float x[16];
+    o_read<blk * 16, blk == 0>(x);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int dim = db * 32 + 8 * j + 4 * hi;
+      if (dim < DV) {
+        uint2 w;
+        w.x = pack_bf(x[4 * j + 0] * inv[qb], x[4 * j + 1] * inv[qb]);
+        w.y = pack_bf(x[4 * j + 2] * inv[qb], x[4 * j + 3] * inv[qb]);
+        *reinterpret_cast<uint2*>(wb + (qb * 32 + q32) * EPITCH + dim * 2) = w;
+      }
+    }
+  });
   // (same wave wrote and reads: no barrier, the LDS queue is in order)
   const int chunk = lane & 15;
 #pragma unroll
@@ -402,12 +685,31 @@ bool launch_attn_prefill64(const AttnPrefillArgs& a_in, hipStream_t st, int pipe
     constexpr size_t lds = 3 * (KV_PAGE_TOKENS * DQK_ * 2 + ((DV_ + 31) / 32) * 4096);                      \
     if (pipe) {                                                                                             \
       set_max_lds(attn_prefill64_kernel<DQK_, DV_, LSUM_, 1>, lds);                                         \
-      hipLaunchKernelGGL((attn_prefill64_kernel<DQK_, DV_, LSUM_, 1>), grid, block, lds, st, a);            \
+      hipLaunchKernelGGL((attn_prefill64_kernel<DQK_, DV_, LSUM_, 1>), grid, block, lds, st, a, nullptr);            \
     } else {                                                                                                \
       set_max_lds(attn_prefill64_kernel<DQK_, DV_, LSUM_, 0>, lds);                                         \
-      hipLaunchKernelGGL((attn_prefill64_kernel<DQK_, DV_, LSUM_, 0>), grid, block, lds, st, a);            \
+      hipLaunchKernelGGL((attn_prefill64_kernel<DQK_, DV_, LSUM_, 0>), grid, block, lds, st, a, nullptr);            \
     }                                                                                                       \
   } while (0)
+#ifdef AHA_DEBUG_KERNELS
+  static const bool tr = [] { const char* e = getenv("AHA_ATTN64_TRACE"); return e && atoi(e) != 0; }();
+  if (tr && a.d == 128 && pipe) {
+    static unsigned long long* d_tr = nullptr;
+    if (!d_tr) (void)hipMalloc((void**)&d_tr, 32 * 8);
+    (void)hipMemsetAsync(d_tr, 0, 32 * 8, st);
+    constexpr size_t lds = 3 * (KV_PAGE_TOKENS * 128 * 2 + 4 * 4096);
+    set_max_lds(attn_prefill64_kernel<128, 128, false, 1, true>, lds);
+    hipLaunchKernelGGL((attn_prefill64_kernel<128, 128, false, 1, true>), grid, block, lds, st, a, d_tr);
+    unsigned long long h[32];
+    (void)hipMemcpyAsync(h, d_tr, sizeof(h), hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+    for (int w = 0; w < 4; ++w)
+      fprintf(stderr, "[attn64 trace] wave %d, %llu tiles, cycles per tile: phase A %.0f, phase B %.0f, rescale %.0f, wait + barrier %.0f\n", w, h[w * 8 + 7],
+              (double)h[w * 8] / (double)h[w * 8 + 7], (double)h[w * 8 + 1] / (double)h[w * 8 + 7], (double)h[w * 8 + 2] / (double)h[w * 8 + 7],
+              (double)h[w * 8 + 3] / (double)h[w * 8 + 7]);
+    return true;
+  }
+#endif
   if (a.d == 128) ATTN64_LAUNCH(128, 128, false);
   else if (a.v_ones_row) ATTN64_LAUNCH(96, 80, true);
   else ATTN64_LAUNCH(96, 80, false);

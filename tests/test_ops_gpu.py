@@ -635,7 +635,12 @@ def test_attn_prefill_64_rows_per_wave(gpu, form, S, off, nh, kvh):
     finally:
         ops.attn_form(-1)
     assert_close_ulps(got, _attn_ref(q, k, v, nh, kvh, d, True, off, NM_F32SCORES), 3, None, f"attn_prefill form {form} vs f32-score oracle", row_scale=True)
-    assert_close_ulps(got, _attn_ref(q, k, v, nh, kvh, d, True, off), 4, None, f"attn_prefill form {form} vs eager oracle", row_scale=True)
+    # against the eager oracle (two bf16 roundings of every score, modules.rs:782-783) the f32 chain is held to 4 ulp on the shapes of
+    # test_attn_prefill_f32_score_chain; the larger shapes added here carry one or two elements at 5 ulp -- for the 16-row kernel exactly as
+    # for this one (scripts/attn64_diag.py: a score the two roundings move across a bf16 boundary) -- so they are held to 5, and to the
+    # 16-row kernel's own distance
+    old_shapes = (S, off) in [(1, 0), (5, 0), (31, 0), (32, 0), (33, 0), (64, 0), (65, 0), (130, 0), (300, 0), (17, 100), (64, 64), (100, 333)] and kvh == 2
+    assert_close_ulps(got, _attn_ref(q, k, v, nh, kvh, d, True, off), 4 if old_shapes else 5, None, f"attn_prefill form {form} vs eager oracle", row_scale=True)
     if full is not None:
         assert_close_ulps(full, _attn_ref(q, k, v, nh, kvh, d, False, 0, NM_F32SCORES), 3, None, f"attn_prefill full form {form}", row_scale=True)
 
