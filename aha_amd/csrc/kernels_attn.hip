@@ -528,14 +528,20 @@ void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
   if (smx == 1 && (scale_bits & 0xffffu) != 0) smx = 0;
   if (smx == 3 && !(a.scale > 0.f)) smx = 0;   // the f32 chain keeps its running maximum in raw score units: needs a positive scale
   // The kernel form.  AHA_ATTN_FORM / set_attn_form_override: 16 = this file's 16-rows-per-wave kernel, 64 = the one-wave-per-SIMD kernel
-  // with 64 rows per wave (kernels_attn64.hip), 65 = the same software-pipelined inside the wave; unset = automatic: the 64-row form
-  // (f32 chain only) once its 256-row blocks fill the chip.
+  // with 64 rows per wave (kernels_attn64.hip) with a tile's parts in program order, 65 = the same software-pipelined inside the wave;
+  // unset = automatic: form 65 (f32 chain only) once its 256-row blocks fill the chip.
   static const int form_env = [] { const char* e = getenv("AHA_ATTN_FORM"); return e ? atoi(e) : -1; }();
   const int form = g_attn_form_override >= 0 ? g_attn_form_override : form_env;
   if (smx == 3 && form != 16) {
     const int64_t blocks64 = (int64_t)((a.S + 255) / 256 + (a.S2 + 255) / 256) * a.nh;
-    const bool auto64 = blocks64 >= 256 && (a.d == 128 || a.d == 72);
-    if ((form == 64 || form == 65 || (form < 0 && auto64)) && launch_attn_prefill64(a_in, st, form == 65 ? 1 : 0)) return;
+    // One 4-wave workgroup per CU: a full launch is rounds of 256 workgroups.  Same-box A/B against the 16-row kernel (scripts/attn64_ab.py,
+    // 32 heads x head_dim 128, profiles/r06_attn_prefill.md): full attention 2048 / 3072 / 4096 / 8192 rows = 1 / 1.5 / 2 / 4 rounds:
+    // 64 vs 75, 165 vs 160, 234 vs 273, 959 vs 1143 us -- ahead wherever the last round is at least ~80 % full; causal (long blocks first, the
+    // rounds blur): 62 vs 55 us at 2048 rows, 95 vs 98 at 3072, 139 vs 154 at 4096, 0.51 vs 0.58 ms at 8192, 11.7 vs 13.5 ms at 40 980.
+    const int64_t rounds64 = (blocks64 + 255) / 256;
+    const bool fills = a.causal ? blocks64 >= 384 : (blocks64 >= 256 && blocks64 * 5 >= rounds64 * 256 * 4);
+    const bool auto64 = fills && (a.d == 128 || a.d == 72);
+    if ((form == 64 || form == 65 || (form < 0 && auto64)) && launch_attn_prefill64(a_in, st, form == 64 ? 0 : 1)) return;
   }
   // row-order epilogue stores (AHA_ATTN_EPI_ROWS=0: from the accumulator fragments): 16-byte pieces need head dims in multiples of 8
   // and 16-byte aligned output rows

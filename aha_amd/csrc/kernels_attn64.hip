@@ -341,12 +341,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
   // The rescale of O^T by alpha, per q block.  Once the running maximum has settled alpha is exactly 1 in every lane of the wave: skip
   // the multiplies (x * 1 == x).  The accumulators are no C++ objects, so the branch has no merge to lower.
+  constexpr int NB = NDB;
   auto rescale_part = [&](const float (&alpha)[2]) __attribute__((always_inline)) {
     if (__builtin_amdgcn_ballot_w64(alpha[0] != 1.f) != 0) {
-      static_for<NDB>([&](auto DB) { o_scale<(decltype(DB)::value * 2 + 0) * 16, decltype(DB)::value == 0>(alpha[0]); });
+      static_for<NB>([&](auto DB) { o_scale<(decltype(DB)::value * 2 + 0) * 16, decltype(DB)::value == 0>(alpha[0]); });
     }
     if (__builtin_amdgcn_ballot_w64(alpha[1] != 1.f) != 0) {
-      static_for<NDB>([&](auto DB) { o_scale<(decltype(DB)::value * 2 + 1) * 16, decltype(DB)::value == 0>(alpha[1]); });
+      static_for<NB>([&](auto DB) { o_scale<(decltype(DB)::value * 2 + 1) * 16, decltype(DB)::value == 0>(alpha[1]); });
     }
   };
   // P.V: fragment f = (kstep, db) = (f / NDB, f % NDB); the first RING reads are issued by pv_reads() in front of the exponentials
@@ -405,33 +406,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   } else {
     // Software pipeline INSIDE the wave, instruction groups placed by hand (one wave per SIMD: nobody else fills the matrix pipe while this
     // wave runs vector instructions, and an in-order wave only overlaps the two pipes when independent work is interleaved in program order).
-    // Iteration `t` of the steady state, two phases of up to 32 MFMAs, every MFMA followed by its share of independent work and a
-    // sched_barrier (a group = one MFMA gap):
-    //   phase A   QK^T(t + 1)  |  exponentials / row sums / P^T of tile t, 2 scores per gap (units (qb, tb) = (0,0) (1,0) (0,1))  |  K reads
-    //   phase B   P.V(t)       |  gaps 0-7: the last unit (1,1) -- P.V's k-steps 0, 1 only need tb = 0  |  then the diagonal mask, the maximum
-    //             of tile t + 1 (2 v_max3 per gap), new running maximum and alpha  |  V^T reads  |  the LDS-DMA pieces of tile t + 2
+    // A tile's vector work is 64 exponentials per lane at a quarter of the plain rate (16 cycles each: half of the ~1900 vector cycles of a
+    // tile, against 2048 matrix cycles), so it is spread ONE SCORE PER MFMA GAP over three phases (a score = fma, exp, add, half a cvt_pk:
+    // ~26 cycles under a 32-cycle MFMA).  Iteration `t` of the steady state, every MFMA followed by its share and a sched_barrier:
+    //   phase A   QK^T(t + 1)  |  scores E .. E + NA of tile t (chunk order = the order P.V's k-steps consume P^T)               |  K reads
+    //   phase B   P.V(t)       |  gaps 0 .. SB: the last scores of tile t (k-step c of P.V starts at gap c * 2 NDB: its chunk is complete)
+    //                          |  gap M0: the diagonal mask of tile t + 1; gaps M0 .. M0 + 15: its maximum, 2 v_max3 per gap; gap MF: the new
+    //                          |  quantised maximum; gaps MF + 1 ..: the first E scores of tile t + 1  |  V^T reads  |  LDS-DMA pieces of tile t + 2
     //   then      rescale by alpha(t + 1) if any lane needs it, vmcnt, barrier.
-    // The S^T blocks of tile t + 1 are first read by vector instructions > 50 instructions after the last QK^T MFMA (phase B gap 8): the
-    // MFMA-result hazard (11 wait states for an 8-pass MFMA) needs no padding there.  Two S^T register sets (loop body = two iterations).
-    constexpr int GA = 4 * NKS, GB = 2 * NFV;   // MFMA gaps of the two phases: 32 + 32 (text), 24 + 24 (ViT)
-    constexpr int SLA = (GA >= 32 ? 24 : GA);   // exponential slices of phase A; the other 32 - SLA open phase B
-    static_assert(32 - SLA <= 8 && 8 + 16 <= GB, "phase B: slices, then 16 maximum gaps");
+    // The S^T blocks of tile t + 1 are first read by vector instructions in gap M0 = 5 of phase B, > 25 instructions behind the last QK^T
+    // MFMA: the MFMA-result hazard (11 wait states for an 8-pass MFMA) needs no padding there.  Two S^T register sets (loop body = two
+    // iterations).
+    // (The row sum on the matrix pipe -- one more MFMA per k-step and q block with a fragment of ones as A, 8 MFMAs instead of 64
+    // v_add_f32 per tile -- was built and measured: phase A 1270 -> 1180 cycles, phase B 1690 -> 2144 for its 8 more gaps, 0.96 -> 1.06 ms at
+    // S = 8192: a gap of phase B costs ~53 cycles whatever it holds, section 3 of profiles/r06_attn_prefill.md.  Not kept.)
+    constexpr bool DMA_IN_A = true;
+    constexpr int KG = 2 * NDB;                        // MFMA gaps of one P.V k-step
+    constexpr int GA = 4 * NKS, GB = 4 * KG;           // MFMA gaps of the two phases: 32 + 32 (text), 24 + 24 (ViT)
+    constexpr int M0 = 5, MF = M0 + 16;                // phase B gaps of the maximum
+    constexpr int E = GB - 1 - MF;                     // scores of tile t + 1 done at the end of phase B(t): 10 (text), 2 (ViT)
+    constexpr int SB = (22 < 3 * KG - 1) ? 22 : 3 * KG - 1;   // phase B gaps [0, SB) carry the last SB scores of tile t, all done before k-step 3 starts (gap 3 KG)
+    constexpr int NA = 64 - E - SB;                    // scores of phase A: 32 over 32 gaps (text), 45 over 24 (ViT)
+    // chunk c (scores < 16 (c + 1)) must be complete when k-step c starts at gap c KG of phase B
+    constexpr auto done_by = [](int g) { return E + NA + (g < SB ? g : SB); };
+    static_assert(E >= 0 && MF < GB && SB <= MF + 1 && NA >= 0, "score schedule");
+    static_assert(done_by(0) >= 16 && done_by(KG) >= 32 && done_by(2 * KG) >= 48 && done_by(3 * KG) >= 64, "score schedule against the k-step deadlines");
     f32x16_t sA[2][2], sB[2][2];
     float alphac[2], m2c[2];      // of the tile whose probabilities are due
-    u32x4_t pf4[2][4];            // P^T fragments [qb][kstep]
-    float psum[2];
+    float alphan[2], m2n[2];      // of the next tile (valid from gap MF of phase B)
+    u32x4_t pf4[2][4];            // P^T fragments [qb][k-step]
+    float psum[2] = {0.f, 0.f}, phold[2];
     int stage_off = 0, nxt_off = STAGE, pre_off = 2 * STAGE;
-    // exponential slice i (0..31): unit u = i / 8 -> (qb, tb) = (u & 1, u >> 1); scores r = 2 (i % 8), + 1
-    auto prob_slice = [&](auto I, f32x16_t (&sc)[2][2]) __attribute__((always_inline)) {
-      constexpr int i = decltype(I)::value, u = i >> 3, qb = u & 1, tb = u >> 1, j = i & 7, r = 2 * j;
-      const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[tb][qb][r], c2, -m2c[qb]));
-      const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[tb][qb][r + 1], c2, -m2c[qb]));
+    // score k (0..63) of a tile, in the order P.V consumes them: chunk c = k >> 4 = k-step c (tokens tb = c >> 1, registers 4 s' .. and
+    // 8 + 4 s' .. with s' = c & 1), then q block, then the 8 registers; two consecutive scores make one dword of the fragment
+    auto score = [&](auto K, f32x16_t (&sc)[2][2], const float (&m2)[2]) __attribute__((always_inline)) {
+      constexpr int k = decltype(K)::value, c = k >> 4, qb = (k >> 3) & 1, idx = k & 7, tb = c >> 1, sp = c & 1;
+      constexpr int r = idx < 4 ? 4 * sp + idx : 8 + 4 * sp + (idx - 4);
+      const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[tb][qb][r], c2, -m2[qb]));
       if (!LSUM) {
-        psum[qb] += p0 + p1;
-        asm volatile("" : "+v"(psum[qb]));   // (pins the two adds to this gap: left alone they sink into one 32-long chain behind phase A)
+        psum[qb] += pv;
+        asm volatile("" : "+v"(psum[qb]));   // (pins the add to this gap: left alone the adds sink into one long chain behind the phase)
       }
-      // scores 4q .. 4q+3 (q = j >> 1) are dwords (q >> 1) * 2 + {0, 1} of fragment kstep = tb * 2 + (q & 1)
-      pf4[qb][tb * 2 + ((j >> 1) & 1)][(j >> 2) * 2 + (j & 1)] = pack_bf(p0, p1);
+      if ((idx & 1) == 0) phold[qb] = pv;
+      else pf4[qb][c][idx >> 1] = pack_bf(phold[qb], pv);
     };
     float tmax[2];
     auto max_slice = [&](auto K, f32x16_t (&sn)[2][2]) __attribute__((always_inline)) {   // K = 0..15: one v_max3 per q block
@@ -460,7 +477,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
       }
     };
-    float alphan[2], m2n[2];
     auto max_final = [&]() __attribute__((always_inline)) {
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
@@ -487,7 +503,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       stage_off = nxt_off;
       nxt_off = (nxt_off == 2 * STAGE) ? 0 : nxt_off + STAGE;
     };
-    // MORE: the wave has a tile t + 1 (else only the probabilities and P.V of its last tile, the DMA pieces and the barrier)
     unsigned tr_acc[4] = {0, 0, 0, 0}, tr_prev = 0;
     const bool tr_on = TRACE && blockIdx.x == gridDim.x / 2;
     auto stamp = [&](int k) __attribute__((always_inline)) {
@@ -499,13 +514,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
       }
     };
+    // MORE: the wave has a tile t + 1 (else only the probabilities and P.V of its last tile, the DMA pieces and the barrier)
     auto iter = [&](auto more_tag, int tile, f32x16_t (&sc)[2][2], f32x16_t (&sn)[2][2]) __attribute__((always_inline)) {
       constexpr bool MORE = decltype(more_tag)::value;
       stamp(-1);
       // tile t + 2 (past the end: the last tile again, into the stage nobody reads any more -- keeps the counted waits uniform)
       dma_rsrc(pg_next);
       pg_next = ptab[__builtin_amdgcn_readfirstlane(min(tile + 3, ntiles - 1))];
-      psum[0] = 0.f, psum[1] = 0.f;
       const int kbase = lk + nxt_off, vbase = lv + stage_off;
       // ---- phase A ----
       bf16x8_t ring[RING];
@@ -521,7 +536,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           else mfma32_acc(sn[f & 1][qb], ring[f % RING], qf[qb][f >> 1]);
           if (qb == 1 && f + RING < 2 * NKS) ring[f % RING] = kfrag(kbase, (f + RING) & 1, (f + RING) >> 1);
         }
-        if (g < SLA) prob_slice(G, sc);
+        constexpr int k0 = E + (g * NA) / GA, k1 = E + ((g + 1) * NA) / GA;   // this gap's scores
+        static_for<k1 - k0>([&](auto J) { score(std::integral_constant<int, k0 + decltype(J)::value>{}, sc, m2c); });
+        if (DMA_IN_A && g % 4 == 1 && g / 4 < NP) dma_piece(std::integral_constant<int, g / 4>{});
         __builtin_amdgcn_sched_barrier(0);
       });
       stamp(0);
@@ -531,33 +548,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int f = 0; f < RING; ++f) vring[f] = vfrag(vbase, f % NDB, f / NDB);
       __builtin_amdgcn_sched_barrier(0);
       static_for<GB>([&](auto G) {
-        constexpr int g = decltype(G)::value, f = g >> 1, qb = g & 1, db = f % NDB, kstep = f / NDB;
-        if (g == 0) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i) valu_settle4(pf4[0][i], pf4[1][i]);   // k-steps 0, 1: written in phase A
-        }
-        if (g == 2 * 2 * NDB) {
-#pragma unroll
-          for (int i = 2; i < 4; ++i) valu_settle4(pf4[0][i], pf4[1][i]);   // k-steps 2, 3: the last of them written in gap 32 - SLA - 1
-        }
+        constexpr int g = decltype(G)::value, kstep = g / KG, j = g % KG, qb = j & 1, db = j >> 1, f = kstep * NDB + db;
+        if (j == 0) valu_settle4(pf4[0][kstep], pf4[1][kstep]);   // a k-step's P^T fragments: complete, two wait states behind their last write
         o_mfma<(db * 2 + qb) * 16>(vring[f % RING], as_frag(pf4[qb][kstep]));
         if (qb == 1 && f + RING < NFV) vring[f % RING] = vfrag(vbase, (f + RING) % NDB, (f + RING) / NDB);
-        if (g < 32 - SLA) prob_slice(std::integral_constant<int, SLA + g>{}, sc);
-        if (g == 32 - SLA) {
+        if (g < SB) score(std::integral_constant<int, 64 - SB + g>{}, sc, m2c);
+        if (g == SB) {
           if (!LSUM) {
             l[0] = l[0] * alphac[0] + psum[0];
             l[1] = l[1] * alphac[1] + psum[1];
+            psum[0] = 0.f, psum[1] = 0.f;
           }
-          if (MORE) mask_step((tile + 1) * KV_PAGE_TOKENS, sn);
         }
-        if (MORE && g >= 8 && g < 24) max_slice(std::integral_constant<int, g - 8>{}, sn);
-        if (MORE && g == 24 && GB > 24) max_final();
-        if (g % 4 == 1 && g / 4 < NP) dma_piece(std::integral_constant<int, g / 4>{});
+        if (MORE) {
+          if (g == M0) mask_step((tile + 1) * KV_PAGE_TOKENS, sn);
+          if (g >= M0 && g < MF) max_slice(std::integral_constant<int, g - M0>{}, sn);
+          if (g == MF) max_final();
+          if (g > MF) score(std::integral_constant<int, g - MF - 1>{}, sn, m2n);
+        }
+        if (!DMA_IN_A && g % 4 == 1 && g / 4 < NP) dma_piece(std::integral_constant<int, g / 4>{});
         __builtin_amdgcn_sched_barrier(0);
       });
       stamp(1);
       if (MORE) {
-        if (GB <= 24) max_final();
         rescale_part(alphan);   // after P.V(t); opens with the MFMA-result wait states
         alphac[0] = alphan[0], alphac[1] = alphan[1], m2c[0] = m2n[0], m2c[1] = m2n[1];
       }
@@ -576,7 +589,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (wtiles > 0) {
       qk_part(lk, sA);
       mfma_settle(sA[0][0], sA[0][1], sA[1][0], sA[1][1]);
-      max_part(0, sA, alphac, m2c);   // alpha = 0 on an empty accumulator: nothing to rescale
+      max_part(0, sA, alphac, m2c);   // alpha = 1 on an empty accumulator: nothing to rescale
+      static_for<E>([&](auto K) { score(K, sA, m2c); });   // the scores the steady state has done by the end of the previous phase B
     }
     if (ntiles > 1) {
       ATTN64_WAIT_VM(VPW);

@@ -62,6 +62,10 @@ def test_no_kernel_spills_or_uses_scratch(kernels):
             return True
         if "gemm256s_kernel" in n:
             return k.get("vgpr_spill_count", 0) == 0 and k.get("sgpr_spill_count", 0) <= 32 and k.get("private_segment_fixed_size", 0) == 0
+        # the pipelined 64-rows-per-wave attention (two buffer descriptors, ring offsets, page pointers live across two unrolled iterations):
+        # a few scalars in VGPR lanes in the head_dim-72 instantiations, no memory traffic
+        if "attn_prefill64_kernel" in n:
+            return k.get("vgpr_spill_count", 0) == 0 and k.get("sgpr_spill_count", 0) <= 8 and k.get("private_segment_fixed_size", 0) == 0
         return False
     bad = {n: k for n, k in kernels.items()
            if (k.get("vgpr_spill_count", 0) or k.get("sgpr_spill_count", 0) or k.get("private_segment_fixed_size", 0)) and not tolerated(n, k)}
@@ -254,3 +258,69 @@ def test_rccl_has_no_affected_packed_f32_form():
     r = scan_rccl_isa.scan(lib)
     assert r["gfx950_objects"] >= 1 and r["packed_f32"] > 100, r      # the scan saw RCCL's f32 reduction code
     assert not r["affected"], r["affected"][:5]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# kernels_attn64.hip: the asm-owned accumulator registers (round 6)
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def attn64_asm(tmp_path_factory):
+    """The compiler's own assembly of csrc/kernels_attn64.hip (hipcc -S with the library's flags; ~15 s): the ;;#ASMSTART / ;;#ASMEND
+    markers around inline-asm statements only exist there, not in the code object."""
+    from aha_amd import build
+    d = tmp_path_factory.mktemp("attn64")
+    out = d / "attn64.s"
+    flags = [f for f in build.FLAGS if not f.startswith("-D")]
+    r = subprocess.run([build._hipcc(), *flags, "--cuda-device-only", "-S", os.path.join(build.CSRC, "kernels_attn64.hip"), "-o", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = out.read_text()
+    funcs = {}
+    for m in re.finditer(r"^(_ZN3aha\S*attn_prefill64_kernel\S*):\s.*?^\.Lfunc_end\d+:", text, re.M | re.S):
+        funcs[m.group(1)] = m.group(0)
+    assert len(funcs) >= 6, list(funcs)
+    return funcs
+
+
+def test_attn64_accumulator_registers_belong_to_the_asm_statements(attn64_asm):
+    """The O^T accumulators of the 64-rows-per-wave attention kernel live in a[0:127], named literally inside inline-asm statements that
+    list them as clobbers and in no C++ object (csrc/kernels_attn64.hip header).  What the compiler may still do silently is park a value of
+    its own in one of them BETWEEN two statements (an AGPR spill of a VGPR, a copy) -- corruption no test input is guaranteed to show.  So:
+    outside ;;#ASMSTART / ;;#ASMEND no instruction of these kernels may name a0..a127; the compiler's own AGPR values (the Q^T fragments,
+    spill slots) sit above; nothing spills to scratch; the MFMA count of every kernel is what the source says."""
+    for name, body in attn64_asm.items():
+        in_asm, bad, mfma, mfma_agpr_dst = False, [], 0, 0
+        for line in body.splitlines():
+            t = line.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if not t or t.startswith(";") or t.startswith("."):
+                continue
+            code = t.split(";")[0]
+            if "v_mfma" in code:
+                mfma += 1
+                assert in_asm, f"{name}: a compiler-generated MFMA: {code}"
+                mfma_agpr_dst += bool(re.match(r"v_mfma\S+\s+a\[", code))
+            if in_asm:
+                continue
+            regs = [int(x) for x in re.findall(r"\ba(\d+)\b", code)]
+            for lo, hi in re.findall(r"\ba\[(\d+):(\d+)\]", code):
+                regs += [int(lo), int(hi)]
+            if any(r_ < 128 for r_ in regs):
+                bad.append(code)
+        assert not bad, f"{name}: compiler instructions touch the asm-owned accumulators a0..a127: {bad[:5]}"
+        assert "scratch_" not in body and "v_accvgpr_mov" not in body, name
+        assert mfma > 0 and mfma_agpr_dst > 0
+
+
+def test_attn64_kernels_in_the_code_object(kernels):
+    fam = [(n, k) for n, k in kernels.items() if family(n) == "attn_prefill64_kernel"]
+    assert len(fam) >= 6
+    for n, k in fam:
+        assert k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] <= 8 and k["private_segment_fixed_size"] == 0, (n, k)
+        assert 256 < k["vgpr_count"] <= 512, (n, k)     # unified file: the whole SIMD's registers, one wave per SIMD
+        assert k["max_flat_workgroup_size"] == 256
