@@ -74,8 +74,9 @@ __device__ __forceinline__ void softmax_scores(f32x4_t (&st)[4], float scale, Va
   constexpr float LOG2E = 1.4426950408889634f;
   if constexpr (SMX == 3) {
     // f32 score chain (round 5): the scores stay the f32 QK^T accumulators -- no bf16(q.k), no bf16(. * scale) -- through mask, maximum
-    // and exponential (the decode kernel's convention; the reference's eager path rounds twice, modules.rs:782-783, the oracle's
-    // `attn_scores_rounded` switch).  The running maximum is kept in RAW score units (scale > 0) and the scale rides the exponent's
+    // and exponential (the reference's eager path rounds twice, modules.rs:782-783: the oracle's `attn_scores_rounded` switch; since
+    // round 6 the decode kernels keep f32 scores too, softmax_tile below, so a position sees ONE convention whether it arrives by prefill
+    // or by decode).  The running maximum is kept in RAW score units (scale > 0) and the scale rides the exponent's
     // fma: p = exp2(s * (scale log2 e) - m * (scale log2 e)).  ~40 of the ~92 vector instructions per tile go away.
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub)
@@ -151,11 +152,36 @@ __device__ __forceinline__ void softmax_probs(const f32x4_t (&st)[4], float m2, 
     pf[kk] = as_frag(u);
   }
 }
+// The decode kernels' tile update (one query row per step).  Round 6 (round-5 advisor, medium): the scores stay f32 here too -- s = (q . k) *
+// scale in f32, no bf16(q.k), no bf16(. * scale) -- the prefill kernels' default convention (SMX 3, kernels_attn64.hip), where through
+// round 5 decode kept the eager path's two roundings (modules.rs:782-783) and the same cache position was scored under two conventions
+// depending on how it had arrived.  m stays in SCALED score units (natural-log domain): the split merges (attn_decode_body.h,
+// attn_decode_combine_kernel) are unchanged.  AHA_ATTN_DECODE_ROUNDED (compile-time, debug builds) restores the rounded chain.
 template <typename ValidFn>
 __device__ __forceinline__ void softmax_tile(f32x4_t (&st)[4], float scale, ValidFn valid, int G, float& m, float& l,
                                              float& alpha, bf16x8_t (&pf)[2]) {
   float m2;
+#ifdef AHA_ATTN_DECODE_ROUNDED
   softmax_scores(st, scale, valid, G, m, alpha, m2);
+#else
+  constexpr float LOG2E = 1.4426950408889634f;
+  float tmax = -INFINITY;
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s = st[sub][r] * scale;
+      if (!valid(sub * 16 + G * 4 + r)) s = -INFINITY;
+      st[sub][r] = s;
+      tmax = fmaxf(tmax, s);
+    }
+  tmax = group_max(tmax);
+  const float m_new = fmaxf(m, tmax);
+  const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: keep everything at zero
+  alpha = __expf(m - m_use);                               // m = -inf -> 0
+  m2 = m_use * LOG2E;
+  m = m_new;
+#endif
   softmax_probs(st, m2, alpha, l, pf);
 }
 

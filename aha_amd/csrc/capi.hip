@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -356,8 +357,10 @@ int aha_hip_gemm(const void* A, const void* W, void* C, int32_t M, int32_t N, in
   // op-level entry (tests, scripts): one split-K scratch per DEVICE, grown on demand; not for concurrent callers
   struct OpScratch { void* ws = nullptr; size_t ws_bytes = 0; void* ctrs = nullptr; };
   static std::map<int, OpScratch> scratch_by_dev;
+  static std::mutex scratch_mu;   // the map is reachable from several devices / threads; a device's scratch itself is still one caller at a time
   int cur_dev = 0;
   if (hipGetDevice(&cur_dev) != hipSuccess) (void)hipGetLastError();
+  std::unique_lock<std::mutex> scratch_lk(scratch_mu);
   OpScratch& sc = scratch_by_dev[cur_dev];
   const size_t want = std::max((size_t)4 * M * N * 4, (size_t)96 << 20);   // split-K slabs / >= 384 chunks of the persistent kernel
   if (want > sc.ws_bytes && want <= ((size_t)1 << 30)) {
@@ -371,6 +374,7 @@ int aha_hip_gemm(const void* A, const void* W, void* C, int32_t M, int32_t N, in
   g.workspace = sc.ws;
   g.workspace_bytes = sc.ws_bytes;
   g.sk_counters = sc.ws ? sc.ctrs : nullptr;
+  scratch_lk.unlock();   // (std::map nodes are stable: `sc` stays valid)
   launch_gemm(g, (hipStream_t)stream);
   AHA_HIP_CHECK(hipGetLastError());
   return AHA_OK;
@@ -422,8 +426,10 @@ struct TmpPages {
   void* store = nullptr;
   uint64_t* d_ptrs = nullptr;
   int32_t* d_len = nullptr;
+  void* fused = nullptr;   // head_dim 64 entry: the [K | V] rows the audio tower's packer reads (freed here: every early return is covered)
   KvLayer kv{};
   ~TmpPages() {
+    if (fused) hipFree(fused);
     if (store) hipFree(store);
     if (d_ptrs) hipFree(d_ptrs);
     if (d_len) hipFree(d_len);
@@ -489,7 +495,6 @@ int aha_hip_attn_prefill(const void* q, const void* k, const void* v, void* o, i
   }
   hipStream_t st = (hipStream_t)stream;
   TmpPages t;
-  void* fused = nullptr;
   if (d == 128) {
     int rc = build_tmp_pages(t, k, v, L, kvh, d, st);
     if (rc) return rc;
@@ -503,10 +508,10 @@ int aha_hip_attn_prefill(const void* q, const void* k, const void* v, void* o, i
     AHA_HIP_CHECK(hipMalloc((void**)&t.d_ptrs, npages * 8));
     AHA_HIP_CHECK(hipMemcpy(t.d_ptrs, ptrs.data(), npages * 8, hipMemcpyHostToDevice));
     t.kv.page_ptrs = t.d_ptrs; t.kv.layer_off = 0; t.kv.kvh = kvh; t.kv.d = d;
-    AHA_HIP_CHECK(hipMalloc(&fused, row * 2 * L));
-    AHA_HIP_CHECK(hipMemcpy2DAsync(fused, row * 2, k, row, row, L, hipMemcpyDeviceToDevice, st));
-    AHA_HIP_CHECK(hipMemcpy2DAsync((char*)fused + row, row * 2, v, row, row, L, hipMemcpyDeviceToDevice, st));
-    launch_kv_pack_generic(fused, (int64_t)2 * kvh * d, 0, kvh * d, t.kv, L, kvh, d, st);
+    AHA_HIP_CHECK(hipMalloc(&t.fused, row * 2 * L));
+    AHA_HIP_CHECK(hipMemcpy2DAsync(t.fused, row * 2, k, row, row, L, hipMemcpyDeviceToDevice, st));
+    AHA_HIP_CHECK(hipMemcpy2DAsync((char*)t.fused + row, row * 2, v, row, row, L, hipMemcpyDeviceToDevice, st));
+    launch_kv_pack_generic(t.fused, (int64_t)2 * kvh * d, 0, kvh * d, t.kv, L, kvh, d, st);
     AHA_HIP_CHECK(hipGetLastError());
   }
   AttnPrefillArgs a{};
@@ -527,8 +532,7 @@ int aha_hip_attn_prefill(const void* q, const void* k, const void* v, void* o, i
     hipEventDestroy(e0); hipEventDestroy(e1);
   }
   hipError_t e = hipGetLastError();
-  hipStreamSynchronize(st);
-  if (fused) hipFree(fused);
+  hipStreamSynchronize(st);   // (t's destructor frees the pages and the fused rows: after the stream has drained)
   AHA_HIP_CHECK(e);
   return AHA_OK;
   API_GUARD_END

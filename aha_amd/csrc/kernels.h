@@ -191,6 +191,8 @@ int gemm_streamk_workers();
 int gemm_streamk_cus();                // CUs of the device, rounded down to a multiple of 8            // workgroups of the persistent kernel = CUs - reserved, a multiple of 8
 int get_gemm_reserved_cus();           // the raw setting (-1 = unset)
 void set_gemm_reserved_cus(int n);     // CUs the persistent GEMM leaves free (RCCL beside the GEMMs under TP); < 0: AHA_GEMM_RESERVE_CUS
+bool acquire_gemm_cu_reservation(int cus);   // the automatic, reference-counted reservation of a communication stream (kernels_gemm_sk.hip)
+void release_gemm_cu_reservation();
 int debug_streamk_plan(int M, int N, int K, int tile_n, int workers, int group, size_t ws_bytes, int* out, int cap, int* off_out, int* info);
 void debug_plan_gemm(int M, int N, int K, int act, bool has_bias, bool has_res, size_t ws_bytes, int* out);   // host only: {tile, splitk, n_split}
 void set_gemm_plan_override(int tile, int splitk);  // tests: force the 128 / 256 tile kernel and a split-K factor; 0 = automatic

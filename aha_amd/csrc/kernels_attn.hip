@@ -4,8 +4,9 @@
 // causal mask tensor_utils.rs:78-106):
 //     scores = bf16(q . k^T) ; scores = bf16(scores * scale) ; (+ -inf above the diagonal) ; softmax ; P . v ; -> bf16
 // q head i reads kv head i / g.  Softmax runs online in f32; P feeds the MFMA as bf16.  The two bf16 roundings of the scores are what
-// the DECODE kernels and the prefill kernel's score chains 0 / 1 reproduce; the prefill kernel's default chain since round 5 (SMX 3)
-// keeps the scores in f32 through scale, mask, maximum and exponential (attn_common.h; DESIGN.md section 2, deviation (iii)).
+// the prefill kernel's score chains 0 / 1 reproduce (the bit-faithful forms, opt-in); the default chain of the prefill kernels since
+// round 5 (SMX 3) and of the decode kernels since round 6 keeps the scores in f32 through scale, mask, maximum and exponential
+// (attn_common.h; DESIGN.md section 2, deviation (iii)): one convention for a cache position, however it arrived.
 //
 // Fragment scheme (v_mfma_f32_16x16x32_bf16, wave64; G = lane>>4, c = lane&15):
 //   S^T tile = K . Q^T :  A = K   (row = token c, k = dims G*8..+8  -> 16 B piece `lane` of a fragment-major K fragment)
@@ -561,6 +562,7 @@ void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
   } while (0)
   if (a.d == 128) {
     const size_t lds = 2 * KV_PAGE_TOKENS * 2 * (128 + 128);
+#ifdef AHA_DEBUG_KERNELS   // per-part cycle trace and the ablation instantiations (results wrong by construction): debug builds only
     static const bool ptrace = [] { const char* e = getenv("AHA_ATTN_PTRACE"); return e && atoi(e) != 0; }();
     if (ptrace && nwv == 8) {   // debug: per-part cycle sums of two waves of the middle block
       static unsigned long long* d_tr = nullptr;
@@ -585,6 +587,7 @@ void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
       if (abl == 4) hipLaunchKernelGGL((attn_prefill_kernel<128, 128, 1, 8, false, 4>), grid, block, lds, st, a, nullptr);
       return;
     }
+#endif
     ATTN_LAUNCH(128, 128);
   } else if (a.d == 64) {  // Qwen3-ASR audio encoder
     const size_t lds = 2 * KV_PAGE_TOKENS * 2 * (64 + 64);

@@ -32,12 +32,29 @@ namespace aha {
 // hipFuncSetAttribute acts on the CURRENT device's copy of a kernel: "once" flags are one bit per device id (a process may drive several
 // GPUs through the device= argument of the Python API).
 struct DevOnce {
-  std::atomic<unsigned long long> mask{0};
-  bool first() {
+  std::atomic<unsigned long long> mask[4] = {};   // device ids 0..255, one bit each (not folded: device 64 is not device 0)
+  std::mutex mu;
+  // `if (auto g = once.first()) { hipFuncSetAttribute(...); }`: the guard holds the mutex for the whole if statement and publishes the
+  // device's bit in its destructor, AFTER the attribute calls -- a second thread on the same device either sees the bit (attributes in
+  // place) or waits for the mutex (round-5 advisor: the bit used to be set before the caller ran hipFuncSetAttribute, so a concurrent
+  // launch of a > 64 KiB dynamic-LDS kernel could slip in between and fail).
+  struct Guard {
+    DevOnce* o;
+    int dev;
+    bool need;
+    std::unique_lock<std::mutex> lk;
+    explicit operator bool() const { return need; }
+    ~Guard() {
+      if (need && dev >= 0 && dev < 256) o->mask[dev >> 6].fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
+  };
+  Guard first() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) (void)hipGetLastError();
-    const unsigned long long bit = 1ull << (dev & 63);
-    return !(mask.fetch_or(bit) & bit);
+    auto seen = [&] { return dev >= 0 && dev < 256 && (mask[dev >> 6].load(std::memory_order_acquire) >> (dev & 63) & 1); };
+    if (seen()) return Guard{this, dev, false, {}};
+    std::unique_lock<std::mutex> lk(mu);
+    return Guard{this, dev, !seen(), std::move(lk)};   // (ids >= 256: set the attribute every time, never a stale "done")
   }
 };
 
@@ -549,7 +566,7 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
   if constexpr (has_n192<ACT, B, R>()) {
     if (n192 && splitk <= 1 && a.K % BK == 0 && 256.0 * 2.0 * (double)std::max(a.lda, a.ldw) < 1.0e9) {
       static DevOnce once192;
-      if (once192.first()) {
+      if (auto once_guard = once192.first()) {
         hipFuncSetAttribute((const void*)gemm256q_kernel<ACT, B, R, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute((const void*)gemm256q_kernel<ACT, B, R, true, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       }
@@ -578,13 +595,14 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
     const bool q_addr_ok = 256.0 * 2.0 * (double)std::max(a.lda, a.ldw) < 1.0e9;
     if (quad && q_addr_ok && a.K % BK == 0 && (nk >= 32 || !R || (!B && ACT != ACT_GELU_TANH && ACT != ACT_GELU_ERF))) {
       static DevOnce onceq;
-      if (onceq.first()) {
+      if (auto once_guard = onceq.first()) {
         hipFuncSetAttribute((const void*)gemm256q_kernel<ACT, B, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       }
+#ifdef AHA_DEBUG_KERNELS   // measurement scaffolding (A/B of the barrier schedule; ablations whose results are wrong by construction): debug builds only
       static const bool bar2 = [] { const char* e = getenv("AHA_GEMM_BAR2"); return e ? atoi(e) != 0 : true; }();
       if (!bar2 && ACT == ACT_NONE && !B && !R) {   // A/B: one barrier per phase
         static DevOnce once1;
-        if (once1.first()) {
+        if (auto once_guard = once1.first()) {
           hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_NONE, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         }
         hipLaunchKernelGGL((gemm256q_kernel<ACT_NONE, false, false, false>), dim3(ntm * ntn), dim3(256), lds, st, a, nk, 0);
@@ -593,7 +611,7 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
       static const int abl = [] { const char* e = getenv("AHA_GEMM_ABL"); return e ? atoi(e) : 0; }();
       if (abl >= 1 && abl <= 3 && ACT == ACT_NONE && !B && !R) {   // ablations (debug; results are wrong by construction)
         static DevOnce once2;
-        if (once2.first()) {
+        if (auto once_guard = once2.first()) {
           hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_NONE, false, false, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
           hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_NONE, false, false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
           hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_NONE, false, false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -603,18 +621,20 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
         if (abl == 3) hipLaunchKernelGGL((gemm256q_kernel<ACT_NONE, false, false, true, 3>), dim3(ntm * ntn), dim3(256), lds, st, a, nk, 0);
         return;
       }
+#endif
       hipLaunchKernelGGL((gemm256q_kernel<ACT, B, R>), dim3(ntm * ntn), dim3(256), lds, st, a, nk, 0);
       return;
     }
     {
       static DevOnce once2;
-      if (once2.first()) {
+      if (auto once_guard = once2.first()) {
         hipFuncSetAttribute((const void*)gemm256p_kernel<ACT, B, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       }
+#ifdef AHA_DEBUG_KERNELS   // ablations (results wrong by construction) and the segment timeline: debug builds only
       static const int mode = [] { const char* e = getenv("AHA_GEMM_MODE"); return e ? atoi(e) : 0; }();
       if (mode >= 2 && mode <= 4 && ACT == ACT_NONE && !B && !R) {   // ablations (debug; results are wrong by construction)
         static DevOnce once3;
-        if (once3.first()) {
+        if (auto once_guard = once3.first()) {
           hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_NONE, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
           hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_NONE, false, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
           hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_NONE, false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -645,12 +665,13 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
                 (double)(h[42] - h[40]) / ((double)(h[43] - h[41]) * 10.0));
         return;
       }
+#endif
       hipLaunchKernelGGL((gemm256p_kernel<ACT, B, R>), dim3(ntm * ntn), dim3(512), lds, st, a, zero_block(), nk);
     }
     return;
   }
   static DevOnce once_p;
-  if (once_p.first()) {
+  if (auto once_guard = once_p.first()) {
     hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_PARTIAL_F32, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   GemmArgs p = a;  // pass 1: f32 slabs [splitk][M][N] in the caller's workspace
@@ -663,7 +684,7 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
   static const bool quad_sk = [] { const char* e = getenv("AHA_GEMM_QUAD"); return e ? atoi(e) != 0 : true; }();
   if (quad_sk && a.K % BK == 0 && 256.0 * 2.0 * (double)std::max(a.lda, a.ldw) < 1.0e9) {
     static DevOnce onceq;
-    if (onceq.first()) {
+    if (auto once_guard = onceq.first()) {
       hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_PARTIAL_F32, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_PARTIAL_F32, false, false, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
@@ -726,8 +747,14 @@ GemmPlan plan_gemm(const GemmArgs& a) {
   const double t128 = (double)((a.M + 127) / 128) * ((a.N + 127) / 128);
   const double t256 = (double)((a.M + 255) / 256) * ((a.N + 255) / 256);
   // 128^2 kernel: 0.68 us per tile and k step is the throughput of a CU holding four blocks; a launch that leaves CUs with a single
-  // block (or none) runs at that block's own latency, ~1.4 us per k step
-  const double cost128 = std::max(ceil(t128 / 256.0) * nk * 0.68, t128 < 512.0 ? nk * 1.4 + 4.0 : 0.0);
+  // block (or none) runs at that block's own latency.  Round 6: that latency was priced at 1.4 us per k step from cfg 3's deep-K shapes;
+  // on the short-K shapes of BASELINE cfg 4 (Qwen3-ASR: M = 390 / 406 rows, K = 896 / 1024 = 14-16 k steps) a lone block measures
+  // ~0.75 us per k step + ~4.5 us of launch, prologue and epilogue (scripts/tune_gemm.py, profiles/r06_tune_gemm_small.txt: qkv 14.4 us on
+  // 128^2 tiles against 18.4-21.1 on the 256-row kernels the old constant chose, fc1 14.7 against 18.8, text qkv 16.3 against 20.4) --
+  // and a GELU-erf epilogue on the 28 CUs that hold 256^2 tiles costs more than the GEMM (52 us in the model).  AHA_GEMM_LAT128 = the
+  // per-k-step microseconds (A/B).
+  static const double lat128 = [] { const char* e = getenv("AHA_GEMM_LAT128"); return e ? atof(e) : 0.75; }();
+  const double cost128 = std::max(ceil(t128 / 256.0) * nk * 0.68, t128 < 512.0 ? nk * lat128 + 4.5 : 0.0);
   const bool can_split = a.act != ACT_SILU_MUL_PAIRS && a.act != ACT_PARTIAL_F32 && a.workspace != nullptr && (a.N & 3) == 0;
   GemmPlan best{128, 1};
   double best_cost = cost128;
@@ -952,7 +979,7 @@ void launch_gemm_grouped(const GemmArgs& a_in, hipStream_t st) {
 #define AHA_GROUPED(ACT_, NF3_)                                                                                                      \
   do {                                                                                                                                \
     static DevOnce once;                                                                                                              \
-    if (once.first())                                                                                                                 \
+    if (auto once_guard = once.first())                                                                                                                 \
       hipFuncSetAttribute((const void*)gemm256q_kernel<ACT_, false, false, true, 0, NF3_, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL((gemm256q_kernel<ACT_, false, false, true, 0, NF3_, false, true>), grid, dim3(256), lds, st, a, nk, 0);        \
   } while (0)

@@ -456,6 +456,29 @@ void sk_launch_one(const GemmArgs& a, const SkEntry* e, hipStream_t st) {
 
 void set_gemm_reserved_cus(int n) { g_reserved_cus.store(n); }
 int get_gemm_reserved_cus() { return g_reserved_cus.load(); }
+// The AUTOMATIC reservation a model's communication stream asks for (model.hip ensure_comm_stream): process-global state with several
+// possible holders (two tensor-parallel ranks as two models of one process), so it is reference-counted under a mutex -- the first holder
+// saves the caller's setting and reserves, the last one to leave restores it (round-5 advisor: saved / restored per model, closing model A
+// took the reservation away from model B, and two racing threads could both "save" and one restore 16 for good).  Returns whether the
+// caller now holds a share (false: the user chose a number through the API or AHA_GEMM_RESERVE_CUS -- nothing to hold or release).
+static std::mutex g_resv_mu;
+static int g_resv_holders = 0, g_resv_prev = -1;
+bool acquire_gemm_cu_reservation(int cus) {
+  std::lock_guard<std::mutex> lk(g_resv_mu);
+  if (g_resv_holders > 0) {
+    ++g_resv_holders;
+    return true;
+  }
+  if (getenv("AHA_GEMM_RESERVE_CUS") || gemm_streamk_workers() != gemm_streamk_cus()) return false;
+  g_resv_prev = g_reserved_cus.load();
+  g_reserved_cus.store(cus);
+  g_resv_holders = 1;
+  return true;
+}
+void release_gemm_cu_reservation() {
+  std::lock_guard<std::mutex> lk(g_resv_mu);
+  if (g_resv_holders > 0 && --g_resv_holders == 0) g_reserved_cus.store(g_resv_prev);
+}
 void set_streamk_forced_cut(int code) {
   std::lock_guard<std::mutex> lk(g_sk_mu);
   if (code != g_sk_force_cut.load()) sk_drop_entries_locked(-1);   // cached plans were made under the other setting

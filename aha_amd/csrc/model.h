@@ -129,8 +129,7 @@ struct aha_model {
   // sequence-parallel prefill with the collectives of a row-parallel projection overlapped with its GEMM (model.hip
   // gemm_row_parallel): RCCL runs on its own high-priority stream, ordered against the compute stream by events
   hipStream_t comm_stream = nullptr;
-  bool reserved_cus_set = false;   // ensure_comm_stream reserved CUs for the collectives: undone with the communicator
-  int reserved_cus_prev = -1;
+  bool reserved_cus_set = false;   // this model holds a share of the reference-counted CU reservation (released with the communicator)
   hipEvent_t ev_gemm[8] = {};
   hipEvent_t ev_ag[8] = {};   // chunk i of a chunked all-gather has landed (norm_gather_gemm)
   hipEvent_t ev_comm = nullptr;

@@ -999,11 +999,8 @@ static int ensure_comm_stream(aha_model* m) {
   // (aha_hip_set_gemm_reserved_cus / AHA_GEMM_RESERVE_CUS); process-wide while this model's communicator lives.
   // The setting is restored when this model's communicator is torn down (tp_rccl.hip): un-sharded models and op-level GEMMs of the same
   // process are planned on all CUs again from then on (round-4 advisor).
-  if (!getenv("AHA_GEMM_RESERVE_CUS") && gemm_streamk_workers() == gemm_streamk_cus()) {
-    m->reserved_cus_prev = get_gemm_reserved_cus();
-    m->reserved_cus_set = true;
-    set_gemm_reserved_cus(16);
-  }
+  // (reference-counted: several models of one process may each hold a share, kernels_gemm_sk.hip acquire_gemm_cu_reservation)
+  m->reserved_cus_set = acquire_gemm_cu_reservation(16);
   int lo = 0, hi = 0;
   AHA_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // (numerically lowest = highest priority)
   AHA_HIP_CHECK(hipStreamCreateWithPriority(&m->comm_stream, hipStreamNonBlocking, hi));

@@ -110,7 +110,7 @@ void tp_destroy(aha_model* m) {
   if (m->comm_stream) hipStreamDestroy(m->comm_stream);
   m->comm_stream = nullptr;
   if (m->reserved_cus_set) {   // the CU reservation of ensure_comm_stream (model.hip) ends with the communication stream
-    set_gemm_reserved_cus(m->reserved_cus_prev);
+    release_gemm_cu_reservation();
     m->reserved_cus_set = false;
   }
   for (auto& e : m->ev_gemm) {
