@@ -165,8 +165,22 @@ def test_gemm_ragged_n_is_split_by_the_automatic_plan(gpu):
     y = NM.r(torch.nn.functional.gelu(NM.linear(A.float(), W.float(), b.float()), approximate="tanh"))
     ref = NM.r(res.float() + y)
     got = ops.gemm(A.to(gpu), W.to(gpu), b.to(gpu), res.to(gpu), _lib.ACT_GELU_TANH)
-    assert_close_ulps(got, ref, 2, 0.97, "ragged-N gemm, automatic plan")
-    assert_close_ulps(got[:, 4000:], ref[:, 4000:], 2, 0.97, "ragged-N gemm around the seam")
+    # the GELU bound of test_gemm_four_wave_kernel_short_k_bias_gelu (exp2 / rcp GELU behind a reordered f32 sum): 3 ulps, at most two per
+    # million beyond 2 -- whichever tile the plan picks for these rows (round 6: 128^2 tiles here; one of 2.6 M outputs lands at 3 ulps)
+    assert_close_ulps(got, ref, 3, 0.97, "ragged-N gemm, automatic plan")
+    g32, r32 = got.float().cpu(), ref.float().cpu()
+    tol2 = 2 * ulp_bf16(torch.maximum(r32.abs(), r32.pow(2).mean().sqrt()))
+    assert ((g32 - r32).abs() > tol2).float().mean().item() < 2e-6, "ragged-N gemm, automatic plan: too many outputs beyond 2 ulps"
+    assert_close_ulps(got[:, 4000:], ref[:, 4000:], 3, 0.97, "ragged-N gemm around the seam")
+    ops.gemm_plan(256, 1)     # ... and the two-launch split of the 256-row kernel the test is named after, forced
+    try:
+        got256 = ops.gemm(A.to(gpu), W.to(gpu), b.to(gpu), res.to(gpu), _lib.ACT_GELU_TANH)
+    finally:
+        ops.gemm_plan(0, 0)
+    assert_close_ulps(got256, ref, 3, 0.97, "ragged-N gemm, 256-row tiles")
+    g32 = got256.float().cpu()
+    assert ((g32 - r32).abs() > tol2).float().mean().item() < 2e-6, "ragged-N gemm, 256-row tiles: too many outputs beyond 2 ulps"
+    assert_close_ulps(got256[:, 4000:], ref[:, 4000:], 3, 0.97, "ragged-N gemm around the seam, 256-row tiles")
     plain = ops.gemm(A.to(gpu), W.to(gpu))
     assert_close_ulps(plain, NM.linear(A.float(), W.float()), 1, 0.98, "ragged-N plain gemm")
 
@@ -512,7 +526,8 @@ def test_attn_decode(gpu, L, nh, kvh):
     got = ops.attn_decode(q[0].contiguous().to(gpu), k.to(gpu), v.to(gpu), nh, kvh, d)
     # unrounded-f32 P vs the oracle's bf16-rounded P: <= 1 ulp of the output plus accumulation order
     assert_close_ulps(got, ref, 3, None, "attn_decode")
-    assert_close_ulps(got, _attn_ref(q, k, v, nh, kvh, d, False, 0)[0], 4, None, "attn_decode vs the eager oracle")
+    # (per head, at the head's largest |output|: the row scale the prefill tests use -- a dim near zero is a sum of cancelling terms)
+    assert_close_ulps(got.reshape(nh, d), _attn_ref(q, k, v, nh, kvh, d, False, 0)[0].reshape(nh, d), 4, None, "attn_decode vs the eager oracle", row_scale=True)
     assert float((got.float().cpu() - ref).abs().max()) < 0.02
 
 
