@@ -164,6 +164,10 @@ struct GemmArgs {
   const void* norm_w = nullptr;
   void* norm_out = nullptr;
   float norm_eps = 0.f;
+  // norm_b != nullptr: the riding norm is a LayerNorm (candle_nn::LayerNorm, weight norm_w + bias norm_b over N: the ViT block's norm1 /
+  // norm2, /root/reference/src/models/qwen3vl/model.rs:346-370) instead of an RMSNorm.  Folded into a split-K reduce pass where the plan has
+  // one (gemm_splitk_reduce_layernorm_kernel), else launch_gemm appends launch_layernorm_rows: the same bits either way.
+  const void* norm_b = nullptr;
   void* workspace = nullptr;     // optional f32 scratch for split-K slabs (splitk * M * N * 4 bytes) / the persistent kernel's chunks
   size_t workspace_bytes = 0;
   void* sk_counters = nullptr;   // optional SK_MAX_COUNTERS zeroed u32 words that belong to `workspace` (one per tile cut along K by the

@@ -38,6 +38,24 @@ def main():
     h.update(lg.tobytes())
     vm.close()
     ops.gemm_plan(0, 0)
+    # round 6: the ViT block's LayerNorms ride on its GEMM calls (norm2 on proj, norm1 of the next block on fc2: csrc/vision_tower.hip,
+    # kernels_gemm.hip gemm_splitk_reduce_layernorm_kernel).  The vision tower at its REAL widths (1152 / 16 heads / 4304), 4 blocks with one
+    # DeepStack merger in the middle (after a merger the next norm1 is its own launch), 1024 patches: once with every GEMM forced onto two K
+    # slices (reduce pass everywhere), once with the automatic plans.
+    from aha_amd.configs import Qwen3VLConfig, Qwen3VLVisionConfig
+    wide = Qwen3VLConfig(text=vcfg.text, vision=Qwen3VLVisionConfig(depth=4, out_hidden_size=256, deepstack_visual_indexes=[1]),
+                         image_token_id=2000, video_token_id=2001, vision_start_token_id=2002, vision_end_token_id=2003)
+    ww = qwen3vl_weights(wide, seed=3)
+    for plan in ((256, 2), (0, 0)):
+        ops.gemm_plan(*plan)
+        wm = HipInferenceModel(wide, ww)
+        wids, wdata = synthetic_image_request(wide, 512, 40, torch.Generator().manual_seed(6))
+        lg, tok = wm.forward_initial(wids, 0, wdata)
+        h.update(lg.tobytes())
+        h.update(np.asarray(wm.debug_image_embeds(0, 256)).tobytes())
+        h.update(np.asarray(wm.debug_image_embeds(1, 256)).tobytes())
+        wm.close()
+    ops.gemm_plan(0, 0)
     print("FUSE_NORM_DIGEST", h.hexdigest(), flush=True)
 
 
