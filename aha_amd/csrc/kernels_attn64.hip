@@ -420,45 +420,87 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // (The row sum on the matrix pipe -- one more MFMA per k-step and q block with a fragment of ones as A, 8 MFMAs instead of 64
     // v_add_f32 per tile -- was built and measured: phase A 1270 -> 1180 cycles, phase B 1690 -> 2144 for its 8 more gaps, 0.96 -> 1.06 ms at
     // S = 8192: a gap of phase B costs ~53 cycles whatever it holds, section 3 of profiles/r06_attn_prefill.md.  Not kept.)
-    constexpr bool DMA_IN_A = true;
+    constexpr bool DMA_IN_A = true;                    // the LDS-DMA pieces of tile t + 2 ride in phase A (phase B: 1595 -> 1500 cycles, A + 55)
     constexpr int KG = 2 * NDB;                        // MFMA gaps of one P.V k-step
     constexpr int GA = 4 * NKS, GB = 4 * KG;           // MFMA gaps of the two phases: 32 + 32 (text), 24 + 24 (ViT)
-    constexpr int M0 = 5, MF = M0 + 16;                // phase B gaps of the maximum
-    constexpr int E = GB - 1 - MF;                     // scores of tile t + 1 done at the end of phase B(t): 10 (text), 2 (ViT)
-    constexpr int SB = (22 < 3 * KG - 1) ? 22 : 3 * KG - 1;   // phase B gaps [0, SB) carry the last SB scores of tile t, all done before k-step 3 starts (gap 3 KG)
-    constexpr int NA = 64 - E - SB;                    // scores of phase A: 32 over 32 gaps (text), 45 over 24 (ViT)
-    // chunk c (scores < 16 (c + 1)) must be complete when k-step c starts at gap c KG of phase B
-    constexpr auto done_by = [](int g) { return E + NA + (g < SB ? g : SB); };
-    static_assert(E >= 0 && MF < GB && SB <= MF + 1 && NA >= 0, "score schedule");
-    static_assert(done_by(0) >= 16 && done_by(KG) >= 32 && done_by(2 * KG) >= 48 && done_by(3 * KG) >= 64, "score schedule against the k-step deadlines");
+    constexpr int MAXG = GB >= 32 ? 16 : 8;            // phase B gaps that carry the maximum of tile t + 1: 32 / MAXG v_max3 each
+    constexpr int M0 = 5, MF = M0 + MAXG;              // ... gaps [M0, MF); gap MF: the new quantised maximum
+    constexpr int SB = MF + 1;                         // phase B gaps [0, SB) carry the last SB scores of tile t, gaps [SB, GB) the first E of tile t + 1
+    constexpr int E = GB - SB;                         // 10 (text), 10 (ViT)
+    constexpr int NA = 64 - GB;                        // scores of phase A: 32 over 32 gaps (text), 40 over 24 (ViT); phase B gap g = position NA + g
+    // A score is a chain of three dependent vector instructions (fma -> exp -> add / cvt_pk); issued back to back each waits out the previous
+    // one's latency (measured: ~8 cycles per instruction in a gap of {MFMA, fma, exp, add} where independent instructions issue every ~4).
+    // So the chain is itself software-pipelined over the stream of scores: position p issues stage 3 of score p - 2, stage 2 of score
+    // p - 1 and stage 1 of score p -- three independent instructions -- and the stream runs on across the phases and across iterations (the
+    // last two scores of a phase B finish in the first two positions of the next iteration).  A k-step of P.V therefore finds its P^T
+    // fragments complete two positions after its last score: the static_asserts below.
+    static_assert(E >= 2 && MF < GB && SB <= 3 * KG - 2 && NA >= 0, "score schedule");
+    static_assert(47 - E + 2 - NA < 2 * KG && 31 - E + 2 - NA < KG, "score schedule against the k-step deadlines");
     f32x16_t sA[2][2], sB[2][2];
     float alphac[2], m2c[2];      // of the tile whose probabilities are due
     float alphan[2], m2n[2];      // of the next tile (valid from gap MF of phase B)
     u32x4_t pf4[2][4];            // P^T fragments [qb][k-step]
     float psum[2] = {0.f, 0.f}, phold[2];
+    float tfr[2], per[2];         // stage 1 -> 2 and stage 2 -> 3 registers of the score pipeline, by position parity
     int stage_off = 0, nxt_off = STAGE, pre_off = 2 * STAGE;
     // score k (0..63) of a tile, in the order P.V consumes them: chunk c = k >> 4 = k-step c (tokens tb = c >> 1, registers 4 s' .. and
-    // 8 + 4 s' .. with s' = c & 1), then q block, then the 8 registers; two consecutive scores make one dword of the fragment
-    auto score = [&](auto K, f32x16_t (&sc)[2][2], const float (&m2)[2]) __attribute__((always_inline)) {
-      constexpr int k = decltype(K)::value, c = k >> 4, qb = (k >> 3) & 1, idx = k & 7, tb = c >> 1, sp = c & 1;
-      constexpr int r = idx < 4 ? 4 * sp + idx : 8 + 4 * sp + (idx - 4);
-      const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[tb][qb][r], c2, -m2[qb]));
-      if (!LSUM) {
-        psum[qb] += pv;
-        asm volatile("" : "+v"(psum[qb]));   // (pins the add to this gap: left alone the adds sink into one long chain behind the phase)
+    // 8 + 4 s' .. with s' = c & 1), then q block, then the 8 registers; two consecutive scores make one dword of the fragment.
+    // Position p of an iteration (0..63) -> score: p < 64 - E: score E + p of the current tile; else score p - (64 - E) of the next one.
+    // (The three stages are asm statements, one instruction each: C++ arithmetic is free to sink to its use -- the fma next to its exp, all
+    // adds into one chain behind the phase -- and an empty asm that pins a value costs an s_nop of boundary padding per use: 45 per tile.)
+    const float c2v = c2;
+    auto s1 = [&](auto P, f32x16_t (&sc)[2][2], f32x16_t (&sn)[2][2]) __attribute__((always_inline)) {
+      constexpr int p = decltype(P)::value, nxt = p >= 64 - E, k = nxt ? p - (64 - E) : E + p;
+      constexpr int c = k >> 4, qb = (k >> 3) & 1, idx = k & 7, tb = c >> 1, sp = c & 1, r = idx < 4 ? 4 * sp + idx : 8 + 4 * sp + (idx - 4);
+      // (locals first: an asm operand inside a generic lambda does not capture by itself)
+      float& t = tfr[p & 1];
+      const float x = nxt ? sn[tb][qb][r] : sc[tb][qb][r], mm = nxt ? m2n[qb] : m2c[qb], cc = c2v;
+      asm volatile("v_fma_f32 %0, %1, %2, -%3" : "=v"(t) : "v"(x), "v"(cc), "v"(mm));
+    };
+    auto s2 = [&](auto P) __attribute__((always_inline)) {
+      constexpr int p = (decltype(P)::value + 64) & 63;
+      float& e = per[p & 1];
+      const float t = tfr[p & 1];
+      asm volatile("v_exp_f32 %0, %1" : "=v"(e) : "v"(t));
+    };
+    auto s3 = [&](auto P) __attribute__((always_inline)) {
+      constexpr int p = (decltype(P)::value + 64) & 63, nxt = p >= 64 - E, k = nxt ? p - (64 - E) : E + p;
+      constexpr int c = k >> 4, qb = (k >> 3) & 1, idx = k & 7;
+      const float pv = per[p & 1];
+      float& ps = psum[qb];
+      float& ph = phold[qb];
+      if (!LSUM) asm volatile("v_add_f32 %0, %0, %1" : "+v"(ps) : "v"(pv));
+      if ((idx & 1) == 0) {
+        ph = pv;
+      } else {
+        uint32_t w;
+        const float lo = ph;
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(lo), "v"(pv));
+        pf4[qb][c][idx >> 1] = w;
       }
-      if ((idx & 1) == 0) phold[qb] = pv;
-      else pf4[qb][c][idx >> 1] = pack_bf(phold[qb], pv);
+    };
+    // one position of the stream; FILL = how many of the older stages exist (the prologue starts the stream: 0, 1, then 2)
+    auto position = [&](auto P, f32x16_t (&sc)[2][2], f32x16_t (&sn)[2][2]) __attribute__((always_inline)) {
+      constexpr int p = decltype(P)::value;
+      s3(std::integral_constant<int, p - 2>{});
+      s2(std::integral_constant<int, p - 1>{});
+      s1(P, sc, sn);
     };
     float tmax[2];
-    auto max_slice = [&](auto K, f32x16_t (&sn)[2][2]) __attribute__((always_inline)) {   // K = 0..15: one v_max3 per q block
+    auto max_slice = [&](auto K, f32x16_t (&sn)[2][2]) __attribute__((always_inline)) {   // K = 0..15: one v_max3 per q block, one statement
       constexpr int k = decltype(K)::value;
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        auto sv = [&](int i) { return sn[i >> 4][qb][i & 15]; };
-        if (k == 0) tmax[qb] = max3(sv(0), sv(1), sv(2));
-        else if (k < 15) tmax[qb] = max3(tmax[qb], sv(2 * k + 1), sv(2 * k + 2));
-        else tmax[qb] = max3(tmax[qb], sv(31), sv(31));
+      auto sv = [&](int qb, int i) { return sn[i >> 4][qb][i & 15]; };
+      float& t0 = tmax[0];
+      float& t1 = tmax[1];
+      if (k == 0) {
+        const float a0 = sv(0, 0), a1 = sv(0, 1), a2 = sv(0, 2), b0 = sv(1, 0), b1 = sv(1, 1), b2 = sv(1, 2);
+        asm volatile("v_max3_f32 %0, %2, %3, %4\n\tv_max3_f32 %1, %5, %6, %7" : "=&v"(t0), "=&v"(t1) : "v"(a0), "v"(a1), "v"(a2), "v"(b0), "v"(b1), "v"(b2));
+      } else if (k < 15) {
+        const float a1 = sv(0, 2 * k + 1), a2 = sv(0, 2 * k + 2), b1 = sv(1, 2 * k + 1), b2 = sv(1, 2 * k + 2);
+        asm volatile("v_max3_f32 %0, %0, %2, %3\n\tv_max3_f32 %1, %1, %4, %5" : "+v"(t0), "+v"(t1) : "v"(a1), "v"(a2), "v"(b1), "v"(b2));
+      } else {
+        const float a1 = sv(0, 31), b1 = sv(1, 31);
+        asm volatile("v_max3_f32 %0, %0, %2, %2\n\tv_max3_f32 %1, %1, %3, %3" : "+v"(t0), "+v"(t1) : "v"(a1), "v"(b1));
       }
     };
     auto mask_step = [&](int t0, f32x16_t (&sn)[2][2]) __attribute__((always_inline)) {
@@ -536,8 +578,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           else mfma32_acc(sn[f & 1][qb], ring[f % RING], qf[qb][f >> 1]);
           if (qb == 1 && f + RING < 2 * NKS) ring[f % RING] = kfrag(kbase, (f + RING) & 1, (f + RING) >> 1);
         }
-        constexpr int k0 = E + (g * NA) / GA, k1 = E + ((g + 1) * NA) / GA;   // this gap's scores
-        static_for<k1 - k0>([&](auto J) { score(std::integral_constant<int, k0 + decltype(J)::value>{}, sc, m2c); });
+        constexpr int p0 = (g * NA) / GA, p1 = ((g + 1) * NA) / GA;   // this gap's positions of the score stream
+        static_for<p1 - p0>([&](auto J) { position(std::integral_constant<int, p0 + decltype(J)::value>{}, sc, sn); });
         if (DMA_IN_A && g % 4 == 1 && g / 4 < NP) dma_piece(std::integral_constant<int, g / 4>{});
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -552,8 +594,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (j == 0) valu_settle4(pf4[0][kstep], pf4[1][kstep]);   // a k-step's P^T fragments: complete, two wait states behind their last write
         o_mfma<(db * 2 + qb) * 16>(vring[f % RING], as_frag(pf4[qb][kstep]));
         if (qb == 1 && f + RING < NFV) vring[f % RING] = vfrag(vbase, (f + RING) % NDB, (f + RING) / NDB);
-        if (g < SB) score(std::integral_constant<int, 64 - SB + g>{}, sc, m2c);
-        if (g == SB) {
+        if (g == SB + 2) {   // every score of tile t has been summed (stage 3 lags two positions)
           if (!LSUM) {
             l[0] = l[0] * alphac[0] + psum[0];
             l[1] = l[1] * alphac[1] + psum[1];
@@ -562,9 +603,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         if (MORE) {
           if (g == M0) mask_step((tile + 1) * KV_PAGE_TOKENS, sn);
-          if (g >= M0 && g < MF) max_slice(std::integral_constant<int, g - M0>{}, sn);
+          if (g >= M0 && g < MF) static_for<16 / MAXG>([&](auto J) { max_slice(std::integral_constant<int, (g - M0) * (16 / MAXG) + decltype(J)::value>{}, sn); });
           if (g == MF) max_final();
-          if (g > MF) score(std::integral_constant<int, g - MF - 1>{}, sn, m2n);
+        }
+        if (g < SB || MORE) {
+          position(std::integral_constant<int, NA + g>{}, sc, sn);
+        } else if (g == SB) {        // the wave's last tile: the stream ends here, its last two scores drain
+          s3(std::integral_constant<int, NA + g - 2>{});
+          s2(std::integral_constant<int, NA + g - 1>{});
+        } else if (g == SB + 1) {
+          s3(std::integral_constant<int, NA + g - 2>{});
         }
         if (!DMA_IN_A && g % 4 == 1 && g / 4 < NP) dma_piece(std::integral_constant<int, g / 4>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -590,7 +638,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       qk_part(lk, sA);
       mfma_settle(sA[0][0], sA[0][1], sA[1][0], sA[1][1]);
       max_part(0, sA, alphac, m2c);   // alpha = 1 on an empty accumulator: nothing to rescale
-      static_for<E>([&](auto K) { score(K, sA, m2c); });   // the scores the steady state has done by the end of the previous phase B
+      // the scores the steady state has under way at the end of a phase B: the first E of the tile, the last two of them two / one stage
+      // short of complete (as positions 64 - E .. 63 of a virtual previous iteration whose "next" tile is tile 0)
+      m2n[0] = m2c[0], m2n[1] = m2c[1];
+      static_for<E>([&](auto J) {
+        constexpr int j = decltype(J)::value, p = 64 - E + j;
+        if (j >= 2) s3(std::integral_constant<int, p - 2>{});
+        if (j >= 1) s2(std::integral_constant<int, p - 1>{});
+        s1(std::integral_constant<int, p>{}, sA, sA);
+      });
     }
     if (ntiles > 1) {
       ATTN64_WAIT_VM(VPW);
@@ -707,18 +763,24 @@ bool launch_attn_prefill64(const AttnPrefillArgs& a_in, hipStream_t st, int pipe
   } while (0)
 #ifdef AHA_DEBUG_KERNELS
   static const bool tr = [] { const char* e = getenv("AHA_ATTN64_TRACE"); return e && atoi(e) != 0; }();
-  if (tr && a.d == 128 && pipe) {
+  if (tr && pipe && (a.d == 128 || a.v_ones_row)) {
     static unsigned long long* d_tr = nullptr;
     if (!d_tr) (void)hipMalloc((void**)&d_tr, 32 * 8);
     (void)hipMemsetAsync(d_tr, 0, 32 * 8, st);
-    constexpr size_t lds = 3 * (KV_PAGE_TOKENS * 128 * 2 + 4 * 4096);
-    set_max_lds(attn_prefill64_kernel<128, 128, false, 1, true>, lds);
-    hipLaunchKernelGGL((attn_prefill64_kernel<128, 128, false, 1, true>), grid, block, lds, st, a, d_tr);
+    if (a.d == 128) {
+      constexpr size_t lds = 3 * (KV_PAGE_TOKENS * 128 * 2 + 4 * 4096);
+      set_max_lds(attn_prefill64_kernel<128, 128, false, 1, true>, lds);
+      hipLaunchKernelGGL((attn_prefill64_kernel<128, 128, false, 1, true>), grid, block, lds, st, a, d_tr);
+    } else {
+      constexpr size_t lds = 3 * (KV_PAGE_TOKENS * 96 * 2 + 3 * 4096);
+      set_max_lds(attn_prefill64_kernel<96, 80, true, 1, true>, lds);
+      hipLaunchKernelGGL((attn_prefill64_kernel<96, 80, true, 1, true>), grid, block, lds, st, a, d_tr);
+    }
     unsigned long long h[32];
     (void)hipMemcpyAsync(h, d_tr, sizeof(h), hipMemcpyDeviceToHost, st);
     (void)hipStreamSynchronize(st);
     for (int w = 0; w < 4; ++w)
-      fprintf(stderr, "[attn64 trace] wave %d, %llu tiles, cycles per tile: phase A %.0f, phase B %.0f, rescale %.0f, wait + barrier %.0f\n", w, h[w * 8 + 7],
+      fprintf(stderr, "[attn64 trace] d %d wave %d, %llu tiles, cycles per tile: phase A %.0f, phase B %.0f, rescale %.0f, wait + barrier %.0f\n", a.d, w, h[w * 8 + 7],
               (double)h[w * 8] / (double)h[w * 8 + 7], (double)h[w * 8 + 1] / (double)h[w * 8 + 7], (double)h[w * 8 + 2] / (double)h[w * 8 + 7],
               (double)h[w * 8 + 3] / (double)h[w * 8 + 7]);
     return true;
