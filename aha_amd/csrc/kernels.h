@@ -140,6 +140,10 @@ struct AttnPrefillArgs {
   // the softmax row sum and the f32-chain kernels may drop their own.  Only the packer that wrote the pages can promise it: unset, the
   // kernels keep the f32 sum of the probabilities.
   int v_ones_row = 0;
+  // Rows of the WHOLE request this launch is a part of (0 = S + S2).  The automatic choice of the kernel form goes by it, so that a
+  // context-parallel rank's share of a prompt runs the form the un-sharded prompt would: the forms agree to the parity bound, not bit for bit
+  // (another MFMA shape = another accumulation order), and tests/test_cp_gpu.py demands bit-identical rows.
+  int rows_hint = 0;
 };
 void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st);
 // the one-wave-per-SIMD, 64-q-rows-per-wave form (kernels_attn64.hip); false = not a shape of that kernel, nothing launched

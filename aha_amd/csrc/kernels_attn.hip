@@ -534,7 +534,7 @@ void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
   static const int form_env = [] { const char* e = getenv("AHA_ATTN_FORM"); return e ? atoi(e) : -1; }();
   const int form = g_attn_form_override >= 0 ? g_attn_form_override : form_env;
   if (smx == 3 && form != 16) {
-    const int64_t blocks64 = (int64_t)((a.S + 255) / 256 + (a.S2 + 255) / 256) * a.nh;
+    const int64_t blocks64 = (a.rows_hint > 0 ? (int64_t)(a.rows_hint + 255) / 256 : (int64_t)((a.S + 255) / 256 + (a.S2 + 255) / 256)) * a.nh;
     // One 4-wave workgroup per CU: a full launch is rounds of 256 workgroups.  Same-box A/B against the 16-row kernel (scripts/attn64_ab.py,
     // 32 heads x head_dim 128, profiles/r06_attn_prefill.md): full attention 2048 / 3072 / 4096 / 8192 rows = 1 / 1.5 / 2 / 4 rounds:
     // 64 vs 75, 165 vs 160, 234 vs 273, 959 vs 1143 us -- ahead wherever the last round is at least ~80 % full; causal (long blocks first, the

@@ -744,7 +744,17 @@ void set_max_lds(K kernel, size_t lds) {
 bool launch_attn_prefill64(const AttnPrefillArgs& a_in, hipStream_t st, int pipe) {
   AttnPrefillArgs a = a_in;
   if (!(a.d == 128 || a.d == 72) || a.d % 8 != 0 || ((uintptr_t)a.o & 15) != 0 || !(a.scale > 0.f)) return false;
-  if (a.S2 > 0 && !(a.causal && a.kvh % 8 == 0 && a.nh % a.kvh == 0)) return false;
+  if (a.S2 > 0 && !(a.causal && a.kvh % 8 == 0 && a.nh % a.kvh == 0)) {
+    // two segments where the one-launch block order does not apply: two launches of THIS form (not the 16-row kernel: a context-parallel
+    // rank must run the form the un-sharded prompt runs)
+    AttnPrefillArgs b = a;
+    b.S2 = 0;
+    if (!launch_attn_prefill64(b, st, pipe)) return false;
+    b.q = (const char*)a.q + (int64_t)a.S * (a.q_ld ? a.q_ld : (int64_t)a.nh * (a.d == 72 ? 96 : a.d)) * 2;
+    b.o = (char*)a.o + (int64_t)a.S * a.nh * a.d * 2;
+    b.S = a.S2, b.kv_offset = a.kv_offset2, b.kv_total = a.kv_total2;
+    return launch_attn_prefill64(b, st, pipe);
+  }
   const bool xcd_order = a.kvh % 8 == 0 && a.nh % a.kvh == 0;
   const int nqb = (a.S + ATTN64_ROWS - 1) / ATTN64_ROWS + (a.S2 + ATTN64_ROWS - 1) / ATTN64_ROWS;
   a.nqb = xcd_order ? nqb : 0;

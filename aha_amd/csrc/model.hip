@@ -1768,6 +1768,7 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
       AttnPrefillArgs a{};
       a.q = rows(m->p_q, sg.l0, nq); a.kv = model_kv_layer(m, li); a.o = rows(m->p_attn, sg.l0, nq); a.S = sg.len; a.nh = nh; a.kvh = kvh; a.d = d;
       a.kv_offset = kv_off + sg.r0; a.kv_total = kv_off + sg.r0 + sg.len; a.causal = 1; a.scale = m->attn_scale;
+      a.rows_hint = (int)S;   // the kernel form by the whole prompt: a context-parallel rank's rows stay bit-identical to the un-sharded prefill
       double Lk = a.kv_total, flops = 4.0 * sg.len * (a.kv_offset + 0.5 * sg.len) * nq, rows_io = sg.len;
       if (one_launch) {
         const RowSeg& s2 = segs[1];

@@ -123,7 +123,11 @@ def test_context_parallel_with_automatic_plans_and_short_prompts(gpu, monkeypatc
     more = ids[:70]
     a = single.forward_initial(more, S)[0].copy()
     b = run_ranks([lambda m=m: m.forward_initial(more, S)[0].copy() for m in ranks])
-    close(b[0], a, "continuation after a context-parallel prefill")
+    # (the continuation itself is the same un-sharded computation on every side; what differs is the cache it reads, written under the
+    # ranks' GEMM plans at M = 750 rows against the single GPU's at M = 1500: since round 6 the 128^2 / 256-row choice differs between
+    # those two M on this 512-wide toy model (kernels_gemm.hip plan_gemm, the short-K latency constant), each kernel inside its own
+    # oracle bound -- measured 0.0042 std rms, 0.0030 before)
+    close(b[0], a, "continuation after a context-parallel prefill", rms=0.006)
     for m in ranks + [single]:
         m.clear_cache()
     short = ids[:200]
