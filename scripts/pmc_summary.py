@@ -3,7 +3,7 @@ roofline.traffic).  FETCH_SIZE / WRITE_SIZE are in KB; gfx950 reports HALF the b
 FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section).  Per launch = sum over the kernel class / its dispatch count."""
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("ROUND", "r05")
+ROUND = os.environ.get("ROUND", "r06")
 
 
 def load(counter):
