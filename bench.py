@@ -26,8 +26,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_PEAK_TFLOPS = 2500.0  # bf16 dense
-PMC_FILE = "r05_pmc_traffic_gemv.json"      # scripts/pmc_summary.py
-STATS_FILE = "r05_cfg3_kernel_stats.md"     # scripts/stats_to_md.py of `rocprofv3 --kernel-trace --stats -- python bench.py ...`
+PMC_FILE = "r06_pmc_traffic_gemv.json"      # scripts/pmc_summary.py
+STATS_FILE = "r06_cfg3_kernel_stats.md"     # scripts/stats_to_md.py of `rocprofv3 --kernel-trace --stats -- python bench.py ...`
 
 
 METRICS = {
