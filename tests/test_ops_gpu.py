@@ -691,6 +691,38 @@ def test_attn_prefill_64_rows_per_wave_peaky_and_long(gpu, form):
     assert_close_ulps(got2, old2.float().cpu(), 3, None, f"attn_prefill S=2048 form {form} vs the 16-row kernel", row_scale=True)
 
 
+def test_attn_prefill_64_rows_per_wave_random_shapes_repeatable(gpu):
+    """The 64-row kernel's MFMAs, exponentials and accumulator traffic are inline asm: hipcc neither counts their memory operations nor
+    pads their hazards (cdna_hip_programming.md section 5.7), and a missed wait state shows as wrong values on SOME waves of SOME launches.
+    So beyond the fixed shapes: 48 random (rows, cache offset, heads, causal / full) launches, each run three times on both forms -- the
+    three outputs must be bit-identical (a hazard is timing-dependent), finite, and within 3 bf16 ulp of the row scale of the 16-row
+    kernel's output (itself held to the oracle above)."""
+    from aha_amd import ops
+    rng = np.random.default_rng(64)
+    d = 128
+    for case in range(48):
+        kvh = int(rng.choice([2, 4, 8]))
+        nh = kvh * int(rng.choice([1, 2, 4]))
+        S = int(rng.integers(1, 1400))
+        causal = bool(rng.integers(0, 2))
+        off = int(rng.integers(0, 700)) if causal else 0
+        L = S + off
+        q, k, v = rnd((S, nh * d), 1000 + case), rnd((L, kvh * d), 2000 + case, float(rng.choice([0.3, 1.0]))), rnd((L, kvh * d), 3000 + case)
+        if case % 5 == 0 and L > 40:     # a dominating key late in the cache: the rescale path
+            k[L - 7] = (q[S - 1, :d] * 2.0).repeat(kvh)
+        qg, kg, vg = q.to(gpu), k.to(gpu), v.to(gpu)
+        try:
+            ops.attn_form(16)
+            base = ops.attn_prefill(qg, kg, vg, nh, kvh, d, off, causal)
+            for form in (64, 65):
+                ops.attn_form(form)
+                outs = [ops.attn_prefill(qg, kg, vg, nh, kvh, d, off, causal) for _ in range(3)]
+                assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), f"case {case} form {form}: not repeatable"
+                assert_close_ulps(outs[0], base.float().cpu(), 3, None, f"case {case} (S {S} off {off} nh {nh} kvh {kvh} causal {causal}) form {form}", row_scale=True)
+        finally:
+            ops.attn_form(-1)
+
+
 @pytest.mark.parametrize("smx", [0, 1, 3])
 @pytest.mark.parametrize("S", [13, 64, 390, 777])
 def test_attn_prefill_head_dim_64_full(gpu, smx, S):
