@@ -114,6 +114,79 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
   else epilogue<ACT, HAS_BIAS, HAS_RES, 4>(a, acc, m0 + wm * 64, n0 + wn * 64, G, c);
 }
 
+// ---- variant 1b: the same 128 x 128 tile with a RING of LDS stages (round 6) ---------------------------------------------------------
+// gemm_glds_kernel stages a K tile, drains, multiplies, and relies on the three or four blocks a CU holds to hide each other's memory
+// round trip.  A launch of <= 256 blocks has ONE block per CU: every k step then costs the whole trip of its own tile -- 1.4 us per k step
+// on cold weights, where the multiply is 0.3 us (BASELINE cfg 4, Qwen3-ASR: 112 GEMMs of 390 / 406 rows per prefill run this way, 21-27 us
+// each for 2.5-5 GFLOP, profiles/r06_cfg4_kernel_stats.md).  Here the block prefetches for itself: NST stages of [A tile | W tile], tile
+// kt + NST - 1 requested while tile kt is multiplied, ONE counted s_waitcnt vmcnt per k step (the NST - 1 newer groups of 8 pieces stay in
+// flight) and two raw barriers (a __syncthreads would drain the DMA queue).  Tiles past the end are requested from the zero block so
+// that the counts stay uniform.  Same tile, same mma_tile, same k order, same epilogue: bit-identical to gemm_glds_kernel.
+template <int ACT, bool HAS_BIAS, bool HAS_RES, int NST, bool ROWS = true>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void gemm_glds_ring_kernel(GemmArgs a, const void* zeros) {
+  char* const smem = gemm_smem;  // NST x [A tile | W tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, c = lane & 15;
+  const int wm = wave >> 1, wn = wave & 1;
+  int m0, n0;
+  tile_of_block(a, m0, n0);
+  const bf16_t* A = (const bf16_t*)a.A;
+  const bf16_t* W = (const bf16_t*)a.W;
+  const int nk = (a.K + BK - 1) / BK;
+  const bf16_t* ga[4];
+  const bf16_t* gw[4];
+  int kofs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (j * 4 + wave) * 8 + (lane >> 3);
+    const int sl = (lane & 7) ^ ((row >> 1) & 7);  // logical k-slot this lane fetches
+    kofs[j] = sl * 8;
+    ga[j] = A + (int64_t)min(m0 + row, a.M - 1) * a.lda + sl * 8;
+    gw[j] = W + (int64_t)min(n0 + row, a.N - 1) * a.ldw + sl * 8;
+  }
+  f32x4_t acc[4][4];  // [ni][mi]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  auto stage_tile = [&](int kt, int st) __attribute__((always_inline)) {
+    char* sa = smem + st * (2 * TILE_BYTES);
+    char* sw = sa + TILE_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = kt < nk && kt * BK + kofs[j] < a.K;
+      const void* pa = ok ? (const void*)(ga[j] + kt * BK) : zeros;
+      const void* pw = ok ? (const void*)(gw[j] + kt * BK) : zeros;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)pa, (lds_ptr_t)(sa + (j * 4 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)pw, (lds_ptr_t)(sw + (j * 4 + wave) * 1024), 16, 0, 0);
+    }
+  };
+#define AHA_RING_BAR()                           \
+  do {                                           \
+    __builtin_amdgcn_sched_barrier(0);           \
+    __builtin_amdgcn_s_barrier();                \
+    __builtin_amdgcn_sched_barrier(0);           \
+  } while (0)
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t) stage_tile(t, t);
+  int st = 0, st_new = NST - 1;
+  for (int kt = 0; kt < nk; ++kt) {
+    stage_tile(kt + NST - 1, st_new);   // into the stage tile kt - 1 left (every wave is past the barrier that ended its reads)
+    // tile kt has landed once only the NST - 1 newer groups of 8 pieces are in flight (vmcnt is a 6-bit field: [3:0] and [15:14])
+    constexpr int KEEP = 8 * (NST - 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (KEEP & 15) | ((KEEP >> 4) << 14));
+    AHA_RING_BAR();
+    mma_tile(smem + st * (2 * TILE_BYTES), smem + st * (2 * TILE_BYTES) + TILE_BYTES, wm, wn, G, c, acc);
+    AHA_RING_BAR();
+    st_new = st;
+    st = (st + 1 == NST) ? 0 : st + 1;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // the requests past the end still write their (zero) pieces: nothing in flight when the epilogue reuses the LDS
+  AHA_RING_BAR();
+#undef AHA_RING_BAR
+  if constexpr (ROWS) epilogue16_rows<ACT, HAS_BIAS, HAS_RES>(a, acc, m0 + wm * 64, n0 + wn * 64, lane, smem + wave * (32 * 144));
+  else epilogue<ACT, HAS_BIAS, HAS_RES, 4>(a, acc, m0 + wm * 64, n0 + wn * 64, G, c);
+}
+
 // ---- 256 x 256 x 64 tiles ----------------------------------------------------------------------------------------------------
 // (The first 256^2 kernel -- 8 waves, one __syncthreads per K tile with the LDS-DMA drained in front of it, 16x16x32 MFMA: 1.41 us
 // per K step alone on the chip, 1.03-1.06 PF at 8192^3 -- was the A/B reference of the two below through round 2 and is retired;
@@ -639,13 +712,35 @@ const void* zero_block() {
 
 template <int ACT, bool B, bool R>
 void launch_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
+  // <= one block per CU: the block hides its own memory round trips behind a four-stage ring (gemm_glds_ring_kernel; 128 KiB of LDS).
+  // AHA_GEMM_RING=0: the single-stage kernel everywhere (A/B; bit-identical outputs)
+  static const bool ring_on = [] { const char* e = getenv("AHA_GEMM_RING"); return e ? atoi(e) != 0 : true; }();
+  const int64_t blocks = (int64_t)grid.x * grid.y * grid.z;
+  const bool ring = ring_on && blocks <= gemm_streamk_cus() && (a.K + BK - 1) / BK >= 4;
+  constexpr int NST = 4;
   // row-order stores need whole 16-byte column groups: N a multiple of 8, rows of C / residual 16-byte aligned; else fragment order
   if constexpr (ACT != ACT_SILU_MUL_PAIRS && ACT != ACT_PARTIAL_F32) {
     if (a.partial_rows && (a.N & 7) == 0 && (a.ldc & 7) == 0 && ((uintptr_t)a.C & 15) == 0 && (!R || ((uintptr_t)a.residual & 15) == 0) &&
         (!B || ((uintptr_t)a.bias & 15) == 0)) {
+      if (ring) {
+        static DevOnce once_ring;
+        if (auto once_guard = once_ring.first()) {
+          hipFuncSetAttribute((const void*)gemm_glds_ring_kernel<ACT, B, R, NST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * 2 * TILE_BYTES);
+        }
+        hipLaunchKernelGGL((gemm_glds_ring_kernel<ACT, B, R, NST, true>), grid, dim3(256), NST * 2 * TILE_BYTES, st, a, zero_block());
+        return;
+      }
       hipLaunchKernelGGL((gemm_glds_kernel<ACT, B, R, true>), grid, dim3(256), 2 * TILE_BYTES, st, a, zero_block());
       return;
     }
+  }
+  if (ring) {
+    static DevOnce once_ring2;
+    if (auto once_guard = once_ring2.first()) {
+      hipFuncSetAttribute((const void*)gemm_glds_ring_kernel<ACT, B, R, NST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * 2 * TILE_BYTES);
+    }
+    hipLaunchKernelGGL((gemm_glds_ring_kernel<ACT, B, R, NST, false>), grid, dim3(256), NST * 2 * TILE_BYTES, st, a, zero_block());
+    return;
   }
   hipLaunchKernelGGL((gemm_glds_kernel<ACT, B, R>), grid, dim3(256), 2 * TILE_BYTES, st, a, zero_block());
 }
