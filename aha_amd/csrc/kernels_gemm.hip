@@ -166,16 +166,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     __builtin_amdgcn_s_barrier();                \
     __builtin_amdgcn_sched_barrier(0);           \
   } while (0)
+  // one piece pair (A + W) of tile kt into stage st: the 8 pieces of a tile ride between the MFMAs of the tile being multiplied (a piece costs
+  // ~60 cycles of issue among MFMAs, 100-185 in a burst next to fragment reads: issued as a burst in front of the wait they were the k step)
+  auto stage_piece = [&](int kt, int st_, int j) __attribute__((always_inline)) {
+    char* sa = smem + st_ * (2 * TILE_BYTES);
+    char* sw = sa + TILE_BYTES;
+    const bool ok = kt < nk && kt * BK + kofs[j] < a.K;
+    const void* pa = ok ? (const void*)(ga[j] + kt * BK) : zeros;
+    const void* pw = ok ? (const void*)(gw[j] + kt * BK) : zeros;
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)pa, (lds_ptr_t)(sa + (j * 4 + wave) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)pw, (lds_ptr_t)(sw + (j * 4 + wave) * 1024), 16, 0, 0);
+  };
 #pragma unroll
   for (int t = 0; t < NST - 1; ++t) stage_tile(t, t);
   int st = 0, st_new = NST - 1;
   for (int kt = 0; kt < nk; ++kt) {
-    stage_tile(kt + NST - 1, st_new);   // into the stage tile kt - 1 left (every wave is past the barrier that ended its reads)
-    // tile kt has landed once only the NST - 1 newer groups of 8 pieces are in flight (vmcnt is a 6-bit field: [3:0] and [15:14])
-    constexpr int KEEP = 8 * (NST - 1);
+    // tile kt has landed once only the NST - 2 newer groups of 8 pieces are in flight (tile kt + NST - 1 is requested below, between the
+    // MFMAs; vmcnt is a 6-bit field: [3:0] and [15:14])
+    constexpr int KEEP = 8 * (NST - 2);
     __builtin_amdgcn_s_waitcnt(0x0F70 | (KEEP & 15) | ((KEEP >> 4) << 14));
     AHA_RING_BAR();
-    mma_tile(smem + st * (2 * TILE_BYTES), smem + st * (2 * TILE_BYTES) + TILE_BYTES, wm, wn, G, c, acc);
+    {   // mma_tile (gemm256_body.h) with the staging of tile kt + NST - 1 -- into the stage tile kt - 1 left -- between its MFMA groups
+      const char* sa = smem + st * (2 * TILE_BYTES);
+      const char* sw = sa + TILE_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t af[4], wf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          af[i] = as_frag(*reinterpret_cast<const u32x4_t*>(sa + swz(wm * 64 + i * 16 + c, ks * 4 + G)));
+          wf[i] = as_frag(*reinterpret_cast<const u32x4_t*>(sw + swz(wn * 64 + i * 16 + c, ks * 4 + G)));
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(wf[ni], af[mi], acc[ni][mi]);
+          if ((ni & 1) == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            stage_piece(kt + NST - 1, st_new, ks * 2 + (ni >> 1));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
     AHA_RING_BAR();
     st_new = st;
     st = (st + 1 == NST) ? 0 : st + 1;
