@@ -268,7 +268,7 @@ int aha_hip_debug_plan_gemm(int32_t M, int32_t N, int32_t K, int32_t act, int32_
     return AHA_ERR_INVALID;
   }
   int o[3];
-  debug_plan_gemm(M, N, K, act, has_bias != 0, has_residual != 0, workspace_bytes, o);
+  debug_plan_gemm(M, N, K, act, has_bias != 0, (has_residual & 1) != 0, workspace_bytes, o, (has_residual & 2) != 0);
   out3[0] = o[0]; out3[1] = o[1]; out3[2] = o[2];
   return AHA_OK;
 }

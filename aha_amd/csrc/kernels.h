@@ -202,11 +202,20 @@ void set_gemm_reserved_cus(int n);     // CUs the persistent GEMM leaves free (R
 bool acquire_gemm_cu_reservation(int cus);   // the automatic, reference-counted reservation of a communication stream (kernels_gemm_sk.hip)
 void release_gemm_cu_reservation();
 int debug_streamk_plan(int M, int N, int K, int tile_n, int workers, int group, size_t ws_bytes, int* out, int cap, int* off_out, int* info);
-void debug_plan_gemm(int M, int N, int K, int act, bool has_bias, bool has_res, size_t ws_bytes, int* out);   // host only: {tile, splitk, n_split}
+void debug_plan_gemm(int M, int N, int K, int act, bool has_bias, bool has_res, size_t ws_bytes, int* out, bool has_norm = false);   // host only: {tile, splitk, n_split}
 void set_gemm_plan_override(int tile, int splitk);  // tests: force the 128 / 256 tile kernel and a split-K factor; 0 = automatic
-struct GemmWorkspaceScope {
-  GemmWorkspaceScope(void* ws, size_t bytes, void* sk_counters = nullptr) { set_gemm_workspace(ws, bytes, sk_counters); }
-  ~GemmWorkspaceScope() { set_gemm_workspace(nullptr, 0, nullptr); }
+void get_gemm_workspace(void** ws, size_t* bytes, void** sk_counters);
+struct GemmWorkspaceScope {   // nests: the vision tower's own workspace inside the prefill's
+  GemmWorkspaceScope(void* ws, size_t bytes, void* sk_counters = nullptr) {
+    get_gemm_workspace(&prev_ws, &prev_bytes, &prev_ctrs);
+    set_gemm_workspace(ws, bytes, sk_counters);
+  }
+  ~GemmWorkspaceScope() { set_gemm_workspace(prev_ws, prev_bytes, prev_ctrs); }
+  GemmWorkspaceScope(const GemmWorkspaceScope&) = delete;
+  GemmWorkspaceScope& operator=(const GemmWorkspaceScope&) = delete;
+  void* prev_ws = nullptr;
+  size_t prev_bytes = 0;
+  void* prev_ctrs = nullptr;
 };
 // x[i] = bf16(x[i] + bf16(sum[i])): Linear output tensor (all-reduced f32 partials) -> bf16, then the residual add -> bf16
 void launch_residual_add_f32(void* x, const float* sum, int64_t n, hipStream_t st);

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
 // flight) and two raw barriers (a __syncthreads would drain the DMA queue).  Tiles past the end are requested from the zero block so
 // that the counts stay uniform.  Same tile, same mma_tile, same k order, same epilogue: bit-identical to gemm_glds_kernel.
 template <int ACT, bool HAS_BIAS, bool HAS_RES, int NST, bool ROWS = true>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void gemm_glds_ring_kernel(GemmArgs a, const void* zeros) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_glds_ring_kernel(GemmArgs a, const void* zeros, int kt_per_slice) {
   char* const smem = gemm_smem;  // NST x [A tile | W tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, c = lane & 15;
   const int wm = wave >> 1, wn = wave & 1;
@@ -131,7 +131,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
   tile_of_block(a, m0, n0);
   const bf16_t* A = (const bf16_t*)a.A;
   const bf16_t* W = (const bf16_t*)a.W;
-  const int nk = (a.K + BK - 1) / BK;
+  // gridDim.y > 1 = split-K (ACT_PARTIAL_F32 only): slice z owns k tiles [z * kt_per_slice, ...) and writes the f32 slab a.C + z*M*ldc
+  int kt0 = 0, nk = (a.K + BK - 1) / BK;
+  if constexpr (ACT == ACT_PARTIAL_F32) {
+    kt0 = (int)blockIdx.y * kt_per_slice;
+    nk = min(nk, kt0 + kt_per_slice);
+    a.C = (float*)a.C + (int64_t)blockIdx.y * a.M * a.ldc;
+  }
   const bf16_t* ga[4];
   const bf16_t* gw[4];
   int kofs[4];
@@ -178,40 +184,69 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     __builtin_amdgcn_global_load_lds((glb_ptr_t)pw, (lds_ptr_t)(sw + (j * 4 + wave) * 1024), 16, 0, 0);
   };
 #pragma unroll
-  for (int t = 0; t < NST - 1; ++t) stage_tile(t, t);
-  int st = 0, st_new = NST - 1;
-  for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed once only the NST - 2 newer groups of 8 pieces are in flight (tile kt + NST - 1 is requested below, between the
-    // MFMAs; vmcnt is a 6-bit field: [3:0] and [15:14])
-    constexpr int KEEP = 8 * (NST - 2);
-    __builtin_amdgcn_s_waitcnt(0x0F70 | (KEEP & 15) | ((KEEP >> 4) << 14));
-    AHA_RING_BAR();
-    {   // mma_tile (gemm256_body.h) with the staging of tile kt + NST - 1 -- into the stage tile kt - 1 left -- between its MFMA groups
-      const char* sa = smem + st * (2 * TILE_BYTES);
-      const char* sw = sa + TILE_BYTES;
+  for (int t = 0; t < NST - 1; ++t) stage_tile(kt0 + t, t);
+  // One wave per SIMD: nothing else hides a fragment read's LDS round trip, so the reads run one half tile (32 of the 64 k) AHEAD of the
+  // MFMAs, in two register sets -- F1 = (kt, k 32-63) is requested among the MFMAs on F0 = (kt, k 0-31), F0 = (kt + 1, k 0-31) in
+  // front of the MFMAs on F1.  ONE barrier per k step, between the two halves: in front of it a wave waits for its own pieces of tile
+  // kt + 1 (counted vmcnt: the NST - 3 newer tiles and the first half of the tile being requested stay in flight) and for its LDS reads
+  // (lgkmcnt(0): they were issued 16 MFMAs ago), so past the barrier tile kt + 1 is whole and nobody reads tile kt - 1 any more -- which is
+  // the stage the pieces of tile kt + NST - 1 go to.  (Reading first and multiplying after cost 0.52 us per k step for 0.21 us of MFMAs.)
+  auto read_frags = [&](int st_, int ks, bf16x8_t (&af)[4], bf16x8_t (&wf)[4]) __attribute__((always_inline)) {
+    const char* sa = smem + st_ * (2 * TILE_BYTES);
+    const char* sw = sa + TILE_BYTES;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8_t af[4], wf[4];
+    for (int i = 0; i < 4; ++i) {
+      af[i] = as_frag(*reinterpret_cast<const u32x4_t*>(sa + swz(wm * 64 + i * 16 + c, ks * 4 + G)));
+      wf[i] = as_frag(*reinterpret_cast<const u32x4_t*>(sw + swz(wn * 64 + i * 16 + c, ks * 4 + G)));
+    }
+  };
+  auto mma_half = [&](const bf16x8_t (&af)[4], const bf16x8_t (&wf)[4], int kt_new, int st_new_, int j0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          af[i] = as_frag(*reinterpret_cast<const u32x4_t*>(sa + swz(wm * 64 + i * 16 + c, ks * 4 + G)));
-          wf[i] = as_frag(*reinterpret_cast<const u32x4_t*>(sw + swz(wn * 64 + i * 16 + c, ks * 4 + G)));
-        }
+    for (int ni = 0; ni < 4; ++ni) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(wf[ni], af[mi], acc[ni][mi]);
-          if ((ni & 1) == 1) {
-            __builtin_amdgcn_sched_barrier(0);
-            stage_piece(kt + NST - 1, st_new, ks * 2 + (ni >> 1));
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
+      for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(wf[ni], af[mi], acc[ni][mi]);
+      if ((ni & 1) == 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        stage_piece(kt_new, st_new_, j0 + (ni >> 1));
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+  };
+  bf16x8_t a0[4], w0[4], a1[4], w1[4];
+  {
+    constexpr int KEEP0 = 8 * (NST - 2);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (KEEP0 & 15) | ((KEEP0 >> 4) << 14));
     AHA_RING_BAR();
+    read_frags(0, 0, a0, w0);
+  }
+  int st = 0, st_new = NST - 1;
+  for (int kt = kt0; kt < nk; ++kt) {
+    const int st_next = (st + 1 == NST) ? 0 : st + 1;
+    // (F1 is requested after the first four MFMAs on F0, not in front of them: the compiler's wait for F0 is an lgkmcnt(0), and with F1
+    // already in the queue it would wait for both)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(w0[ni], a0[mi], acc[ni][mi]);
+      if (ni == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(st, 1, a1, w1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if ((ni & 1) == 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        stage_piece(kt + NST - 1, st_new, ni >> 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    constexpr int KEEP = 8 * (NST - 3) + 4;   // vmcnt is a 6-bit field: [3:0] and [15:14]; lgkmcnt(0) = bits [11:8]
+    __builtin_amdgcn_s_waitcnt(0x0070 | (KEEP & 15) | ((KEEP >> 4) << 14));
+    AHA_RING_BAR();
+    read_frags(st_next, 0, a0, w0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_half(a1, w1, kt + NST - 1, st_new, 2);
     st_new = st;
-    st = (st + 1 == NST) ? 0 : st + 1;
+    st = st_next;
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // the requests past the end still write their (zero) pieces: nothing in flight when the epilogue reuses the LDS
   AHA_RING_BAR();
@@ -760,7 +795,7 @@ void launch_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
         if (auto once_guard = once_ring.first()) {
           hipFuncSetAttribute((const void*)gemm_glds_ring_kernel<ACT, B, R, NST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * 2 * TILE_BYTES);
         }
-        hipLaunchKernelGGL((gemm_glds_ring_kernel<ACT, B, R, NST, true>), grid, dim3(256), NST * 2 * TILE_BYTES, st, a, zero_block());
+        hipLaunchKernelGGL((gemm_glds_ring_kernel<ACT, B, R, NST, true>), grid, dim3(256), NST * 2 * TILE_BYTES, st, a, zero_block(), (a.K + BK - 1) / BK);
         return;
       }
       hipLaunchKernelGGL((gemm_glds_kernel<ACT, B, R, true>), grid, dim3(256), 2 * TILE_BYTES, st, a, zero_block());
@@ -772,7 +807,7 @@ void launch_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
     if (auto once_guard = once_ring2.first()) {
       hipFuncSetAttribute((const void*)gemm_glds_ring_kernel<ACT, B, R, NST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * 2 * TILE_BYTES);
     }
-    hipLaunchKernelGGL((gemm_glds_ring_kernel<ACT, B, R, NST, false>), grid, dim3(256), NST * 2 * TILE_BYTES, st, a, zero_block());
+    hipLaunchKernelGGL((gemm_glds_ring_kernel<ACT, B, R, NST, false>), grid, dim3(256), NST * 2 * TILE_BYTES, st, a, zero_block(), (a.K + BK - 1) / BK);
     return;
   }
   hipLaunchKernelGGL((gemm_glds_kernel<ACT, B, R>), grid, dim3(256), 2 * TILE_BYTES, st, a, zero_block());
@@ -784,6 +819,56 @@ void launch_act(const GemmArgs& a, dim3 grid, hipStream_t st) {
   else if (a.bias) launch_one<ACT, true, false>(a, grid, st);
   else if (a.residual) launch_one<ACT, false, true>(a, grid, st);
   else launch_one<ACT, false, false>(a, grid, st);
+}
+
+// pass 2 of a split-K plan: the f32 slabs in a.workspace summed, then the epilogue chain -- with the norm riding on the call folded in where a
+// reduce pass owns whole rows (RMSNorm: launch_reduce_norm; LayerNorm: launch_reduce_layernorm)
+template <int ACT, bool B, bool R>
+void launch_splitk_reduce(const GemmArgs& a, int nsl, hipStream_t st, bool* norm_fused) {
+  const int64_t quads = (int64_t)a.M * (a.N >> 2);
+  if (norm_fused != nullptr) *norm_fused = false;
+  if (a.norm_w != nullptr && a.norm_b == nullptr && norm_fused != nullptr && ACT == ACT_NONE && !B && a.N % 512 == 0 &&
+      launch_reduce_norm<R>(a, (const float*)a.workspace, nsl, st)) {
+    *norm_fused = true;
+    return;
+  }
+  if (a.norm_w != nullptr && a.norm_b != nullptr && norm_fused != nullptr && ACT == ACT_NONE &&
+      launch_reduce_layernorm<B, R>(a, (const float*)a.workspace, nsl, st)) {
+    *norm_fused = true;
+    return;
+  }
+  hipLaunchKernelGGL((gemm_splitk_reduce_kernel<ACT, B, R>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, a,
+                     (const float*)a.workspace, nsl);
+}
+
+// Split-K on 128^2 tiles (round 6): tiles x slices blocks of gemm_glds_ring_kernel<ACT_PARTIAL_F32> -- at most one per CU -- write f32 slabs,
+// the reduce pass above finishes.  For the few-row projections with a long K (BASELINE cfg 4: o_proj / down_proj / fc2 at 390-406 rows, 32
+// tiles of 128^2): the 256^2 split plans put 32-48 blocks on the chip, 18.6 us + the reduce pass.
+template <int ACT, bool B, bool R>
+void launch_ring_splitk(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fused) {
+  constexpr int NST = 4;
+  static DevOnce once;
+  if (auto once_guard = once.first()) {
+    hipFuncSetAttribute((const void*)gemm_glds_ring_kernel<ACT_PARTIAL_F32, false, false, NST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * 2 * TILE_BYTES);
+  }
+  GemmArgs p = a;  // pass 1: f32 slabs [slices][M][N] in the caller's workspace
+  p.C = a.workspace;
+  p.ldc = a.N;
+  p.bias = nullptr;
+  p.residual = nullptr;
+  p.act = ACT_PARTIAL_F32;
+  const int nk = (a.K + BK - 1) / BK, kps = (nk + splitk - 1) / splitk, nsl = (nk + kps - 1) / kps;
+  const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
+  hipLaunchKernelGGL((gemm_glds_ring_kernel<ACT_PARTIAL_F32, false, false, NST, false>), dim3(ntm * ntn, nsl), dim3(256), NST * 2 * TILE_BYTES, st, p, zero_block(), kps);
+  launch_splitk_reduce<ACT, B, R>(a, nsl, st, norm_fused);
+}
+
+template <int ACT>
+void launch_ring_splitk_act(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fused) {
+  if (a.bias && a.residual) launch_ring_splitk<ACT, true, true>(a, splitk, st, norm_fused);
+  else if (a.bias) launch_ring_splitk<ACT, true, false>(a, splitk, st, norm_fused);
+  else if (a.residual) launch_ring_splitk<ACT, false, true>(a, splitk, st, norm_fused);
+  else launch_ring_splitk<ACT, false, false>(a, splitk, st, norm_fused);
 }
 
 // the (ACT, bias, residual) combinations that have a 192-column instantiation (gemm256q_kernel<.., NF3 = true>): gate+up and the
@@ -927,20 +1012,7 @@ void launch256_one(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fus
   } else {
     hipLaunchKernelGGL((gemm256p_kernel<ACT_PARTIAL_F32, false, false>), dim3(ntm * ntn, splitk), dim3(512), lds, st, p, zero_block(), kps, nullptr);
   }
-  const int64_t quads = (int64_t)a.M * (a.N >> 2);
-  if (norm_fused != nullptr) *norm_fused = false;
-  if (a.norm_w != nullptr && a.norm_b == nullptr && norm_fused != nullptr && ACT == ACT_NONE && !B && a.N % 512 == 0 &&
-      launch_reduce_norm<R>(a, (const float*)a.workspace, (nk + kps - 1) / kps, st)) {
-    *norm_fused = true;
-    return;
-  }
-  if (a.norm_w != nullptr && a.norm_b != nullptr && norm_fused != nullptr && ACT == ACT_NONE &&
-      launch_reduce_layernorm<B, R>(a, (const float*)a.workspace, (nk + kps - 1) / kps, st)) {
-    *norm_fused = true;
-    return;
-  }
-  hipLaunchKernelGGL((gemm_splitk_reduce_kernel<ACT, B, R>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, a,
-                     (const float*)a.workspace, (nk + kps - 1) / kps);
+  launch_splitk_reduce<ACT, B, R>(a, (nk + kps - 1) / kps, st, norm_fused);
 }
 
 template <int ACT>
@@ -963,7 +1035,13 @@ struct GemmPlan { int tile, splitk; double cost = 0; bool streamk = false; };   
 int g_force_tile = 0, g_force_splitk = 0;  // aha_hip_debug_gemm_plan (tests): 0 = automatic
 
 GemmPlan plan_gemm(const GemmArgs& a) {
-  if (g_force_tile == 128) return GemmPlan{128, 1};
+  if (g_force_tile == 128) {
+    int sk = g_force_splitk > 1 ? g_force_splitk : 1;
+    const int nk_ = (a.K + BK - 1) / BK;
+    if (sk > 1 && (a.act == ACT_SILU_MUL_PAIRS || a.act == ACT_PARTIAL_F32 || !a.workspace || (a.N & 3) || nk_ / sk < 2 ||
+                   (size_t)sk * a.M * a.N * 4 > a.workspace_bytes)) sk = 1;
+    return GemmPlan{128, sk};
+  }
   if (g_force_tile == 1256 || g_force_tile == 1192) {   // tests: the persistent kernel wherever it has an instantiation and a workspace
     const int tn = g_force_tile - 1000;
     if (a.M >= 1 && a.K % BK == 0 && streamk_has_kernel(a.act, a.bias != nullptr, a.residual != nullptr, tn == 192) &&
@@ -993,16 +1071,38 @@ GemmPlan plan_gemm(const GemmArgs& a) {
   // and a GELU-erf epilogue on the 28 CUs that hold 256^2 tiles costs more than the GEMM (52 us in the model).  AHA_GEMM_LAT128 = the
   // per-k-step microseconds (A/B).
   static const double lat128 = [] { const char* e = getenv("AHA_GEMM_LAT128"); return e ? atof(e) : 0.75; }();
-  const double cost128 = std::max(ceil(t128 / 256.0) * nk * 0.68, t128 < 512.0 ? nk * lat128 + 4.5 : 0.0);
+  // (the ring kernel -- <= one block per CU, >= 4 k steps, launch_one -- runs a lone block's k step in ~0.5 us: AHA_GEMM_LAT_RING)
+  static const double lat_ring = [] { const char* e = getenv("AHA_GEMM_LAT_RING"); return e ? atof(e) : 0.5; }();
+  const bool ring128 = t128 <= (double)gemm_streamk_cus() && nk >= 4;
+  // (a norm riding on the call is folded into a split plan's reduce pass; behind an unsplit ring launch it is a ~6-us launch of its own --
+  // cfg 2 o_proj, 2048 x 1024 x 2048: 23.1 us unsplit against 27.6 us as 256^2 x 4 slices, but 4.99 against 4.57 ms per prefill)
+  const double cost128 = std::max(ceil(t128 / 256.0) * nk * 0.68, t128 < 512.0 ? nk * (ring128 ? lat_ring : lat128) + 4.5 : 0.0) +
+                         (ring128 && a.norm_w ? 6.0 : 0.0);
   const bool can_split = a.act != ACT_SILU_MUL_PAIRS && a.act != ACT_PARTIAL_F32 && a.workspace != nullptr && (a.N & 3) == 0;
   GemmPlan best{128, 1};
   double best_cost = cost128;
+  // 128^2 tiles x K slices on the ring kernel, one block per CU at most (launch_ring_splitk).  The reduce pass of these few-row shapes is
+  // small and launch-sized: ~2 TB/s over its (slices + 1) slabs, not the 4 TB/s of the 256^2 plans' larger ones (scripts/tune_gemm.py at
+  // 406 x 1024: 4 -> 8 slices + 1.9 us with four k steps less)
+  static const bool ring_sk_on = [] { const char* e = getenv("AHA_GEMM_RING_SPLITK"); return e ? atoi(e) != 0 : true; }();
+  if (ring_sk_on && can_split && nk >= 24 && !e_tile && !(e_sk && atoi(e_sk) == 1)) {   // (K >= 1536: below, the slices save ~2 us by the model -- inside its error)
+    for (int sk : {2, 3, 4, 6, 8}) {
+      if (e_sk && atoi(e_sk) != sk) continue;
+      if ((size_t)sk * a.M * a.N * 4 > a.workspace_bytes || nk / sk < 4 || t128 * sk > (double)gemm_streamk_cus()) continue;
+      const double c = ceil(nk / sk) * lat_ring + 4.5 + (double)(sk + 1) * a.M * a.N * 4.0 / 2.0e6 + 3.0;
+      if (c < best_cost) {
+        best = GemmPlan{128, sk};
+        best_cost = c;
+      }
+    }
+  }
   // 256^2 units: tiles x K slices.  A CU retires one 64-deep k step of a 256^2 tile in ~1.5 us with the whole chip busy on the
   // four-wave kernel (1.75 us on the eight-wave one; both clock-bound there); the last, partly filled round of units costs a full round, so the
   // split factor is chosen to make tiles * sk land just under a multiple of the CU count -- any factor, not only powers of
   // two (M = 1542: qkv 168 tiles x 3 = 504 units).  The reduce pass streams (sk + 1) x M x N x 4 bytes.
   static const int sks[] = {1, 2, 3, 4, 5, 6, 8};
   for (int sk : sks) {
+    if (a.M < 256) break;   // (a 256-row tile of fewer rows: the 128^2 plans above)
     if (sk > 1 && (!can_split || (size_t)sk * a.M * a.N * 4 > a.workspace_bytes || nk / sk < 8)) continue;
     const bool q4 = a.K % BK == 0 && (sk > 1 || nk >= 32 || !a.residual || (!a.bias && a.act != ACT_GELU_TANH && a.act != ACT_GELU_ERF));   // gemm256q (launch256_one)
     double c = ceil(t256 * sk / 256.0) * ceil(nk / sk) * (q4 ? 1.5 : 1.75);
@@ -1097,7 +1197,7 @@ GemmPlan plan_gemm(const GemmArgs& a) {
   static const char* e_dbg = getenv("AHA_GEMM_PLAN_DEBUG");
   if (e_dbg && atoi(e_dbg)) fprintf(stderr, "[gemm plan] M=%d N=%d K=%d act=%d -> tile %d splitk %d%s (cost %.1f us, 128^2 %.1f us)\n", a.M, a.N, a.K, a.act, best.tile, best.splitk, best.streamk ? " persistent" : "", best_cost, cost128);
   best.cost = best_cost;
-  if (a.M < 256) best = GemmPlan{128, 1, cost128};
+  if (a.M < 256 && best.tile != 128) best = GemmPlan{128, 1, cost128};
   if (e_tile && atoi(e_tile) == 128) best = GemmPlan{128, 1, cost128};
   return best;
 }
@@ -1106,12 +1206,13 @@ GemmPlan plan_gemm(const GemmArgs& a) {
 
 // The launch(es) launch_gemm would issue for a shape, without issuing them (host only): out[0..2] = {tile, splitk, 1 if the columns are
 // split into a multiple of 256 + a tail launch}.  `ws_bytes` > 0 stands for a caller workspace of that size.
-void debug_plan_gemm(int M, int N, int K, int act, bool has_bias, bool has_res, size_t ws_bytes, int* out) {
+void debug_plan_gemm(int M, int N, int K, int act, bool has_bias, bool has_res, size_t ws_bytes, int* out, bool has_norm) {
   GemmArgs a{};
   a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldc = act == ACT_SILU_MUL_PAIRS ? N / 2 : N; a.act = act;
   static int dummy;
   a.bias = has_bias ? &dummy : nullptr;
   a.residual = has_res ? &dummy : nullptr;
+  a.norm_w = has_norm ? &dummy : nullptr;
   a.workspace = ws_bytes ? &dummy : nullptr;
   a.workspace_bytes = ws_bytes;
   a.sk_counters = ws_bytes ? &dummy : nullptr;
@@ -1135,6 +1236,11 @@ void set_gemm_plan_override(int tile, int splitk) {
 static thread_local void* tl_ws = nullptr;
 static thread_local size_t tl_ws_bytes = 0;
 static thread_local void* tl_sk_counters = nullptr;
+void get_gemm_workspace(void** ws, size_t* bytes, void** sk_counters) {
+  *ws = tl_ws;
+  *bytes = tl_ws_bytes;
+  *sk_counters = tl_sk_counters;
+}
 void set_gemm_workspace(void* ws, size_t bytes, void* sk_counters) {
   tl_ws = ws;
   tl_ws_bytes = bytes;
@@ -1249,6 +1355,15 @@ static void launch_planned(const GemmArgs& a, const GemmPlan& plan, hipStream_t 
       case ACT_SILU: launch256_act<ACT_SILU>(a, plan.splitk, st, norm_fused, n192 && plan.splitk > 1); break;
       case ACT_SILU_MUL_PAIRS: launch256_one<ACT_SILU_MUL_PAIRS, false, false>(a, 1, st, nullptr, n192); break;
       case ACT_PARTIAL_F32: launch256_one<ACT_PARTIAL_F32, false, false>(a, 1, st); break;
+    }
+    return;
+  }
+  if (plan.splitk > 1 && a.workspace != nullptr && a.act != ACT_SILU_MUL_PAIRS && a.act != ACT_PARTIAL_F32) {
+    switch (a.act) {
+      case ACT_NONE: launch_ring_splitk_act<ACT_NONE>(a, plan.splitk, st, norm_fused); break;
+      case ACT_GELU_TANH: launch_ring_splitk_act<ACT_GELU_TANH>(a, plan.splitk, st, norm_fused); break;
+      case ACT_GELU_ERF: launch_ring_splitk_act<ACT_GELU_ERF>(a, plan.splitk, st, norm_fused); break;
+      case ACT_SILU: launch_ring_splitk_act<ACT_SILU>(a, plan.splitk, st, norm_fused); break;
     }
     return;
   }

@@ -38,6 +38,8 @@ struct VisionModel {
   // scratch (grown on demand)
   size_t cap = 0;
   std::vector<void*> owned;
+  void* gemm_ws = nullptr;   // split-K slabs of the tower's GEMMs (vision_ensure_scratch)
+  size_t gemm_ws_bytes = 0;
   void *pix = nullptr, *x = nullptr, *h = nullptr, *qkv = nullptr, *q = nullptr, *attn = nullptr, *mlp = nullptr, *mh = nullptr;
   int32_t *d_idx = nullptr, *d_rowcol = nullptr, *d_page_of = nullptr, *d_slot_of = nullptr, *d_vis_rows = nullptr;
   float* d_cs_tab = nullptr;   // rotary (cos, sin) per patch and lane, shared by all blocks (launch_vit_rope_table)
@@ -206,6 +208,11 @@ static int vision_ensure_scratch(aha_model* m, size_t N, size_t npages) {
   v->deep.assign(v->ds_idx.size(), nullptr);
   for (size_t k = 0; k < v->ds_idx.size(); ++k)
     if ((rc = al(n4 * v->out * 2, &v->deep[k]))) return rc;
+  // The tower's own split-K slabs (up to 8 slices of an N = D GEMM over every patch row): the plans of its GEMMs are a function of the
+  // tower's shapes alone -- not of the prompt the images sit in (the prefill's workspace is sized by the prompt's rows), and the same
+  // whether the tower runs inside forward_initial or alone (aha_hip_vision_encode, which used to run without any: fc2 unsplit)
+  v->gemm_ws_bytes = std::min((size_t)8 * cap * D * 4, (size_t)1 << 30);
+  if ((rc = al(v->gemm_ws_bytes, &v->gemm_ws))) return rc;
   v->cap = cap;
   return AHA_OK;
 }
@@ -380,6 +387,7 @@ int vision_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, cons
   }
   int rc;
   if ((rc = vision_ensure_scratch(m, (size_t)N, (size_t)pages))) return rc;
+  GemmWorkspaceScope ws_scope(v->gemm_ws, v->gemm_ws_bytes, m->d_sk_ctrs);
   hipStream_t st = m->stream;
   // ---- uploads ---------------------------------------------------------------------------------------------------
   if (mm->pixel_dtype == AHA_BF16) {

@@ -359,7 +359,8 @@ int aha_hip_debug_attn_form(int32_t form);
  * 192-column tiles wherever it has an instantiation and a workspace (128^2 kernel elsewhere). */
 int aha_hip_debug_gemm_plan(int32_t tile, int32_t splitk);
 /* Host only (no GPU): the plan the GEMM launcher would pick for a shape -- out3 = {tile (128 | 256), split-K factor, 1 if the
- * columns run as a multiple of 256 + a tail launch}; workspace_bytes = size of the caller's split-K scratch (0 = none).  Lets the
+ * columns run as a multiple of 256 + a tail launch}; workspace_bytes = size of the caller's split-K scratch (0 = none); has_residual
+ * bit 0 = a residual is added, bit 1 = an RMSNorm of the output rides on the call (o_proj / down_proj in the layer loop).  Lets the
  * CPU tier pin the plans of the BASELINE shapes (csrc/kernels_gemm.hip plan_gemm is a cost model fitted on MI355X). */
 int aha_hip_debug_plan_gemm(int32_t M, int32_t N, int32_t K, int32_t act, int32_t has_bias, int32_t has_residual, size_t workspace_bytes,
                             int32_t* out3);

@@ -12,10 +12,12 @@ shapes = [("qkv", 1542, 6144, 4096), ("o", 1542, 4096, 4096), ("down", 1542, 409
           ("gateup_2k", 2048, 6144, 1024),
           ("asr_qkv", 390, 2688, 896), ("asr_o", 390, 896, 896), ("asr_fc1", 390, 3584, 896), ("asr_fc2", 390, 896, 3584),
           ("asr_t_qkv", 406, 4096, 1024), ("asr_t_o", 406, 1024, 2048), ("asr_t_gateup", 406, 6144, 1024), ("asr_t_down", 406, 1024, 3072),
+          ("c1_qkv", 128, 4096, 1024), ("c1_o", 128, 1024, 2048), ("c1_down", 128, 1024, 3072),
+          ("s8b_qkv", 128, 6144, 4096), ("s8b_o", 128, 4096, 4096), ("s8b_down", 128, 4096, 12288), ("s16_o", 16, 4096, 4096),
           ("qkv_41k", 40980, 6144, 4096), ("o_41k", 40980, 4096, 4096)]
 if len(sys.argv) > 1:
     shapes = [x for x in shapes if any(x[0].startswith(p) for p in sys.argv[1:])]
-plans = [(0, 0), (128, 1), (128, 2), (128, 4), (256, 1), (192, 1), (256, 2), (256, 3), (256, 4), (256, 6)]
+plans = [(0, 0), (128, 1), (128, 2), (128, 3), (128, 4), (128, 6), (128, 8), (256, 1), (192, 1), (256, 2), (256, 3), (256, 4), (256, 6)]
 def t(A, W, it=10):
     for _ in range(2): ops.gemm(A, W)
     torch.cuda.synchronize()

@@ -262,16 +262,23 @@ def test_gemm_plans_of_the_baseline_shapes(hip_lib):
     # widths) and one context-parallel rank of cfg 5 (~5200 compact rows)
     P = _lib.ACT_SILU_MUL_PAIRS
     assert [plan(128, 4096, 1024)[0], plan(128, 1024, 2048, res=1)[0], plan(128, 6144, 1024, act=P)[0], plan(128, 1024, 3072, res=1)[0]] == [128] * 4
-    assert (plan(2048, 4096, 1024), plan(2048, 1024, 2048, res=1), plan(2048, 6144, 1024, act=P), plan(2048, 1024, 3072, res=1)) == \
+    assert (plan(2048, 4096, 1024), plan(2048, 1024, 2048, res=3), plan(2048, 6144, 1024, act=P), plan(2048, 1024, 3072, res=3)) == \
         ((192, 1, 0), (256, 4, 0), (192, 1, 0), (192, 3, 0))
-    # cfg 4 (Qwen3-ASR: M = 406 text rows, 390 audio rows).  Round 6: the short-K projections (14-16 k steps) run on the 128^2 kernel --
-    # a lone block measures ~0.75 us per k step, not the 1.4 us the model assumed from cfg 3's deep-K shapes (scripts/tune_gemm.py,
-    # profiles/r06_tune_gemm_small.txt: text qkv 16.3 us against 20.4, gate+up 17.4 against 21.0, tower qkv 14.4 against 18.5, fc1 14.7
-    # against 18.8 plus an erf-GELU epilogue that ran on 28 CUs: 52 us in the model); prefill 6.60 -> 6.05 ms same box
-    assert (plan(406, 4096, 1024), plan(406, 1024, 2048, res=1), plan(406, 6144, 1024, act=P), plan(406, 1024, 3072, res=1)) == \
-        ((128, 1, 0), (256, 4, 0), (128, 1, 0), (256, 6, 0))
+    # cfg 4 (Qwen3-ASR: M = 406 text rows, 390 audio rows).  Round 6: the short-K projections (14-16 k steps) run unsplit on the 128^2 ring
+    # kernel (gemm_glds_ring_kernel: one block per CU at most, a four-stage LDS-DMA ring, fragment reads half a tile ahead of the MFMAs),
+    # the long-K ones (o_proj / down_proj / fc2: 32-56 k steps over 28-32 tiles) as 128^2 tiles x K slices on the same kernel + the reduce
+    # pass that holds the riding RMSNorm (scripts/tune_gemm.py: 15.6 / 16.8 / 17.2 us against 21.9 / 23.5 / 24.6 for the 256^2 slices);
+    # prefill 6.60 -> 4.45 ms.  has_residual bit 1 = a norm rides on the call (folded into a reduce pass, a launch of its own otherwise)
+    assert (plan(406, 4096, 1024), plan(406, 1024, 2048, res=3), plan(406, 6144, 1024, act=P), plan(406, 1024, 3072, res=3)) == \
+        ((128, 1, 0), (128, 4, 0), (128, 1, 0), (128, 6, 0))
     assert (plan(390, 2688, 896, bias=1), plan(390, 896, 896, bias=1, res=1), plan(390, 3584, 896, act=_lib.ACT_GELU_ERF, bias=1),
-            plan(390, 896, 3584, bias=1, res=1)) == ((128, 1, 0), (128, 1, 0), (128, 1, 0), (256, 6, 0))
+            plan(390, 896, 3584, bias=1, res=1)) == ((128, 1, 0), (128, 1, 0), (128, 1, 0), (128, 8, 0))
+    # cfg 2 o_proj with its riding norm stays on the 256^2 slices (unsplit ring launch 23.1 us + a norm launch against 27.6 us norm included);
+    # few-row launches of the 8B widths (128-token prompts, 16-row batches) split K on the ring kernel too; K < 1536 never does
+    assert plan(2048, 1024, 2048, res=3) == (256, 4, 0)
+    assert (plan(128, 6144, 4096), plan(128, 4096, 4096, res=3), plan(128, 4096, 12288, res=3), plan(16, 4096, 4096)) == \
+        ((128, 4, 0), (128, 6, 0), (128, 8, 0), (128, 8, 0))
+    assert plan(64, 512, 1024, res=3) == (128, 1, 0) and plan(406, 1024, 2048, res=3, ws=0) == (128, 1, 0)
     assert (plan(5184, 6144, 4096), plan(5184, 4096, 4096, res=1), plan(5184, 24576, 4096, act=P), plan(5184, 4096, 12288, res=1)) == \
         ((256, 1, 0), (256, 1, 0), (256, 1, 0), (256, 3, 0))
     with pytest.raises(Exception):

@@ -131,6 +131,31 @@ def test_gemm_four_wave_kernel_edges(gpu, splitk, M, N, K):
     assert_close_ulps(full, ref, 2, 0.97, f"gemm256q bias+residual splitk {splitk}")
 
 
+@pytest.mark.parametrize("splitk", [2, 3, 4, 6, 8])
+@pytest.mark.parametrize("M,N,K", [(406, 1024, 2048), (390, 896, 3584), (128, 512, 4096), (16, 1024, 1536), (130, 1000, 1032), (257, 520, 4104), (64, 136, 520)])
+def test_gemm_ring_kernel_k_slices(gpu, splitk, M, N, K):
+    """128^2 tiles x K slices on gemm_glds_ring_kernel<ACT_PARTIAL_F32> + the reduce pass (the cfg 4 o_proj / down_proj / fc2 plans, forced
+    here on every slice count): uneven slices, K tails inside the last slice (1032, 4104, 520), fewer k steps per slice than ring stages
+    (520 = 9 k tiles over 8 slices), ragged M / N; bias + residual through the reduce pass; bit-repeatable (a hazard in the staging
+    ring would show as a run-to-run difference); and the automatic plan of the same shape inside the same bound."""
+    from aha_amd import ops, _lib
+    A, W, b, res = rnd((M, K), 45), rnd((N, K), 46, 0.02), rnd((N,), 47, 0.5), rnd((M, N), 48)
+    ref_plain = NM.linear(A.float(), W.float())
+    ref = NM.r(res.float() + NM.linear(A.float(), W.float(), b.float()))
+    Ad, Wd, bd, rd = A.to(gpu), W.to(gpu), b.to(gpu), res.to(gpu)
+    ops.gemm_plan(128, splitk)
+    try:
+        plain = ops.gemm(Ad, Wd)
+        full = ops.gemm(Ad, Wd, bd, rd, _lib.ACT_NONE)
+        for _ in range(8):
+            assert torch.equal(ops.gemm(Ad, Wd), plain)
+    finally:
+        ops.gemm_plan(0, 0)
+    assert_close_ulps(plain, ref_plain, 1, 0.98, f"ring kernel, {splitk} K slices")
+    assert_close_ulps(full, ref, 2, 0.97, f"ring kernel, {splitk} K slices, bias + residual")
+    assert_close_ulps(ops.gemm(Ad, Wd), ref_plain, 1, 0.98, "automatic plan")
+
+
 @pytest.mark.parametrize("M,N,K", [(600, 512, 1152), (4096, 3456, 1152), (300, 768, 192)])
 def test_gemm_four_wave_kernel_short_k_bias_gelu(gpu, M, N, K):
     """Short K loops (18 and 3 K tiles) with a bias / bias + GELU epilogue and no residual run on the four-wave 256^2 kernel (the
