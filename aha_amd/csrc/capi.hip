@@ -252,9 +252,9 @@ int aha_hip_debug_attn_form(int32_t form) {
 }
 int aha_hip_debug_gemm_plan(int32_t tile, int32_t splitk) {
   const bool sk = tile == 1256 || tile == 1192;   // the persistent kernel; splitk = style * 10 + cuts of the last round (0 = the planner's)
-  if ((tile != 0 && tile != 128 && tile != 256 && tile != 192 && !sk) || splitk < 0 || (!sk && splitk > 8) ||
+  if ((tile != 0 && tile != 128 && tile != 2128 && tile != 256 && tile != 192 && !sk) || splitk < 0 || (!sk && splitk > 8) ||
       (sk && !(splitk <= 4 || (splitk >= 11 && splitk <= 13)))) {
-    set_error("debug_gemm_plan: tile must be 0, 128, 192 (256 x 192, where instantiated), 256 or 1256 / 1192 (persistent kernel); splitk 0..8 "
+    set_error("debug_gemm_plan: tile must be 0, 128, 2128 (256 x 128), 192 (256 x 192, where instantiated), 256 or 1256 / 1192 (persistent kernel); splitk 0..8 "
               "(persistent: 0..4 equal pieces, 11..13 big pieces + remainder)");
     return AHA_ERR_INVALID;
   }

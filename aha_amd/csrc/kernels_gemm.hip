@@ -122,13 +122,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
 // kt + NST - 1 requested while tile kt is multiplied, ONE counted s_waitcnt vmcnt per k step (the NST - 1 newer groups of 8 pieces stay in
 // flight) and two raw barriers (a __syncthreads would drain the DMA queue).  Tiles past the end are requested from the zero block so
 // that the counts stay uniform.  Same tile, same mma_tile, same k order, same epilogue: bit-identical to gemm_glds_kernel.
-template <int ACT, bool HAS_BIAS, bool HAS_RES, int NST, bool ROWS = true>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_glds_ring_kernel(GemmArgs a, const void* zeros, int kt_per_slice) {
+// WM = wave rows of the block (round 6, second form): 2 = the 128 x 128 tile on four waves; 4 = a 256 x 128 tile on EIGHT waves (two per
+// SIMD, each still 64 x 64: while one wave of a SIMD is held in the issue of its LDS-DMA pieces -- ~60 cycles each, the MFMA pipe idle
+// behind a lone wave -- the other one multiplies).  A stage is [A tile: WM x 8 KiB | W tile: 16 KiB]; every wave stages four 8-row
+// pieces of A and 16 / (2 WM) of W per k step.  For launches whose 128^2 tiling overflows one block per CU where 256 x 128 tiles
+// do not (ViT proj: 288 -> 144 blocks; cfg 2 qkv: 512 -> 256).
+template <int ACT, bool HAS_BIAS, bool HAS_RES, int NST, bool ROWS = true, int WM = 2>
+__global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2))) void gemm_glds_ring_kernel(GemmArgs a, const void* zeros, int kt_per_slice) {
+  constexpr int NW = 2 * WM, A_BYTES = WM * 64 * BK * 2, STAGE = A_BYTES + TILE_BYTES;
+  constexpr int NPW = 16 / NW;            // W pieces per wave and k step (A: always 4)
+  constexpr int LPT = 4 + NPW;            // LDS-DMA loads per wave and K tile
   char* const smem = gemm_smem;  // NST x [A tile | W tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, c = lane & 15;
   const int wm = wave >> 1, wn = wave & 1;
   int m0, n0;
-  tile_of_block(a, m0, n0);
+  tile_of_block<WM * 64, BN>(a, m0, n0);
   const bf16_t* A = (const bf16_t*)a.A;
   const bf16_t* W = (const bf16_t*)a.W;
   // gridDim.y > 1 = split-K (ACT_PARTIAL_F32 only): slice z owns k tiles [z * kt_per_slice, ...) and writes the f32 slab a.C + z*M*ldc
@@ -139,82 +147,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     a.C = (float*)a.C + (int64_t)blockIdx.y * a.M * a.ldc;
   }
   const bf16_t* ga[4];
-  const bf16_t* gw[4];
-  int kofs[4];
+  const bf16_t* gw[NPW];
+  int kofs[4];   // (the k slot a lane fetches depends on its row inside the 8-row piece only: the same for every piece)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int row = (j * 4 + wave) * 8 + (lane >> 3);
+    const int row = (j * NW + wave) * 8 + (lane >> 3);
     const int sl = (lane & 7) ^ ((row >> 1) & 7);  // logical k-slot this lane fetches
     kofs[j] = sl * 8;
     ga[j] = A + (int64_t)min(m0 + row, a.M - 1) * a.lda + sl * 8;
-    gw[j] = W + (int64_t)min(n0 + row, a.N - 1) * a.ldw + sl * 8;
+    if (j < NPW) gw[j] = W + (int64_t)min(n0 + row, a.N - 1) * a.ldw + sl * 8;
   }
   f32x4_t acc[4][4];  // [ni][mi]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  auto stage_tile = [&](int kt, int st) __attribute__((always_inline)) {
-    char* sa = smem + st * (2 * TILE_BYTES);
-    char* sw = sa + TILE_BYTES;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bool ok = kt < nk && kt * BK + kofs[j] < a.K;
-      const void* pa = ok ? (const void*)(ga[j] + kt * BK) : zeros;
-      const void* pw = ok ? (const void*)(gw[j] + kt * BK) : zeros;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)pa, (lds_ptr_t)(sa + (j * 4 + wave) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)pw, (lds_ptr_t)(sw + (j * 4 + wave) * 1024), 16, 0, 0);
-    }
-  };
 #define AHA_RING_BAR()                           \
   do {                                           \
     __builtin_amdgcn_sched_barrier(0);           \
     __builtin_amdgcn_s_barrier();                \
     __builtin_amdgcn_sched_barrier(0);           \
   } while (0)
-  // one piece pair (A + W) of tile kt into stage st: the 8 pieces of a tile ride between the MFMAs of the tile being multiplied (a piece costs
-  // ~60 cycles of issue among MFMAs, 100-185 in a burst next to fragment reads: issued as a burst in front of the wait they were the k step)
+  // piece j of tile kt into stage st_: 8 rows of A and (j < NPW) 8 rows of W.  The pieces of a tile ride between the MFMAs of the tile being
+  // multiplied (a piece costs ~60 cycles of issue among MFMAs, 100-185 in a burst next to fragment reads)
   auto stage_piece = [&](int kt, int st_, int j) __attribute__((always_inline)) {
-    char* sa = smem + st_ * (2 * TILE_BYTES);
-    char* sw = sa + TILE_BYTES;
+    char* sa = smem + st_ * STAGE;
+    char* sw = sa + A_BYTES;
     const bool ok = kt < nk && kt * BK + kofs[j] < a.K;
     const void* pa = ok ? (const void*)(ga[j] + kt * BK) : zeros;
-    const void* pw = ok ? (const void*)(gw[j] + kt * BK) : zeros;
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)pa, (lds_ptr_t)(sa + (j * 4 + wave) * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)pw, (lds_ptr_t)(sw + (j * 4 + wave) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)pa, (lds_ptr_t)(sa + (j * NW + wave) * 1024), 16, 0, 0);
+    if (j < NPW) {
+      const void* pw = ok ? (const void*)(gw[j < NPW ? j : 0] + kt * BK) : zeros;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)pw, (lds_ptr_t)(sw + (j * NW + wave) * 1024), 16, 0, 0);
+    }
   };
 #pragma unroll
-  for (int t = 0; t < NST - 1; ++t) stage_tile(kt0 + t, t);
-  // One wave per SIMD: nothing else hides a fragment read's LDS round trip, so the reads run one half tile (32 of the 64 k) AHEAD of the
-  // MFMAs, in two register sets -- F1 = (kt, k 32-63) is requested among the MFMAs on F0 = (kt, k 0-31), F0 = (kt + 1, k 0-31) in
+  for (int t = 0; t < NST - 1; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stage_piece(kt0 + t, t, j);
+  // One wave per SIMD (WM = 2): nothing else hides a fragment read's LDS round trip, so the reads run one half tile (32 of the 64 k) AHEAD of
+  // the MFMAs, in two register sets -- F1 = (kt, k 32-63) is requested among the MFMAs on F0 = (kt, k 0-31), F0 = (kt + 1, k 0-31) in
   // front of the MFMAs on F1.  ONE barrier per k step, between the two halves: in front of it a wave waits for its own pieces of tile
   // kt + 1 (counted vmcnt: the NST - 3 newer tiles and the first half of the tile being requested stay in flight) and for its LDS reads
   // (lgkmcnt(0): they were issued 16 MFMAs ago), so past the barrier tile kt + 1 is whole and nobody reads tile kt - 1 any more -- which is
   // the stage the pieces of tile kt + NST - 1 go to.  (Reading first and multiplying after cost 0.52 us per k step for 0.21 us of MFMAs.)
   auto read_frags = [&](int st_, int ks, bf16x8_t (&af)[4], bf16x8_t (&wf)[4]) __attribute__((always_inline)) {
-    const char* sa = smem + st_ * (2 * TILE_BYTES);
-    const char* sw = sa + TILE_BYTES;
+    const char* sa = smem + st_ * STAGE;
+    const char* sw = sa + A_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       af[i] = as_frag(*reinterpret_cast<const u32x4_t*>(sa + swz(wm * 64 + i * 16 + c, ks * 4 + G)));
       wf[i] = as_frag(*reinterpret_cast<const u32x4_t*>(sw + swz(wn * 64 + i * 16 + c, ks * 4 + G)));
     }
   };
-  auto mma_half = [&](const bf16x8_t (&af)[4], const bf16x8_t (&wf)[4], int kt_new, int st_new_, int j0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(wf[ni], af[mi], acc[ni][mi]);
-      if ((ni & 1) == 1) {
-        __builtin_amdgcn_sched_barrier(0);
-        stage_piece(kt_new, st_new_, j0 + (ni >> 1));
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  };
   bf16x8_t a0[4], w0[4], a1[4], w1[4];
   {
-    constexpr int KEEP0 = 8 * (NST - 2);
+    constexpr int KEEP0 = LPT * (NST - 2);
     __builtin_amdgcn_s_waitcnt(0x0F70 | (KEEP0 & 15) | ((KEEP0 >> 4) << 14));
     AHA_RING_BAR();
     read_frags(0, 0, a0, w0);
@@ -239,12 +227,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    constexpr int KEEP = 8 * (NST - 3) + 4;   // vmcnt is a 6-bit field: [3:0] and [15:14]; lgkmcnt(0) = bits [11:8]
+    // the first half requested pieces 0 and 1 (A and W: 4 loads for either WM); vmcnt is a 6-bit field: [3:0] and [15:14]; lgkmcnt(0) = bits [11:8]
+    constexpr int KEEP = LPT * (NST - 3) + 4;
     __builtin_amdgcn_s_waitcnt(0x0070 | (KEEP & 15) | ((KEEP >> 4) << 14));
     AHA_RING_BAR();
     read_frags(st_next, 0, a0, w0);
     __builtin_amdgcn_sched_barrier(0);
-    mma_half(a1, w1, kt + NST - 1, st_new, 2);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(w1[ni], a1[mi], acc[ni][mi]);
+      if ((ni & 1) == 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        stage_piece(kt + NST - 1, st_new, 2 + (ni >> 1));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     st_new = st;
     st = st_next;
   }
@@ -779,23 +777,46 @@ const void* zero_block() {
 }
 
 template <int ACT, bool B, bool R>
-void launch_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
+void launch_one(const GemmArgs& a, dim3 grid, hipStream_t st, bool tall = false) {
   // <= one block per CU: the block hides its own memory round trips behind a four-stage ring (gemm_glds_ring_kernel; 128 KiB of LDS).
   // AHA_GEMM_RING=0: the single-stage kernel everywhere (A/B; bit-identical outputs)
   static const bool ring_on = [] { const char* e = getenv("AHA_GEMM_RING"); return e ? atoi(e) != 0 : true; }();
   const int64_t blocks = (int64_t)grid.x * grid.y * grid.z;
   const bool ring = ring_on && blocks <= gemm_streamk_cus() && (a.K + BK - 1) / BK >= 4;
   constexpr int NST = 4;
+  const int nk = (a.K + BK - 1) / BK;
   // row-order stores need whole 16-byte column groups: N a multiple of 8, rows of C / residual 16-byte aligned; else fragment order
+  bool rows = false;
+  if constexpr (ACT != ACT_SILU_MUL_PAIRS && ACT != ACT_PARTIAL_F32)
+    rows = a.partial_rows && (a.N & 7) == 0 && (a.ldc & 7) == 0 && ((uintptr_t)a.C & 15) == 0 && (!R || ((uintptr_t)a.residual & 15) == 0) &&
+           (!B || ((uintptr_t)a.bias & 15) == 0);
+  if (tall) {   // 256 x 128 tiles on eight waves, three stages of 48 KiB (plan tile 2128; `grid` counts those tiles)
+    constexpr int NST3 = 3, LDS3 = NST3 * (4 * 64 * BK * 2 + TILE_BYTES);
+    if constexpr (ACT != ACT_SILU_MUL_PAIRS && ACT != ACT_PARTIAL_F32) {
+      if (rows) {
+        static DevOnce once_t;
+        if (auto once_guard = once_t.first()) {
+          hipFuncSetAttribute((const void*)gemm_glds_ring_kernel<ACT, B, R, NST3, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
+        }
+        hipLaunchKernelGGL((gemm_glds_ring_kernel<ACT, B, R, NST3, true, 4>), grid, dim3(512), LDS3, st, a, zero_block(), nk);
+        return;
+      }
+    }
+    static DevOnce once_t2;
+    if (auto once_guard = once_t2.first()) {
+      hipFuncSetAttribute((const void*)gemm_glds_ring_kernel<ACT, B, R, NST3, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
+    }
+    hipLaunchKernelGGL((gemm_glds_ring_kernel<ACT, B, R, NST3, false, 4>), grid, dim3(512), LDS3, st, a, zero_block(), nk);
+    return;
+  }
   if constexpr (ACT != ACT_SILU_MUL_PAIRS && ACT != ACT_PARTIAL_F32) {
-    if (a.partial_rows && (a.N & 7) == 0 && (a.ldc & 7) == 0 && ((uintptr_t)a.C & 15) == 0 && (!R || ((uintptr_t)a.residual & 15) == 0) &&
-        (!B || ((uintptr_t)a.bias & 15) == 0)) {
+    if (rows) {
       if (ring) {
         static DevOnce once_ring;
         if (auto once_guard = once_ring.first()) {
           hipFuncSetAttribute((const void*)gemm_glds_ring_kernel<ACT, B, R, NST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * 2 * TILE_BYTES);
         }
-        hipLaunchKernelGGL((gemm_glds_ring_kernel<ACT, B, R, NST, true>), grid, dim3(256), NST * 2 * TILE_BYTES, st, a, zero_block(), (a.K + BK - 1) / BK);
+        hipLaunchKernelGGL((gemm_glds_ring_kernel<ACT, B, R, NST, true>), grid, dim3(256), NST * 2 * TILE_BYTES, st, a, zero_block(), nk);
         return;
       }
       hipLaunchKernelGGL((gemm_glds_kernel<ACT, B, R, true>), grid, dim3(256), 2 * TILE_BYTES, st, a, zero_block());
@@ -807,18 +828,18 @@ void launch_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
     if (auto once_guard = once_ring2.first()) {
       hipFuncSetAttribute((const void*)gemm_glds_ring_kernel<ACT, B, R, NST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * 2 * TILE_BYTES);
     }
-    hipLaunchKernelGGL((gemm_glds_ring_kernel<ACT, B, R, NST, false>), grid, dim3(256), NST * 2 * TILE_BYTES, st, a, zero_block(), (a.K + BK - 1) / BK);
+    hipLaunchKernelGGL((gemm_glds_ring_kernel<ACT, B, R, NST, false>), grid, dim3(256), NST * 2 * TILE_BYTES, st, a, zero_block(), nk);
     return;
   }
   hipLaunchKernelGGL((gemm_glds_kernel<ACT, B, R>), grid, dim3(256), 2 * TILE_BYTES, st, a, zero_block());
 }
 
 template <int ACT>
-void launch_act(const GemmArgs& a, dim3 grid, hipStream_t st) {
-  if (a.bias && a.residual) launch_one<ACT, true, true>(a, grid, st);
-  else if (a.bias) launch_one<ACT, true, false>(a, grid, st);
-  else if (a.residual) launch_one<ACT, false, true>(a, grid, st);
-  else launch_one<ACT, false, false>(a, grid, st);
+void launch_act(const GemmArgs& a, dim3 grid, hipStream_t st, bool tall = false) {
+  if (a.bias && a.residual) launch_one<ACT, true, true>(a, grid, st, tall);
+  else if (a.bias) launch_one<ACT, true, false>(a, grid, st, tall);
+  else if (a.residual) launch_one<ACT, false, true>(a, grid, st, tall);
+  else launch_one<ACT, false, false>(a, grid, st, tall);
 }
 
 // pass 2 of a split-K plan: the f32 slabs in a.workspace summed, then the epilogue chain -- with the norm riding on the call folded in where a
@@ -1035,6 +1056,7 @@ struct GemmPlan { int tile, splitk; double cost = 0; bool streamk = false; };   
 int g_force_tile = 0, g_force_splitk = 0;  // aha_hip_debug_gemm_plan (tests): 0 = automatic
 
 GemmPlan plan_gemm(const GemmArgs& a) {
+  if (g_force_tile == 2128) return GemmPlan{(a.K + BK - 1) / BK >= 2 ? 2128 : 128, 1};
   if (g_force_tile == 128) {
     int sk = g_force_splitk > 1 ? g_force_splitk : 1;
     const int nk_ = (a.K + BK - 1) / BK;
@@ -1081,15 +1103,28 @@ GemmPlan plan_gemm(const GemmArgs& a) {
   const bool can_split = a.act != ACT_SILU_MUL_PAIRS && a.act != ACT_PARTIAL_F32 && a.workspace != nullptr && (a.N & 3) == 0;
   GemmPlan best{128, 1};
   double best_cost = cost128;
+  // 256 x 128 tiles on the eight-wave ring kernel (plan tile 2128): where the 128^2 tiling overflows one block per CU and this one does not
+  static const bool tall_on = [] { const char* e = getenv("AHA_GEMM_TALL"); return e ? atoi(e) != 0 : true; }();
+  static const double lat_tall = [] { const char* e = getenv("AHA_GEMM_LAT_TALL"); return e ? atof(e) : 0.85; }();
+  const double t2128 = (double)((a.M + 255) / 256) * ((a.N + 127) / 128);
+  if (tall_on && a.M >= 256 && nk >= 8 && nk <= 24 && t128 > (double)gemm_streamk_cus() && t2128 <= (double)gemm_streamk_cus() && !e_tile && !e_sk &&
+      a.act != ACT_PARTIAL_F32) {
+    const double c = nk * lat_tall + 5.0;   // (a riding norm is a launch of its own here as behind the 128^2 tiling this competes with)
+    if (c < best_cost) {
+      best = GemmPlan{2128, 1};
+      best_cost = c;
+    }
+  }
   // 128^2 tiles x K slices on the ring kernel, one block per CU at most (launch_ring_splitk).  The reduce pass of these few-row shapes is
   // small and launch-sized: ~2 TB/s over its (slices + 1) slabs, not the 4 TB/s of the 256^2 plans' larger ones (scripts/tune_gemm.py at
   // 406 x 1024: 4 -> 8 slices + 1.9 us with four k steps less)
   static const bool ring_sk_on = [] { const char* e = getenv("AHA_GEMM_RING_SPLITK"); return e ? atoi(e) != 0 : true; }();
   if (ring_sk_on && can_split && nk >= 24 && !e_tile && !(e_sk && atoi(e_sk) == 1)) {   // (K >= 1536: below, the slices save ~2 us by the model -- inside its error)
+    const double red_rate = (double)a.M * a.N < 1.0e6 ? 2.0e6 : 4.0e6;   // (bytes per us: a reduce pass of < 1 M outputs does not fill the chip)
     for (int sk : {2, 3, 4, 6, 8}) {
       if (e_sk && atoi(e_sk) != sk) continue;
       if ((size_t)sk * a.M * a.N * 4 > a.workspace_bytes || nk / sk < 4 || t128 * sk > (double)gemm_streamk_cus()) continue;
-      const double c = ceil(nk / sk) * lat_ring + 4.5 + (double)(sk + 1) * a.M * a.N * 4.0 / 2.0e6 + 3.0;
+      const double c = ceil(nk / sk) * lat_ring + 4.5 + (double)(sk + 1) * a.M * a.N * 4.0 / red_rate + 3.0;
       if (c < best_cost) {
         best = GemmPlan{128, sk};
         best_cost = c;
@@ -1358,7 +1393,7 @@ static void launch_planned(const GemmArgs& a, const GemmPlan& plan, hipStream_t 
     }
     return;
   }
-  if (plan.splitk > 1 && a.workspace != nullptr && a.act != ACT_SILU_MUL_PAIRS && a.act != ACT_PARTIAL_F32) {
+  if (plan.tile == 128 && plan.splitk > 1 && a.workspace != nullptr && a.act != ACT_SILU_MUL_PAIRS && a.act != ACT_PARTIAL_F32) {
     switch (a.act) {
       case ACT_NONE: launch_ring_splitk_act<ACT_NONE>(a, plan.splitk, st, norm_fused); break;
       case ACT_GELU_TANH: launch_ring_splitk_act<ACT_GELU_TANH>(a, plan.splitk, st, norm_fused); break;
@@ -1367,15 +1402,16 @@ static void launch_planned(const GemmArgs& a, const GemmPlan& plan, hipStream_t 
     }
     return;
   }
-  const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
+  const bool tall = plan.tile == 2128;   // 256 x 128 tiles of the eight-wave ring kernel
+  const int ntm = tall ? (a.M + 255) / 256 : (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
   dim3 grid(ntm * ntn);
   switch (a.act) {
-    case ACT_NONE: launch_act<ACT_NONE>(a, grid, st); break;
-    case ACT_GELU_TANH: launch_act<ACT_GELU_TANH>(a, grid, st); break;
-    case ACT_GELU_ERF: launch_act<ACT_GELU_ERF>(a, grid, st); break;
-    case ACT_SILU: launch_act<ACT_SILU>(a, grid, st); break;
-    case ACT_SILU_MUL_PAIRS: launch_one<ACT_SILU_MUL_PAIRS, false, false>(a, grid, st); break;
-    case ACT_PARTIAL_F32: launch_one<ACT_PARTIAL_F32, false, false>(a, grid, st); break;
+    case ACT_NONE: launch_act<ACT_NONE>(a, grid, st, tall); break;
+    case ACT_GELU_TANH: launch_act<ACT_GELU_TANH>(a, grid, st, tall); break;
+    case ACT_GELU_ERF: launch_act<ACT_GELU_ERF>(a, grid, st, tall); break;
+    case ACT_SILU: launch_act<ACT_SILU>(a, grid, st, tall); break;
+    case ACT_SILU_MUL_PAIRS: launch_one<ACT_SILU_MUL_PAIRS, false, false>(a, grid, st, tall); break;
+    case ACT_PARTIAL_F32: launch_one<ACT_PARTIAL_F32, false, false>(a, grid, st, tall); break;
   }
 }
 

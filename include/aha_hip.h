@@ -354,7 +354,8 @@ int aha_hip_debug_attn_variant(int32_t smx);
  * -1 = automatic (the 64-row form once its 256-row blocks fill the chip).  Same rounding points in every form; the accumulation order of
  * the two MFMA shapes differs, so outputs agree to the parity bound, not bit for bit. */
 int aha_hip_debug_attn_form(int32_t form);
-/* Test hook: force the GEMM tile (128 or 256) and split-K factor of every following GEMM launch of the process;
+/* Test hook: force the GEMM tile (128, 256, 192 = 256 x 192, 2128 = 256 x 128 on the eight-wave ring kernel) and split-K factor of every
+ * following GEMM launch of the process;
  * (0, 0) restores the automatic choice (csrc/kernels_gemm.hip plan_gemm).  tile 1256 / 1192: the persistent kernel on 256- /
  * 192-column tiles wherever it has an instantiation and a workspace (128^2 kernel elsewhere). */
 int aha_hip_debug_gemm_plan(int32_t tile, int32_t splitk);

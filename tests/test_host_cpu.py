@@ -247,12 +247,12 @@ def test_gemm_plans_of_the_baseline_shapes(hip_lib):
     assert plan(1792, 24576, 4096, act=_lib.ACT_SILU_MUL_PAIRS) == (256, 1, 0)
     assert plan(1542, 4096, 12288, res=1) == (256, 2, 0)
     assert plan(1542, 4096, 4096, res=1, ws=0) == (128, 1, 0)            # no workspace: no split-K, and 112 tiles lose to the 128^2 kernel
-    # ViT at N = 4096 patches: qkv on 256^2, proj on 128^2, fc1 as 4096 columns + a 208-column tail; fc2 contracts over the MLP width padded
+    # ViT at N = 4096 patches: qkv on 256^2, proj on 256 x 128 (round 6), fc1 as 4096 columns + a 208-column tail; fc2 contracts over the MLP width padded
     # to whole K tiles (4352; csrc/vision_tower.hip Ipad) as two K slices of 192-column tiles = 192 blocks (scripts/bench_gemm_fc2.py:
     # 50.8 us against 54.9 us for three slices of 256^2 tiles and 61.6-64.9 us for the unpadded K = 4304 on the 8-wave kernel)
     assert plan(4096, 1152, 4352, bias=1, res=1) == (192, 2, 0)
     assert plan(4096, 3456, 1152, bias=1) == (256, 1, 0)
-    assert plan(4096, 1152, 1152, bias=1, res=1) == (128, 1, 0)
+    assert plan(4096, 1152, 1152, bias=1, res=1) == (2128, 1, 0)   # round 6: 144 tiles of 256 x 128 on the eight-wave ring kernel (288 of 128^2 = one block per CU + 32: 31.7 -> 24.7 us in the model)
     assert plan(4096, 4304, 1152, act=_lib.ACT_GELU_TANH, bias=1) == (256, 1, 1)
     assert plan(4096, 1152, 4304, bias=1, res=1) == (256, 3, 0)
     # below one 256-row tile everything stays on the 128^2 kernel; a 41 k-token prompt fills whole rounds unsplit
@@ -263,7 +263,7 @@ def test_gemm_plans_of_the_baseline_shapes(hip_lib):
     P = _lib.ACT_SILU_MUL_PAIRS
     assert [plan(128, 4096, 1024)[0], plan(128, 1024, 2048, res=1)[0], plan(128, 6144, 1024, act=P)[0], plan(128, 1024, 3072, res=1)[0]] == [128] * 4
     assert (plan(2048, 4096, 1024), plan(2048, 1024, 2048, res=3), plan(2048, 6144, 1024, act=P), plan(2048, 1024, 3072, res=3)) == \
-        ((192, 1, 0), (256, 4, 0), (192, 1, 0), (192, 3, 0))
+        ((2128, 1, 0), (128, 2, 0), (192, 1, 0), (128, 2, 0))   # round 6: qkv = 256 tiles of 256 x 128, o / down = 128^2 tiles x 2 K slices (one round each)
     # cfg 4 (Qwen3-ASR: M = 406 text rows, 390 audio rows).  Round 6: the short-K projections (14-16 k steps) run unsplit on the 128^2 ring
     # kernel (gemm_glds_ring_kernel: one block per CU at most, a four-stage LDS-DMA ring, fragment reads half a tile ahead of the MFMAs),
     # the long-K ones (o_proj / down_proj / fc2: 32-56 k steps over 28-32 tiles) as 128^2 tiles x K slices on the same kernel + the reduce
@@ -273,9 +273,9 @@ def test_gemm_plans_of_the_baseline_shapes(hip_lib):
         ((128, 1, 0), (128, 4, 0), (128, 1, 0), (128, 6, 0))
     assert (plan(390, 2688, 896, bias=1), plan(390, 896, 896, bias=1, res=1), plan(390, 3584, 896, act=_lib.ACT_GELU_ERF, bias=1),
             plan(390, 896, 3584, bias=1, res=1)) == ((128, 1, 0), (128, 1, 0), (128, 1, 0), (128, 8, 0))
-    # cfg 2 o_proj with its riding norm stays on the 256^2 slices (unsplit ring launch 23.1 us + a norm launch against 27.6 us norm included);
+    # cfg 2 o_proj: with its riding norm two K slices of 128^2 tiles (256 blocks; the norm in the reduce pass), without one an unsplit ring launch;
     # few-row launches of the 8B widths (128-token prompts, 16-row batches) split K on the ring kernel too; K < 1536 never does
-    assert plan(2048, 1024, 2048, res=3) == (256, 4, 0)
+    assert plan(2048, 1024, 2048, res=3) == (128, 2, 0) and plan(2048, 1024, 2048, res=1) == (128, 1, 0)
     assert (plan(128, 6144, 4096), plan(128, 4096, 4096, res=3), plan(128, 4096, 12288, res=3), plan(16, 4096, 4096)) == \
         ((128, 4, 0), (128, 6, 0), (128, 8, 0), (128, 8, 0))
     assert plan(64, 512, 1024, res=3) == (128, 1, 0) and plan(406, 1024, 2048, res=3, ws=0) == (128, 1, 0)

@@ -91,10 +91,10 @@ def test_gemm_plain(gpu, M, N, K):
     assert_close_ulps(got, ref, 1, 0.98, "gemm")
 
 
-@pytest.mark.parametrize("tile,splitk", [(128, 0), (256, 1), (256, 2), (256, 4)])
+@pytest.mark.parametrize("tile,splitk", [(128, 0), (2128, 1), (256, 1), (256, 2), (256, 4)])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 520, 1032), (1542, 1024, 4096), (257, 4304, 1152), (513, 72 * 4, 72)])
 def test_gemm_every_tile_kernel(gpu, tile, splitk, M, N, K):
-    """The same op through every GEMM kernel: 128^2 tile, 256^2 tile, 256^2 with K split into 2 / 4 f32 slabs + the reduce
+    """The same op through every GEMM kernel: 128^2 tile, 256 x 128 tile (the eight-wave ring kernel), 256^2 tile, 256^2 with K split into 2 / 4 f32 slabs + the reduce
     pass (odd M / N / K tails, K shorter than a slice).  All must meet the oracle bound; split-K changes only the f32
     summation order."""
     from aha_amd import ops, _lib
