@@ -142,22 +142,22 @@ __device__ __forceinline__ void epi_pairs(const GemmArgs& a, int m, int n, int o
 
 // 16x16x32 fragments: lane holds C[m = .. + c][n = .. + G*4 + 0..3].  mb / nb: first row / column of the wave's sub-tile
 // (MI x 4 fragments of 16 x 16)
-template <int ACT, bool HAS_BIAS, bool HAS_RES, int MI>
-__device__ __forceinline__ void epilogue(const GemmArgs& a, f32x4_t (&acc)[4][MI], int mb, int nb, int G, int c) {
+template <int ACT, bool HAS_BIAS, bool HAS_RES, int MI, int NI = 4>
+__device__ __forceinline__ void epilogue(const GemmArgs& a, f32x4_t (&acc)[NI][MI], int mb, int nb, int G, int c) {
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = mb + mi * 16 + c;
     if (m >= a.M) continue;
     if (ACT == ACT_SILU_MUL_PAIRS) {
 #pragma unroll
-      for (int np = 0; np < 2; ++np) {
+      for (int np = 0; np < NI / 2; ++np) {
         const float gt[4] = {acc[2 * np][mi][0], acc[2 * np][mi][1], acc[2 * np][mi][2], acc[2 * np][mi][3]};
         const float up[4] = {acc[2 * np + 1][mi][0], acc[2 * np + 1][mi][1], acc[2 * np + 1][mi][2], acc[2 * np + 1][mi][3]};
         epi_pairs(a, m, nb + np * 32 + G * 4, nb / 2 + np * 16 + G * 4, gt, up);
       }
     } else {
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
+      for (int ni = 0; ni < NI; ++ni)
         epi_group<ACT, HAS_BIAS, HAS_RES>(a, m, nb + ni * 16 + G * 4, acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
     }
   }
@@ -168,19 +168,20 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x4_t (&acc)[4][MI
 // 16-byte bias / residual loads and stores, eight whole 128-byte row segments per instruction instead of 8-byte pieces on 16 rows
 // (the ViT proj GEMM -- bias + residual, 288 blocks reaching their epilogues together -- spent a third of its time there).
 // Not for ACT_SILU_MUL_PAIRS / ACT_PARTIAL_F32 (they keep the fragment-order epilogue above).  wbuf: this wave's 32 x 144 B.
-template <int ACT, bool HAS_BIAS, bool HAS_RES>
-__device__ __forceinline__ void epilogue16_rows(const GemmArgs& a, f32x4_t (&acc)[4][4], int mb, int nb, int lane, char* wbuf) {
+// NI = 16-column fragments of the wave's sub-tile (4: 64 columns, 8 lanes per row, 8 rows per pass; 2: 32 columns, 4 lanes per row, 16 rows)
+template <int ACT, bool HAS_BIAS, bool HAS_RES, int NI = 4>
+__device__ __forceinline__ void epilogue16_rows(const GemmArgs& a, f32x4_t (&acc)[NI][4], int mb, int nb, int lane, char* wbuf) {
   static_assert(ACT != ACT_SILU_MUL_PAIRS && ACT != ACT_PARTIAL_F32, "fragment-order epilogue for these");
-  constexpr int PITCH = 144;
+  constexpr int PITCH = NI * 32 + 16, LPR = NI * 2, RPI = 64 / LPR;
   const int G = lane >> 4, c = lane & 15;
-  const int rr = lane >> 3, cc = lane & 7;
+  const int rr = lane / LPR, cc = lane % LPR;
   const int n = nb + cc * 8;
 #pragma unroll
   for (int band = 0; band < 2; ++band) {
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
+      for (int ni = 0; ni < NI; ++ni) {
         const f32x4_t& v = acc[ni][band * 2 + mh];
         uint2 w2;
         w2.x = pack_bf(v[0], v[1]);   // Linear output -> bf16
@@ -188,8 +189,8 @@ __device__ __forceinline__ void epilogue16_rows(const GemmArgs& a, f32x4_t (&acc
         *reinterpret_cast<uint2*>(wbuf + (mh * 16 + c) * PITCH + (ni * 16 + G * 4) * 2) = w2;
       }
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int row = it * 8 + rr, m = mb + band * 32 + row;
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int row = it * RPI + rr, m = mb + band * 32 + row;
       const uint4 d4 = *reinterpret_cast<const uint4*>(wbuf + row * PITCH + cc * 16);
       uint32_t d[4] = {d4.x, d4.y, d4.z, d4.w};
       if (m < a.M && n < a.N) {

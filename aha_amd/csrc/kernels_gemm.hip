@@ -117,24 +117,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
 // ---- variant 1b: the same 128 x 128 tile with a RING of LDS stages (round 6) ---------------------------------------------------------
 // gemm_glds_kernel stages a K tile, drains, multiplies, and relies on the three or four blocks a CU holds to hide each other's memory
 // round trip.  A launch of <= 256 blocks has ONE block per CU: every k step then costs the whole trip of its own tile -- 1.4 us per k step
-// on cold weights, where the multiply is 0.3 us (BASELINE cfg 4, Qwen3-ASR: 112 GEMMs of 390 / 406 rows per prefill run this way, 21-27 us
-// each for 2.5-5 GFLOP, profiles/r06_cfg4_kernel_stats.md).  Here the block prefetches for itself: NST stages of [A tile | W tile], tile
-// kt + NST - 1 requested while tile kt is multiplied, ONE counted s_waitcnt vmcnt per k step (the NST - 1 newer groups of 8 pieces stay in
-// flight) and two raw barriers (a __syncthreads would drain the DMA queue).  Tiles past the end are requested from the zero block so
-// that the counts stay uniform.  Same tile, same mma_tile, same k order, same epilogue: bit-identical to gemm_glds_kernel.
-// WM = wave rows of the block (round 6, second form): 2 = the 128 x 128 tile on four waves; 4 = a 256 x 128 tile on EIGHT waves (two per
-// SIMD, each still 64 x 64: while one wave of a SIMD is held in the issue of its LDS-DMA pieces -- ~60 cycles each, the MFMA pipe idle
-// behind a lone wave -- the other one multiplies).  A stage is [A tile: WM x 8 KiB | W tile: 16 KiB]; every wave stages four 8-row
-// pieces of A and 16 / (2 WM) of W per k step.  For launches whose 128^2 tiling overflows one block per CU where 256 x 128 tiles
-// do not (ViT proj: 288 -> 144 blocks; cfg 2 qkv: 512 -> 256).
-template <int ACT, bool HAS_BIAS, bool HAS_RES, int NST, bool ROWS = true, int WM = 2>
-__global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2))) void gemm_glds_ring_kernel(GemmArgs a, const void* zeros, int kt_per_slice) {
-  constexpr int NW = 2 * WM, A_BYTES = WM * 64 * BK * 2, STAGE = A_BYTES + TILE_BYTES;
-  constexpr int NPW = 16 / NW;            // W pieces per wave and k step (A: always 4)
-  constexpr int LPT = 4 + NPW;            // LDS-DMA loads per wave and K tile
+// on cold weights, where the multiply is 0.21 us (BASELINE cfg 4, Qwen3-ASR: 187 GEMMs of 390 / 406 rows per prefill ran this way, 21-27 us
+// each for 2.5-5 GFLOP).  Here the block prefetches for itself: NST stages of [A tile | W tile], tile kt + NST - 1 requested while tile kt
+// is multiplied, its pieces issued between the MFMA groups, ONE counted s_waitcnt vmcnt and ONE raw barrier per k step (a __syncthreads
+// would drain the DMA queue).  Tiles past the end are requested from the zero block so that the counts stay uniform.  Same tile, same k
+// order per accumulator, same epilogue chain: bit-identical to gemm_glds_kernel.
+// The block is WM x WN waves, each 64 rows x (128 / WN) columns:
+//   WM 2, WN 4 = the 128 x 128 tile on EIGHT waves of 64 x 32 (two per SIMD: while one wave of a SIMD is held in the issue of its LDS-DMA
+//                pieces -- ~60 cycles each, the MFMA pipe idle behind a lone wave -- the other one multiplies; four waves of 64 x 64 cost
+//                0.49 us per k step, cfg 4 prefill 4.42 against 4.12 ms same box); four stages of 32 KiB;
+//   WM 4, WN 2 = a 256 x 128 tile on eight waves of 64 x 64, three stages of 48 KiB: for launches whose 128^2 tiling overflows one block
+//                per CU where 256 x 128 tiles do not (ViT proj: 288 -> 144 blocks; cfg 2 qkv: 512 -> 256).
+// A stage is [A tile: WM x 8 KiB | W tile: 16 KiB] in 8-row pieces of 1 KiB; wave w stages pieces j * NW + w.
+template <int ACT, bool HAS_BIAS, bool HAS_RES, int NST, bool ROWS = true, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2))) void gemm_glds_ring_kernel(GemmArgs a, const void* zeros, int kt_per_slice) {
+  constexpr int NW = WM * WN, A_BYTES = WM * 64 * BK * 2, STAGE = A_BYTES + TILE_BYTES;
+  constexpr int NI = 8 / WN;              // 16-column fragments of a wave's 64 x (128 / WN) sub-tile
+  constexpr int NPA = WM * 8 / NW, NPW = 16 / NW;   // 8-row pieces of A / W per wave and k step
+  constexpr int NPJ = NPA > NPW ? NPA : NPW;        // piece slots j = 0 .. NPJ - 1 (slot j: A piece j if j < NPA, W piece j if j < NPW)
+  constexpr int LPT = NPA + NPW;                    // LDS-DMA loads per wave and K tile
+  constexpr int FH = (NPA < NPJ / 2 ? NPA : NPJ / 2) + (NPW < NPJ / 2 ? NPW : NPJ / 2);   // ... of them in the first half of a k step
+  static_assert(NPJ == 2 || NPJ == 4, "piece slots per half: 1 or 2");
   char* const smem = gemm_smem;  // NST x [A tile | W tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, c = lane & 15;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   int m0, n0;
   tile_of_block<WM * 64, BN>(a, m0, n0);
   const bf16_t* A = (const bf16_t*)a.A;
@@ -146,20 +152,20 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2))) v
     nk = min(nk, kt0 + kt_per_slice);
     a.C = (float*)a.C + (int64_t)blockIdx.y * a.M * a.ldc;
   }
-  const bf16_t* ga[4];
+  const bf16_t* ga[NPA];
   const bf16_t* gw[NPW];
-  int kofs[4];   // (the k slot a lane fetches depends on its row inside the 8-row piece only: the same for every piece)
+  int kofs[NPJ];   // (the k slot a lane fetches depends on its row inside the 8-row piece and the piece's parity: the same for A and W)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NPJ; ++j) {
     const int row = (j * NW + wave) * 8 + (lane >> 3);
     const int sl = (lane & 7) ^ ((row >> 1) & 7);  // logical k-slot this lane fetches
     kofs[j] = sl * 8;
-    ga[j] = A + (int64_t)min(m0 + row, a.M - 1) * a.lda + sl * 8;
+    if (j < NPA) ga[j] = A + (int64_t)min(m0 + row, a.M - 1) * a.lda + sl * 8;
     if (j < NPW) gw[j] = W + (int64_t)min(n0 + row, a.N - 1) * a.ldw + sl * 8;
   }
-  f32x4_t acc[4][4];  // [ni][mi]
+  f32x4_t acc[NI][4];  // [ni][mi]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #define AHA_RING_BAR()                           \
@@ -174,8 +180,10 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2))) v
     char* sa = smem + st_ * STAGE;
     char* sw = sa + A_BYTES;
     const bool ok = kt < nk && kt * BK + kofs[j] < a.K;
-    const void* pa = ok ? (const void*)(ga[j] + kt * BK) : zeros;
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)pa, (lds_ptr_t)(sa + (j * NW + wave) * 1024), 16, 0, 0);
+    if (j < NPA) {
+      const void* pa = ok ? (const void*)(ga[j < NPA ? j : 0] + kt * BK) : zeros;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)pa, (lds_ptr_t)(sa + (j * NW + wave) * 1024), 16, 0, 0);
+    }
     if (j < NPW) {
       const void* pw = ok ? (const void*)(gw[j < NPW ? j : 0] + kt * BK) : zeros;
       __builtin_amdgcn_global_load_lds((glb_ptr_t)pw, (lds_ptr_t)(sw + (j * NW + wave) * 1024), 16, 0, 0);
@@ -184,23 +192,33 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2))) v
 #pragma unroll
   for (int t = 0; t < NST - 1; ++t)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) stage_piece(kt0 + t, t, j);
+    for (int j = 0; j < NPJ; ++j) stage_piece(kt0 + t, t, j);
   // One wave per SIMD (WM = 2): nothing else hides a fragment read's LDS round trip, so the reads run one half tile (32 of the 64 k) AHEAD of
   // the MFMAs, in two register sets -- F1 = (kt, k 32-63) is requested among the MFMAs on F0 = (kt, k 0-31), F0 = (kt + 1, k 0-31) in
   // front of the MFMAs on F1.  ONE barrier per k step, between the two halves: in front of it a wave waits for its own pieces of tile
   // kt + 1 (counted vmcnt: the NST - 3 newer tiles and the first half of the tile being requested stay in flight) and for its LDS reads
   // (lgkmcnt(0): they were issued 16 MFMAs ago), so past the barrier tile kt + 1 is whole and nobody reads tile kt - 1 any more -- which is
   // the stage the pieces of tile kt + NST - 1 go to.  (Reading first and multiplying after cost 0.52 us per k step for 0.21 us of MFMAs.)
-  auto read_frags = [&](int st_, int ks, bf16x8_t (&af)[4], bf16x8_t (&wf)[4]) __attribute__((always_inline)) {
+  auto read_frags = [&](int st_, int ks, bf16x8_t (&af)[4], bf16x8_t (&wf)[NI]) __attribute__((always_inline)) {
     const char* sa = smem + st_ * STAGE;
     const char* sw = sa + A_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       af[i] = as_frag(*reinterpret_cast<const u32x4_t*>(sa + swz(wm * 64 + i * 16 + c, ks * 4 + G)));
-      wf[i] = as_frag(*reinterpret_cast<const u32x4_t*>(sw + swz(wn * 64 + i * 16 + c, ks * 4 + G)));
+      if (i < NI) wf[i] = as_frag(*reinterpret_cast<const u32x4_t*>(sw + swz(wn * (NI * 16) + i * 16 + c, ks * 4 + G)));
     }
   };
-  bf16x8_t a0[4], w0[4], a1[4], w1[4];
+  // piece slot jh (of this half's NPJ / 2) goes behind MFMA group g when g == (jh + 1) * NI / (NPJ / 2) - 1
+  auto pieces_behind = [&](int g, int kt_new, int st_new_, int jbase) __attribute__((always_inline)) {
+#pragma unroll
+    for (int jh = 0; jh < NPJ / 2; ++jh)
+      if (g == (jh + 1) * NI / (NPJ / 2) - 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        stage_piece(kt_new, st_new_, jbase + jh);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  };
+  bf16x8_t a0[4], w0[NI], a1[4], w1[NI];
   {
     constexpr int KEEP0 = LPT * (NST - 2);
     __builtin_amdgcn_s_waitcnt(0x0F70 | (KEEP0 & 15) | ((KEEP0 >> 4) << 14));
@@ -213,7 +231,7 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2))) v
     // (F1 is requested after the first four MFMAs on F0, not in front of them: the compiler's wait for F0 is an lgkmcnt(0), and with F1
     // already in the queue it would wait for both)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
+    for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(w0[ni], a0[mi], acc[ni][mi]);
       if (ni == 0) {
@@ -221,27 +239,19 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2))) v
         read_frags(st, 1, a1, w1);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if ((ni & 1) == 1) {
-        __builtin_amdgcn_sched_barrier(0);
-        stage_piece(kt + NST - 1, st_new, ni >> 1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      pieces_behind(ni, kt + NST - 1, st_new, 0);
     }
-    // the first half requested pieces 0 and 1 (A and W: 4 loads for either WM); vmcnt is a 6-bit field: [3:0] and [15:14]; lgkmcnt(0) = bits [11:8]
-    constexpr int KEEP = LPT * (NST - 3) + 4;
+    // the first half requested FH of the tile's LPT pieces; vmcnt is a 6-bit field: [3:0] and [15:14]; lgkmcnt(0) = bits [11:8]
+    constexpr int KEEP = LPT * (NST - 3) + FH;
     __builtin_amdgcn_s_waitcnt(0x0070 | (KEEP & 15) | ((KEEP >> 4) << 14));
     AHA_RING_BAR();
     read_frags(st_next, 0, a0, w0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
+    for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(w1[ni], a1[mi], acc[ni][mi]);
-      if ((ni & 1) == 1) {
-        __builtin_amdgcn_sched_barrier(0);
-        stage_piece(kt + NST - 1, st_new, 2 + (ni >> 1));
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      pieces_behind(ni, kt + NST - 1, st_new, NPJ / 2);
     }
     st_new = st;
     st = st_next;
@@ -249,8 +259,8 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2))) v
   __builtin_amdgcn_s_waitcnt(0x0F70);   // the requests past the end still write their (zero) pieces: nothing in flight when the epilogue reuses the LDS
   AHA_RING_BAR();
 #undef AHA_RING_BAR
-  if constexpr (ROWS) epilogue16_rows<ACT, HAS_BIAS, HAS_RES>(a, acc, m0 + wm * 64, n0 + wn * 64, lane, smem + wave * (32 * 144));
-  else epilogue<ACT, HAS_BIAS, HAS_RES, 4>(a, acc, m0 + wm * 64, n0 + wn * 64, G, c);
+  if constexpr (ROWS) epilogue16_rows<ACT, HAS_BIAS, HAS_RES, NI>(a, acc, m0 + wm * 64, n0 + wn * (NI * 16), lane, smem + wave * (32 * 144));
+  else epilogue<ACT, HAS_BIAS, HAS_RES, 4, NI>(a, acc, m0 + wm * 64, n0 + wn * (NI * 16), G, c);
 }
 
 // ---- 256 x 256 x 64 tiles ----------------------------------------------------------------------------------------------------
@@ -776,6 +786,16 @@ const void* zero_block() {
   return z;
 }
 
+// one launch of the ring kernel (WM x WN waves, NST stages); > 64 KiB of dynamic LDS needs the opt-in once per instantiation and device
+template <int ACT, bool B, bool R, bool ROWS, int WM, int WN, int NST>
+void launch_ring(const GemmArgs& a, dim3 grid, hipStream_t st, int kt_per_slice) {
+  constexpr int LDS = NST * (WM * 64 * BK * 2 + TILE_BYTES);
+  static DevOnce once;
+  if (auto once_guard = once.first()) {
+    hipFuncSetAttribute((const void*)gemm_glds_ring_kernel<ACT, B, R, NST, ROWS, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  }
+  hipLaunchKernelGGL((gemm_glds_ring_kernel<ACT, B, R, NST, ROWS, WM, WN>), grid, dim3(WM * WN * 64), LDS, st, a, zero_block(), kt_per_slice);
+}
 template <int ACT, bool B, bool R>
 void launch_one(const GemmArgs& a, dim3 grid, hipStream_t st, bool tall = false) {
   // <= one block per CU: the block hides its own memory round trips behind a four-stage ring (gemm_glds_ring_kernel; 128 KiB of LDS).
@@ -783,7 +803,6 @@ void launch_one(const GemmArgs& a, dim3 grid, hipStream_t st, bool tall = false)
   static const bool ring_on = [] { const char* e = getenv("AHA_GEMM_RING"); return e ? atoi(e) != 0 : true; }();
   const int64_t blocks = (int64_t)grid.x * grid.y * grid.z;
   const bool ring = ring_on && blocks <= gemm_streamk_cus() && (a.K + BK - 1) / BK >= 4;
-  constexpr int NST = 4;
   const int nk = (a.K + BK - 1) / BK;
   // row-order stores need whole 16-byte column groups: N a multiple of 8, rows of C / residual 16-byte aligned; else fragment order
   bool rows = false;
@@ -791,45 +810,22 @@ void launch_one(const GemmArgs& a, dim3 grid, hipStream_t st, bool tall = false)
     rows = a.partial_rows && (a.N & 7) == 0 && (a.ldc & 7) == 0 && ((uintptr_t)a.C & 15) == 0 && (!R || ((uintptr_t)a.residual & 15) == 0) &&
            (!B || ((uintptr_t)a.bias & 15) == 0);
   if (tall) {   // 256 x 128 tiles on eight waves, three stages of 48 KiB (plan tile 2128; `grid` counts those tiles)
-    constexpr int NST3 = 3, LDS3 = NST3 * (4 * 64 * BK * 2 + TILE_BYTES);
     if constexpr (ACT != ACT_SILU_MUL_PAIRS && ACT != ACT_PARTIAL_F32) {
-      if (rows) {
-        static DevOnce once_t;
-        if (auto once_guard = once_t.first()) {
-          hipFuncSetAttribute((const void*)gemm_glds_ring_kernel<ACT, B, R, NST3, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
-        }
-        hipLaunchKernelGGL((gemm_glds_ring_kernel<ACT, B, R, NST3, true, 4>), grid, dim3(512), LDS3, st, a, zero_block(), nk);
-        return;
-      }
+      if (rows) return launch_ring<ACT, B, R, true, 4, 2, 3>(a, grid, st, nk);
     }
-    static DevOnce once_t2;
-    if (auto once_guard = once_t2.first()) {
-      hipFuncSetAttribute((const void*)gemm_glds_ring_kernel<ACT, B, R, NST3, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
+    return launch_ring<ACT, B, R, false, 4, 2, 3>(a, grid, st, nk);
+  }
+  if (ring) {
+    if constexpr (ACT != ACT_SILU_MUL_PAIRS && ACT != ACT_PARTIAL_F32) {
+      if (rows) return launch_ring<ACT, B, R, true, 2, 4, 4>(a, grid, st, nk);
     }
-    hipLaunchKernelGGL((gemm_glds_ring_kernel<ACT, B, R, NST3, false, 4>), grid, dim3(512), LDS3, st, a, zero_block(), nk);
-    return;
+    return launch_ring<ACT, B, R, false, 2, 4, 4>(a, grid, st, nk);
   }
   if constexpr (ACT != ACT_SILU_MUL_PAIRS && ACT != ACT_PARTIAL_F32) {
     if (rows) {
-      if (ring) {
-        static DevOnce once_ring;
-        if (auto once_guard = once_ring.first()) {
-          hipFuncSetAttribute((const void*)gemm_glds_ring_kernel<ACT, B, R, NST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * 2 * TILE_BYTES);
-        }
-        hipLaunchKernelGGL((gemm_glds_ring_kernel<ACT, B, R, NST, true>), grid, dim3(256), NST * 2 * TILE_BYTES, st, a, zero_block(), nk);
-        return;
-      }
       hipLaunchKernelGGL((gemm_glds_kernel<ACT, B, R, true>), grid, dim3(256), 2 * TILE_BYTES, st, a, zero_block());
       return;
     }
-  }
-  if (ring) {
-    static DevOnce once_ring2;
-    if (auto once_guard = once_ring2.first()) {
-      hipFuncSetAttribute((const void*)gemm_glds_ring_kernel<ACT, B, R, NST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * 2 * TILE_BYTES);
-    }
-    hipLaunchKernelGGL((gemm_glds_ring_kernel<ACT, B, R, NST, false>), grid, dim3(256), NST * 2 * TILE_BYTES, st, a, zero_block(), nk);
-    return;
   }
   hipLaunchKernelGGL((gemm_glds_kernel<ACT, B, R>), grid, dim3(256), 2 * TILE_BYTES, st, a, zero_block());
 }
@@ -867,11 +863,6 @@ void launch_splitk_reduce(const GemmArgs& a, int nsl, hipStream_t st, bool* norm
 // tiles of 128^2): the 256^2 split plans put 32-48 blocks on the chip, 18.6 us + the reduce pass.
 template <int ACT, bool B, bool R>
 void launch_ring_splitk(const GemmArgs& a, int splitk, hipStream_t st, bool* norm_fused) {
-  constexpr int NST = 4;
-  static DevOnce once;
-  if (auto once_guard = once.first()) {
-    hipFuncSetAttribute((const void*)gemm_glds_ring_kernel<ACT_PARTIAL_F32, false, false, NST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * 2 * TILE_BYTES);
-  }
   GemmArgs p = a;  // pass 1: f32 slabs [slices][M][N] in the caller's workspace
   p.C = a.workspace;
   p.ldc = a.N;
@@ -880,7 +871,7 @@ void launch_ring_splitk(const GemmArgs& a, int splitk, hipStream_t st, bool* nor
   p.act = ACT_PARTIAL_F32;
   const int nk = (a.K + BK - 1) / BK, kps = (nk + splitk - 1) / splitk, nsl = (nk + kps - 1) / kps;
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_glds_ring_kernel<ACT_PARTIAL_F32, false, false, NST, false>), dim3(ntm * ntn, nsl), dim3(256), NST * 2 * TILE_BYTES, st, p, zero_block(), kps);
+  launch_ring<ACT_PARTIAL_F32, false, false, false, 2, 4, 4>(p, dim3(ntm * ntn, nsl), st, kps);
   launch_splitk_reduce<ACT, B, R>(a, nsl, st, norm_fused);
 }
 
