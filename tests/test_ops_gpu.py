@@ -156,6 +156,48 @@ def test_gemm_ring_kernel_k_slices(gpu, splitk, M, N, K):
     assert_close_ulps(ops.gemm(Ad, Wd), ref_plain, 1, 0.98, "automatic plan")
 
 
+@pytest.mark.parametrize("epi", ["plain", "bias_res", "bias_gelu"])
+@pytest.mark.parametrize("M,N,K", [(200, 640, 1152), (390, 896, 896), (406, 1000, 1032), (70, 1736, 264), (512, 1152, 1152)])
+def test_gemm_ring_kernel_is_bit_identical_to_the_single_stage_kernel(gpu, epi, M, N, K):
+    """gemm_glds_ring_kernel (launches of at most one block per CU: eight waves of 64 x 32 behind a four-stage LDS-DMA ring, and the
+    256 x 128 form) against gemm_glds_kernel (four waves of 64 x 64, one stage): same tile, same k order per accumulator, same epilogue
+    chain => the same bits.  A row's result does not depend on the other rows of the launch, so the same rows are computed twice under
+    the forced 128^2 plan -- alone (<= 256 blocks: the ring kernel) and as the head of a 36 x taller matrix (> 256 blocks: the
+    single-stage kernel) -- and once under the forced 256 x 128 plan; each repeated (a hazard in the ring shows as a difference)."""
+    from aha_amd import ops, _lib
+    A, W, b = rnd((M, K), 51), rnd((N, K), 52, 0.02), rnd((N,), 53, 0.5)
+    big = torch.cat([A] + [rnd((M, K), 60 + i) for i in range(35)], 0)
+    res, res_big = rnd((M, N), 54), None
+    Ad, Wd, bd, bigd = A.to(gpu), W.to(gpu), b.to(gpu), big.to(gpu)
+    if epi == "bias_res":
+        res_big = torch.cat([res, torch.zeros(35 * M, N, dtype=res.dtype)], 0).to(gpu)
+
+    def run(a, r):
+        if epi == "plain":
+            return ops.gemm(a, Wd)
+        if epi == "bias_res":
+            return ops.gemm(a, Wd, bd, r, _lib.ACT_NONE)
+        return ops.gemm(a, Wd, bd, None, _lib.ACT_GELU_TANH)
+    assert (36 * M + 127) // 128 * ((N + 127) // 128) > 256 >= (M + 127) // 128 * ((N + 127) // 128)
+    ops.gemm_plan(128, 1)
+    try:
+        alone = run(Ad, res.to(gpu))
+        for _ in range(6):
+            assert torch.equal(run(Ad, res.to(gpu)), alone)
+        head = run(bigd, res_big)[:M]
+    finally:
+        ops.gemm_plan(0, 0)
+    assert torch.equal(alone, head)
+    ops.gemm_plan(2128, 1)
+    try:
+        tall = run(Ad, res.to(gpu))
+        for _ in range(6):
+            assert torch.equal(run(Ad, res.to(gpu)), tall)
+    finally:
+        ops.gemm_plan(0, 0)
+    assert torch.equal(alone, tall)
+
+
 @pytest.mark.parametrize("M,N,K", [(600, 512, 1152), (4096, 3456, 1152), (300, 768, 192)])
 def test_gemm_four_wave_kernel_short_k_bias_gelu(gpu, M, N, K):
     """Short K loops (18 and 3 K tiles) with a bias / bias + GELU epilogue and no residual run on the four-wave 256^2 kernel (the
