@@ -6,56 +6,84 @@
 namespace aha {
 
 // ---- A0: frames x Hann -> |DFT_400|^2 -> mel(201 -> 128) -> log10 (feature_extraction_whisper.rs:93-115) -----------------
-// One block per STFT frame.  The 400-point real DFT is evaluated directly (201 bins x 400 taps, f32 FMA, twiddles from a
-// 400-entry LDS table indexed by k*n mod 400): 0.2 GFLOP for 30 s of audio, launch-latency-bound, no FFT library.
+// One block per FOUR STFT frames (round 6; one per frame before).  The 400-point real DFT is evaluated directly (201 bins x 400 taps, f32 FMA,
+// twiddles from a 400-entry LDS table of (cos, sin) pairs indexed by k*n mod 400): 0.2 GFLOP for 30 s of audio, no FFT library.  The table
+// reads are the cost -- lane k reads entry k*n mod 400, a many-way bank conflict for most n -- so one 8-byte read now serves four frames'
+// taps (their samples are one broadcast 16-byte read), and likewise a mel weight serves four frames: 136 -> ~40 us at 3000 frames.
+// Every (frame, bin) and (frame, mel) sum keeps its order (n = 0..399, k = 0..200): bit-identical to the one-frame kernel.
 // Frame f covers padded samples [160 f, 160 f + 400) of reflect-padded input (pad 200 each side); the right pad carries
 // the reference's indexing quirk (tensor_utils.rs:525-549): it mirrors original samples [L-400, L-200), not [L-201, L-1).
+constexpr int MEL_FPB = 4;   // frames per block
 __global__ __launch_bounds__(256) void logmel_power_kernel(const float* __restrict__ x, int64_t L, const float* __restrict__ window,
                                                            const float* __restrict__ twid,  // (400,2): cos, sin of 2 pi j / 400
                                                            const float* __restrict__ melfb, // (201,128)
                                                            float* __restrict__ out,         // (128, F) log10 mel
                                                            float* __restrict__ frame_max, int F) {
-  __shared__ float fr[400];
-  __shared__ float tc[400], ts[400];
-  __shared__ float pw[208];
-  __shared__ float red[4];
-  const int f = blockIdx.x, tid = threadIdx.x;
+  __shared__ float4 fr[400];     // [tap][frame of the block]
+  __shared__ float2 tw[400];
+  __shared__ float4 pw[208];     // [bin][frame of the block]
+  __shared__ float red[MEL_FPB][4];
+  const int f0 = blockIdx.x * MEL_FPB, tid = threadIdx.x;
   for (int n = tid; n < 400; n += 256) {
-    const int64_t p = (int64_t)160 * f + n;  // index into the padded signal of length L + 400
-    int64_t src;
-    if (p < 200) src = 200 - p;                       // left reflect: padded[p] = x[200 - p]
-    else if (p < 200 + L) src = p - 200;
-    else src = (L - 200 - 1) - (p - (200 + L));       // right pad (quirk): reversed x[L-400 .. L-200)
-    fr[n] = x[src] * window[n];
-    tc[n] = twid[2 * n];
-    ts[n] = twid[2 * n + 1];
+    float v[MEL_FPB];
+#pragma unroll
+    for (int q = 0; q < MEL_FPB; ++q) {
+      const int64_t p = (int64_t)160 * (f0 + q) + n;  // index into the padded signal of length L + 400
+      int64_t src;
+      if (p < 200) src = 200 - p;                       // left reflect: padded[p] = x[200 - p]
+      else if (p < 200 + L) src = p - 200;
+      else src = (L - 200 - 1) - (p - (200 + L));       // right pad (quirk): reversed x[L-400 .. L-200)
+      v[q] = f0 + q < F ? x[src] * window[n] : 0.f;
+    }
+    fr[n] = make_float4(v[0], v[1], v[2], v[3]);
+    tw[n] = make_float2(twid[2 * n], twid[2 * n + 1]);
   }
   __syncthreads();
   if (tid < 201) {
-    float re = 0.f, im = 0.f;
+    float re[MEL_FPB] = {0.f, 0.f, 0.f, 0.f}, im[MEL_FPB] = {0.f, 0.f, 0.f, 0.f};
     int j = 0;  // (k*n) mod 400
     for (int n = 0; n < 400; ++n) {
-      const float v = fr[n];
-      re = fmaf(v, tc[j], re);
-      im = fmaf(v, ts[j], im);
+      const float4 v4 = fr[n];
+      const float2 t = tw[j];
+      const float v[MEL_FPB] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int q = 0; q < MEL_FPB; ++q) {
+        re[q] = fmaf(v[q], t.x, re[q]);
+        im[q] = fmaf(v[q], t.y, im[q]);
+      }
       j += tid;
       if (j >= 400) j -= 400;
     }
-    pw[tid] = re * re + im * im;  // norm_sqr (audio_utils.rs:1303-1311)
+    // norm_sqr (audio_utils.rs:1303-1311)
+    pw[tid] = make_float4(re[0] * re[0] + im[0] * im[0], re[1] * re[1] + im[1] * im[1], re[2] * re[2] + im[2] * im[2], re[3] * re[3] + im[3] * im[3]);
   }
   __syncthreads();
-  float lg = -INFINITY;
+  float lg[MEL_FPB] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   if (tid < 128) {
-    float m = 0.f;
-    for (int k = 0; k < 201; ++k) m = fmaf(melfb[k * 128 + tid], pw[k], m);
-    m = fmaxf(m, 1e-10f);
-    lg = logf(m) * (float)(1.0 / 2.302585092994046);  // log10 = ln * (1/ln 10) (modules.rs:1256-1258)
-    out[(int64_t)tid * F + f] = lg;
+    float m[MEL_FPB] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 201; ++k) {
+      const float w = melfb[k * 128 + tid];
+      const float4 p4 = pw[k];
+      m[0] = fmaf(w, p4.x, m[0]);
+      m[1] = fmaf(w, p4.y, m[1]);
+      m[2] = fmaf(w, p4.z, m[2]);
+      m[3] = fmaf(w, p4.w, m[3]);
+    }
+#pragma unroll
+    for (int q = 0; q < MEL_FPB; ++q) {
+      if (f0 + q >= F) continue;
+      const float mm = fmaxf(m[q], 1e-10f);
+      lg[q] = logf(mm) * (float)(1.0 / 2.302585092994046);  // log10 = ln * (1/ln 10) (modules.rs:1256-1258)
+      out[(int64_t)tid * F + f0 + q] = lg[q];
+    }
   }
-  lg = wave_max(lg);
-  if ((tid & 63) == 0) red[tid >> 6] = lg;
+#pragma unroll
+  for (int q = 0; q < MEL_FPB; ++q) {
+    const float g = wave_max(lg[q]);
+    if ((tid & 63) == 0) red[q][tid >> 6] = g;
+  }
   __syncthreads();
-  if (tid == 0) frame_max[f] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  if (tid < MEL_FPB && f0 + tid < F) frame_max[f0 + tid] = fmaxf(fmaxf(red[tid][0], red[tid][1]), fmaxf(red[tid][2], red[tid][3]));
 }
 // max over frames, then x = (max(x, gmax - 8) + 4) * 0.25 (feature_extraction_whisper.rs:110-113)
 __global__ __launch_bounds__(256) void logmel_finalize_kernel(float* __restrict__ out, const float* __restrict__ frame_max, int F) {
@@ -72,7 +100,7 @@ __global__ __launch_bounds__(256) void logmel_finalize_kernel(float* __restrict_
 void launch_logmel(const float* x, int64_t L, const float* window, const float* twid, const float* melfb, float* out,
                    float* frame_max, int F, hipStream_t st) {
   if (F <= 0) return;
-  hipLaunchKernelGGL(logmel_power_kernel, dim3(F), dim3(256), 0, st, x, L, window, twid, melfb, out, frame_max, F);
+  hipLaunchKernelGGL(logmel_power_kernel, dim3((F + MEL_FPB - 1) / MEL_FPB), dim3(256), 0, st, x, L, window, twid, melfb, out, frame_max, F);
   hipLaunchKernelGGL(logmel_finalize_kernel, dim3(64), dim3(256), 0, st, out, frame_max, F);
 }
 
