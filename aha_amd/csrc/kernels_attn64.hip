@@ -157,7 +157,9 @@ constexpr int ATTN64_ROWS = 256;   // q rows per workgroup
 template <int DQK, int DV, bool LSUM, int PIPE, bool TRACE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_prefill64_kernel(AttnPrefillArgs a, unsigned long long* trace = nullptr) {
   constexpr int KS = DQK / 32;          // 32-dim fragment columns of a K block
-  constexpr int NKS = DQK / 16;         // k-steps of QK^T
+  // k-steps of QK^T that carry data.  DQK = 96 is head_dim 72 padded (VIT_DQK): dims 72..95 of every Q and K row are zeros, so the sixth
+  // 16-deep k-step (dims 80..95) only adds zeros -- skipped: 20 instead of 24 QK^T MFMAs and 10 instead of 12 K fragment reads per tile
+  constexpr int NKS = DQK == 96 ? 5 : DQK / 16;
   constexpr int NDB = (DV + 31) / 32;   // 32-dim output blocks
   constexpr int KBYTES = KV_PAGE_TOKENS * DQK * 2, VBYTES = DV * KV_PAGE_TOKENS * 2;
   constexpr int VSPAN = NDB * 4096;     // bytes of V^T the fragment reads cover (ViT: 12 KB of a 10-KB block; the rest arrives as zeros)
@@ -422,12 +424,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // S = 8192: a gap of phase B costs ~53 cycles whatever it holds, section 3 of profiles/r06_attn_prefill.md.  Not kept.)
     constexpr bool DMA_IN_A = true;                    // the LDS-DMA pieces of tile t + 2 ride in phase A (phase B: 1595 -> 1500 cycles, A + 55)
     constexpr int KG = 2 * NDB;                        // MFMA gaps of one P.V k-step
-    constexpr int GA = 4 * NKS, GB = 4 * KG;           // MFMA gaps of the two phases: 32 + 32 (text), 24 + 24 (ViT)
+    constexpr int GA = 4 * NKS, GB = 4 * KG;           // MFMA gaps of the two phases: 32 + 32 (text), 20 + 24 (ViT)
+    constexpr int PSTEP = GA / NP;                     // an LDS-DMA piece every PSTEP gaps of phase A: 4 (text: 8 pieces), 3 (ViT: 6)
+    static_assert(PSTEP >= 2 && (NP - 1) * PSTEP + 1 < GA, "every piece of tile t + 2 has a gap in phase A");
     constexpr int MAXG = GB >= 32 ? 16 : 8;            // phase B gaps that carry the maximum of tile t + 1: 32 / MAXG v_max3 each
     constexpr int M0 = 5, MF = M0 + MAXG;              // ... gaps [M0, MF); gap MF: the new quantised maximum
     constexpr int SB = MF + 1;                         // phase B gaps [0, SB) carry the last SB scores of tile t, gaps [SB, GB) the first E of tile t + 1
     constexpr int E = GB - SB;                         // 10 (text), 10 (ViT)
-    constexpr int NA = 64 - GB;                        // scores of phase A: 32 over 32 gaps (text), 40 over 24 (ViT); phase B gap g = position NA + g
+    constexpr int NA = 64 - GB;                        // scores of phase A: 32 over 32 gaps (text), 40 over 20 (ViT); phase B gap g = position NA + g
     // A score is a chain of three dependent vector instructions (fma -> exp -> add / cvt_pk); issued back to back each waits out the previous
     // one's latency (measured: ~8 cycles per instruction in a gap of {MFMA, fma, exp, add} where independent instructions issue every ~4).
     // So the chain is itself software-pipelined over the stream of scores: position p issues stage 3 of score p - 2, stage 2 of score
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         constexpr int p0 = (g * NA) / GA, p1 = ((g + 1) * NA) / GA;   // this gap's positions of the score stream
         static_for<p1 - p0>([&](auto J) { position(std::integral_constant<int, p0 + decltype(J)::value>{}, sc, sn); });
-        if (DMA_IN_A && g % 4 == 1 && g / 4 < NP) dma_piece(std::integral_constant<int, g / 4>{});
+        if (DMA_IN_A && g % PSTEP == 1 && g / PSTEP < NP) dma_piece(std::integral_constant<int, g / PSTEP>{});
         __builtin_amdgcn_sched_barrier(0);
       });
       stamp(0);
@@ -614,7 +618,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         } else if (g == SB + 1) {
           s3(std::integral_constant<int, NA + g - 2>{});
         }
-        if (!DMA_IN_A && g % 4 == 1 && g / 4 < NP) dma_piece(std::integral_constant<int, g / 4>{});
+        if (!DMA_IN_A && g % (GB / NP) == 1 && g / (GB / NP) < NP) dma_piece(std::integral_constant<int, g / (GB / NP)>{});
         __builtin_amdgcn_sched_barrier(0);
       });
       stamp(1);

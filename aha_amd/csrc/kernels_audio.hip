@@ -45,11 +45,16 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(const float* __restri
     for (int n = 0; n < 400; ++n) {
       const float4 v4 = fr[n];
       const float2 t = tw[j];
+      // (sin in a register of its own: clang packs the four frames' FMAs in pairs and, with (cos, sin) as one register pair, broadcasts
+      // the pair's HIGH element into both halves -- v_pk_fma_f32 op_sel:[0,1,0], the form that reads the wrong element beside a kernel of
+      // another stream on MI355X: tests/test_isa_cpu.py, profiles/r03_simd_coresidency.md)
+      float tx = t.x, ty = t.y;
+      asm volatile("" : "+v"(tx), "+v"(ty));
       const float v[MEL_FPB] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
       for (int q = 0; q < MEL_FPB; ++q) {
-        re[q] = fmaf(v[q], t.x, re[q]);
-        im[q] = fmaf(v[q], t.y, im[q]);
+        re[q] = fmaf(v[q], tx, re[q]);
+        im[q] = fmaf(v[q], ty, im[q]);
       }
       j += tid;
       if (j >= 400) j -= 400;
