@@ -43,7 +43,15 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(k2 * u));
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+// candle silu: x / (1 + e^-x), written as x * rcp(1 + exp2(-x log2 e)) on the hardware exp2 / rcp (1 ulp each): 6 vector operations where
+// expf + an IEEE division are ~26 (range scaling, div_scale / div_fmas / div_fixup) -- the gate+up epilogue applies it to 96 pairs per
+// lane and tile, ~6 us of a 256 x 192 tile's time with nothing to overlap it (round 6; like gelu_tanh_f above).  The result is rounded to
+// bf16 by the caller; against the exact form it differs in < 0.01 % of the elements, by one bf16 ulp.  -DAHA_SILU_EXACT: the old form (A/B).
+#ifdef AHA_SILU_EXACT
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+#else
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+#endif
 
 // XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs, so give each XCD a contiguous run of tiles
 // (which share A row panels / W column panels in its private L2).  Bijective for any grid size.
