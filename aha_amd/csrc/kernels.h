@@ -76,6 +76,7 @@ struct RopeArgs {
   float eps;
   int kv_start_host = -1;   // the same value as *kv_start when the caller knows it on the host (prefill): selects the row-vectorised kernel
   const void* rope_tab = nullptr;  // optional (S, 128) bf16: cos[64] | sin[64] of every token's angles (launch_rope_table), else computed in place
+  int skip_q = 0;           // row-vectorised prefill kernel only: the q heads are normed and rotated by the attention kernel's Q load (AttnPrefillArgs::q_norm_w); K and V only here
 };
 void launch_qknorm_rope(const RopeArgs& a, hipStream_t st);
 // cos / sin of pos[axis(i)] * inv_freq[i], rounded to bf16 as apply_rotary_pos_emb casts them (rope.rs:96-132): computed ONCE per
@@ -144,8 +145,16 @@ struct AttnPrefillArgs {
   // context-parallel rank's share of a prompt runs the form the un-sharded prompt would: the forms agree to the parity bound, not bit for bit
   // (another MFMA shape = another accumulation order), and tests/test_cp_gpu.py demands bit-identical rows.
   int rows_hint = 0;
+  // q-norm + RoPE of Q inside the kernel's Q load (round 6; head_dim 128, the 16-rows-per-wave kernel): `q` then points at the RAW q heads of
+  // the qkv GEMM's output (q_ld = its row stride), q_norm_w = the (128) bf16 RMSNorm weight, q_rope_tab = the (rows, 128) bf16 cos | sin
+  // table of launch_rope_table for the same rows as q, q_eps the norm's epsilon.  Same operations in the same order as qknorm_rope_rows_kernel
+  // (bit-identical q); ask attn_prefill_takes_qfuse first -- the 64-row form does not take it.
+  const void* q_norm_w = nullptr;
+  const void* q_rope_tab = nullptr;
+  float q_eps = 0.f;
 };
 void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st);
+bool attn_prefill_takes_qfuse(const AttnPrefillArgs& a);   // would launch_attn_prefill run a kernel that norms + rotates Q itself for these arguments?
 // the one-wave-per-SIMD, 64-q-rows-per-wave form (kernels_attn64.hip); false = not a shape of that kernel, nothing launched
 bool launch_attn_prefill64(const AttnPrefillArgs& a, hipStream_t st, int pipe);
 void set_attn_form_override(int form);     // test hook: -1 = automatic, 16 = the 16-rows-per-wave kernel, 64 / 65 = the 64-row kernel (plain / pipelined)

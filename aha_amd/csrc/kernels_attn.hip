@@ -89,6 +89,78 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV =
     const bf16_t* qp = (const bf16_t*)a.q + (int64_t)qrow * (a.q_ld ? a.q_ld : (int64_t)a.nh * DQK) + (int64_t)head * DQK;
 #pragma unroll
     for (int k4 = 0; k4 < KS; ++k4) qf[t][k4] = as_frag(ld16(qp + k4 * 32 + G * 8));
+    // q-norm + RoPE of Q in the Q load (round 6; AttnPrefillArgs::q_norm_w): `q` is the raw q heads of the qkv GEMM.  The lane holds dims
+    // k4 * 32 + G * 8 + j of its row: the rotate_half partner (dims +- 64) is fragment k4 +- 2 of the SAME lane, and the sum of squares
+    // follows qknorm_rope_rows_kernel's butterfly over the 64 partial terms fma(x[l], x[l], x[l + 64]^2), l = k4 * 32 + G * 8 + j -- partner
+    // l ^ 32 = the other fragment, l ^ 16 / l ^ 8 = lane ^ 32 / lane ^ 16, l ^ 4, 2, 1 in registers -- so the sum, and with it every later
+    // expression (kernels_elem.hip), has the same bits: tests/test_model_gpu.py (digest with AHA_ATTN_QFUSE=0).
+    if constexpr (DQK == 128) {
+      if (a.q_norm_w != nullptr) {
+        float x[4][8], w[4][8], cs[2][8], sn[2][8];
+        const bf16_t* tp = (const bf16_t*)a.q_rope_tab + (int64_t)qrow * 128;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          union { bf16x8_t b; u32x4_t u; } xv;
+          xv.b = qf[t][k4];
+          const u32x4_t wv = ld16((const bf16_t*)a.q_norm_w + k4 * 32 + G * 8);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            x[k4][2 * j] = lo_bf(xv.u[j]); x[k4][2 * j + 1] = hi_bf(xv.u[j]);
+            w[k4][2 * j] = lo_bf(wv[j]); w[k4][2 * j + 1] = hi_bf(wv[j]);
+          }
+          if (k4 < 2) {
+            const u32x4_t c4 = ld16(tp + k4 * 32 + G * 8), s4 = ld16(tp + 64 + k4 * 32 + G * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              cs[k4][2 * j] = lo_bf(c4[j]); cs[k4][2 * j + 1] = hi_bf(c4[j]);
+              sn[k4][2 * j] = lo_bf(s4[j]); sn[k4][2 * j + 1] = hi_bf(s4[j]);
+            }
+          }
+        }
+        float sq[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sq[j] = fmaf(x[0][j], x[0][j], x[2][j] * x[2][j]) + fmaf(x[1][j], x[1][j], x[3][j] * x[3][j]);   // l ^ 32
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {   // l ^ 16
+          const unsigned u = __float_as_uint(sq[j]);
+          const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+          sq[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {   // l ^ 8
+          const unsigned u = __float_as_uint(sq[j]);
+          const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+          sq[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+        const float u0 = sq[0] + sq[4], u1 = sq[1] + sq[5], u2 = sq[2] + sq[6], u3 = sq[3] + sq[7];   // l ^ 4
+        const float v0 = u0 + u2, v1 = u1 + u3;                                                        // l ^ 2
+        const float ss = v0 + v1;                                                                      // l ^ 1
+        const float rinv = 1.0f / sqrtf(ss / 128.0f + a.q_eps);
+        float xn[4][8];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xn[k4][j] = rbf(x[k4][j] * rinv * w[k4][j]);
+#pragma unroll
+        for (int k4 = 0; k4 < 2; ++k4) {
+          u32x4_t lo4, hi4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float yl[2], yh[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int jj = 2 * j + e;
+              yl[e] = rbf(rbf(xn[k4][jj] * cs[k4][jj]) + rbf(-xn[k4 + 2][jj] * sn[k4][jj]));
+              yh[e] = rbf(rbf(xn[k4 + 2][jj] * cs[k4][jj]) + rbf(xn[k4][jj] * sn[k4][jj]));
+            }
+            lo4[j] = pack_bf(yl[0], yl[1]);
+            hi4[j] = pack_bf(yh[0], yh[1]);
+          }
+          qf[t][k4] = as_frag(lo4);
+          qf[t][k4 + 2] = as_frag(hi4);
+        }
+      }
+    }
   }
   const int blk_last_q = min(qb + 16 * QT * NWV - 1, seg_rows - 1);
   const int last_tok = a.causal ? min(seg_off + blk_last_q, seg_tot - 1) : seg_tot - 1;
@@ -483,6 +555,43 @@ void set_attn_variant_override(int smx) { g_attn_smx_override = smx; }
 static int g_attn_form_override = -1;
 void set_attn_form_override(int form) { g_attn_form_override = form; }
 
+// The kernel form launch_attn_prefill picks for these arguments: 0 = this file's 16-rows-per-wave kernel, 64 / 65 = kernels_attn64.hip
+static int attn_prefill_form(const AttnPrefillArgs& a, int smx);
+static int attn_prefill_smx(const AttnPrefillArgs& a);
+static int attn_prefill_smx(const AttnPrefillArgs& a) {
+  static const int smx_env = [] { const char* e = getenv("AHA_ATTN_SMX"); return e ? atoi(e) : 3; }();
+  union { float f; uint32_t u; } sb;
+  sb.f = a.scale;
+  const uint32_t scale_bits = sb.u;
+  int smx = g_attn_smx_override >= 0 ? g_attn_smx_override : smx_env;
+  if (smx == 1 && (scale_bits & 0xffffu) != 0) smx = 0;
+  if (smx == 3 && !(a.scale > 0.f)) smx = 0;   // the f32 chain keeps its running maximum in raw score units: needs a positive scale
+  return smx;
+}
+static int attn_prefill_form(const AttnPrefillArgs& a, int smx) {
+  // The kernel form.  AHA_ATTN_FORM / set_attn_form_override: 16 = this file's 16-rows-per-wave kernel, 64 = the one-wave-per-SIMD kernel
+  // with 64 rows per wave (kernels_attn64.hip) with a tile's parts in program order, 65 = the same software-pipelined inside the wave;
+  // unset = automatic: form 65 (f32 chain only) once its 256-row blocks fill the chip.
+  static const int form_env = [] { const char* e = getenv("AHA_ATTN_FORM"); return e ? atoi(e) : -1; }();
+  const int form = g_attn_form_override >= 0 ? g_attn_form_override : form_env;
+  if (smx != 3 || form == 16) return 0;
+  const int64_t blocks64 = (a.rows_hint > 0 ? (int64_t)(a.rows_hint + 255) / 256 : (int64_t)((a.S + 255) / 256 + (a.S2 + 255) / 256)) * a.nh;
+  // One 4-wave workgroup per CU: a full launch is rounds of 256 workgroups.  Same-box A/B against the 16-row kernel (scripts/attn64_ab.py,
+  // 32 heads x head_dim 128, profiles/r06_attn_prefill.md): full attention 2048 / 3072 / 4096 / 8192 rows = 1 / 1.5 / 2 / 4 rounds:
+  // 64 vs 75, 165 vs 160, 234 vs 273, 959 vs 1143 us -- ahead wherever the last round is at least ~80 % full; causal (long blocks first, the
+  // rounds blur): 62 vs 55 us at 2048 rows, 95 vs 98 at 3072, 139 vs 154 at 4096, 0.51 vs 0.58 ms at 8192, 11.7 vs 13.5 ms at 40 980.
+  const int64_t rounds64 = (blocks64 + 255) / 256;
+  const bool fills = a.causal ? blocks64 >= 384 : (blocks64 >= 256 && blocks64 * 5 >= rounds64 * 256 * 4);
+  const bool auto64 = fills && (a.d == 128 || a.d == 72);
+  if (form == 64) return 64;
+  if (form == 65 || (form < 0 && auto64)) return 65;
+  return 0;
+}
+bool attn_prefill_takes_qfuse(const AttnPrefillArgs& a) {
+  static const bool on = [] { const char* e = getenv("AHA_ATTN_QFUSE"); return e ? atoi(e) != 0 : true; }();
+  return on && a.d == 128 && attn_prefill_form(a, attn_prefill_smx(a)) == 0;
+}
+
 void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
   if (a_in.S <= 0) return;
   AttnPrefillArgs a = a_in;
@@ -508,6 +617,7 @@ void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
     launch_attn_prefill(b, st);
     b.q = (const char*)a.q + (int64_t)a.S * (a.q_ld ? a.q_ld : (int64_t)a.nh * (a.d == 72 ? 96 : a.d)) * 2;
     b.o = (char*)a.o + (int64_t)a.S * a.nh * a.d * 2;
+    if (a.q_rope_tab) b.q_rope_tab = (const char*)a.q_rope_tab + (int64_t)a.S * 128 * 2;   // the table rows travel with the q rows
     b.S = a.S2, b.kv_offset = a.kv_offset2, b.kv_total = a.kv_total2;
     launch_attn_prefill(b, st);
     return;
@@ -521,29 +631,11 @@ void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
   //   0 = the reference's rounding chain bf16(bf16(q.k) * bf16(scale)) (modules.rs:782-783) in the vector ALU, 1 = the same bits with the
   //       scale multiply on the matrix pipe (needs a bf16-exact scale: every model path has one; an op-level caller with another scale
   //       gets 0) -- the bit-faithful forms, kept for A/B and for the parity tables of rounds 1-4
-  static const int smx_env = [] { const char* e = getenv("AHA_ATTN_SMX"); return e ? atoi(e) : 3; }();
-  union { float f; uint32_t u; } sb;
-  sb.f = a.scale;
-  const uint32_t scale_bits = sb.u;
-  int smx = g_attn_smx_override >= 0 ? g_attn_smx_override : smx_env;
-  if (smx == 1 && (scale_bits & 0xffffu) != 0) smx = 0;
-  if (smx == 3 && !(a.scale > 0.f)) smx = 0;   // the f32 chain keeps its running maximum in raw score units: needs a positive scale
-  // The kernel form.  AHA_ATTN_FORM / set_attn_form_override: 16 = this file's 16-rows-per-wave kernel, 64 = the one-wave-per-SIMD kernel
-  // with 64 rows per wave (kernels_attn64.hip) with a tile's parts in program order, 65 = the same software-pipelined inside the wave;
-  // unset = automatic: form 65 (f32 chain only) once its 256-row blocks fill the chip.
-  static const int form_env = [] { const char* e = getenv("AHA_ATTN_FORM"); return e ? atoi(e) : -1; }();
-  const int form = g_attn_form_override >= 0 ? g_attn_form_override : form_env;
-  if (smx == 3 && form != 16) {
-    const int64_t blocks64 = (a.rows_hint > 0 ? (int64_t)(a.rows_hint + 255) / 256 : (int64_t)((a.S + 255) / 256 + (a.S2 + 255) / 256)) * a.nh;
-    // One 4-wave workgroup per CU: a full launch is rounds of 256 workgroups.  Same-box A/B against the 16-row kernel (scripts/attn64_ab.py,
-    // 32 heads x head_dim 128, profiles/r06_attn_prefill.md): full attention 2048 / 3072 / 4096 / 8192 rows = 1 / 1.5 / 2 / 4 rounds:
-    // 64 vs 75, 165 vs 160, 234 vs 273, 959 vs 1143 us -- ahead wherever the last round is at least ~80 % full; causal (long blocks first, the
-    // rounds blur): 62 vs 55 us at 2048 rows, 95 vs 98 at 3072, 139 vs 154 at 4096, 0.51 vs 0.58 ms at 8192, 11.7 vs 13.5 ms at 40 980.
-    const int64_t rounds64 = (blocks64 + 255) / 256;
-    const bool fills = a.causal ? blocks64 >= 384 : (blocks64 >= 256 && blocks64 * 5 >= rounds64 * 256 * 4);
-    const bool auto64 = fills && (a.d == 128 || a.d == 72);
-    if ((form == 64 || form == 65 || (form < 0 && auto64)) && launch_attn_prefill64(a_in, st, form == 64 ? 0 : 1)) return;
-  }
+  const int smx = attn_prefill_smx(a);
+  // (a caller that handed over raw q heads -- q_norm_w -- asked attn_prefill_takes_qfuse first; should the form have changed since, the
+  // 16-row kernel below is the one that norms and rotates)
+  const int form_pick = a.q_norm_w != nullptr ? 0 : attn_prefill_form(a, smx);
+  if (form_pick != 0 && launch_attn_prefill64(a_in, st, form_pick == 64 ? 0 : 1)) return;
   // row-order epilogue stores (AHA_ATTN_EPI_ROWS=0: from the accumulator fragments): 16-byte pieces need head dims in multiples of 8
   // and 16-byte aligned output rows
   static const int epi_env = [] { const char* e = getenv("AHA_ATTN_EPI_ROWS"); return e ? atoi(e) : 1; }();

@@ -190,7 +190,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_rows_kernel(RopeArgs a, int n
   const int bid = (int)blockIdx.x;
   if (bid < n_qk_blocks) {
     // ---- role A: q / k heads ----
-    const int nchunk = (nqk + ROPE_ROWS_CHUNK - 1) / ROPE_ROWS_CHUNK;
+    const int first = a.skip_q ? a.nh : 0;   // skip_q: the attention kernel norms + rotates the q heads in its Q load
+    const int nchunk = (nqk - first + ROPE_ROWS_CHUNK - 1) / ROPE_ROWS_CHUNK;
     const int64_t wid = (int64_t)bid * 4 + wave;
     const int tg = (int)(wid / nchunk), chunk = (int)(wid % nchunk);
     const int tq = lane >> 4, sub = lane & 15, sp = sub & 7;
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_rows_kernel(RopeArgs a, int n
       }
     }
     const bf16_t* row = (const bf16_t*)a.qkv + (int64_t)tokc * a.ld + sub * 8;
-    const int slot0 = chunk * ROPE_ROWS_CHUNK, slot1 = min(nqk, slot0 + ROPE_ROWS_CHUNK);
+    const int slot0 = first + chunk * ROPE_ROWS_CHUNK, slot1 = min(nqk, slot0 + ROPE_ROWS_CHUNK);
     const int ctok = a.kv_start_host + tokc;
     const int page = ctok / KV_PAGE_TOKENS, t = ctok % KV_PAGE_TOKENS;
     char* kbase = reinterpret_cast<char*>(a.kv.page_ptrs[page] + a.kv.layer_off);
@@ -340,7 +341,7 @@ void launch_qknorm_rope(const RopeArgs& a, hipStream_t st) {
   if (rows_on && a.kv_start_host >= 0 && a.kv.page_ptrs != nullptr && a.d == 128 && a.S >= 16) {
     static const int chunk_env = [] { const char* e = getenv("AHA_ROPE_CHUNK"); return e ? atoi(e) : 8; }();
     const int chunk = chunk_env == 10 ? 10 : 8;
-    const int nqk = a.nh + a.kvh, nchunk = (nqk + chunk - 1) / chunk;
+    const int nqk = (a.skip_q ? 0 : a.nh) + a.kvh, nchunk = (nqk + chunk - 1) / chunk;
     const int64_t qk_waves = (int64_t)((a.S + 3) / 4) * nchunk;
     const int n_qk_blocks = (int)((qk_waves + 3) / 4);
     const int npages = (a.kv_start_host + a.S - 1) / KV_PAGE_TOKENS - a.kv_start_host / KV_PAGE_TOKENS + 1;

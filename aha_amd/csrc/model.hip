@@ -1747,6 +1747,19 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
       }
     }
     in_norm_done = false;
+    // q-norm + RoPE of the q heads inside the attention kernel's Q load where that kernel takes it (round 6: head_dim 128 on the 16-row
+    // form, i.e. every prompt below ~3 k tokens): the rope kernel then handles K and V only and the attention reads the raw q heads of p_qkv
+    bool q_fused = d == 128 && m->p_rope != nullptr;
+    {
+      const bool one = segs.size() == 2 && segs[1].l0 == segs[0].l0 + segs[0].len && segs[1].r0 > segs[0].r0;
+      for (size_t si = 0; si < segs.size() && q_fused; ++si) {
+        AttnPrefillArgs pa{};
+        pa.S = segs[si].len; pa.nh = nh; pa.kvh = kvh; pa.d = d; pa.causal = 1; pa.scale = m->attn_scale; pa.rows_hint = (int)S;
+        if (one) pa.S2 = segs[1].len;
+        q_fused = attn_prefill_takes_qfuse(pa);
+        if (one) break;
+      }
+    }
     for (const RowSeg& sg : segs) {
       RopeArgs r{};
       r.qkv = rows(m->p_qkv, sg.l0, nq + 2 * nkv); r.ld = nq + 2 * nkv; r.q_norm_w = L.q_norm; r.k_norm_w = L.k_norm;
@@ -1755,7 +1768,8 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
       r.S = sg.len; r.nh = nh; r.kvh = kvh; r.d = d; r.eps = c.rms_norm_eps;
       r.kv_start_host = kv_off + sg.r0;   // == d_state->kv_start (push_state above) for the whole prompt
       r.rope_tab = rows(m->p_rope, sg.l0, 128);
-      ProfScope ps(m, "elem", (double)sg.len * (nq + 2 * nkv) * 4, 0);
+      r.skip_q = q_fused ? 1 : 0;
+      ProfScope ps(m, "elem", (double)sg.len * ((q_fused ? 0 : nq) + 2 * nkv) * 4, 0);
       launch_qknorm_rope(r, st);
     }
     if (cp && (rc = cp_gather_kv(m, li, cpp))) return rc;
@@ -1769,6 +1783,10 @@ static int forward_initial_impl(aha_model* m, const uint32_t* ids, size_t n, siz
       a.q = rows(m->p_q, sg.l0, nq); a.kv = model_kv_layer(m, li); a.o = rows(m->p_attn, sg.l0, nq); a.S = sg.len; a.nh = nh; a.kvh = kvh; a.d = d;
       a.kv_offset = kv_off + sg.r0; a.kv_total = kv_off + sg.r0 + sg.len; a.causal = 1; a.scale = m->attn_scale;
       a.rows_hint = (int)S;   // the kernel form by the whole prompt: a context-parallel rank's rows stay bit-identical to the un-sharded prefill
+      if (q_fused) {
+        a.q = rows(m->p_qkv, sg.l0, nq + 2 * nkv); a.q_ld = nq + 2 * nkv;
+        a.q_norm_w = L.q_norm; a.q_rope_tab = rows(m->p_rope, sg.l0, 128); a.q_eps = c.rms_norm_eps;
+      }
       double Lk = a.kv_total, flops = 4.0 * sg.len * (a.kv_offset + 0.5 * sg.len) * nq, rows_io = sg.len;
       if (one_launch) {
         const RowSeg& s2 = segs[1];
