@@ -340,14 +340,18 @@ void launch_qknorm_rope(const RopeArgs& a, hipStream_t st) {
   static const bool rows_on = [] { const char* e = getenv("AHA_ROPE_ROWS"); return e ? atoi(e) != 0 : true; }();
   if (rows_on && a.kv_start_host >= 0 && a.kv.page_ptrs != nullptr && a.d == 128 && a.S >= 16) {
     static const int chunk_env = [] { const char* e = getenv("AHA_ROPE_CHUNK"); return e ? atoi(e) : 8; }();
-    const int chunk = chunk_env == 10 ? 10 : 8;
+    // K heads only (skip_q): two heads per wave -- eight would leave S / 4 waves walking all kv heads one after the other (cfg 3: 386 waves on
+    // 1024 SIMDs, ~3.7 us of dependent vector work each)
+    static const int chunk_k = [] { const char* e = getenv("AHA_ROPE_CHUNK_K"); return e ? atoi(e) : 2; }();
+    const int chunk = a.skip_q ? (chunk_k == 8 ? 8 : 2) : (chunk_env == 10 ? 10 : 8);
     const int nqk = (a.skip_q ? 0 : a.nh) + a.kvh, nchunk = (nqk + chunk - 1) / chunk;
     const int64_t qk_waves = (int64_t)((a.S + 3) / 4) * nchunk;
     const int n_qk_blocks = (int)((qk_waves + 3) / 4);
     const int npages = (a.kv_start_host + a.S - 1) / KV_PAGE_TOKENS - a.kv_start_host / KV_PAGE_TOKENS + 1;
     const int n_v_blocks = (npages * a.kvh * 128 + 255) / 256;
     const dim3 grid((unsigned)(n_qk_blocks + n_v_blocks));
-    if (chunk == 8) hipLaunchKernelGGL(qknorm_rope_rows_kernel<8>, grid, dim3(256), 0, st, a, n_qk_blocks);
+    if (chunk == 2) hipLaunchKernelGGL(qknorm_rope_rows_kernel<2>, grid, dim3(256), 0, st, a, n_qk_blocks);
+    else if (chunk == 8) hipLaunchKernelGGL(qknorm_rope_rows_kernel<8>, grid, dim3(256), 0, st, a, n_qk_blocks);
     else hipLaunchKernelGGL(qknorm_rope_rows_kernel<10>, grid, dim3(256), 0, st, a, n_qk_blocks);
     return;
   }
