@@ -156,6 +156,52 @@ def test_gemm_ring_kernel_k_slices(gpu, splitk, M, N, K):
     assert_close_ulps(ops.gemm(Ad, Wd), ref_plain, 1, 0.98, "automatic plan")
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_gemm_random_shapes_on_the_automatic_plan(gpu, seed):
+    """Eight draws of six random (M, N, K, epilogue) each through launch_gemm's AUTOMATIC plan -- few rows to a few hundred (the ring kernel,
+    its K slices), 256-2000 rows with short and long K (256 x 128 / 256 x 192 / 256^2 tiles, split-K, ragged-N splits), ragged M / N / K
+    (multiples of 8) -- against the oracle chain of the epilogue; a second call must repeat the bits."""
+    import random
+    from aha_amd import ops, _lib
+    rng = random.Random(1000 + seed)
+    for case in range(6):
+        M = rng.choice([rng.randint(1, 64), rng.randint(65, 450), rng.randint(256, 2000)])
+        N = 8 * rng.choice([rng.randint(8, 64), rng.randint(64, 560)])
+        K = 8 * rng.choice([rng.randint(8, 40), rng.randint(40, 540)])
+        epi = rng.choice(["plain", "bias", "bias_res", "res", "bias_gelu", "silu_pairs"])
+        if epi == "silu_pairs":
+            N = max(32, N // 32 * 32)
+        A, W = rnd((M, K), 7000 + seed * 10 + case), rnd((N, K), 7100 + seed * 10 + case, 0.02)
+        b, r = rnd((N,), 7200 + seed * 10 + case, 0.5), rnd((M, N), 7300 + seed * 10 + case)
+        Ad, Wd, bd, rd = A.to(gpu), W.to(gpu), b.to(gpu), r.to(gpu)
+        lin = NM.linear(A.float(), W.float())
+        what = f"seed {seed} case {case}: M={M} N={N} K={K} {epi}"
+        if epi == "plain":
+            got, ref, ulps = ops.gemm(Ad, Wd), lin, 1
+            again = ops.gemm(Ad, Wd)
+        elif epi == "bias":
+            got, ref, ulps = ops.gemm(Ad, Wd, bd), NM.linear(A.float(), W.float(), b.float()), 2
+            again = ops.gemm(Ad, Wd, bd)
+        elif epi == "bias_res":
+            got, ref, ulps = ops.gemm(Ad, Wd, bd, rd, _lib.ACT_NONE), NM.r(r.float() + NM.linear(A.float(), W.float(), b.float())), 2
+            again = ops.gemm(Ad, Wd, bd, rd, _lib.ACT_NONE)
+        elif epi == "res":
+            got, ref, ulps = ops.gemm(Ad, Wd, None, rd, _lib.ACT_NONE), NM.r(r.float() + lin), 2
+            again = ops.gemm(Ad, Wd, None, rd, _lib.ACT_NONE)
+        elif epi == "bias_gelu":
+            ref = NM.r(torch.nn.functional.gelu(NM.linear(A.float(), W.float(), b.float()), approximate="tanh"))
+            got, ulps = ops.gemm(Ad, Wd, bd, None, _lib.ACT_GELU_TANH), 3
+            again = ops.gemm(Ad, Wd, bd, None, _lib.ACT_GELU_TANH)
+        else:   # gate / up rows interleaved in blocks of 16 (the model loader's layout): out[:, j] = silu(gate_j) * up_j
+            Wg, Wu = W[: N // 2], W[N // 2:]
+            Wf = ops.interleave_gate_up(Wg, Wu)
+            ref = NM.r(NM.r(oq.silu(NM.linear(A.float(), Wg.float()))) * NM.linear(A.float(), Wu.float()))
+            got, ulps = ops.gemm(Ad, Wf.to(gpu), None, None, _lib.ACT_SILU_MUL_PAIRS), 2
+            again = ops.gemm(Ad, Wf.to(gpu), None, None, _lib.ACT_SILU_MUL_PAIRS)
+        assert torch.equal(got, again), what + ": not repeatable"
+        assert_close_ulps(got, ref, ulps, 0.95, what)
+
+
 @pytest.mark.parametrize("epi", ["plain", "bias_res", "bias_gelu"])
 @pytest.mark.parametrize("M,N,K", [(200, 640, 1152), (390, 896, 896), (406, 1000, 1032), (70, 1736, 264), (512, 1152, 1152)])
 def test_gemm_ring_kernel_is_bit_identical_to_the_single_stage_kernel(gpu, epi, M, N, K):
