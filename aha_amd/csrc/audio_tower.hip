@@ -288,10 +288,13 @@ static int audio_ensure_scratch(aha_model* m, size_t frames, size_t samples) {
   return AHA_OK;
 }
 
+// ln_w / ln_b / ln_out: a LayerNorm of the finished rows riding on the call (eps 1e-5) -- inside the reduce pass where the plan has one
+// (gemm_splitk_reduce_layernorm_kernel, bit-identical to the two launches), a launch_layernorm_rows behind the GEMM otherwise
 static void agemm(aha_model* m, const void* A, const void* W, void* C, int M, int N, int K, const void* bias, const void* residual,
-                  int act) {
+                  int act, const void* ln_w = nullptr, const void* ln_b = nullptr, void* ln_out = nullptr) {
   GemmArgs g{};
   g.A = A; g.W = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N; g.bias = bias; g.residual = residual; g.act = act;
+  if (ln_w) { g.norm_w = ln_w; g.norm_b = ln_b; g.norm_out = ln_out; g.norm_eps = 1e-5f; }
   ProfScope ps(m, "gemm", ((double)M * K + (double)N * K + (double)M * N * (residual ? 2 : 1)) * 2, 2.0 * M * N * K);
   launch_gemm(g, m->stream);
 }
@@ -386,9 +389,13 @@ int audio_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, const
   kv.kvh = a->nh;
   kv.d = a->hd;
   const int D = a->D;
+  // round 6: the LayerNorm behind fc2 + residual -- norm1 of the next layer, ln_post after the last -- rides on the fc2 call (its plan at the
+  // real widths is K slices + a reduce pass: one launch less per layer); AHA_AUD_FUSE_LN=0: every LayerNorm its own launch (same bits)
+  static const bool fuse_ln = [] { const char* e = getenv("AHA_AUD_FUSE_LN"); return e ? atoi(e) != 0 : true; }();
+  bool h_ready = false;   // a->h already holds the LayerNorm of a->x
   for (int li = 0; li < a->layers; ++li) {
     const AudLayerW& L = a->L[li];
-    {
+    if (!h_ready) {
       ProfScope ps(m, "elem", (double)n_tok * D * 4, 0);
       launch_layernorm_rows(a->x, L.ln1w, L.ln1b, a->h, n_tok, D, 1e-5f, st);
     }
@@ -410,9 +417,16 @@ int audio_forward_and_scatter(aha_model* m, const uint32_t* ids, size_t n, const
       launch_layernorm_rows(a->x, L.ln2w, L.ln2b, a->h, n_tok, D, 1e-5f, st);
     }
     agemm(m, a->h, L.fc1_w, a->mlp, n_tok, a->ffn, D, L.fc1_b, nullptr, ACT_GELU_ERF);
-    agemm(m, a->mlp, L.fc2_w, a->x, n_tok, D, a->ffn, L.fc2_b, a->x, ACT_NONE);
+    if (fuse_ln) {
+      const bool last = li + 1 == a->layers;
+      agemm(m, a->mlp, L.fc2_w, a->x, n_tok, D, a->ffn, L.fc2_b, a->x, ACT_NONE, last ? a->lnp_w : a->L[li + 1].ln1w,
+            last ? a->lnp_b : a->L[li + 1].ln1b, a->h);
+      h_ready = true;
+    } else {
+      agemm(m, a->mlp, L.fc2_w, a->x, n_tok, D, a->ffn, L.fc2_b, a->x, ACT_NONE);
+    }
   }
-  {
+  if (!h_ready) {
     ProfScope ps(m, "elem", (double)n_tok * D * 4, 0);
     launch_layernorm_rows(a->x, a->lnp_w, a->lnp_b, a->h, n_tok, D, 1e-5f, st);
   }

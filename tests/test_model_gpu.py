@@ -344,13 +344,14 @@ def test_norm_inside_the_split_k_reduce_is_bit_identical(gpu):
     # round 6: the same for the ViT block's LayerNorms (riding on proj / fc2; AHA_VIT_FUSE_LN=0 launches each on its own): three runs,
     # one digest -- folded into the reduce pass, appended as launch_layernorm_rows by the GEMM call, launched by the tower itself
     # ... and for q-norm + RoPE of the q heads inside the prefill attention's Q load (AttnPrefillArgs::q_norm_w; AHA_ATTN_QFUSE=0: the rope
-    # kernel handles the q heads as before): a fourth run, the same digest
+    # kernel handles the q heads as before): a fourth run, the same digest; a fifth with the audio tower's LayerNorms as their own launches
+    # (AHA_AUD_FUSE_LN=0; the worker's Qwen3-ASR prefill)
     for env in (dict(AHA_GEMM_FUSE_NORM="0"), dict(AHA_GEMM_FUSE_NORM="1"), dict(AHA_GEMM_FUSE_NORM="1", AHA_VIT_FUSE_LN="0"),
-                dict(AHA_GEMM_FUSE_NORM="1", AHA_ATTN_QFUSE="0")):
+                dict(AHA_GEMM_FUSE_NORM="1", AHA_ATTN_QFUSE="0"), dict(AHA_GEMM_FUSE_NORM="1", AHA_AUD_FUSE_LN="0")):
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "fuse_norm_worker.py")],
                            env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("FUSE_NORM_DIGEST")]
         assert line, r.stdout[-2000:]
         digests.append(line[0].split()[1])
-    assert digests[0] == digests[1] == digests[2] == digests[3], f"a norm inside the reduce pass (or q-norm + RoPE inside the attention) changed the logits: {digests}"
+    assert digests[0] == digests[1] == digests[2] == digests[3] == digests[4], f"a norm inside the reduce pass (or q-norm + RoPE inside the attention) changed the logits: {digests}"

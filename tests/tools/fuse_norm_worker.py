@@ -56,6 +56,27 @@ def main():
         h.update(np.asarray(wm.debug_image_embeds(1, 256)).tobytes())
         wm.close()
     ops.gemm_plan(0, 0)
+    # round 6: the audio tower's LayerNorm behind fc2 + residual (norm1 of the next layer, ln_post after the last) rides on the fc2 call
+    # (csrc/audio_tower.hip; AHA_AUD_FUSE_LN=0: its own launch).  A Qwen3-ASR prefill with every GEMM forced onto two K slices (reduce pass
+    # everywhere) and once more with the 128^2 ring kernel's K slices; audio embeddings and logits into the digest.
+    from aha_amd.configs import tiny_qwen3_asr
+    from aha_amd.model import MultiModalData
+    from aha_amd.weights import qwen3_asr_weights
+    from oracle import qwen3_asr as oa   # (host-side feature extraction for the request only: the digest compares HIP runs with each other)
+    acfg = tiny_qwen3_asr(layers=3)
+    aw = qwen3_asr_weights(acfg, seed=2)
+    wave = np.clip(np.random.default_rng(11).normal(0, 0.1, 16000 * 4), -1, 1).astype(np.float32)
+    feats = oa.log_mel(wave)
+    n_tok = oa.get_feat_extract_output_lengths(feats.shape[1])
+    aids = [5, 6, 7, acfg.audio_start_token_id] + [acfg.audio_token_id] * n_tok + [acfg.audio_end_token_id, 8, 9]
+    for plan in ((256, 2), (128, 2), (0, 0)):
+        ops.gemm_plan(*plan)
+        am = HipInferenceModel(acfg, aw)
+        lg, tok = am.forward_initial(aids, 0, MultiModalData(audio_features=feats))
+        h.update(lg.tobytes())
+        h.update(np.asarray(am.debug_audio_embeds(n_tok)).tobytes())
+        am.close()
+    ops.gemm_plan(0, 0)
     print("FUSE_NORM_DIGEST", h.hexdigest(), flush=True)
 
 
